@@ -1,0 +1,195 @@
+"""Pin the oracle (CPU restatement) against outputs of the REAL reference.
+
+Fixtures in tests/golden/ were produced by tools/make_goldens.py importing
+/root/reference in the build container; inputs are regenerated here from the seed.
+"""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import procedural_state_dict, synthetic_batch
+from oracle.model import dice_loss_multiclass, normalization, standardization
+
+TOL = 1e-4  # oracle vs reference: same algorithm, fp32 rounding only
+
+
+def _sub(t, sc, sp, off=1):
+    return t.detach()[:, ::sc, off::sp, off::sp].numpy()
+
+
+def _drop_masks(depth, rate, batch, seed):
+    g = np.random.default_rng([seed, depth, batch, 7])
+    dpr = torch.linspace(0, rate, depth).tolist()
+    masks = []
+    for i in range(depth):
+        pair = []
+        for j in range(2):
+            m = (g.uniform(size=batch) < 1.0 - dpr[i]).astype(np.float32)
+            if i == depth - 1 and j == 0:
+                m[0] = 0.0
+            if i == depth // 2 and j == 1:
+                m[-1] = 0.0
+            pair.append(torch.from_numpy(m))
+        masks.append(tuple(pair))
+    return masks
+
+
+def _aux_mask(batch, ch, seed):
+    g = np.random.default_rng([seed, batch, ch, 11])
+    return torch.from_numpy((g.uniform(size=(batch, ch)) < 0.9).astype(np.float32))
+
+
+def _grad_sample(g, n):
+    f = g.detach().flatten()
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy()
+
+
+def test_preprocess_matches_reference(golden_dir):
+    g = np.load(golden_dir / "tensors_preprocess.npz")
+    x = standardization(normalization(torch.from_numpy(g["u8"]).float()),
+                        torch.from_numpy(g["mean"]), torch.from_numpy(g["std"]))
+    np.testing.assert_allclose(x.numpy(), g["out"], rtol=0, atol=1e-6)
+
+
+def test_preprocess_known_answers():
+    """The reference's own known-answer vectors (tests/test_utils_tensors.py:14-50)."""
+    n = normalization(torch.tensor([[0.0, 127.5, 255.0]]))
+    assert torch.allclose(n, torch.tensor([[0.0, 0.5, 1.0]]), atol=1e-6)
+    n = normalization(torch.tensor([0.0, 255.0]), 0, 255, -1.0, 1.0)
+    assert torch.allclose(n, torch.tensor([-1.0, 1.0]), atol=1e-6)
+    t = torch.tensor([[[[1.0, 2.0], [3.0, 4.0]]]])
+    s = standardization(t, torch.tensor([2.5]), torch.tensor([1.118034]))
+    assert torch.allclose(s, (t - 2.5) / 1.118034, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    g = np.load(golden_dir / "dofa_tiny.npz")
+    meta = json.loads(str(g["meta"]))
+    m = oracle.DOFASegmentationModel("dofa_tiny_test", (meta["img"],) * 2,
+                                     num_classes=meta["num_classes"],
+                                     _encoder_kwargs=meta["tiny"])
+    m.load_state_dict(procedural_state_dict(m, meta["seed"]))
+    batch = synthetic_batch(meta["batch"], 3, meta["img"], meta["num_classes"], meta["seed"])
+    return g, meta, m, batch
+
+
+def test_tiny_eval(tiny):
+    g, meta, m, batch = tiny
+    m.eval()
+    with torch.no_grad():
+        taps = m.encoder(batch["image"], batch["wavelengths"])
+        feats = m.neck(taps)
+        r = m(batch["image"], batch["wavelengths"])
+        w, b = None, None
+        from oracle.encoder import position_embedding
+        pe = m.encoder.patch_embed
+        w, b = pe.weight_generator(pe.fclayer(position_embedding(128, batch["wavelengths"] * 1000)))
+    np.testing.assert_allclose(w.numpy(), g["dyn_weight"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(b.numpy(), g["dyn_bias"], atol=TOL, rtol=0)
+    for i in range(4):
+        np.testing.assert_allclose(taps[i].numpy(), g[f"eval_tap{i}"], atol=TOL, rtol=0)
+        np.testing.assert_allclose(feats[i].numpy(), g[f"eval_neck{i}"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(r.out.numpy(), g["eval_out"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(r.aux.numpy(), g["eval_aux"], atol=TOL, rtol=0)
+    mask = oracle.model.predict_mask(r).numpy()
+    top2 = r.out.topk(2, dim=1).values
+    decided = ((top2[:, 0] - top2[:, 1]) > 1e-3).numpy()
+    assert (mask == g["eval_mask"])[decided].all()
+    assert (mask == g["eval_mask"]).mean() > 0.9999
+
+
+def test_tiny_train_step(tiny):
+    g, meta, m, batch = tiny
+    m.train()
+    for n, p in m.named_parameters():
+        p.requires_grad = "encoder" not in n
+        p.grad = None
+    b = meta["batch"]
+    masks = _drop_masks(meta["tiny"]["depth"], 0.1, b, meta["seed"])
+    r = m(batch["image"], batch["wavelengths"], masks, _aux_mask(b, 256, meta["seed"]))
+    np.testing.assert_allclose(r.out.detach().numpy(), g["train_out"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(r.aux.detach().numpy(), g["train_aux"], atol=TOL, rtol=0)
+    loss = oracle.model.training_loss(r, batch["mask"])
+    assert abs(loss.item() - float(g["train_loss"])) < 1e-5
+    loss.backward()
+    for n in meta["grad_names"]:
+        p = dict(m.named_parameters())[n]
+        ref_norm = float(g["gradnorm/" + n])
+        # conv biases feeding a train-mode BN have an analytically ZERO gradient: what is
+        # stored there is rounding noise, so tolerances carry an absolute floor.
+        assert abs(p.grad.double().norm().item() - ref_norm) <= 1e-3 * ref_norm + 1e-5, n
+        np.testing.assert_allclose(_grad_sample(p.grad, 2048), g["grad/" + n],
+                                   atol=0.02 * float(np.abs(g["grad/" + n]).max()) + 2e-6,
+                                   rtol=1e-3, err_msg=n)
+    bufs = dict(m.named_buffers())
+    for k in g.files:
+        if k.startswith("buf/"):
+            np.testing.assert_allclose(bufs[k[4:]].numpy(), g[k], atol=1e-5, rtol=1e-5, err_msg=k)
+
+
+def test_base_512_eval(golden_dir):
+    g = np.load(golden_dir / "dofa_base_512_eval.npz")
+    meta = json.loads(str(g["meta"]))
+    m = oracle.DOFASegmentationModel("dofa_base", (512, 512), num_classes=meta["num_classes"])
+    m.load_state_dict(procedural_state_dict(m, meta["seed"]))
+    m.eval()
+    batch = synthetic_batch(meta["batch"], 3, 512, meta["num_classes"], meta["seed"])
+    with torch.no_grad():
+        taps = m.encoder(batch["image"], batch["wavelengths"])
+        feats = m.neck(taps)
+        dec = m.decoder(feats)
+        r = m(batch["image"], batch["wavelengths"])
+    for i in range(4):
+        np.testing.assert_allclose(_sub(taps[i], 16, 5), g[f"tap{i}_s"], atol=TOL, rtol=0)
+        np.testing.assert_allclose(_sub(feats[i], 16, 5), g[f"neck{i}_s"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(_sub(dec, 8, 6), g["dec_s"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(_sub(r.out, 1, 8, 3), g["out_s8"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(_sub(r.aux, 1, 8, 3), g["aux_s8"], atol=2e-4, rtol=0)
+    mask = oracle.model.predict_mask(r).numpy()
+    top2 = r.out.topk(2, dim=1).values
+    decided = ((top2[:, 0] - top2[:, 1]) > 1e-3).numpy()
+    assert (mask == g["mask"])[decided].all()
+    assert (mask != g["mask"]).sum() <= 8
+
+
+def test_base_512_train(golden_dir):
+    g = np.load(golden_dir / "dofa_base_512_train.npz")
+    meta = json.loads(str(g["meta"]))
+    m = oracle.DOFASegmentationModel("dofa_base", (512, 512), num_classes=meta["num_classes"],
+                                     freeze_layers=["encoder"])
+    m.load_state_dict(procedural_state_dict(m, meta["seed"]))
+    m.train()
+    b = meta["batch"]
+    batch = synthetic_batch(b, 3, 512, meta["num_classes"], meta["seed"])
+    r = m(batch["image"], batch["wavelengths"], _drop_masks(12, 0.1, b, meta["seed"]),
+          _aux_mask(b, 256, meta["seed"]))
+    np.testing.assert_allclose(_sub(r.out, 1, 8, 3), g["out_s8"], atol=2e-4, rtol=0)
+    loss = oracle.model.training_loss(r, batch["mask"])
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    loss.backward()
+    params = dict(m.named_parameters())
+    assert sorted(meta["grad_names"]) == sorted(n for n, p in params.items() if p.grad is not None)
+    for n in meta["grad_names"]:
+        ref_norm = float(g["gradnorm/" + n])
+        got = params[n].grad.double().norm().item()
+        assert abs(got - ref_norm) <= 1e-3 * ref_norm + 1e-5, (n, got, ref_norm)
+
+
+def test_dice_loss_properties():
+    """smp DiceLoss restatement: perfect prediction -> ~0; absent classes masked out."""
+    y = torch.randint(0, 3, (2, 8, 8))
+    logits = torch.nn.functional.one_hot(y, 5).permute(0, 3, 1, 2).float() * 50.0
+    assert dice_loss_multiclass(logits, y).item() < 1e-5
+    # uniform logits: p=1/5 everywhere; classes 3,4 absent contribute 0 but still divide by 5
+    val = dice_loss_multiclass(torch.zeros(2, 5, 8, 8), y).item()
+    exp = 0.0
+    for c in range(3):
+        n = (y == c).sum().item()
+        exp += 1 - (2 * n / 5) / (128 / 5 + n)
+    assert abs(val - exp / 5) < 1e-6
