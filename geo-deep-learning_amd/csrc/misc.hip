@@ -1,0 +1,843 @@
+// Small HBM-bound kernels around the GEMMs: V transpose, row softmax, DOFA patchify / dynamic
+// kernel packing, casts, broadcast adds, u8 normalise, classifier tail, Dice loss, Adam.
+#include "gdl_common.h"
+
+namespace {
+
+inline unsigned grid_for(int64_t total, int per_block = 256) {
+  int64_t g = (total + per_block - 1) / per_block;
+  return (unsigned)(g < 1 ? 1 : (g > 32768 ? 32768 : g));
+}
+
+// ------------------------------------------------------------------ V^T for attention
+// qkv [B,N,3,H,hd] -> vt [B,H,hd,Npad] (keys >= N zero).  32x32 LDS tile transpose.
+template <typename T>
+__global__ __launch_bounds__(256) void v_transpose_kernel(const T* __restrict__ qkv, int N, int H, int hd,
+                                                          T* __restrict__ vt, int Npad) {
+  __shared__ T tile[32][33];
+  const int bh = blockIdx.z, b = bh / H, h = bh % H;
+  const int n0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t rowstride = (int64_t)3 * H * hd;
+  const T* src = qkv + (int64_t)b * N * rowstride + (int64_t)2 * H * hd + (int64_t)h * hd;
+  for (int j = ty; j < 32; j += 8) {
+    const int n = n0 + j, d = d0 + tx;
+    tile[j][tx] = (n < N && d < hd) ? src[(int64_t)n * rowstride + d] : (T)0;
+  }
+  __syncthreads();
+  T* dst = vt + ((int64_t)bh * hd) * Npad;
+  for (int j = ty; j < 32; j += 8) {
+    const int d = d0 + j, n = n0 + tx;
+    if (d < hd && n < Npad) dst[(int64_t)d * Npad + n] = tile[tx][j];
+  }
+}
+
+// ------------------------------------------------------------------ row softmax
+// one wave per row; row cached in registers when it fits (n_cols <= 64*MAXV)
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const void* __restrict__ in, void* out, int64_t rows,
+                                                           int n_valid, int n_cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t base = row * n_cols;
+  float v[MAXV];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = c < n_valid ? ElemIO<T>::load(in, base + c) : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = wave_max(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    v[i] = (i * 64 + lane) < n_valid ? expf(v[i] - mx) : 0.f;
+    s += v[i];
+  }
+  const float inv = 1.f / wave_sum(s);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < n_cols) ElemIO<T>::store(out, base + c, v[i] * inv);
+  }
+}
+
+// ------------------------------------------------------------------ DOFA patch embed helpers
+// im2col for conv2d(kernel P, stride P, padding pad) on NCHW f32 -> [B*Gh*Gw][Kpad]
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, int C, int H, int W,
+                                                       int P, int pad, int Gh, int Gw, void* cols, int Kpad) {
+  const int64_t total = (int64_t)B * Gh * Gw * Kpad;
+  const int K = C * P * P;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int kk = (int)(i % Kpad);
+    int64_t t = i / Kpad;
+    const int gx = (int)(t % Gw); t /= Gw;
+    const int gy = (int)(t % Gh);
+    const int b = (int)(t / Gh);
+    float v = 0.f;
+    if (kk < K) {
+      const int s = kk % P, r = (kk / P) % P, c = kk / (P * P);
+      const int y = gy * P + r - pad, x = gx * P + s - pad;
+      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+        v = img[(((int64_t)b * C + c) * H + y) * W + x];
+    }
+    ElemIO<T>::store(cols, i, v);
+  }
+}
+
+// generated kernel G [C][P*P][D] f32 (dofa_v2.py:157-166) -> conv weight [D][Kpad] (k = c*P*P + rs), * scaler
+template <typename T>
+__global__ __launch_bounds__(256) void dofa_pack_kernel(const float* __restrict__ g, int C, int PP, int D,
+                                                        float scaler, void* out, int Kpad) {
+  const int64_t total = (int64_t)D * Kpad;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int kk = (int)(i % Kpad), d = (int)(i / Kpad);
+    float v = 0.f;
+    if (kk < C * PP) v = g[(int64_t)kk * D + d] * scaler;
+    ElemIO<T>::store(out, i, v);
+  }
+}
+
+// ------------------------------------------------------------------ elementwise
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const void* __restrict__ in, void* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    ElemIO<TO>::store(out, i, ElemIO<TI>::load(in, i));
+}
+
+__global__ __launch_bounds__(256) void scale_f32_kernel(const float* __restrict__ in, float* out, int64_t n, float s) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = in[i] * s;
+}
+
+// out[r,:] = a[(r % a_rows),:] + (b ? b[(r % b_rows),:] : 0)
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ a, int64_t a_rows, int64_t a_stride,
+                                                       const float* __restrict__ b, int64_t b_rows, int64_t b_stride,
+                                                       float* out, int64_t out_stride, int64_t rows, int D) {
+  const int64_t total = rows * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / D;
+    const int c = (int)(i - r * D);
+    float v = a[(r % a_rows) * a_stride + c];
+    if (b) v += b[(r % b_rows) * b_stride + c];
+    out[r * out_stride + c] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __restrict__ in, float* out, int C,
+                                                           int64_t HW, int64_t total4, const float* __restrict__ mean,
+                                                           const float* __restrict__ stdv) {
+  // 4 pixels per thread (HW % 4 == 0): (x/255 - mean)/std exactly as utils/tensors.py:10-35
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(((i * 4) / HW) % C);
+    const uchar4 u = *(const uchar4*)(in + i * 4);
+    const float m = mean[c], s = stdv[c];
+    float4 o;
+    o.x = ((float)u.x / 255.0f - m) / s; o.y = ((float)u.y / 255.0f - m) / s;
+    o.z = ((float)u.z / 255.0f - m) / s; o.w = ((float)u.w / 255.0f - m) / s;
+    *(float4*)(out + i * 4) = o;
+  }
+}
+
+// ------------------------------------------------------------------ classifier tail
+// 1x1 conv to K<=8 classes: one wave per pixel, 4 channels per lane per step.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void head_1x1_kernel(const void* __restrict__ feat, int64_t P, int C, int64_t f_sP,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       const float* __restrict__ chan_scale, int64_t pix_per_img,
+                                                       float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  float acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0.f;
+  const float* cs = chan_scale ? chan_scale + (p / pix_per_img) * C : nullptr;
+  for (int c = lane * 4; c < C; c += 256) {
+    float v[4];
+    if constexpr (sizeof(T) == 4) {
+      const float4 t = *(const float4*)((const float*)feat + p * f_sP + c);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+      const uint2 t = *(const uint2*)((const uint16_t*)feat + p * f_sP + c);
+      v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+      v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    }
+    if (cs) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] *= cs[c + j];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float4 ww = *(const float4*)(w + (int64_t)k * C + c);
+      acc[k] += (v[0] * ww.x + v[1] * ww.y) + (v[2] * ww.z + v[3] * ww.w);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float s = wave_sum(acc[k]);
+    if (lane == 0) out[p * K + k] = s + (bias ? bias[k] : 0.f);
+  }
+}
+
+// backward of the 1x1 head wrt features and weights
+//  dfeat[p,c] = sum_k dlog[p,k] * w[k,c] (* chan_scale) ; dw[k,c] = sum_p dlog[p,k]*feat[p,c]*cs ; db[k] = sum_p dlog[p,k]
+template <typename T, int K>
+__global__ __launch_bounds__(256) void head_1x1_bwd_feat_kernel(const float* __restrict__ dlog, int64_t P, int C,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ chan_scale,
+                                                                int64_t pix_per_img, void* dfeat, int64_t d_sP) {
+  const int cv = C / 4;
+  const int64_t total = P * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / cv;
+    const int c = (int)(i - p * cv) * 4;
+    float g[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) g[k] = dlog[p * K + k];
+    float o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float4 ww = *(const float4*)(w + (int64_t)k * C + c);
+      o[0] += g[k] * ww.x; o[1] += g[k] * ww.y; o[2] += g[k] * ww.z; o[3] += g[k] * ww.w;
+    }
+    if (chan_scale) {
+      const float* cs = chan_scale + (p / pix_per_img) * C + c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] *= cs[j];
+    }
+    if constexpr (sizeof(T) == 4) *(float4*)((float*)dfeat + p * d_sP + c) = make_float4(o[0], o[1], o[2], o[3]);
+    else *(uint2*)((uint16_t*)dfeat + p * d_sP + c) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+  }
+}
+
+// dw partials: grid (C/256, nsplit); each lane 4 channels; ws[split][K][C]; db via extra row K
+template <typename T, int K>
+__global__ __launch_bounds__(256) void head_1x1_bwd_w_partial(const void* __restrict__ feat, const float* __restrict__ dlog,
+                                                              int64_t P, int C, int64_t f_sP,
+                                                              const float* __restrict__ chan_scale,
+                                                              int64_t pix_per_img, float* __restrict__ ws) {
+  __shared__ float red[4][K][256];
+  __shared__ float redb[4][K];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int nsplit = gridDim.y;
+  const int64_t per = (P + nsplit - 1) / nsplit;
+  const int64_t p0 = per * blockIdx.y, p1 = p0 + per < P ? p0 + per : P;
+  float acc[K][4];
+  float accb[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { accb[k] = 0.f; acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.f; }
+  for (int64_t p = p0 + wv; p < p1; p += 4) {
+    float v[4] = {0, 0, 0, 0};
+    if (c < C) {
+      if constexpr (sizeof(T) == 4) {
+        const float4 t = *(const float4*)((const float*)feat + p * f_sP + c);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+        const uint2 t = *(const uint2*)((const uint16_t*)feat + p * f_sP + c);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+      }
+      if (chan_scale) {
+        const float* cs = chan_scale + (p / pix_per_img) * C + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= cs[j];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float g = dlog[p * K + k];
+      accb[k] += g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[k][j] += g * v[j];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wv][k][lane * 4 + j] = acc[k][j];
+    if (lane == 0) redb[wv][k] = accb[k];
+  }
+  __syncthreads();
+  const int t = threadIdx.x, cc = blockIdx.x * 256 + t;
+  float* wsb = ws + (int64_t)blockIdx.y * (K + 1) * C;
+  if (cc < C) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) wsb[(int64_t)k * C + cc] = (red[0][k][t] + red[1][k][t]) + (red[2][k][t] + red[3][k][t]);
+  }
+  if (blockIdx.x == 0 && t < K) wsb[(int64_t)K * C + t] = (redb[0][t] + redb[1][t]) + (redb[2][t] + redb[3][t]);
+}
+
+template <int K>
+__global__ void head_1x1_bwd_w_final(const float* __restrict__ ws, int nsplit, int C, float* __restrict__ dw,
+                                     float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < K * C) {
+    double s = 0;
+    for (int sp = 0; sp < nsplit; ++sp) s += ws[(int64_t)sp * (K + 1) * C + i];
+    dw[i] = (float)s;
+  }
+  if (i < K && db) {
+    double s = 0;
+    for (int sp = 0; sp < nsplit; ++sp) s += ws[(int64_t)sp * (K + 1) * C + (int64_t)K * C + i];
+    db[i] = (float)s;
+  }
+}
+
+__device__ __forceinline__ void src_index2(float ratio, int dst, int in_size, int& i0, int& i1, float& l1) {
+  float s = ratio * ((float)dst + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+}
+
+// NHWC [B,Hi,Wi,K] f32 -> NCHW [B,K,Ho,Wo] f32, bilinear align_corners=False
+template <int K>
+__global__ __launch_bounds__(256) void upsample_logits_kernel(const float* __restrict__ in, int B, int Hi, int Wi,
+                                                              float* __restrict__ out, int Ho, int Wo) {
+  const int64_t total = (int64_t)B * Ho * Wo;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    const int64_t t = i / Wo;
+    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    int y0, y1, x0, x1; float ly, lx;
+    src_index2(ry, oy, Hi, y0, y1, ly);
+    src_index2(rx, ox, Wi, x0, x1, lx);
+    const float* p00 = in + (((int64_t)b * Hi + y0) * Wi + x0) * K;
+    const float* p01 = in + (((int64_t)b * Hi + y0) * Wi + x1) * K;
+    const float* p10 = in + (((int64_t)b * Hi + y1) * Wi + x0) * K;
+    const float* p11 = in + (((int64_t)b * Hi + y1) * Wi + x1) * K;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      out[(((int64_t)b * K + k) * Ho + oy) * Wo + ox] = hy * (hx * p00[k] + lx * p01[k]) + ly * (hx * p10[k] + lx * p11[k]);
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void upsample_logits_bwd_kernel(const float* __restrict__ dout, int B, int Ho, int Wo,
+                                                                  float* __restrict__ din, int Hi, int Wi) {
+  const int64_t total = (int64_t)B * Hi * Wi;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ix = (int)(i % Wi);
+    const int64_t t = i / Wi;
+    const int iy = (int)(t % Hi), b = (int)(t / Hi);
+    int oy_lo = (int)floorf(((float)iy - 0.5f) / ry - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / ry - 0.5f) + 1;
+    int ox_lo = (int)floorf(((float)ix - 0.5f) / rx - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / rx - 0.5f) + 1;
+    oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+    oy_hi = oy_hi > Ho - 1 ? Ho - 1 : oy_hi; ox_hi = ox_hi > Wo - 1 ? Wo - 1 : ox_hi;
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float ly;
+      src_index2(ry, oy, Hi, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float lx;
+        src_index2(rx, ox, Wi, x0, x1, lx);
+        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx == 0.f) continue;
+        const float w = wy * wx;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += w * dout[(((int64_t)b * K + k) * Ho + oy) * Wo + ox];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) din[i * K + k] = acc[k];
+  }
+}
+
+// softmax(dim=1).argmax(dim=1): first index of the maximal f32 softmax value (torch semantics)
+template <int K>
+__global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* __restrict__ logits, int B, int64_t HW,
+                                                             int64_t* __restrict__ mask) {
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / HW, p = i - b * HW;
+    float x[K], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { x[k] = logits[(b * K + k) * HW + p]; mx = fmaxf(mx, x[k]); }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { x[k] = expf(x[k] - mx); s += x[k]; }
+    int best = 0; float bv = x[0] / s;
+#pragma unroll
+    for (int k = 1; k < K; ++k) { const float v = x[k] / s; if (v > bv) { bv = v; best = k; } }
+    mask[i] = best;
+  }
+}
+
+// ------------------------------------------------------------------ Dice loss (smp multiclass)
+// pass 1: per-block partial sums of I_c = sum p_c*[y==c], S_c = sum p_c, N_c = count(y==c)
+template <int K>
+__global__ __launch_bounds__(256) void dice_partial_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                           int B, int64_t HW, float* __restrict__ ws) {
+  __shared__ float red[4][3 * K];
+  const int64_t total = (int64_t)B * HW;
+  float I[K], S[K], Nc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) I[k] = S[k] = Nc[k] = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / HW, p = i - b * HW;
+    float x[K], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { x[k] = logits[(b * K + k) * HW + p]; mx = fmaxf(mx, x[k]); }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { x[k] = expf(x[k] - mx); s += x[k]; }
+    const float inv = 1.f / s;
+    const int y = (int)target[i];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float pk = x[k] * inv;
+      S[k] += pk;
+      if (y == k) { I[k] += pk; Nc[k] += 1.f; }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float a = wave_sum(I[k]), bsum = wave_sum(S[k]), c = wave_sum(Nc[k]);
+    if (lane == 0) { red[wv][k] = a; red[wv][K + k] = bsum; red[wv][2 * K + k] = c; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 * K)
+    ws[(int64_t)blockIdx.x * 3 * K + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <int K>
+__global__ void dice_final_kernel(const float* __restrict__ ws, int nblk, float eps, float* __restrict__ sums,
+                                  float* __restrict__ loss) {
+  __shared__ double tot[3 * K];
+  const int t = threadIdx.x;
+  if (t < 3 * K) {
+    double s = 0;
+    for (int i = 0; i < nblk; ++i) s += ws[(int64_t)i * 3 * K + t];
+    tot[t] = s;
+    sums[t] = (float)s;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double l = 0;
+    for (int k = 0; k < K; ++k) {
+      const double I = tot[k], card = tot[K + k] + tot[2 * K + k];
+      const double dice = 2.0 * I / (card > eps ? card : eps);
+      if (tot[2 * K + k] > 0) l += 1.0 - dice;
+    }
+    loss[0] = (float)(l / K);
+  }
+}
+
+// pass 2: dL/dlogits; sums = [I | S | N] as produced above
+template <int K>
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                       int B, int64_t HW, const float* __restrict__ sums, float eps,
+                                                       const float* __restrict__ upstream, float grad_scale,
+                                                       float* __restrict__ dlogits, int accumulate) {
+  float ca[K], cb[K];  // dL/dp_c = ca[c]*[y==c] + cb[c]
+  const float up = (upstream ? upstream[0] : 1.f) * grad_scale;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float I = sums[k], card = sums[K + k] + sums[2 * K + k];
+    const bool on = sums[2 * K + k] > 0.f && card > eps;
+    ca[k] = on ? -2.f / (K * card) * up : 0.f;
+    cb[k] = on ? 2.f * I / (K * card * card) * up : 0.f;
+  }
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / HW, p = i - b * HW;
+    float x[K], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { x[k] = logits[(b * K + k) * HW + p]; mx = fmaxf(mx, x[k]); }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { x[k] = expf(x[k] - mx); s += x[k]; }
+    const float inv = 1.f / s;
+    const int y = (int)target[i];
+    float g[K], dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      x[k] *= inv;
+      g[k] = cb[k] + (y == k ? ca[k] : 0.f);
+      dot += x[k] * g[k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int64_t o = (b * K + k) * HW + p;
+      const float v = x[k] * (g[k] - dot);
+      dlogits[o] = accumulate ? dlogits[o] + v : v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ optimizer
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef) {
+  const float norm = sqrtf(sumsq[0]);
+  const float c = max_norm / (norm + 1e-6f);   // torch.nn.utils.clip_grad_norm_
+  coef[0] = c < 1.f ? c : 1.f;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float lr, float b1, float b2,
+                                                   float eps, float wd, float bc1, float bc2,
+                                                   const float* __restrict__ clip_coef) {
+  const float cc = clip_coef ? clip_coef[0] : 1.f;
+  const float step = lr / bc1, rs = 1.f / sqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float gi = g[i] * cc;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = pi - step * mi / (sqrtf(vi) * rs + eps);
+  }
+}
+
+// x[o, r, :] *= s[o]   (DropPath: o = sample; Dropout2d on NHWC handled via chan_scale elsewhere)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_outer_kernel(void* x, const float* __restrict__ s, int64_t outer, int64_t inner) {
+  const int64_t total = outer * inner;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    ElemIO<T>::store(x, i, ElemIO<T>::load(x, i) * s[i / inner]);
+}
+
+// position_embedding (dofa_v2.py:9-35): out[m, :D/2] = sin(pos*omega), out[m, D/2:] = cos(pos*omega).
+// The frequency table omega[D/2] (a constant of the module) comes from the host so that the only
+// difference to the reference is the sin/cos implementation (angles reach ~2000 rad).
+__global__ void sincos_embed_kernel(const float* __restrict__ pos, const float* __restrict__ omega_tab,
+                                    int M, int D, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = D / 2;
+  if (i >= M * half) return;
+  const int m = i / half, d = i - m * half;
+  const float v = pos[m] * omega_tab[d];
+  out[(int64_t)m * D + d] = sinf(v);
+  out[(int64_t)m * D + half + d] = cosf(v);
+}
+
+// eval-mode BatchNorm folded into the conv epilogue: scale = g*rsqrt(var+eps), shift = b - mean*scale
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mean, const float* __restrict__ var, float eps, int C,
+                               float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float s = gamma[c] / sqrtf(var[c] + eps);
+  scale[c] = s;
+  shift[c] = beta[c] - mean[c] * s;
+}
+
+// forward weights [N][T][C] (T = R*S taps) -> data-gradient weights [C][T][N] with the taps flipped
+// (t' = T-1-t): dx = conv(dy, w_dgrad, pad = R-1-pad).  32x32 LDS tile transpose per tap.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const void* __restrict__ w, int N, int T, int Cc,
+                                                         void* out) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z, n0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int n = n0 + j, c = c0 + tx;
+    tile[j][tx] = (n < N && c < Cc) ? ElemIO<TI>::load(w, ((int64_t)n * T + t) * Cc + c) : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, n = n0 + tx;
+    if (c < Cc && n < N) ElemIO<TO>::store(out, ((int64_t)c * T + (T - 1 - t)) * N + n, tile[tx][j]);
+  }
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+extern "C" int gdl_sincos_embed(const float* pos, const float* omega, int M, int D, float* out, gdl_stream_t stream) {
+  GDL_CHECK_ARG(pos && omega && out && D % 2 == 0 && M > 0, "gdl_sincos_embed: bad args");
+  const int total = M * (D / 2);
+  hipLaunchKernelGGL(sincos_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos, omega, M, D, out);
+  GDL_CHECK_LAUNCH("gdl_sincos_embed");
+  return GDL_OK;
+}
+
+extern "C" int gdl_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                           int C, float* scale, float* shift, gdl_stream_t stream) {
+  GDL_CHECK_ARG(gamma && beta && mean && var && scale && shift, "gdl_bn_fold: null pointer");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, C, scale, shift);
+  GDL_CHECK_LAUNCH("gdl_bn_fold");
+  return GDL_OK;
+}
+
+extern "C" int gdl_pack_dgrad(const void* w, int w_dtype, int N, int T, int C, void* out, int out_dtype,
+                              gdl_stream_t stream) {
+  GDL_CHECK_ARG(w && out && N > 0 && T > 0 && C > 0, "gdl_pack_dgrad: bad args");
+  dim3 grid((C + 31) / 32, (N + 31) / 32, T);
+  hipStream_t s = (hipStream_t)stream;
+  if (w_dtype == GDL_F32 && out_dtype == GDL_BF16) hipLaunchKernelGGL((pack_dgrad_kernel<float, bf16_tag>), grid, dim3(256), 0, s, w, N, T, C, out);
+  else if (w_dtype == GDL_F32) hipLaunchKernelGGL((pack_dgrad_kernel<float, float>), grid, dim3(256), 0, s, w, N, T, C, out);
+  else if (out_dtype == GDL_BF16) hipLaunchKernelGGL((pack_dgrad_kernel<bf16_tag, bf16_tag>), grid, dim3(256), 0, s, w, N, T, C, out);
+  else hipLaunchKernelGGL((pack_dgrad_kernel<bf16_tag, float>), grid, dim3(256), 0, s, w, N, T, C, out);
+  GDL_CHECK_LAUNCH("gdl_pack_dgrad");
+  return GDL_OK;
+}
+
+extern "C" int gdl_v_transpose(const void* qkv, int dtype, int B, int N, int H, int hd, void* vt, int Npad,
+                               gdl_stream_t stream) {
+  GDL_CHECK_ARG(qkv && vt && Npad >= N, "gdl_v_transpose: bad args");
+  dim3 grid((Npad + 31) / 32, (hd + 31) / 32, B * H);
+  if (dtype == GDL_BF16)
+    hipLaunchKernelGGL(v_transpose_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, N, H, hd, (uint16_t*)vt, Npad);
+  else
+    hipLaunchKernelGGL(v_transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, N, H, hd, (float*)vt, Npad);
+  GDL_CHECK_LAUNCH("gdl_v_transpose");
+  return GDL_OK;
+}
+
+extern "C" int gdl_softmax_rows(const void* in, void* out, int dtype, int64_t rows, int n_valid, int n_cols,
+                                gdl_stream_t stream) {
+  GDL_CHECK_ARG(in && out && n_valid > 0 && n_valid <= n_cols, "gdl_softmax_rows: bad args");
+  GDL_CHECK_ARG(n_cols <= 64 * 96, "gdl_softmax_rows: n_cols=%d too large (max 6144)", n_cols);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+#define SM(T, V) hipLaunchKernelGGL((softmax_rows_kernel<T, V>), dim3(grid), dim3(256), 0, s, in, out, rows, n_valid, n_cols)
+  const int v = (n_cols + 63) / 64;
+  if (dtype == GDL_BF16) {
+    if (v <= 4) SM(bf16_tag, 4); else if (v <= 24) SM(bf16_tag, 24); else SM(bf16_tag, 96);
+  } else {
+    if (v <= 4) SM(float, 4); else if (v <= 24) SM(float, 24); else SM(float, 96);
+  }
+#undef SM
+  GDL_CHECK_LAUNCH("gdl_softmax_rows");
+  return GDL_OK;
+}
+
+extern "C" int gdl_patchify(const float* img, int B, int C, int H, int W, int P, int pad, int Gh, int Gw, void* cols,
+                            int out_dtype, int Kpad, gdl_stream_t stream) {
+  GDL_CHECK_ARG(img && cols && Kpad >= C * P * P, "gdl_patchify: bad args");
+  const int64_t total = (int64_t)B * Gh * Gw * Kpad;
+  if (out_dtype == GDL_BF16)
+    hipLaunchKernelGGL(patchify_kernel<bf16_tag>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, B, C, H, W, P, pad, Gh, Gw, cols, Kpad);
+  else
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, B, C, H, W, P, pad, Gh, Gw, cols, Kpad);
+  GDL_CHECK_LAUNCH("gdl_patchify");
+  return GDL_OK;
+}
+
+extern "C" int gdl_dofa_pack_kernel(const float* g, int C, int PP, int D, float scaler, void* out, int out_dtype, int Kpad,
+                                    gdl_stream_t stream) {
+  GDL_CHECK_ARG(g && out && Kpad >= C * PP, "gdl_dofa_pack_kernel: bad args");
+  const int64_t total = (int64_t)D * Kpad;
+  if (out_dtype == GDL_BF16)
+    hipLaunchKernelGGL(dofa_pack_kernel<bf16_tag>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, C, PP, D, scaler, out, Kpad);
+  else
+    hipLaunchKernelGGL(dofa_pack_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, C, PP, D, scaler, out, Kpad);
+  GDL_CHECK_LAUNCH("gdl_dofa_pack_kernel");
+  return GDL_OK;
+}
+
+extern "C" int gdl_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, gdl_stream_t stream) {
+  GDL_CHECK_ARG(in && out, "gdl_cast: null pointer");
+  if (n <= 0) return GDL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(grid_for(n));
+  if (in_dtype == GDL_F32 && out_dtype == GDL_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_tag>), grid, dim3(256), 0, s, in, out, n);
+  else if (in_dtype == GDL_BF16 && out_dtype == GDL_F32) hipLaunchKernelGGL((cast_kernel<bf16_tag, float>), grid, dim3(256), 0, s, in, out, n);
+  else if (in_dtype == GDL_F32) hipLaunchKernelGGL((cast_kernel<float, float>), grid, dim3(256), 0, s, in, out, n);
+  else hipLaunchKernelGGL((cast_kernel<bf16_tag, bf16_tag>), grid, dim3(256), 0, s, in, out, n);
+  GDL_CHECK_LAUNCH("gdl_cast");
+  return GDL_OK;
+}
+
+extern "C" int gdl_scale_f32(const float* in, float* out, int64_t n, float s, gdl_stream_t stream) {
+  GDL_CHECK_ARG(in && out, "gdl_scale_f32: null pointer");
+  if (n <= 0) return GDL_OK;
+  hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, out, n, s);
+  GDL_CHECK_LAUNCH("gdl_scale_f32");
+  return GDL_OK;
+}
+
+extern "C" int gdl_add_rows(const float* a, int64_t a_rows, int64_t a_stride, const float* b, int64_t b_rows,
+                            int64_t b_stride, float* out, int64_t out_stride, int64_t rows, int D,
+                            gdl_stream_t stream) {
+  GDL_CHECK_ARG(a && out && a_rows > 0 && (!b || b_rows > 0), "gdl_add_rows: bad args");
+  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, a, a_rows, a_stride, b,
+                     b_rows, b_stride, out, out_stride, rows, D);
+  GDL_CHECK_LAUNCH("gdl_add_rows");
+  return GDL_OK;
+}
+
+extern "C" int gdl_normalize_u8(const uint8_t* in, float* out, int B, int C, int64_t HW, const float* mean,
+                                const float* stdv, gdl_stream_t stream) {
+  GDL_CHECK_ARG(in && out && mean && stdv, "gdl_normalize_u8: null pointer");
+  GDL_CHECK_ARG(HW % 4 == 0, "gdl_normalize_u8: H*W must be a multiple of 4");
+  const int64_t total4 = (int64_t)B * C * HW / 4;
+  hipLaunchKernelGGL(normalize_u8_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, in, out, C, HW, total4, mean, stdv);
+  GDL_CHECK_LAUNCH("gdl_normalize_u8");
+  return GDL_OK;
+}
+
+extern "C" int gdl_scale_outer(void* x, int dtype, const float* s, int64_t outer, int64_t inner, gdl_stream_t stream) {
+  GDL_CHECK_ARG(x && s, "gdl_scale_outer: null pointer");
+  const int64_t total = outer * inner;
+  if (total <= 0) return GDL_OK;
+  if (dtype == GDL_BF16) hipLaunchKernelGGL(scale_outer_kernel<bf16_tag>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, s, outer, inner);
+  else hipLaunchKernelGGL(scale_outer_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, s, outer, inner);
+  GDL_CHECK_LAUNCH("gdl_scale_outer");
+  return GDL_OK;
+}
+
+#define K_SWITCH(K, ...)                                                     \
+  switch (K) {                                                               \
+    case 1: { constexpr int KK = 1; __VA_ARGS__; } break;                    \
+    case 2: { constexpr int KK = 2; __VA_ARGS__; } break;                    \
+    case 3: { constexpr int KK = 3; __VA_ARGS__; } break;                    \
+    case 4: { constexpr int KK = 4; __VA_ARGS__; } break;                    \
+    case 5: { constexpr int KK = 5; __VA_ARGS__; } break;                    \
+    case 6: { constexpr int KK = 6; __VA_ARGS__; } break;                    \
+    case 7: { constexpr int KK = 7; __VA_ARGS__; } break;                    \
+    case 8: { constexpr int KK = 8; __VA_ARGS__; } break;                    \
+    default: gdl_set_error("num classes K=%d unsupported (1..8)", K); return GDL_ERR_UNSUPPORTED; \
+  }
+
+extern "C" int gdl_head_1x1(const void* feat, int dtype, int64_t P, int C, int64_t f_sP, const float* w,
+                            const float* bias, const float* chan_scale, int64_t pix_per_img, float* out, int K,
+                            gdl_stream_t stream) {
+  GDL_CHECK_ARG(feat && w && out && C % 4 == 0 && f_sP % 4 == 0 && pix_per_img > 0, "gdl_head_1x1: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((P + 3) / 4);
+  K_SWITCH(K, if (dtype == GDL_BF16) hipLaunchKernelGGL((head_1x1_kernel<uint16_t, KK>), dim3(grid), dim3(256), 0, s, feat, P, C, f_sP, w, bias, chan_scale, pix_per_img, out);
+              else hipLaunchKernelGGL((head_1x1_kernel<float, KK>), dim3(grid), dim3(256), 0, s, feat, P, C, f_sP, w, bias, chan_scale, pix_per_img, out));
+  GDL_CHECK_LAUNCH("gdl_head_1x1");
+  return GDL_OK;
+}
+
+extern "C" int64_t gdl_head_1x1_bwd_workspace(int64_t P, int C, int K) {
+  int64_t ns = P / 256; if (ns < 1) ns = 1; if (ns > 128) ns = 128;
+  return ns * (K + 1) * (int64_t)C * sizeof(float);
+}
+
+extern "C" int gdl_head_1x1_bwd(const void* feat, int dtype, const float* dlog, int64_t P, int C, int64_t f_sP,
+                                const float* w, const float* chan_scale, int64_t pix_per_img, void* dfeat,
+                                int64_t d_sP, float* dw, float* db, int K, float* ws, int64_t ws_bytes,
+                                gdl_stream_t stream) {
+  GDL_CHECK_ARG(feat && dlog && w && dw && ws && C % 4 == 0 && f_sP % 4 == 0, "gdl_head_1x1_bwd: bad args");
+  GDL_CHECK_ARG(ws_bytes >= gdl_head_1x1_bwd_workspace(P, C, K), "gdl_head_1x1_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t ns = P / 256; if (ns < 1) ns = 1; if (ns > 128) ns = 128;
+  const int nsplit = (int)ns;
+  dim3 gridw((C + 255) / 256, nsplit);
+  const int64_t total = P * (C / 4);
+  K_SWITCH(K,
+    if (dtype == GDL_BF16) {
+      if (dfeat) hipLaunchKernelGGL((head_1x1_bwd_feat_kernel<uint16_t, KK>), dim3(grid_for(total)), dim3(256), 0, s, dlog, P, C, w, chan_scale, pix_per_img, dfeat, d_sP);
+      hipLaunchKernelGGL((head_1x1_bwd_w_partial<uint16_t, KK>), gridw, dim3(256), 0, s, feat, dlog, P, C, f_sP, chan_scale, pix_per_img, ws);
+    } else {
+      if (dfeat) hipLaunchKernelGGL((head_1x1_bwd_feat_kernel<float, KK>), dim3(grid_for(total)), dim3(256), 0, s, dlog, P, C, w, chan_scale, pix_per_img, dfeat, d_sP);
+      hipLaunchKernelGGL((head_1x1_bwd_w_partial<float, KK>), gridw, dim3(256), 0, s, feat, dlog, P, C, f_sP, chan_scale, pix_per_img, ws);
+    }
+    hipLaunchKernelGGL((head_1x1_bwd_w_final<KK>), dim3((KK * C + 255) / 256), dim3(256), 0, s, ws, nsplit, C, dw, db));
+  GDL_CHECK_LAUNCH("gdl_head_1x1_bwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_upsample_logits(const float* in, int B, int Hi, int Wi, int K, float* out, int Ho, int Wo,
+                                   gdl_stream_t stream) {
+  GDL_CHECK_ARG(in && out, "gdl_upsample_logits: null pointer");
+  const int64_t total = (int64_t)B * Ho * Wo;
+  K_SWITCH(K, hipLaunchKernelGGL((upsample_logits_kernel<KK>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, B, Hi, Wi, out, Ho, Wo));
+  GDL_CHECK_LAUNCH("gdl_upsample_logits");
+  return GDL_OK;
+}
+
+extern "C" int gdl_upsample_logits_bwd(const float* dout, int B, int Ho, int Wo, int K, float* din, int Hi, int Wi,
+                                       gdl_stream_t stream) {
+  GDL_CHECK_ARG(dout && din, "gdl_upsample_logits_bwd: null pointer");
+  const int64_t total = (int64_t)B * Hi * Wi;
+  K_SWITCH(K, hipLaunchKernelGGL((upsample_logits_bwd_kernel<KK>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout, B, Ho, Wo, din, Hi, Wi));
+  GDL_CHECK_LAUNCH("gdl_upsample_logits_bwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_softmax_argmax(const float* logits, int B, int K, int64_t HW, int64_t* mask, gdl_stream_t stream) {
+  GDL_CHECK_ARG(logits && mask, "gdl_softmax_argmax: null pointer");
+  const int64_t total = (int64_t)B * HW;
+  K_SWITCH(K, hipLaunchKernelGGL((softmax_argmax_kernel<KK>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, logits, B, HW, mask));
+  GDL_CHECK_LAUNCH("gdl_softmax_argmax");
+  return GDL_OK;
+}
+
+static int dice_blocks(int64_t total) {
+  int64_t g = (total + 1023) / 1024;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+extern "C" int64_t gdl_dice_loss_workspace(int B, int K, int64_t HW) {
+  return (int64_t)dice_blocks((int64_t)B * HW) * 3 * K * sizeof(float);
+}
+
+extern "C" int gdl_dice_loss_fwd(const float* logits, const int64_t* target, int B, int K, int64_t HW, float eps,
+                                 float* sums, float* loss, float* ws, int64_t ws_bytes, gdl_stream_t stream) {
+  GDL_CHECK_ARG(logits && target && sums && loss && ws, "gdl_dice_loss_fwd: null pointer");
+  GDL_CHECK_ARG(ws_bytes >= gdl_dice_loss_workspace(B, K, HW), "gdl_dice_loss_fwd: workspace too small");
+  const int nblk = dice_blocks((int64_t)B * HW);
+  hipStream_t s = (hipStream_t)stream;
+  K_SWITCH(K, hipLaunchKernelGGL((dice_partial_kernel<KK>), dim3(nblk), dim3(256), 0, s, logits, target, B, HW, ws);
+              hipLaunchKernelGGL((dice_final_kernel<KK>), dim3(1), dim3(64), 0, s, ws, nblk, eps, sums, loss));
+  GDL_CHECK_LAUNCH("gdl_dice_loss_fwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_dice_loss_bwd(const float* logits, const int64_t* target, int B, int K, int64_t HW, float eps,
+                                 const float* sums, const float* upstream, float grad_scale, float* dlogits,
+                                 int accumulate, gdl_stream_t stream) {
+  GDL_CHECK_ARG(logits && target && sums && dlogits, "gdl_dice_loss_bwd: null pointer");
+  const int64_t total = (int64_t)B * HW;
+  K_SWITCH(K, hipLaunchKernelGGL((dice_bwd_kernel<KK>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, logits, target, B, HW, sums, eps, upstream, grad_scale, dlogits, accumulate));
+  GDL_CHECK_LAUNCH("gdl_dice_loss_bwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_sumsq(const float* x, int64_t n, float* out_accum, gdl_stream_t stream) {
+  GDL_CHECK_ARG(x && out_accum, "gdl_sumsq: null pointer");
+  if (n <= 0) return GDL_OK;
+  int64_t g = (n + 4095) / 4096; if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, n, out_accum);
+  GDL_CHECK_LAUNCH("gdl_sumsq");
+  return GDL_OK;
+}
+
+extern "C" int gdl_clip_coef(const float* sumsq, float max_norm, float* coef, gdl_stream_t stream) {
+  GDL_CHECK_ARG(sumsq && coef, "gdl_clip_coef: null pointer");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, coef);
+  GDL_CHECK_LAUNCH("gdl_clip_coef");
+  return GDL_OK;
+}
+
+extern "C" int gdl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, float bc1, float bc2,
+                             const float* clip_coef, gdl_stream_t stream) {
+  GDL_CHECK_ARG(p && g && m && v, "gdl_adam_step: null pointer");
+  if (n <= 0) return GDL_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                     eps, weight_decay, bc1, bc2, clip_coef);
+  GDL_CHECK_LAUNCH("gdl_adam_step");
+  return GDL_OK;
+}

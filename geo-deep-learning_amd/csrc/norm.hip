@@ -1,0 +1,334 @@
+// LayerNorm / BatchNorm kernels (HBM-bound; wave-shuffle reductions, 16-byte accesses).
+#include "gdl_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- LayerNorm forward
+// One wave per row, row kept in registers (D <= 64*4*VPL), f32 statistics.
+template <int VPL>  // float4 vectors per lane
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x,
+                                                            int64_t x_stride,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, void* y,
+                                                            int y_dtype, int64_t rows, int D,
+                                                            float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * x_stride;
+  float4 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = c < D ? *(const float4*)(xr + c) : make_float4(0, 0, 0, 0);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c >= D) continue;
+    const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    const float o0 = (v[i].x - mean) * rstd * g.x + b.x, o1 = (v[i].y - mean) * rstd * g.y + b.y;
+    const float o2 = (v[i].z - mean) * rstd * g.z + b.z, o3 = (v[i].w - mean) * rstd * g.w + b.w;
+    if (y_dtype == GDL_BF16) {
+      *(uint2*)((uint16_t*)y + row * D + c) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+    } else {
+      *(float4*)((float*)y + row * D + c) = make_float4(o0, o1, o2, o3);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- BatchNorm (NHWC, [P][C])
+// A wave covers 256 channels (4 per lane); blockDim = 256 = 4 pixel lanes x 64.
+// grid = (ceil(C/256), nsplit).  Partial sums -> workspace[split][2][C].
+template <typename T>
+__device__ __forceinline__ void load4(const void* p, int64_t off, float (&o)[4]) {
+  if constexpr (sizeof(T) == 4) {
+    const float4 v = *(const float4*)((const float*)p + off);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  } else {
+    const uint2 v = *(const uint2*)((const uint16_t*)p + off);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store4(void* p, int64_t off, const float (&o)[4]) {
+  if constexpr (sizeof(T) == 4) {
+    *(float4*)((float*)p + off) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+    *(uint2*)((uint16_t*)p + off) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_partial(const void* __restrict__ x, int64_t P, int C,
+                                                        int64_t x_sP, float* __restrict__ ws) {
+  __shared__ float red[2][4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int nsplit = gridDim.y;
+  const int64_t per = (P + nsplit - 1) / nsplit;
+  const int64_t p0 = per * blockIdx.y, p1 = p0 + per < P ? p0 + per : P;
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (c < C) {
+    for (int64_t p = p0 + w; p < p1; p += 4) {
+      float v[4];
+      load4<T>(x, p * x_sP + c, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[0][w][lane * 4 + j] = s[j]; red[1][w][lane * 4 + j] = q[j]; }
+  __syncthreads();
+  const int t = threadIdx.x;
+  const int cc = blockIdx.x * 256 + t;
+  if (cc < C) {
+    const float ss = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+    const float qq = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+    ws[((int64_t)blockIdx.y * 2 + 0) * C + cc] = ss;
+    ws[((int64_t)blockIdx.y * 2 + 1) * C + cc] = qq;
+  }
+}
+
+__global__ void bn_stats_final(const float* __restrict__ ws, int nsplit, int C, int64_t P,
+                               float* __restrict__ mean, float* __restrict__ var, float* running_mean,
+                               float* running_var, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, q = 0;
+  for (int i = 0; i < nsplit; ++i) { s += ws[((int64_t)i * 2) * C + c]; q += ws[((int64_t)i * 2 + 1) * C + c]; }
+  const double m = s / (double)P;
+  double v = q / (double)P - m * m;
+  v = v > 0 ? v : 0;
+  mean[c] = (float)m;
+  var[c] = (float)v;
+  if (running_mean) {  // nn.BatchNorm2d: unbiased variance for the running estimate
+    const double unb = P > 1 ? v * (double)P / (double)(P - 1) : v;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ x, void* y, int64_t P,
+                                                       int C, int64_t x_sP, int64_t y_sP,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ var,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps,
+                                                       int relu) {
+  const int cv = C / 4;
+  const int64_t total = P * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / cv;
+    const int c = (int)(i - p * cv) * 4;
+    float v[4];
+    load4<T>(x, p * x_sP + c, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sc = rsqrtf(var[c + j] + eps) * gamma[c + j];
+      float o = (v[j] - mean[c + j]) * sc + beta[c + j];
+      v[j] = relu ? fmaxf(o, 0.f) : o;
+    }
+    store4<T>(y, p * y_sP + c, v);
+  }
+}
+
+// backward pass 1: dbeta = sum g, dgamma = sum g*xhat with g = dy * [bn(x) > 0]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial(const void* __restrict__ x,
+                                                      const void* __restrict__ dy, int64_t P, int C,
+                                                      int64_t x_sP, int64_t dy_sP,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ var,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, int relu,
+                                                      float* __restrict__ ws) {
+  __shared__ float red[2][4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int nsplit = gridDim.y;
+  const int64_t per = (P + nsplit - 1) / nsplit;
+  const int64_t p0 = per * blockIdx.y, p1 = p0 + per < P ? p0 + per : P;
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (c < C) {
+    float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mu[j] = mean[c + j]; rs[j] = rsqrtf(var[c + j] + eps); ga[j] = gamma[c + j]; be[j] = beta[c + j];
+    }
+    for (int64_t p = p0 + w; p < p1; p += 4) {
+      float v[4], g[4];
+      load4<T>(x, p * x_sP + c, v);
+      load4<T>(dy, p * dy_sP + c, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (v[j] - mu[j]) * rs[j];
+        const float gg = (relu && !(xh * ga[j] + be[j] > 0.f)) ? 0.f : g[j];
+        s[j] += gg; q[j] += gg * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[0][w][lane * 4 + j] = s[j]; red[1][w][lane * 4 + j] = q[j]; }
+  __syncthreads();
+  const int t = threadIdx.x, cc = blockIdx.x * 256 + t;
+  if (cc < C) {
+    ws[((int64_t)blockIdx.y * 2 + 0) * C + cc] = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+    ws[((int64_t)blockIdx.y * 2 + 1) * C + cc] = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+  }
+}
+
+__global__ void bn_bwd_final(const float* __restrict__ ws, int nsplit, int C, float* __restrict__ dgamma,
+                             float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, q = 0;
+  for (int i = 0; i < nsplit; ++i) { s += ws[((int64_t)i * 2) * C + c]; q += ws[((int64_t)i * 2 + 1) * C + c]; }
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)q;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_dx(const void* __restrict__ x, const void* __restrict__ dy,
+                                                 void* dx, int64_t P, int64_t P_total, int C, int64_t x_sP, int64_t dy_sP,
+                                                 int64_t dx_sP, const float* __restrict__ mean,
+                                                 const float* __restrict__ var,
+                                                 const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float eps, int relu,
+                                                 const float* __restrict__ dgamma,
+                                                 const float* __restrict__ dbeta) {
+  const int cv = C / 4;
+  const int64_t total = P * cv;
+  const float invP = 1.0f / (float)P_total;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / cv;
+    const int c = (int)(i - p * cv) * 4;
+    float v[4], g[4];
+    load4<T>(x, p * x_sP + c, v);
+    load4<T>(dy, p * dy_sP + c, g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float rs = rsqrtf(var[c + j] + eps), ga = gamma[c + j];
+      const float xh = (v[j] - mean[c + j]) * rs;
+      const float gg = (relu && !(xh * ga + beta[c + j] > 0.f)) ? 0.f : g[j];
+      v[j] = ga * rs * (gg - dbeta[c + j] * invP - xh * dgamma[c + j] * invP);
+    }
+    store4<T>(dx, p * dx_sP + c, v);
+  }
+}
+
+int bn_nsplit(int64_t P) {
+  int64_t n = P / 64;
+  if (n < 1) n = 1;
+  if (n > 256) n = 256;
+  return (int)n;
+}
+
+}  // namespace
+
+extern "C" int gdl_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma,
+                                 const float* beta, void* y, int y_dtype, int64_t rows, int D, float eps,
+                                 gdl_stream_t stream) {
+  GDL_CHECK_ARG(x && gamma && beta && y, "gdl_layernorm_fwd: null pointer");
+  GDL_CHECK_ARG(D > 0 && D % 4 == 0 && D <= 2048, "gdl_layernorm_fwd: D=%d must be a multiple of 4, <= 2048", D);
+  GDL_CHECK_ARG(x_stride % 4 == 0, "gdl_layernorm_fwd: x_stride must be a multiple of 4");
+  if (rows <= 0) return GDL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  const int vpl = (D + 255) / 256;
+#define LN_LAUNCH(V) hipLaunchKernelGGL(layernorm_fwd_kernel<V>, dim3(grid), dim3(256), 0, s, x, x_stride, gamma, beta, y, y_dtype, rows, D, eps)
+  if (vpl <= 1) LN_LAUNCH(1);
+  else if (vpl <= 2) LN_LAUNCH(2);
+  else if (vpl <= 4) LN_LAUNCH(4);
+  else LN_LAUNCH(8);
+#undef LN_LAUNCH
+  GDL_CHECK_LAUNCH("gdl_layernorm_fwd");
+  return GDL_OK;
+}
+
+extern "C" int64_t gdl_bn_stats_workspace(int64_t P, int C) {
+  return (int64_t)bn_nsplit(P) * 2 * C * sizeof(float);
+}
+
+extern "C" int gdl_bn_stats(const void* x, int dtype, int64_t P, int C, int64_t x_sP, float* mean,
+                            float* var, float* running_mean, float* running_var, float momentum, float* ws,
+                            int64_t ws_bytes, gdl_stream_t stream) {
+  GDL_CHECK_ARG(x && mean && var && ws, "gdl_bn_stats: null pointer");
+  GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && P > 0, "gdl_bn_stats: C and stride must be multiples of 4");
+  GDL_CHECK_ARG(ws_bytes >= gdl_bn_stats_workspace(P, C), "gdl_bn_stats: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int nsplit = bn_nsplit(P);
+  dim3 grid((C + 255) / 256, nsplit);
+  if (dtype == GDL_BF16) hipLaunchKernelGGL(bn_stats_partial<uint16_t>, grid, dim3(256), 0, s, x, P, C, x_sP, ws);
+  else hipLaunchKernelGGL(bn_stats_partial<float>, grid, dim3(256), 0, s, x, P, C, x_sP, ws);
+  hipLaunchKernelGGL(bn_stats_final, dim3((C + 255) / 256), dim3(256), 0, s, ws, nsplit, C, P, mean, var, running_mean, running_var, momentum);
+  GDL_CHECK_LAUNCH("gdl_bn_stats");
+  return GDL_OK;
+}
+
+extern "C" int gdl_bn_apply(const void* x, void* y, int dtype, int64_t P, int C, int64_t x_sP, int64_t y_sP,
+                            const float* mean, const float* var, const float* gamma, const float* beta,
+                            float eps, int relu, gdl_stream_t stream) {
+  GDL_CHECK_ARG(x && y && mean && var && gamma && beta, "gdl_bn_apply: null pointer");
+  GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && y_sP % 4 == 0, "gdl_bn_apply: C/strides must be multiples of 4");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = P * (C / 4);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == GDL_BF16)
+    hipLaunchKernelGGL(bn_apply_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, x, y, P, C, x_sP, y_sP, mean, var, gamma, beta, eps, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, s, x, y, P, C, x_sP, y_sP, mean, var, gamma, beta, eps, relu);
+  GDL_CHECK_LAUNCH("gdl_bn_apply");
+  return GDL_OK;
+}
+
+extern "C" int gdl_bn_bwd_reduce(const void* x, const void* dy, int dtype, int64_t P, int C, int64_t x_sP,
+                                 int64_t dy_sP, const float* mean, const float* var, const float* gamma,
+                                 const float* beta, float eps, int relu, float* dgamma, float* dbeta, float* ws,
+                                 int64_t ws_bytes, gdl_stream_t stream) {
+  GDL_CHECK_ARG(x && dy && mean && var && gamma && beta && dgamma && dbeta && ws, "gdl_bn_bwd_reduce: null pointer");
+  GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && dy_sP % 4 == 0, "gdl_bn_bwd_reduce: C/strides % 4");
+  GDL_CHECK_ARG(ws_bytes >= gdl_bn_stats_workspace(P, C), "gdl_bn_bwd_reduce: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int nsplit = bn_nsplit(P);
+  dim3 grid((C + 255) / 256, nsplit);
+  if (dtype == GDL_BF16)
+    hipLaunchKernelGGL(bn_bwd_partial<uint16_t>, grid, dim3(256), 0, s, x, dy, P, C, x_sP, dy_sP, mean, var, gamma, beta, eps, relu, ws);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial<float>, grid, dim3(256), 0, s, x, dy, P, C, x_sP, dy_sP, mean, var, gamma, beta, eps, relu, ws);
+  hipLaunchKernelGGL(bn_bwd_final, dim3((C + 255) / 256), dim3(256), 0, s, ws, nsplit, C, dgamma, dbeta);
+  GDL_CHECK_LAUNCH("gdl_bn_bwd_reduce");
+  return GDL_OK;
+}
+
+extern "C" int gdl_bn_bwd_dx(const void* x, const void* dy, void* dx, int dtype, int64_t P, int C, int64_t x_sP,
+                             int64_t dy_sP, int64_t dx_sP, const float* mean, const float* var,
+                             const float* gamma, const float* beta, float eps, int relu, const float* dgamma_sum,
+                             const float* dbeta_sum, int64_t P_total, gdl_stream_t stream) {
+  GDL_CHECK_ARG(x && dy && dx && mean && var && gamma && beta && dgamma_sum && dbeta_sum, "gdl_bn_bwd_dx: null pointer");
+  GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && dy_sP % 4 == 0 && dx_sP % 4 == 0 && P_total > 0, "gdl_bn_bwd_dx: C/strides % 4");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = P * (C / 4);
+  const unsigned g2 = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == GDL_BF16)
+    hipLaunchKernelGGL(bn_bwd_dx<uint16_t>, dim3(g2), dim3(256), 0, s, x, dy, dx, P, P_total, C, x_sP, dy_sP, dx_sP, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum);
+  else
+    hipLaunchKernelGGL(bn_bwd_dx<float>, dim3(g2), dim3(256), 0, s, x, dy, dx, P, P_total, C, x_sP, dy_sP, dx_sP, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum);
+  GDL_CHECK_LAUNCH("gdl_bn_bwd_dx");
+  return GDL_OK;
+}

@@ -1,0 +1,274 @@
+// Bilinear resize (align_corners=False) and adaptive average pooling on NHWC tensors.
+// HBM-bound: one thread per (pixel, 4-channel vector); f32 arithmetic; gather formulation in
+// both directions (no atomics -> deterministic backward).
+#include "gdl_common.h"
+
+namespace {
+
+template <typename T> struct V4;
+template <> struct V4<float> {
+  static __device__ __forceinline__ void ld(const void* p, int64_t off, float (&o)[4]) {
+    const float4 v = *(const float4*)((const float*)p + off);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  static __device__ __forceinline__ void st(void* p, int64_t off, const float (&o)[4]) {
+    *(float4*)((float*)p + off) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+};
+template <> struct V4<uint16_t> {
+  static __device__ __forceinline__ void ld(const void* p, int64_t off, float (&o)[4]) {
+    const uint2 v = *(const uint2*)((const uint16_t*)p + off);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void st(void* p, int64_t off, const float (&o)[4]) {
+    *(uint2*)((uint16_t*)p + off) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+  }
+};
+
+// torch area_pixel_compute_source_index(align_corners=False) + index/lambda (UpSample.h)
+__device__ __forceinline__ void src_index(float ratio, int dst, int in_size, int& i0, int& i1, float& l1) {
+  float s = ratio * ((float)dst + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const void* __restrict__ in, int B, int Hi,
+                                                           int Wi, int C, int64_t isB, int64_t isH,
+                                                           int64_t isW, void* out, int Ho, int Wo,
+                                                           int64_t osB, int64_t osH, int64_t osW,
+                                                           int accumulate) {
+  const int cv = C / 4;
+  const int64_t total = (int64_t)B * Ho * Wo * cv;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cv) * 4;
+    int64_t t = i / cv;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const int64_t base = (int64_t)b * isB + c;
+    float a[4], bb[4], cc[4], d[4], o[4];
+    if (Hi == Ho && Wi == Wo) {  // identity resize == strided copy / cast / accumulate
+      const int64_t ooff = (int64_t)b * osB + (int64_t)oy * osH + (int64_t)ox * osW + c;
+      V4<TI>::ld(in, base + oy * isH + ox * isW, a);
+      if (accumulate) {
+        V4<TO>::ld(out, ooff, o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] += o[j];
+      }
+      V4<TO>::st(out, ooff, a);
+      continue;
+    }
+    int y0, y1, x0, x1; float ly, lx;
+    src_index(ry, oy, Hi, y0, y1, ly);
+    src_index(rx, ox, Wi, x0, x1, lx);
+    V4<TI>::ld(in, base + y0 * isH + x0 * isW, a);
+    V4<TI>::ld(in, base + y0 * isH + x1 * isW, bb);
+    V4<TI>::ld(in, base + y1 * isH + x0 * isW, cc);
+    V4<TI>::ld(in, base + y1 * isH + x1 * isW, d);
+    const int64_t ooff = (int64_t)b * osB + (int64_t)oy * osH + (int64_t)ox * osW + c;
+    if (accumulate) V4<TO>::ld(out, ooff, o);
+    else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+    const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] += hy * (hx * a[j] + lx * bb[j]) + ly * (hx * cc[j] + lx * d[j]);
+    V4<TO>::st(out, ooff, o);
+  }
+}
+
+// Backward (gather): din[iy,ix] (+)= sum over outputs whose taps touch (iy,ix).
+// Candidate outputs: src in (i-1, i+1)  =>  dst in ((i-0.5)/ratio - 0.5, (i+1.5)/ratio - 0.5).
+template <typename TO_, typename TI_>  // TO_ = dtype of dout, TI_ = dtype of din
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const void* __restrict__ dout, int B, int Ho,
+                                                           int Wo, int C, int64_t osB, int64_t osH,
+                                                           int64_t osW, void* din, int Hi, int Wi,
+                                                           int64_t isB, int64_t isH, int64_t isW,
+                                                           int accumulate) {
+  const int cv = C / 4;
+  const int64_t total = (int64_t)B * Hi * Wi * cv;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cv) * 4;
+    int64_t t = i / cv;
+    const int ix = (int)(t % Wi); t /= Wi;
+    const int iy = (int)(t % Hi);
+    const int b = (int)(t / Hi);
+    int oy_lo = (int)floorf(((float)iy - 0.5f) / ry - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / ry - 0.5f) + 1;
+    int ox_lo = (int)floorf(((float)ix - 0.5f) / rx - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / rx - 0.5f) + 1;
+    oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+    oy_hi = oy_hi > Ho - 1 ? Ho - 1 : oy_hi; ox_hi = ox_hi > Wo - 1 ? Wo - 1 : ox_hi;
+    float acc[4] = {0, 0, 0, 0};
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float ly;
+      src_index(ry, oy, Hi, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float lx;
+        src_index(rx, ox, Wi, x0, x1, lx);
+        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx == 0.f) continue;
+        float g[4];
+        V4<TO_>::ld(dout, (int64_t)b * osB + (int64_t)oy * osH + (int64_t)ox * osW + c, g);
+        const float w = wy * wx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += w * g[j];
+      }
+    }
+    const int64_t ioff = (int64_t)b * isB + (int64_t)iy * isH + (int64_t)ix * isW + c;
+    if (accumulate) {
+      float o[4];
+      V4<TI_>::ld(din, ioff, o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += o[j];
+    }
+    V4<TI_>::st(din, ioff, acc);
+  }
+}
+
+// nn.AdaptiveAvgPool2d: bin i covers [floor(i*In/S), ceil((i+1)*In/S))
+__device__ __forceinline__ void pool_bin(int i, int in, int s, int& lo, int& hi) {
+  lo = (i * in) / s;
+  hi = ((i + 1) * in + s - 1) / s;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const void* __restrict__ in, int B, int Hi, int Wi,
+                                                          int C, int64_t isB, int64_t isH, int64_t isW,
+                                                          void* out, int S) {
+  const int cv = C / 4;
+  const int64_t total = (int64_t)B * S * S * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cv) * 4;
+    int64_t t = i / cv;
+    const int ox = (int)(t % S); t /= S;
+    const int oy = (int)(t % S);
+    const int b = (int)(t / S);
+    int y0, y1, x0, x1;
+    pool_bin(oy, Hi, S, y0, y1);
+    pool_bin(ox, Wi, S, x0, x1);
+    float acc[4] = {0, 0, 0, 0};
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) {
+        float v[4];
+        V4<TI>::ld(in, (int64_t)b * isB + y * isH + x * isW + c, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j];
+      }
+    const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] *= inv;
+    V4<TO>::st(out, (((int64_t)b * S + oy) * S + ox) * C + c, acc);
+  }
+}
+
+template <typename TO_, typename TI_>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const void* __restrict__ dout, int B, int S, int C,
+                                                          void* din, int Hi, int Wi, int64_t isB,
+                                                          int64_t isH, int64_t isW, int accumulate) {
+  const int cv = C / 4;
+  const int64_t total = (int64_t)B * Hi * Wi * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cv) * 4;
+    int64_t t = i / cv;
+    const int x = (int)(t % Wi); t /= Wi;
+    const int y = (int)(t % Hi);
+    const int b = (int)(t / Hi);
+    float acc[4] = {0, 0, 0, 0};
+    for (int oy = 0; oy < S; ++oy) {
+      int y0, y1;
+      pool_bin(oy, Hi, S, y0, y1);
+      if (y < y0 || y >= y1) continue;
+      for (int ox = 0; ox < S; ++ox) {
+        int x0, x1;
+        pool_bin(ox, Wi, S, x0, x1);
+        if (x < x0 || x >= x1) continue;
+        float g[4];
+        V4<TO_>::ld(dout, (((int64_t)b * S + oy) * S + ox) * C + c, g);
+        const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += g[j] * inv;
+      }
+    }
+    const int64_t ioff = (int64_t)b * isB + (int64_t)y * isH + (int64_t)x * isW + c;
+    if (accumulate) {
+      float o[4];
+      V4<TI_>::ld(din, ioff, o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += o[j];
+    }
+    V4<TI_>::st(din, ioff, acc);
+  }
+}
+
+inline unsigned grid_for(int64_t total) {
+  int64_t g = (total + 255) / 256;
+  return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+#define DISPATCH2(KERN, DA, DB, ...)                                                                 \
+  do {                                                                                               \
+    if ((DA) == GDL_BF16 && (DB) == GDL_BF16) hipLaunchKernelGGL((KERN<uint16_t, uint16_t>), __VA_ARGS__); \
+    else if ((DA) == GDL_BF16) hipLaunchKernelGGL((KERN<uint16_t, float>), __VA_ARGS__);             \
+    else if ((DB) == GDL_BF16) hipLaunchKernelGGL((KERN<float, uint16_t>), __VA_ARGS__);             \
+    else hipLaunchKernelGGL((KERN<float, float>), __VA_ARGS__);                                      \
+  } while (0)
+
+}  // namespace
+
+extern "C" int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int Wi, int C, int64_t isB,
+                                int64_t isH, int64_t isW, void* out, int out_dtype, int Ho, int Wo,
+                                int64_t osB, int64_t osH, int64_t osW, int accumulate,
+                                gdl_stream_t stream) {
+  GDL_CHECK_ARG(in && out, "gdl_bilinear_fwd: null pointer");
+  GDL_CHECK_ARG(C % 4 == 0 && isB % 4 == 0 && isH % 4 == 0 && isW % 4 == 0 && osB % 4 == 0 && osH % 4 == 0 &&
+                    osW % 4 == 0, "gdl_bilinear_fwd: C and strides must be multiples of 4");
+  const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+  DISPATCH2(bilinear_fwd_kernel, in_dtype, out_dtype, dim3(grid_for(total)), dim3(256), 0,
+            (hipStream_t)stream, in, B, Hi, Wi, C, isB, isH, isW, out, Ho, Wo, osB, osH, osW, accumulate);
+  GDL_CHECK_LAUNCH("gdl_bilinear_fwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_bilinear_bwd(const void* dout, int dout_dtype, int B, int Ho, int Wo, int C, int64_t osB,
+                                int64_t osH, int64_t osW, void* din, int din_dtype, int Hi, int Wi,
+                                int64_t isB, int64_t isH, int64_t isW, int accumulate, gdl_stream_t stream) {
+  GDL_CHECK_ARG(dout && din, "gdl_bilinear_bwd: null pointer");
+  GDL_CHECK_ARG(C % 4 == 0 && isB % 4 == 0 && isH % 4 == 0 && isW % 4 == 0 && osB % 4 == 0 && osH % 4 == 0 &&
+                    osW % 4 == 0, "gdl_bilinear_bwd: C and strides must be multiples of 4");
+  const int64_t total = (int64_t)B * Hi * Wi * (C / 4);
+  DISPATCH2(bilinear_bwd_kernel, dout_dtype, din_dtype, dim3(grid_for(total)), dim3(256), 0,
+            (hipStream_t)stream, dout, B, Ho, Wo, C, osB, osH, osW, din, Hi, Wi, isB, isH, isW, accumulate);
+  GDL_CHECK_LAUNCH("gdl_bilinear_bwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_adaptive_avgpool_fwd(const void* in, int dtype, int B, int Hi, int Wi, int C, int64_t isB,
+                                        int64_t isH, int64_t isW, void* out, int out_dtype, int So,
+                                        gdl_stream_t stream) {
+  GDL_CHECK_ARG(in && out && So > 0, "gdl_adaptive_avgpool_fwd: bad args");
+  GDL_CHECK_ARG(C % 4 == 0 && isB % 4 == 0 && isH % 4 == 0 && isW % 4 == 0, "gdl_adaptive_avgpool_fwd: C/strides % 4");
+  const int64_t total = (int64_t)B * So * So * (C / 4);
+  DISPATCH2(avgpool_fwd_kernel, dtype, out_dtype, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+            B, Hi, Wi, C, isB, isH, isW, out, So);
+  GDL_CHECK_LAUNCH("gdl_adaptive_avgpool_fwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_adaptive_avgpool_bwd(const void* dout, int dtype, int B, int So, int C, void* din,
+                                        int din_dtype, int Hi, int Wi, int64_t isB, int64_t isH, int64_t isW,
+                                        int accumulate, gdl_stream_t stream) {
+  GDL_CHECK_ARG(dout && din && So > 0, "gdl_adaptive_avgpool_bwd: bad args");
+  GDL_CHECK_ARG(C % 4 == 0 && isB % 4 == 0 && isH % 4 == 0 && isW % 4 == 0, "gdl_adaptive_avgpool_bwd: C/strides % 4");
+  const int64_t total = (int64_t)B * Hi * Wi * (C / 4);
+  DISPATCH2(avgpool_bwd_kernel, dtype, din_dtype, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+            dout, B, So, C, din, Hi, Wi, isB, isH, isW, accumulate);
+  GDL_CHECK_LAUNCH("gdl_adaptive_avgpool_bwd");
+  return GDL_OK;
+}

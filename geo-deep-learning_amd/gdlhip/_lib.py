@@ -1,0 +1,134 @@
+"""ctypes binding of libgdlhip.so (the C-ABI declared in include/gdlhip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is NO
+fallback: if the shared object is missing, every op raises -- the product path never routes
+through PyTorch math or the CPU oracle.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libgdlhip.so"
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+c_i, c_l, c_f, c_p = C.c_int, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvArgs(C.Structure):
+    """Mirror of gdl_conv_args (include/gdlhip.h)."""
+
+    _fields_ = [
+        ("inp", c_p), ("dtype", c_i), ("B", c_i), ("H", c_i), ("W", c_i), ("C", c_i),
+        ("in_sB", c_l), ("in_sH", c_l), ("in_sW", c_l),
+        ("Ho", c_i), ("Wo", c_i), ("R", c_i), ("S", c_i), ("stride", c_i), ("pad", c_i),
+        ("w", c_p), ("w_sN", c_l), ("N", c_i),
+        ("out", c_p), ("out_dtype", c_i), ("out_sB", c_l), ("out_sH", c_l), ("out_sW", c_l),
+        ("alpha", c_f), ("bias", c_p), ("scale", c_p), ("shift", c_p), ("act", c_i),
+        ("batch_scale", c_p), ("resid", c_p), ("resid_dtype", c_i),
+        ("res_sB", c_l), ("res_sH", c_l), ("res_sW", c_l),
+        ("nz", c_i), ("nz_inner", c_i),
+        ("in_sZ0", c_l), ("in_sZ1", c_l), ("w_sZ0", c_l), ("w_sZ1", c_l),
+        ("out_sZ0", c_l), ("out_sZ1", c_l),
+    ]
+
+
+class WgradArgs(C.Structure):
+    """Mirror of gdl_wgrad_args (include/gdlhip.h)."""
+
+    _fields_ = [
+        ("inp", c_p), ("dy", c_p), ("dtype", c_i), ("B", c_i), ("H", c_i), ("W", c_i), ("C", c_i),
+        ("in_sB", c_l), ("in_sH", c_l), ("in_sW", c_l),
+        ("Ho", c_i), ("Wo", c_i), ("R", c_i), ("S", c_i), ("stride", c_i), ("pad", c_i),
+        ("N", c_i), ("dy_sB", c_l), ("dy_sH", c_l), ("dy_sW", c_l),
+        ("dw", c_p), ("dw_sN", c_l), ("accumulate", c_i),
+        ("workspace", c_p), ("workspace_bytes", c_l),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/gdlhip.h
+SIGNATURES = {
+    "gdl_version": (c_i, []),
+    "gdl_last_error": (C.c_char_p, []),
+    "gdl_conv_gemm": (c_i, [C.POINTER(ConvArgs), c_p]),
+    "gdl_conv_wgrad_workspace": (c_l, [C.POINTER(WgradArgs)]),
+    "gdl_conv_wgrad": (c_i, [C.POINTER(WgradArgs), c_p]),
+    "gdl_layernorm_fwd": (c_i, [c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_i, c_f, c_p]),
+    "gdl_bn_stats": (c_i, [c_p, c_i, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_f, c_p, c_l, c_p]),
+    "gdl_bn_stats_workspace": (c_l, [c_l, c_i]),
+    "gdl_bn_apply": (c_i, [c_p, c_p, c_i, c_l, c_i, c_l, c_l, c_p, c_p, c_p, c_p, c_f, c_i, c_p]),
+    "gdl_bn_bwd_reduce": (c_i, [c_p, c_p, c_i, c_l, c_i, c_l, c_l, c_p, c_p, c_p, c_p, c_f, c_i,
+                                c_p, c_p, c_p, c_l, c_p]),
+    "gdl_bn_bwd_dx": (c_i, [c_p, c_p, c_p, c_i, c_l, c_i, c_l, c_l, c_l, c_p, c_p, c_p, c_p, c_f,
+                            c_i, c_p, c_p, c_l, c_p]),
+    "gdl_bilinear_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_i, c_i, c_i,
+                               c_l, c_l, c_l, c_i, c_p]),
+    "gdl_bilinear_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_i, c_i, c_i,
+                               c_l, c_l, c_l, c_i, c_p]),
+    "gdl_adaptive_avgpool_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_i, c_i,
+                                       c_p]),
+    "gdl_adaptive_avgpool_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_l, c_l, c_l,
+                                       c_i, c_p]),
+    "gdl_v_transpose": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "gdl_softmax_rows": (c_i, [c_p, c_p, c_i, c_l, c_i, c_i, c_p]),
+    "gdl_flash_attn_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "gdl_patchify": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "gdl_dofa_pack_kernel": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p]),
+    "gdl_sincos_embed": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
+    "gdl_bn_fold": (c_i, [c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),
+    "gdl_pack_dgrad": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "gdl_cast": (c_i, [c_p, c_i, c_p, c_i, c_l, c_p]),
+    "gdl_scale_f32": (c_i, [c_p, c_p, c_l, c_f, c_p]),
+    "gdl_add_rows": (c_i, [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_p]),
+    "gdl_normalize_u8": (c_i, [c_p, c_p, c_i, c_i, c_l, c_p, c_p, c_p]),
+    "gdl_scale_outer": (c_i, [c_p, c_i, c_p, c_l, c_l, c_p]),
+    "gdl_head_1x1": (c_i, [c_p, c_i, c_l, c_i, c_l, c_p, c_p, c_p, c_l, c_p, c_i, c_p]),
+    "gdl_head_1x1_bwd_workspace": (c_l, [c_l, c_i, c_i]),
+    "gdl_head_1x1_bwd": (c_i, [c_p, c_i, c_p, c_l, c_i, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i,
+                               c_p, c_l, c_p]),
+    "gdl_upsample_logits": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "gdl_upsample_logits_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "gdl_softmax_argmax": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p]),
+    "gdl_dice_loss_workspace": (c_l, [c_i, c_i, c_l]),
+    "gdl_dice_loss_fwd": (c_i, [c_p, c_p, c_i, c_i, c_l, c_f, c_p, c_p, c_p, c_l, c_p]),
+    "gdl_dice_loss_bwd": (c_i, [c_p, c_p, c_i, c_i, c_l, c_f, c_p, c_p, c_f, c_p, c_i, c_p]),
+    "gdl_sumsq": (c_i, [c_p, c_l, c_p, c_p]),
+    "gdl_clip_coef": (c_i, [c_p, c_f, c_p, c_p]),
+    "gdl_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
+}
+
+_lib = None
+
+
+class GdlHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libgdlhip.so and bind every declared symbol; raises if the build is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        msg = (f"{LIB_PATH} not found: the HIP extension is not built. Run "
+               "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+               "There is no PyTorch/CPU fallback for the gdlhip ops.")
+        raise GdlHipError(msg)
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        err = load().gdl_last_error().decode(errors="replace")
+        if status == -1:
+            raise ValueError(f"{what}: {err}")
+        raise GdlHipError(f"{what}: status {status}: {err}")

@@ -1,0 +1,389 @@
+"""Autograd-aware fused ops + precision policy + packed-weight cache.
+
+Everything here is host logic around libgdlhip.so: forward AND backward arithmetic run in the
+HIP kernels (``gdlhip.ops``); ``torch.autograd.Function`` only records the graph so that the
+reference's ``loss.backward()`` / DDP hooks keep working unchanged.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+from torch.autograd import Function
+
+from . import ops
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU  # noqa: F401
+
+
+# ------------------------------------------------------------------ precision policy
+def compute_dtype() -> torch.dtype:
+    """bf16 MFMA path under ``torch.autocast('cuda', bfloat16/float16)``, exact-f32 MFMA otherwise.
+
+    The reference selects precision through Lightning's ``precision:`` flag, i.e. autocast
+    (configs/dofa_config_RGB.yaml:12); the kernels accumulate in f32 either way.
+    """
+    if torch.is_autocast_enabled("cuda"):
+        return torch.bfloat16
+    return torch.float32
+
+
+# ------------------------------------------------------------------ packed-weight cache
+_EPOCH = 0
+_CACHE: dict = {}
+
+
+def bump_weights_epoch() -> None:
+    """Called by the fused optimizer after it rewrites parameters through raw pointers."""
+    global _EPOCH
+    _EPOCH += 1
+
+
+def cached(params: tuple, kind: str, builder):
+    """Memoise ``builder()`` on the identity + version of ``params`` (tensors)."""
+    key = (kind, *[id(p) for p in params])
+    ver = (_EPOCH, *[(p._version, p.data_ptr()) for p in params])
+    hit = _CACHE.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    val = builder()
+    _CACHE[key] = (ver, val)
+    return val
+
+
+def conv_weight_matrix(weight: Tensor) -> Tensor:
+    """[N,C,R,S] conv parameter -> f32 [N, R*S*C] view (free when stored channels_last)."""
+    n = weight.shape[0]
+    w = weight.detach().permute(0, 2, 3, 1)
+    if not w.is_contiguous():
+        w = w.contiguous()  # parameter not stored channels_last: one repack (cached by caller)
+    return w.reshape(n, -1)
+
+
+def gemm_weight(weight: Tensor, cd: torch.dtype) -> Tensor:
+    """GEMM operand ([N, K] K-contiguous, compute dtype) of a Linear / conv parameter."""
+    def build():
+        w = weight.detach() if weight.dim() == 2 else conv_weight_matrix(weight)
+        w = w if w.is_contiguous() else w.contiguous()
+        return w if cd == torch.float32 else ops.cast(w, cd)
+    return cached((weight,), f"gemm:{cd}", build)
+
+
+def dgrad_weight(weight: Tensor, cd: torch.dtype) -> Tensor:
+    """Flipped / transposed operand for the data gradient of a conv parameter."""
+    def build():
+        n, c, r, s = weight.shape
+        return ops.pack_dgrad(conv_weight_matrix(weight), n, r * s, c, cd)
+    return cached((weight,), f"dgrad:{cd}", build)
+
+
+def to_compute(x: Tensor, cd: torch.dtype) -> Tensor:
+    """NHWC tensor in the compute dtype (strided copy+cast through the identity resize)."""
+    if x.dtype == cd:
+        return x
+    return ops.bilinear(x, (x.shape[1], x.shape[2]), out_dtype=cd)
+
+
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+# ------------------------------------------------------------------ conv -> BN -> ReLU
+class _ConvBNActTrain(Function):
+    """Training-mode ConvModule: conv(+bias) -> BatchNorm(batch stats) -> ReLU.
+
+    Reference: models/utils.py:10-52, multilevel_neck.py:28-67 with nn.BatchNorm2d /
+    nn.SyncBatchNorm semantics.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, conv_bias, gamma, beta, running_mean, running_var, momentum, eps,
+                pad, relu, sync_group):
+        cd = x.dtype
+        n, c, r, s = weight.shape
+        wq = gemm_weight(weight, cd)
+        y = ops.conv_gemm(x, wq, R=r, S=s, pad=pad, bias=None if conv_bias is None else conv_bias.detach())
+        world = _world(sync_group) if sync_group is not False else 1
+        if world > 1:
+            mean, var = ops.bn_stats(y)
+            # equal per-rank pixel counts (fixed per-GPU batch): average mean and E[x^2]
+            packed = torch.stack([mean, var + mean * mean])
+            dist.all_reduce(packed, group=sync_group or None)
+            packed /= world
+            mean, var = packed[0].contiguous(), (packed[1] - packed[0] * packed[0]).clamp_min_(0).contiguous()
+            if running_mean is not None:
+                p_tot = y.numel() // n * world
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var, alpha=momentum * p_tot / max(p_tot - 1, 1))
+        else:
+            mean, var = ops.bn_stats(y, running_mean, running_var, momentum)
+        out = ops.bn_apply(y, mean, var, gamma.detach(), beta.detach(), eps, relu)
+        ctx.save_for_backward(x, weight, y, mean, var, gamma, beta)
+        ctx.cfg = (pad, relu, eps, conv_bias is not None, sync_group, world)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, weight, y, mean, var, gamma, beta = ctx.saved_tensors
+        pad, relu, eps, has_bias, sync_group, world = ctx.cfg
+        n, c, r, s = weight.shape
+        if gout.dtype != y.dtype:
+            gout = to_compute(gout, y.dtype)
+        g, b = gamma.detach(), beta.detach()
+        dgamma, dbeta = ops.bn_bwd_reduce(y, gout, mean, var, g, b, eps, relu)
+        p_local = y.numel() // n
+        sg, sb = dgamma, dbeta
+        if world > 1:
+            packed = torch.stack([dgamma, dbeta])
+            dist.all_reduce(packed, group=sync_group or None)
+            sg, sb = packed[0].contiguous(), packed[1].contiguous()
+        dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, p_local * world, out=y)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(x, dy, R=r, S=s, pad=pad).view(n, r, s, c).permute(0, 3, 1, 2)
+        dbias = None
+        if has_bias and ctx.needs_input_grad[2]:
+            # a bias feeding train-mode BN has an analytically zero gradient
+            dbias = torch.zeros(n, device=x.device, dtype=torch.float32)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv_gemm(dy, dgrad_weight(weight, x.dtype), R=r, S=s, pad=r - 1 - pad)
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def conv_bn_act(x: Tensor, conv: nn.Conv2d, norm: nn.Module, *, relu: bool = True) -> Tensor:
+    """ConvModule forward on an NHWC tensor (in the compute dtype); returns NHWC."""
+    r = conv.kernel_size[0]
+    pad = conv.padding[0]
+    training = norm.training
+    if training:
+        if isinstance(norm, nn.SyncBatchNorm):
+            sync_group = norm.process_group  # None -> default group
+        else:
+            sync_group = False
+        momentum = 0.1 if norm.momentum is None else norm.momentum
+        out = _ConvBNActTrain.apply(x, conv.weight, conv.bias, norm.weight, norm.bias,
+                                    norm.running_mean, norm.running_var, momentum, norm.eps, pad,
+                                    relu, sync_group)
+        if norm.num_batches_tracked is not None:
+            norm.num_batches_tracked.add_(1)
+        return out
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        msg = ("gdlhip: autograd through eval-mode BatchNorm is not implemented; call under "
+               "torch.no_grad() for inference or model.train() for training")
+        raise NotImplementedError(msg)
+    cd = x.dtype
+    scale, shift = cached((norm.weight, norm.bias, norm.running_mean, norm.running_var), "bnfold",
+                          lambda: ops.bn_fold(norm.weight.detach(), norm.bias.detach(),
+                                              norm.running_mean, norm.running_var, norm.eps))
+    return ops.conv_gemm(x, gemm_weight(conv.weight, cd), R=r, S=r, pad=pad,
+                         bias=None if conv.bias is None else conv.bias.detach(), scale=scale,
+                         shift=shift, act=ACT_RELU if relu else ACT_NONE)
+
+
+# ------------------------------------------------------------------ resampling
+class _Bilinear(Function):
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.in_size = (x.shape[1], x.shape[2])
+        return ops.bilinear(x, size)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.bilinear_bwd(g, ctx.in_size), None
+
+
+def bilinear(x: Tensor, size) -> Tensor:
+    """F.interpolate(mode='bilinear', align_corners=False) on NHWC."""
+    size = (int(size[0]), int(size[1]))
+    if size == (x.shape[1], x.shape[2]):
+        return x
+    return _Bilinear.apply(x, size)
+
+
+class _UpsampleAdd(Function):
+    """a + bilinear(b -> a's size)  (UperNet top-down path, upernet.py:127-135)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.b_size = (b.shape[1], b.shape[2])
+        out = ops.bilinear(a, (a.shape[1], a.shape[2]), out_dtype=a.dtype,
+                           out=torch.empty(a.shape, device=a.device, dtype=a.dtype))
+        return ops.bilinear(b, (a.shape[1], a.shape[2]), out=out, accumulate=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, ops.bilinear_bwd(g, ctx.b_size)
+
+
+def upsample_add(a: Tensor, b: Tensor) -> Tensor:
+    return _UpsampleAdd.apply(a, b)
+
+
+class _ConcatUpsample(Function):
+    """cat([bilinear(x_i -> size) for x_i], channel dim) written straight into one NHWC buffer
+    (upernet.py:103-109,144-152: no separate concat copy)."""
+
+    @staticmethod
+    def forward(ctx, size, *xs):
+        b = xs[0].shape[0]
+        chans = [x.shape[3] for x in xs]
+        out = torch.empty((b, size[0], size[1], sum(chans)), device=xs[0].device, dtype=xs[0].dtype)
+        off = 0
+        for x, c in zip(xs, chans):
+            ops.bilinear(x, size, out=out[..., off:off + c])
+            off += c
+        ctx.meta = [(x.shape[1], x.shape[2], x.shape[3]) for x in xs]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        grads, off = [], 0
+        for i, (h, w, c) in enumerate(ctx.meta):
+            if ctx.needs_input_grad[i + 1]:
+                grads.append(ops.bilinear_bwd(g[..., off:off + c], (h, w)))
+            else:
+                grads.append(None)
+            off += c
+        return (None, *grads)
+
+
+def concat_upsample(xs, size) -> Tensor:
+    return _ConcatUpsample.apply((int(size[0]), int(size[1])), *xs)
+
+
+class _AdaptivePool(Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.in_size = (x.shape[1], x.shape[2])
+        return ops.adaptive_avgpool(x, s)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.adaptive_avgpool_bwd(g.contiguous(), ctx.in_size), None
+
+
+def adaptive_avgpool(x: Tensor, s: int) -> Tensor:
+    return _AdaptivePool.apply(x, s)
+
+
+# ------------------------------------------------------------------ classifier tail
+class _HeadLogits(Function):
+    """1x1 conv to num_classes + bilinear to the input size -> NCHW f32 logits
+    (segmentation_head.py:22-26 + dofa.py:89-96; fcn_head.py:69-84 with Dropout2d scale)."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, chan_scale, size):
+        low = ops.head_1x1(feat, weight.detach(), None if bias is None else bias.detach(), chan_scale)
+        ctx.save_for_backward(feat, weight, chan_scale)
+        ctx.low_size = (feat.shape[1], feat.shape[2])
+        ctx.has_bias = bias is not None
+        return ops.upsample_logits(low, size)
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, weight, chan_scale = ctx.saved_tensors
+        dlow = ops.upsample_logits_bwd(g.contiguous(), ctx.low_size)
+        dfeat, dw, db = ops.head_1x1_bwd(feat, dlow, weight.detach(), chan_scale,
+                                         need_dfeat=ctx.needs_input_grad[0])
+        return dfeat, dw.view(weight.shape), (db if ctx.has_bias else None), None, None
+
+
+def head_logits(feat: Tensor, conv: nn.Conv2d, size, chan_scale: Tensor | None = None) -> Tensor:
+    return _HeadLogits.apply(feat, conv.weight, conv.bias, chan_scale, (int(size[0]), int(size[1])))
+
+
+class _DiceLoss(Function):
+    """smp DiceLoss(mode='multiclass') (configs/dofa_config_RGB.yaml:58-61)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, eps):
+        loss, sums = ops.dice_loss_fwd(logits, target, eps)
+        ctx.save_for_backward(logits, target, sums)
+        ctx.eps = eps
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, sums = ctx.saved_tensors
+        return ops.dice_loss_bwd(logits, target, sums, g.contiguous().float(), 1.0, ctx.eps), None, None
+
+
+class DiceLoss(nn.Module):
+    """Drop-in for ``segmentation_models_pytorch.losses.DiceLoss(mode="multiclass")``."""
+
+    def __init__(self, mode: str = "multiclass", smooth: float = 0.0, eps: float = 1e-7, **kw) -> None:
+        super().__init__()
+        if mode != "multiclass" or smooth != 0.0 or kw:
+            msg = "gdlhip DiceLoss implements mode='multiclass', smooth=0 (the reference's config)"
+            raise NotImplementedError(msg)
+        self.eps = eps
+
+    def forward(self, y_pred: Tensor, y_true: Tensor) -> Tensor:
+        if y_pred.dtype != torch.float32 or not y_pred.is_contiguous():
+            y_pred = y_pred.float().contiguous()
+        return _DiceLoss.apply(y_pred, y_true.long().contiguous(), self.eps)
+
+
+def predict_mask(logits: Tensor) -> Tensor:
+    """``softmax(dim=1).argmax(dim=1)`` (segmentation_dofa.py:281)."""
+    return ops.softmax_argmax(logits.float().contiguous())
+
+
+# ------------------------------------------------------------------ optimizer
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics with the update (and optional global-norm clipping, Lightning's
+    ``gradient_clip_val``) done by HIP kernels.  Reference: configs/dofa_config_RGB.yaml:11,62-65."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, max_grad_norm: float | None = None) -> None:
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.max_grad_norm = max_grad_norm
+        self._acc = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        todo = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if not todo:
+            return loss
+        clip = None
+        if self.max_grad_norm is not None:
+            dev = todo[0][1].device
+            if self._acc is None:
+                self._acc = torch.zeros(2, device=dev, dtype=torch.float32)
+            self._acc.zero_()
+            for _, p in todo:
+                ops.sumsq_accum(_flat(p.grad), self._acc[0:1])
+            ops.clip_coef(self._acc[0:1], float(self.max_grad_norm), self._acc[1:2])
+            clip = self._acc[1:2]
+        for group, p in todo:
+            st = self.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            b1, b2 = group["betas"]
+            if p.grad.stride() != p.stride():
+                p.grad = _restride(p.grad, p)
+            ops.adam_step(_flat(p), _flat(p.grad), _flat(st["exp_avg"]), _flat(st["exp_avg_sq"]),
+                          group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"], clip)
+        bump_weights_epoch()
+        return loss
+
+
+def _flat(t: Tensor) -> Tensor:
+    """The dense storage of a (possibly channels_last) tensor, as a flat view."""
+    if t.is_contiguous():
+        return t.view(-1)
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return t.permute(0, 2, 3, 1).reshape(-1)
+    msg = f"gdlhip FusedAdam: parameter layout {t.stride()} is not dense"
+    raise ValueError(msg)
+
+
+def _restride(g: Tensor, p: Tensor) -> Tensor:
+    out = torch.empty_like(p, memory_format=torch.preserve_format)
+    out.copy_(g)
+    return out

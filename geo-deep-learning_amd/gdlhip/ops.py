@@ -1,0 +1,603 @@
+"""Tensor-level wrappers over the C-ABI (raw ops, no autograd).
+
+Conventions: activations are NHWC torch tensors ``[B, H, W, C]`` (any strides with
+``stride(-1) == 1``); 2-D ``[rows, C]`` tensors are treated as ``[1, 1, rows, C]``.
+PyTorch only provides device memory and the stream here -- all arithmetic happens in
+libgdlhip.so.  Shape / dtype / alignment errors raise ValueError like the reference's own
+argument checks (dofa_v2.py:439-441, multilevel_neck.py:141-146).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, ConvArgs, WgradArgs, check  # noqa: F401
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t: Tensor | torch.dtype) -> int:
+    d = t if isinstance(t, torch.dtype) else t.dtype
+    try:
+        return _DT[d]
+    except KeyError:
+        raise ValueError(f"gdlhip: unsupported dtype {d}") from None
+
+
+def _p(t: Tensor | None):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts: Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("gdlhip ops need CUDA/HIP device tensors (no CPU fallback)")
+
+
+def _f32vec(t: Tensor | None, n: int, name: str) -> Tensor | None:
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous f32 vector of {n} elements")
+    return t
+
+
+def as_nhwc(x: Tensor) -> Tensor:
+    """Logical NCHW tensor -> NHWC view (copying only if its channels are not contiguous)."""
+    v = x.permute(0, 2, 3, 1)
+    return v if v.stride(-1) == 1 else v.contiguous()
+
+
+def as_nchw(x: Tensor) -> Tensor:
+    """NHWC tensor -> logical NCHW view (== torch.channels_last memory format)."""
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc4(x: Tensor, name: str) -> Tensor:
+    if x.dim() == 2:
+        x = x.unsqueeze(0).unsqueeze(0)
+    if x.dim() != 4 or x.stride(-1) != 1:
+        raise ValueError(f"{name}: expected NHWC tensor with unit channel stride, got "
+                         f"shape {tuple(x.shape)} strides {x.stride()}")
+    return x
+
+
+# ------------------------------------------------------------------ conv / linear (MFMA)
+def conv_gemm(x: Tensor, w: Tensor, *, R: int = 1, S: int = 1, stride: int = 1, pad: int = 0,
+              bias: Tensor | None = None, scale: Tensor | None = None, shift: Tensor | None = None,
+              act: int = ACT_NONE, batch_scale: Tensor | None = None, resid: Tensor | None = None,
+              out: Tensor | None = None, out_dtype: torch.dtype | None = None,
+              alpha: float = 1.0) -> Tensor:
+    """out = epilogue(conv(x, w)); x NHWC [B,H,W,C], w [N, R*S*C] (K order r,s,c)."""
+    _need_cuda(x, w)
+    two_d = x.dim() == 2
+    x4 = _nhwc4(x, "conv_gemm input")
+    B, H, W, Cc = x4.shape
+    N = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != R * S * Cc or w.stride(1) != 1 or w.dtype != x.dtype:
+        raise ValueError(f"conv_gemm: weight must be [{N}, {R * S * Cc}] {x.dtype} K-contiguous, "
+                         f"got {tuple(w.shape)} {w.dtype}")
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - S) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, N), device=x.device, dtype=out_dtype or x.dtype)
+        out4 = out
+    else:
+        out4 = _nhwc4(out, "conv_gemm out")
+        if tuple(out4.shape) != (B, Ho, Wo, N):
+            raise ValueError(f"conv_gemm: out shape {tuple(out4.shape)} != {(B, Ho, Wo, N)}")
+    a = ConvArgs()
+    a.inp, a.dtype = x4.data_ptr(), dt(x)
+    a.B, a.H, a.W, a.C = B, H, W, Cc
+    a.in_sB, a.in_sH, a.in_sW = x4.stride(0), x4.stride(1), x4.stride(2)
+    a.Ho, a.Wo, a.R, a.S, a.stride, a.pad = Ho, Wo, R, S, stride, pad
+    a.w, a.w_sN, a.N = w.data_ptr(), w.stride(0), N
+    a.out, a.out_dtype = out4.data_ptr(), dt(out4)
+    a.out_sB, a.out_sH, a.out_sW = out4.stride(0), out4.stride(1), out4.stride(2)
+    a.alpha = alpha
+    a.bias = None if bias is None else _f32vec(bias, N, "bias").data_ptr()
+    a.scale = None if scale is None else _f32vec(scale, N, "scale").data_ptr()
+    a.shift = None if shift is None else _f32vec(shift, N, "shift").data_ptr()
+    a.act = act
+    a.batch_scale = None if batch_scale is None else _f32vec(batch_scale, B, "batch_scale").data_ptr()
+    if resid is not None:
+        r4 = _nhwc4(resid, "conv_gemm resid")
+        if r4.shape[-1] != N or r4.shape[1:3] != out4.shape[1:3]:
+            raise ValueError("conv_gemm: resid shape mismatch")
+        a.resid, a.resid_dtype = r4.data_ptr(), dt(r4)
+        a.res_sB = r4.stride(0) if r4.shape[0] == B else 0
+        a.res_sH, a.res_sW = r4.stride(1), r4.stride(2)
+    a.nz, a.nz_inner = 1, 1
+    check(_lib.load().gdl_conv_gemm(C.byref(a), _stream()), "gdl_conv_gemm")
+    if two_d and out4 is out:
+        return out.view(Wo, N)
+    return out
+
+
+def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, **kw) -> Tensor:
+    """y[..., N] = epilogue(x[..., K] @ w[N, K]^T); rows may be strided."""
+    K = x.shape[-1]
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, K)
+    if "resid" in kw and kw["resid"] is not None:
+        kw["resid"] = kw["resid"].reshape(-1, w.shape[0])
+    if kw.get("out") is not None:
+        kw["out"] = kw["out"].reshape(-1, w.shape[0])
+    y = conv_gemm(x2, w, bias=bias, **kw)
+    return y.reshape(*lead, w.shape[0])
+
+
+def batched_gemm_raw(a: ConvArgs) -> None:
+    check(_lib.load().gdl_conv_gemm(C.byref(a), _stream()), "gdl_conv_gemm(batched)")
+
+
+def conv_wgrad(x: Tensor, dy: Tensor, *, R: int, S: int, stride: int = 1, pad: int = 0,
+               dw: Tensor | None = None, accumulate: bool = False) -> Tensor:
+    """dw[N, R*S*C] (f32) = sum_pixels dy[.., n] * x[.. + tap, c]."""
+    _need_cuda(x, dy)
+    x4, dy4 = _nhwc4(x, "wgrad x"), _nhwc4(dy, "wgrad dy")
+    if x4.dtype != dy4.dtype:
+        raise ValueError("conv_wgrad: x and dy dtypes differ")
+    B, H, W, Cc = x4.shape
+    _, Ho, Wo, N = dy4.shape
+    if dw is None:
+        dw = torch.empty((N, R * S * Cc), device=x.device, dtype=torch.float32)
+    a = WgradArgs()
+    a.inp, a.dy, a.dtype = x4.data_ptr(), dy4.data_ptr(), dt(x4)
+    a.B, a.H, a.W, a.C = B, H, W, Cc
+    a.in_sB, a.in_sH, a.in_sW = x4.stride(0), x4.stride(1), x4.stride(2)
+    a.Ho, a.Wo, a.R, a.S, a.stride, a.pad, a.N = Ho, Wo, R, S, stride, pad, N
+    a.dy_sB, a.dy_sH, a.dy_sW = dy4.stride(0), dy4.stride(1), dy4.stride(2)
+    a.dw, a.dw_sN, a.accumulate = dw.data_ptr(), dw.stride(0), int(accumulate)
+    lib = _lib.load()
+    nbytes = lib.gdl_conv_wgrad_workspace(C.byref(a))
+    ws = torch.empty(max(nbytes, 4) // 4, device=x.device, dtype=torch.float32)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    check(lib.gdl_conv_wgrad(C.byref(a), _stream()), "gdl_conv_wgrad")
+    return dw
+
+
+# ------------------------------------------------------------------ normalisation
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype: torch.dtype) -> Tensor:
+    _need_cuda(x)
+    if x.dtype != torch.float32 or x.stride(-1) != 1:
+        raise ValueError("layernorm: x must be f32 with unit last stride")
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    y = torch.empty((x2.shape[0], D), device=x.device, dtype=out_dtype)
+    check(_lib.load().gdl_layernorm_fwd(_p(x2), x2.stride(0), _p(_f32vec(gamma, D, "gamma")),
+                                        _p(_f32vec(beta, D, "beta")), _p(y), dt(y), x2.shape[0], D,
+                                        eps, _stream()), "gdl_layernorm_fwd")
+    return y.reshape(x.shape)
+
+
+def _pix(x: Tensor, name: str):
+    """NHWC tensor whose pixels are uniformly strided -> (P, C, pixel stride)."""
+    x4 = _nhwc4(x, name)
+    B, H, W, Cc = x4.shape
+    sB, sH, sW = x4.stride(0), x4.stride(1), x4.stride(2)
+    if W > 1:
+        sP = sW
+    elif H > 1:
+        sP = sH
+    else:
+        sP = sB if B > 1 else Cc
+    ok = (H == 1 or W == 1 or sH == W * sP) and (B == 1 or H * W == 1 or sB == H * W * sP)
+    if not ok:
+        raise ValueError(f"{name}: pixels must be uniformly strided, got strides {x4.stride()}")
+    return B * H * W, Cc, sP
+
+
+def bn_stats(x: Tensor, running_mean: Tensor | None = None, running_var: Tensor | None = None,
+             momentum: float = 0.1):
+    _need_cuda(x)
+    P, Cc, sP = _pix(x, "bn_stats x")
+    mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    var = torch.empty_like(mean)
+    lib = _lib.load()
+    nbytes = lib.gdl_bn_stats_workspace(P, Cc)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    check(lib.gdl_bn_stats(_p(x), dt(x), P, Cc, sP, _p(mean), _p(var), _p(running_mean),
+                           _p(running_var), momentum, _p(ws), nbytes, _stream()), "gdl_bn_stats")
+    return mean, var
+
+
+def bn_apply(x: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, beta: Tensor, eps: float,
+             relu: bool, out: Tensor | None = None) -> Tensor:
+    P, Cc, sP = _pix(x, "bn_apply x")
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    Po, Co, sPo = _pix(out, "bn_apply out")
+    check(_lib.load().gdl_bn_apply(_p(x), _p(out), dt(x), P, Cc, sP, sPo, _p(mean), _p(var),
+                                   _p(gamma), _p(beta), eps, int(relu), _stream()), "gdl_bn_apply")
+    return out
+
+
+def bn_bwd_reduce(x, dy, mean, var, gamma, beta, eps, relu):
+    P, Cc, sP = _pix(x, "bn_bwd x")
+    _, _, sPd = _pix(dy, "bn_bwd dy")
+    if dy.dtype != x.dtype:
+        raise ValueError("bn_bwd: dy dtype must match x")
+    dgamma = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    lib = _lib.load()
+    nbytes = lib.gdl_bn_stats_workspace(P, Cc)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    check(lib.gdl_bn_bwd_reduce(_p(x), _p(dy), dt(x), P, Cc, sP, sPd, _p(mean), _p(var), _p(gamma),
+                                _p(beta), eps, int(relu), _p(dgamma), _p(dbeta), _p(ws), nbytes,
+                                _stream()), "gdl_bn_bwd_reduce")
+    return dgamma, dbeta
+
+
+def bn_bwd_dx(x, dy, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum, p_total,
+              out: Tensor | None = None):
+    P, Cc, sP = _pix(x, "bn_bwd x")
+    _, _, sPd = _pix(dy, "bn_bwd dy")
+    dx = out if out is not None else torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    _, _, sPx = _pix(dx, "bn_bwd dx")
+    check(_lib.load().gdl_bn_bwd_dx(_p(x), _p(dy), _p(dx), dt(x), P, Cc, sP, sPd, sPx, _p(mean),
+                                    _p(var), _p(gamma), _p(beta), eps, int(relu), _p(dgamma_sum),
+                                    _p(dbeta_sum), p_total, _stream()), "gdl_bn_bwd_dx")
+    return dx
+
+
+# ------------------------------------------------------------------ resampling
+def bilinear(x: Tensor, size: tuple[int, int], out: Tensor | None = None,
+             out_dtype: torch.dtype | None = None, accumulate: bool = False) -> Tensor:
+    _need_cuda(x)
+    x4 = _nhwc4(x, "bilinear x")
+    B, Hi, Wi, Cc = x4.shape
+    Ho, Wo = size
+    if out is None:
+        if accumulate:
+            raise ValueError("bilinear: accumulate needs out")
+        out = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=out_dtype or x.dtype)
+    o4 = _nhwc4(out, "bilinear out")
+    if tuple(o4.shape) != (B, Ho, Wo, Cc):
+        raise ValueError(f"bilinear: out shape {tuple(o4.shape)} != {(B, Ho, Wo, Cc)}")
+    check(_lib.load().gdl_bilinear_fwd(_p(x4), dt(x4), B, Hi, Wi, Cc, x4.stride(0), x4.stride(1),
+                                       x4.stride(2), _p(o4), dt(o4), Ho, Wo, o4.stride(0),
+                                       o4.stride(1), o4.stride(2), int(accumulate), _stream()),
+          "gdl_bilinear_fwd")
+    return out
+
+
+def bilinear_bwd(dout: Tensor, in_size: tuple[int, int], din: Tensor | None = None,
+                 din_dtype: torch.dtype | None = None, accumulate: bool = False) -> Tensor:
+    d4 = _nhwc4(dout, "bilinear_bwd dout")
+    B, Ho, Wo, Cc = d4.shape
+    Hi, Wi = in_size
+    if din is None:
+        din = torch.empty((B, Hi, Wi, Cc), device=dout.device, dtype=din_dtype or dout.dtype)
+    i4 = _nhwc4(din, "bilinear_bwd din")
+    check(_lib.load().gdl_bilinear_bwd(_p(d4), dt(d4), B, Ho, Wo, Cc, d4.stride(0), d4.stride(1),
+                                       d4.stride(2), _p(i4), dt(i4), Hi, Wi, i4.stride(0),
+                                       i4.stride(1), i4.stride(2), int(accumulate), _stream()),
+          "gdl_bilinear_bwd")
+    return din
+
+
+def adaptive_avgpool(x: Tensor, s: int, out_dtype: torch.dtype | None = None) -> Tensor:
+    x4 = _nhwc4(x, "avgpool x")
+    B, Hi, Wi, Cc = x4.shape
+    out = torch.empty((B, s, s, Cc), device=x.device, dtype=out_dtype or x.dtype)
+    check(_lib.load().gdl_adaptive_avgpool_fwd(_p(x4), dt(x4), B, Hi, Wi, Cc, x4.stride(0),
+                                               x4.stride(1), x4.stride(2), _p(out), dt(out), s,
+                                               _stream()), "gdl_adaptive_avgpool_fwd")
+    return out
+
+
+def adaptive_avgpool_bwd(dout: Tensor, in_size: tuple[int, int], din: Tensor | None = None,
+                         accumulate: bool = False) -> Tensor:
+    if not dout.is_contiguous():
+        raise ValueError("adaptive_avgpool_bwd: dout must be contiguous NHWC")
+    B, s, _, Cc = dout.shape
+    Hi, Wi = in_size
+    if din is None:
+        din = torch.empty((B, Hi, Wi, Cc), device=dout.device, dtype=dout.dtype)
+    i4 = _nhwc4(din, "avgpool_bwd din")
+    check(_lib.load().gdl_adaptive_avgpool_bwd(_p(dout), dt(dout), B, s, Cc, _p(i4), dt(i4), Hi, Wi,
+                                               i4.stride(0), i4.stride(1), i4.stride(2),
+                                               int(accumulate), _stream()),
+          "gdl_adaptive_avgpool_bwd")
+    return din
+
+
+# ------------------------------------------------------------------ attention (unfused + fused)
+def attention_unfused(qkv: Tensor, num_heads: int) -> Tensor:
+    """softmax(q k^T / sqrt(hd)) v with materialised scores: the exact-f32 parity path.
+
+    qkv: [B, N, 3*H*hd] (timm Attention.qkv output).  Returns [B, N, H*hd].
+    """
+    _need_cuda(qkv)
+    B, N, three_d = qkv.shape
+    D = three_d // 3
+    hd = D // num_heads
+    es = 4 if qkv.dtype == torch.float32 else 2
+    bke = 128 // es
+    if hd % bke != 0 or not qkv.is_contiguous():
+        raise ValueError(f"attention: head_dim {hd} must be a multiple of {bke}; qkv contiguous")
+    npad = (N + 63) // 64 * 64
+    lib = _lib.load()
+    vt = torch.empty((B, num_heads, hd, npad), device=qkv.device, dtype=qkv.dtype)
+    check(lib.gdl_v_transpose(_p(qkv), dt(qkv), B, N, num_heads, hd, _p(vt), npad, _stream()),
+          "gdl_v_transpose")
+    scores = torch.empty((B, num_heads, N, npad), device=qkv.device, dtype=qkv.dtype)
+    a = ConvArgs()
+    a.inp, a.dtype = qkv.data_ptr(), dt(qkv)
+    a.B, a.H, a.W, a.C = 1, 1, N, hd
+    a.in_sB, a.in_sH, a.in_sW = N * 3 * D, N * 3 * D, 3 * D
+    a.Ho, a.Wo, a.R, a.S, a.stride, a.pad = 1, N, 1, 1, 1, 0
+    a.w, a.w_sN, a.N = qkv.data_ptr() + D * es, 3 * D, N
+    a.out, a.out_dtype = scores.data_ptr(), dt(scores)
+    a.out_sB, a.out_sH, a.out_sW = N * npad, N * npad, npad
+    a.alpha, a.act = float(hd) ** -0.5, ACT_NONE
+    a.nz, a.nz_inner = B * num_heads, num_heads
+    a.in_sZ0, a.in_sZ1 = N * 3 * D, hd
+    a.w_sZ0, a.w_sZ1 = N * 3 * D, hd
+    a.out_sZ0, a.out_sZ1 = num_heads * N * npad, N * npad
+    batched_gemm_raw(a)
+    check(lib.gdl_softmax_rows(_p(scores), _p(scores), dt(scores), B * num_heads * N, N, npad,
+                               _stream()), "gdl_softmax_rows")
+    out = torch.empty((B, N, D), device=qkv.device, dtype=qkv.dtype)
+    a = ConvArgs()
+    a.inp, a.dtype = scores.data_ptr(), dt(scores)
+    a.B, a.H, a.W, a.C = 1, 1, N, npad
+    a.in_sB, a.in_sH, a.in_sW = N * npad, N * npad, npad
+    a.Ho, a.Wo, a.R, a.S, a.stride, a.pad = 1, N, 1, 1, 1, 0
+    a.w, a.w_sN, a.N = vt.data_ptr(), npad, hd
+    a.out, a.out_dtype = out.data_ptr(), dt(out)
+    a.out_sB, a.out_sH, a.out_sW = N * D, N * D, D
+    a.alpha, a.act = 1.0, ACT_NONE
+    a.nz, a.nz_inner = B * num_heads, num_heads
+    a.in_sZ0, a.in_sZ1 = num_heads * N * npad, N * npad
+    a.w_sZ0, a.w_sZ1 = num_heads * hd * npad, hd * npad
+    a.out_sZ0, a.out_sZ1 = N * D, hd
+    batched_gemm_raw(a)
+    return out
+
+
+def attention_flash(qkv: Tensor, num_heads: int) -> Tensor:
+    """Fused flash attention forward (bf16, head_dim 64)."""
+    _need_cuda(qkv)
+    B, N, three_d = qkv.shape
+    D = three_d // 3
+    hd = D // num_heads
+    if qkv.dtype != torch.bfloat16 or hd != 64 or not qkv.is_contiguous():
+        raise ValueError("attention_flash: needs contiguous bf16 qkv with head_dim 64")
+    npad = (N + 63) // 64 * 64
+    lib = _lib.load()
+    vt = torch.empty((B, num_heads, hd, npad), device=qkv.device, dtype=qkv.dtype)
+    check(lib.gdl_v_transpose(_p(qkv), dt(qkv), B, N, num_heads, hd, _p(vt), npad, _stream()),
+          "gdl_v_transpose")
+    out = torch.empty((B, N, D), device=qkv.device, dtype=qkv.dtype)
+    check(lib.gdl_flash_attn_fwd(_p(qkv), _p(vt), _p(out), B, num_heads, N, npad,
+                                 float(hd) ** -0.5, _stream()), "gdl_flash_attn_fwd")
+    return out
+
+
+# ------------------------------------------------------------------ DOFA patch embed helpers
+def patchify(img: Tensor, P: int, pad: int, gh: int, gw: int, kpad: int,
+             out_dtype: torch.dtype) -> Tensor:
+    _need_cuda(img)
+    if img.dtype != torch.float32 or not img.is_contiguous():
+        raise ValueError("patchify: image must be contiguous f32 NCHW")
+    B, Cc, H, W = img.shape
+    cols = torch.empty((B * gh * gw, kpad), device=img.device, dtype=out_dtype)
+    check(_lib.load().gdl_patchify(_p(img), B, Cc, H, W, P, pad, gh, gw, _p(cols), dt(cols), kpad,
+                                   _stream()), "gdl_patchify")
+    return cols
+
+
+def dofa_pack_kernel(g: Tensor, Cc: int, PP: int, D: int, scaler: float, kpad: int,
+                     out_dtype: torch.dtype) -> Tensor:
+    if g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != Cc * PP * D:
+        raise ValueError("dofa_pack_kernel: g must be contiguous f32 [C, P*P*D]")
+    out = torch.empty((D, kpad), device=g.device, dtype=out_dtype)
+    check(_lib.load().gdl_dofa_pack_kernel(_p(g), Cc, PP, D, scaler, _p(out), dt(out), kpad,
+                                           _stream()), "gdl_dofa_pack_kernel")
+    return out
+
+
+_OMEGA: dict = {}
+
+
+def sincos_embed(pos: Tensor, D: int) -> Tensor:
+    """position_embedding(D, pos) (dofa_v2.py:9-35); the frequency table is a host constant."""
+    _need_cuda(pos)
+    pos = pos.reshape(-1).contiguous().float()
+    key = (D, pos.device)
+    if key not in _OMEGA:
+        omega = torch.arange(D // 2, dtype=torch.float32)
+        omega /= D / 2.0
+        _OMEGA[key] = (1.0 / 10000**omega).to(pos.device)
+    out = torch.empty((pos.numel(), D), device=pos.device, dtype=torch.float32)
+    check(_lib.load().gdl_sincos_embed(_p(pos), _p(_OMEGA[key]), pos.numel(), D, _p(out), _stream()),
+          "gdl_sincos_embed")
+    return out
+
+
+def bn_fold(gamma: Tensor, beta: Tensor, mean: Tensor, var: Tensor, eps: float):
+    Cc = gamma.numel()
+    scale = torch.empty(Cc, device=gamma.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    check(_lib.load().gdl_bn_fold(_p(gamma), _p(beta), _p(mean), _p(var), eps, Cc, _p(scale),
+                                  _p(shift), _stream()), "gdl_bn_fold")
+    return scale, shift
+
+
+def pack_dgrad(w: Tensor, N: int, T: int, Cc: int, out_dtype: torch.dtype) -> Tensor:
+    """[N, T*C] forward weights -> [C, T*N] flipped/transposed weights for the data gradient."""
+    if not w.is_contiguous() or w.numel() != N * T * Cc:
+        raise ValueError("pack_dgrad: contiguous [N, T*C] weights expected")
+    out = torch.empty((Cc, T * N), device=w.device, dtype=out_dtype)
+    check(_lib.load().gdl_pack_dgrad(_p(w), dt(w), N, T, Cc, _p(out), dt(out), _stream()),
+          "gdl_pack_dgrad")
+    return out
+
+
+# ------------------------------------------------------------------ elementwise
+def cast(x: Tensor, dtype: torch.dtype, out: Tensor | None = None) -> Tensor:
+    _need_cuda(x)
+    if not x.is_contiguous():
+        raise ValueError("cast: contiguous input required")
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    check(_lib.load().gdl_cast(_p(x), dt(x), _p(out), dt(out), x.numel(), _stream()), "gdl_cast")
+    return out
+
+
+def scale_f32(x: Tensor, s: float) -> Tensor:
+    out = torch.empty_like(x)
+    check(_lib.load().gdl_scale_f32(_p(x), _p(out), x.numel(), s, _stream()), "gdl_scale_f32")
+    return out
+
+
+def add_rows(a: Tensor, b: Tensor | None, out: Tensor, rows: int) -> Tensor:
+    """out[r,:] = a[r % a_rows,:] + (b[r % b_rows,:] if b is given); 2-D f32 tensors."""
+    D = a.shape[-1]
+    check(_lib.load().gdl_add_rows(_p(a), a.shape[0], a.stride(0), _p(b),
+                                   0 if b is None else b.shape[0], 0 if b is None else b.stride(0),
+                                   _p(out), out.stride(0), rows, D, _stream()), "gdl_add_rows")
+    return out
+
+
+def normalize_u8(u8: Tensor, mean: Tensor, std: Tensor) -> Tensor:
+    """uint8 NCHW -> (x/255 - mean[c]) / std[c] f32 (utils/tensors.py:10-35)."""
+    _need_cuda(u8)
+    if u8.dtype != torch.uint8 or not u8.is_contiguous():
+        raise ValueError("normalize_u8: contiguous uint8 NCHW expected")
+    B, Cc, H, W = u8.shape
+    out = torch.empty((B, Cc, H, W), device=u8.device, dtype=torch.float32)
+    check(_lib.load().gdl_normalize_u8(_p(u8), _p(out), B, Cc, H * W, _p(_f32vec(mean, Cc, "mean")),
+                                       _p(_f32vec(std, Cc, "std")), _stream()), "gdl_normalize_u8")
+    return out
+
+
+def scale_outer(x: Tensor, s: Tensor) -> Tensor:
+    """x[o, ...] *= s[o] in place."""
+    if not x.is_contiguous():
+        raise ValueError("scale_outer: contiguous tensor required")
+    outer = x.shape[0]
+    check(_lib.load().gdl_scale_outer(_p(x), dt(x), _p(_f32vec(s, outer, "s")), outer,
+                                      x.numel() // outer, _stream()), "gdl_scale_outer")
+    return x
+
+
+# ------------------------------------------------------------------ classifier tail
+def head_1x1(feat: Tensor, w: Tensor, bias: Tensor | None, chan_scale: Tensor | None = None) -> Tensor:
+    """NHWC features -> f32 NHWC logits [B,H,W,K] (K <= 8)."""
+    f4 = _nhwc4(feat, "head feat")
+    B, H, W, Cc = f4.shape
+    P, _, sP = _pix(f4, "head feat")
+    K = w.shape[0]
+    w2 = w.reshape(K, Cc)
+    if w2.dtype != torch.float32 or not w2.is_contiguous():
+        raise ValueError("head_1x1: weight must be contiguous f32 [K, C]")
+    out = torch.empty((B, H, W, K), device=feat.device, dtype=torch.float32)
+    check(_lib.load().gdl_head_1x1(_p(f4), dt(f4), P, Cc, sP, _p(w2), _p(bias), _p(chan_scale),
+                                   H * W, _p(out), K, _stream()), "gdl_head_1x1")
+    return out
+
+
+def head_1x1_bwd(feat: Tensor, dlog: Tensor, w: Tensor, chan_scale: Tensor | None,
+                 need_dfeat: bool = True):
+    f4 = _nhwc4(feat, "head feat")
+    B, H, W, Cc = f4.shape
+    P, _, sP = _pix(f4, "head feat")
+    K = w.shape[0]
+    w2 = w.reshape(K, Cc)
+    dfeat = torch.empty((B, H, W, Cc), device=feat.device, dtype=feat.dtype) if need_dfeat else None
+    dw = torch.empty((K, Cc), device=feat.device, dtype=torch.float32)
+    db = torch.empty(K, device=feat.device, dtype=torch.float32)
+    lib = _lib.load()
+    nbytes = lib.gdl_head_1x1_bwd_workspace(P, Cc, K)
+    ws = torch.empty(nbytes // 4, device=feat.device, dtype=torch.float32)
+    check(lib.gdl_head_1x1_bwd(_p(f4), dt(f4), _p(dlog), P, Cc, sP, _p(w2), _p(chan_scale), H * W,
+                               _p(dfeat), Cc, _p(dw), _p(db), K, _p(ws), nbytes, _stream()),
+          "gdl_head_1x1_bwd")
+    return dfeat, dw, db
+
+
+def upsample_logits(x: Tensor, size: tuple[int, int]) -> Tensor:
+    """f32 NHWC [B,Hi,Wi,K] -> NCHW f32 [B,K,Ho,Wo] (bilinear, align_corners=False)."""
+    B, Hi, Wi, K = x.shape
+    out = torch.empty((B, K, size[0], size[1]), device=x.device, dtype=torch.float32)
+    check(_lib.load().gdl_upsample_logits(_p(x), B, Hi, Wi, K, _p(out), size[0], size[1], _stream()),
+          "gdl_upsample_logits")
+    return out
+
+
+def upsample_logits_bwd(dout: Tensor, in_size: tuple[int, int]) -> Tensor:
+    if dout.dtype != torch.float32 or not dout.is_contiguous():
+        raise ValueError("upsample_logits_bwd: contiguous f32 NCHW grad expected")
+    B, K, Ho, Wo = dout.shape
+    din = torch.empty((B, in_size[0], in_size[1], K), device=dout.device, dtype=torch.float32)
+    check(_lib.load().gdl_upsample_logits_bwd(_p(dout), B, Ho, Wo, K, _p(din), in_size[0],
+                                              in_size[1], _stream()), "gdl_upsample_logits_bwd")
+    return din
+
+
+def softmax_argmax(logits: Tensor) -> Tensor:
+    """softmax(dim=1).argmax(dim=1) on NCHW f32 logits -> int64 [B,H,W]."""
+    _need_cuda(logits)
+    if logits.dtype != torch.float32 or not logits.is_contiguous():
+        raise ValueError("softmax_argmax: contiguous f32 NCHW logits expected")
+    B, K, H, W = logits.shape
+    mask = torch.empty((B, H, W), device=logits.device, dtype=torch.int64)
+    check(_lib.load().gdl_softmax_argmax(_p(logits), B, K, H * W, _p(mask), _stream()),
+          "gdl_softmax_argmax")
+    return mask
+
+
+def dice_loss_fwd(logits: Tensor, target: Tensor, eps: float = 1e-7):
+    _need_cuda(logits, target)
+    if logits.dtype != torch.float32 or not logits.is_contiguous():
+        raise ValueError("dice_loss: contiguous f32 NCHW logits expected")
+    if target.dtype != torch.int64 or not target.is_contiguous():
+        raise ValueError("dice_loss: contiguous int64 target expected")
+    B, K, H, W = logits.shape
+    sums = torch.empty(3 * K, device=logits.device, dtype=torch.float32)
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    lib = _lib.load()
+    nbytes = lib.gdl_dice_loss_workspace(B, K, H * W)
+    ws = torch.empty(nbytes // 4, device=logits.device, dtype=torch.float32)
+    check(lib.gdl_dice_loss_fwd(_p(logits), _p(target), B, K, H * W, eps, _p(sums), _p(loss), _p(ws),
+                                nbytes, _stream()), "gdl_dice_loss_fwd")
+    return loss, sums
+
+
+def dice_loss_bwd(logits: Tensor, target: Tensor, sums: Tensor, upstream: Tensor | None,
+                  grad_scale: float = 1.0, eps: float = 1e-7, out: Tensor | None = None,
+                  accumulate: bool = False) -> Tensor:
+    B, K, H, W = logits.shape
+    if out is None:
+        out = torch.empty_like(logits)
+    check(_lib.load().gdl_dice_loss_bwd(_p(logits), _p(target), B, K, H * W, eps, _p(sums),
+                                        _p(upstream), grad_scale, _p(out), int(accumulate),
+                                        _stream()), "gdl_dice_loss_bwd")
+    return out
+
+
+# ------------------------------------------------------------------ optimizer
+def sumsq_accum(x: Tensor, acc: Tensor) -> None:
+    check(_lib.load().gdl_sumsq(_p(x), x.numel(), _p(acc), _stream()), "gdl_sumsq")
+
+
+def clip_coef(sumsq: Tensor, max_norm: float, coef: Tensor) -> None:
+    check(_lib.load().gdl_clip_coef(_p(sumsq), max_norm, _p(coef), _stream()), "gdl_clip_coef")
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, b1: float, b2: float,
+              eps: float, wd: float, step: int, clip: Tensor | None) -> None:
+    bc1, bc2 = 1.0 - b1**step, 1.0 - b2**step
+    check(_lib.load().gdl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, wd, bc1,
+                                    bc2, _p(clip), _stream()), "gdl_adam_step")

@@ -1,0 +1,246 @@
+/* gdlhip.h -- C ABI of libgdlhip.so: hand-written HIP (gfx950 / CDNA4) kernels for the
+ * DOFA-ViT + UperNet semantic-segmentation hot path of NRCan/geo-deep-learning.
+ *
+ * The reference has no native boundary of its own (it is 100 % Python on torch.nn /
+ * timm / smp): the drop-in boundary is L1 "tensor backend"
+ * (SURVEY.md section 1, row L1).  Every entry point below cites the reference call it
+ * replaces.  Conventions:
+ *   - plain pointers + sizes, no torch types; all tensors are DEVICE pointers owned by
+ *     the caller (PyTorch's caching allocator); the library allocates nothing.
+ *   - activations are NHWC / token-major ("channels last"); strides are in ELEMENTS.
+ *   - every function enqueues on the caller's hipStream_t and returns 0 or a negative
+ *     gdl_status; it never throws or aborts.  gdl_last_error() gives a message.
+ *   - dtype codes: GDL_F32 = 0, GDL_BF16 = 1.
+ */
+#ifndef GDLHIP_H_
+#define GDLHIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gdl_stream_t; /* hipStream_t */
+
+enum { GDL_F32 = 0, GDL_BF16 = 1 };
+enum { GDL_ACT_NONE = 0, GDL_ACT_RELU = 1, GDL_ACT_GELU = 2 };
+enum {
+  GDL_OK = 0,
+  GDL_ERR_INVALID = -1, /* bad argument (shape / alignment / dtype) */
+  GDL_ERR_LAUNCH = -2,  /* hipLaunchKernel or a runtime call failed */
+  GDL_ERR_UNSUPPORTED = -3
+};
+
+int gdl_version(void);
+const char* gdl_last_error(void);
+
+/* ---- implicit-GEMM convolution / linear (MFMA) ---------------------------------------
+ * out[b,oy,ox,n] = epilogue( alpha * sum_{r,s,c} in[b, oy*stride+r-pad, ox*stride+s-pad, c]
+ *                                               * w[n, (r*S+s)*C + c] )
+ * epilogue: v += bias[n]; if (scale) v = v*scale[n] + (shift ? shift[n] : 0);
+ *           v = act(v); if (batch_scale) v *= batch_scale[b]; if (resid) v += resid[b,oy,ox,n];
+ *           store as out_dtype.
+ * A plain Linear / 1x1 conv is R=S=1 (M = B*Ho*Wo rows).  Batched GEMM via nz.
+ * Replaces: F.conv2d / nn.Linear + BatchNorm(eval, folded) + ReLU/GELU + LayerScale +
+ * residual add -- timm Block (dofa_v2.py:248-263), ConvModule (models/utils.py:10-52,
+ * multilevel_neck.py:28-67), upernet.py:62-101, fcn_head.py:36-84; with transposed /
+ * flipped weights it is also the data-gradient of those convs.
+ * Requirements: C % (128/elem_size) == 0, all base pointers and row strides 16-byte
+ * aligned, dtype of `in` and `w` equal (GDL_F32 -> exact-f32 MFMA, GDL_BF16 -> bf16 MFMA
+ * with f32 accumulate).
+ */
+typedef struct {
+  const void* in;
+  int dtype; /* operand dtype of in and w */
+  int B, H, W, C;
+  int64_t in_sB, in_sH, in_sW;
+  int Ho, Wo, R, S, stride, pad;
+  const void* w;
+  int64_t w_sN; /* elements between consecutive n rows (>= R*S*C) */
+  int N;
+  void* out;
+  int out_dtype;
+  int64_t out_sB, out_sH, out_sW;
+  float alpha;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  int act;
+  const float* batch_scale; /* [B] per-sample factor applied before the residual (DropPath) */
+  const void* resid;
+  int resid_dtype;
+  int64_t res_sB, res_sH, res_sW;
+  /* batching over grid.z: z -> (z / nz_inner, z % nz_inner) */
+  int nz, nz_inner;
+  int64_t in_sZ0, in_sZ1, w_sZ0, w_sZ1, out_sZ0, out_sZ1;
+} gdl_conv_args;
+
+int gdl_conv_gemm(const gdl_conv_args* a, gdl_stream_t stream);
+
+/* Weight gradient of the same convolution:
+ * dw[n, (r*S+s)*C + c] (+)= sum_{b,oy,ox} dy[b,oy,ox,n] * in[b, oy*stride+r-pad, ox*stride+s-pad, c]
+ * dw is f32 [N][R*S*C]; accumulate != 0 adds into dw.  (autograd of F.conv2d wrt weight.) */
+typedef struct {
+  const void* in;
+  const void* dy;
+  int dtype;
+  int B, H, W, C;
+  int64_t in_sB, in_sH, in_sW;
+  int Ho, Wo, R, S, stride, pad;
+  int N;
+  int64_t dy_sB, dy_sH, dy_sW;
+  float* dw;
+  int64_t dw_sN;
+  int accumulate;
+  float* workspace;       /* split-K partials, >= gdl_conv_wgrad_workspace() bytes, or NULL */
+  int64_t workspace_bytes;
+} gdl_wgrad_args;
+
+int64_t gdl_conv_wgrad_workspace(const gdl_wgrad_args* a);
+int gdl_conv_wgrad(const gdl_wgrad_args* a, gdl_stream_t stream);
+
+/* ---- normalisation -------------------------------------------------------------------
+ * LayerNorm over the last dim (biased variance, eps inside sqrt): F.layer_norm as used by
+ * timm Block norm1/norm2 (dofa_v2.py:248-263) and nn.TransformerEncoderLayer (dofa_v2.py:73-85).
+ * x: f32 rows with stride x_stride; y: dtype y_dtype, dense [rows][D]. */
+int gdl_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma, const float* beta,
+                      void* y, int y_dtype, int64_t rows, int D, float eps, gdl_stream_t stream);
+
+/* BatchNorm2d, training mode, NHWC [P pixels][C] (F.batch_norm(training=True)).
+ * stats: per-channel sum and sum of squares in f64-free two-level f32 (deterministic). */
+int gdl_bn_stats(const void* x, int dtype, int64_t P, int C, int64_t x_sP, float* mean,
+                 float* var_biased, float* running_mean, float* running_var, float momentum,
+                 float* workspace, int64_t workspace_bytes, gdl_stream_t stream);
+int64_t gdl_bn_stats_workspace(int64_t P, int C);
+/* y = relu?( (x-mean)*rsqrt(var+eps)*gamma + beta ), in place allowed */
+int gdl_bn_apply(const void* x, void* y, int dtype, int64_t P, int C, int64_t x_sP, int64_t y_sP,
+                 const float* mean, const float* var, const float* gamma, const float* beta,
+                 float eps, int relu, gdl_stream_t stream);
+/* backward of y = relu?(bn(x)) from the saved conv output x (the ReLU mask is recomputed as
+ * bn(x) > 0).  Two steps so SyncBatchNorm can all-reduce the sums in between:
+ *   reduce: dbeta = sum g, dgamma = sum g*xhat  (g = dy * mask)
+ *   dx    : gamma*rstd*(g - dbeta_sum/P_total - xhat*dgamma_sum/P_total)                      */
+int gdl_bn_bwd_reduce(const void* x, const void* dy, int dtype, int64_t P, int C, int64_t x_sP,
+                      int64_t dy_sP, const float* mean, const float* var, const float* gamma,
+                      const float* beta, float eps, int relu, float* dgamma, float* dbeta,
+                      float* workspace, int64_t workspace_bytes, gdl_stream_t stream);
+int gdl_bn_bwd_dx(const void* x, const void* dy, void* dx, int dtype, int64_t P, int C, int64_t x_sP,
+                  int64_t dy_sP, int64_t dx_sP, const float* mean, const float* var,
+                  const float* gamma, const float* beta, float eps, int relu,
+                  const float* dgamma_sum, const float* dbeta_sum, int64_t P_total,
+                  gdl_stream_t stream);
+
+/* ---- resampling (NHWC) ---------------------------------------------------------------
+ * F.interpolate(mode="bilinear", align_corners=False) (models/utils.py:96-137,
+ * upernet.py:127-150, models/utils.py:81-93).  accumulate: out += result. */
+int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int Wi, int C, int64_t in_sB,
+                     int64_t in_sH, int64_t in_sW, void* out, int out_dtype, int Ho, int Wo,
+                     int64_t out_sB, int64_t out_sH, int64_t out_sW, int accumulate,
+                     gdl_stream_t stream);
+/* din (+)= bilinear^T(dout) */
+int gdl_bilinear_bwd(const void* dout, int dout_dtype, int B, int Ho, int Wo, int C,
+                     int64_t dout_sB, int64_t dout_sH, int64_t dout_sW, void* din, int din_dtype,
+                     int Hi, int Wi, int64_t din_sB, int64_t din_sH, int64_t din_sW, int accumulate,
+                     gdl_stream_t stream);
+/* nn.AdaptiveAvgPool2d(S) (models/utils.py:73-79) */
+int gdl_adaptive_avgpool_fwd(const void* in, int dtype, int B, int Hi, int Wi, int C, int64_t in_sB,
+                             int64_t in_sH, int64_t in_sW, void* out, int out_dtype, int So,
+                             gdl_stream_t stream);
+int gdl_adaptive_avgpool_bwd(const void* dout, int dtype, int B, int So, int C, void* din,
+                             int din_dtype, int Hi, int Wi, int64_t din_sB, int64_t din_sH,
+                             int64_t din_sW, int accumulate, gdl_stream_t stream);
+
+/* ---- attention -----------------------------------------------------------------------
+ * qkv [B,N,3,H,hd] (output of timm Attention.qkv).  Q and K are consumed in place
+ * (strided GEMM operands); only V is re-laid out: vt [B,H,hd,Npad] (keys >= N zero). */
+int gdl_v_transpose(const void* qkv, int dtype, int B, int N, int H, int hd, void* vt, int Npad,
+                    gdl_stream_t stream);
+/* row softmax over the first n_valid of n_cols columns; pad columns written as 0 */
+int gdl_softmax_rows(const void* in, void* out, int dtype, int64_t rows, int n_valid, int n_cols,
+                     gdl_stream_t stream);
+/* fused flash attention forward (bf16, hd = 64): F.scaled_dot_product_attention inside timm
+ * Attention.  Reads q,k straight from qkv [B,N,3,H,64], v from vt; o[b, n, h*64 + d]. */
+int gdl_flash_attn_fwd(const void* qkv, const void* vt, void* o, int B, int H, int N, int Npad,
+                       float scale, gdl_stream_t stream);
+
+/* ---- DOFA patch embed (dofa_v2.py:157-181) --------------------------------------------
+ * im2col of conv2d(stride=P, padding=1, kernel P): in NCHW f32 [B,C,H,W] ->
+ * cols [B*Gh*Gw][Kpad] (k = (c*P + r)*P + s, zero padded to Kpad), dtype out_dtype. */
+int gdl_patchify(const float* img, int B, int C, int H, int W, int P, int pad, int Gh, int Gw,
+                 void* cols, int out_dtype, int Kpad, gdl_stream_t stream);
+/* generated kernel G [C][P*P][D] f32 (TransformerWeightGenerator.fc_weight output viewed as at
+ * dofa_v2.py:157-166) -> GEMM weight [D][Kpad], k = c*P*P + r*P + s, times `scaler` (0.01) */
+int gdl_dofa_pack_kernel(const float* g, int C, int PP, int D, float scaler, void* out,
+                         int out_dtype, int Kpad, gdl_stream_t stream);
+
+/* position_embedding (dofa_v2.py:9-35): out[m] = [sin(pos[m]*omega[d]) | cos(pos[m]*omega[d])], f32;
+ * omega [D/2] is the module's constant frequency table (1 / 10000^(d/(D/2))). */
+int gdl_sincos_embed(const float* pos, const float* omega, int M, int D, float* out, gdl_stream_t stream);
+/* eval BatchNorm2d folded for the conv epilogue: scale = g/sqrt(var+eps), shift = b - mean*scale */
+int gdl_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                int C, float* scale, float* shift, gdl_stream_t stream);
+/* forward weights [N][T][C] -> data-gradient weights [C][T flipped][N] (autograd of F.conv2d wrt
+ * its input is gdl_conv_gemm on these with pad' = R-1-pad) */
+int gdl_pack_dgrad(const void* w, int w_dtype, int N, int T, int C, void* out, int out_dtype,
+                   gdl_stream_t stream);
+
+/* ---- elementwise ----------------------------------------------------------------------*/
+int gdl_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, gdl_stream_t stream);
+int gdl_scale_f32(const float* in, float* out, int64_t n, float s, gdl_stream_t stream);
+/* out[r,:] = a[r % a_rows,:] + (b ? b[r % b_rows,:] : 0)  (token assembly / broadcast), f32 */
+int gdl_add_rows(const float* a, int64_t a_rows, int64_t a_stride, const float* b, int64_t b_rows,
+                 int64_t b_stride, float* out, int64_t out_stride, int64_t rows, int D,
+                 gdl_stream_t stream);
+/* u8 tile -> (x/255 - mean[c]) / std[c], NCHW f32 (utils/tensors.py:10-35, wds_dataset.py:230-236) */
+int gdl_normalize_u8(const uint8_t* in, float* out, int B, int C, int64_t HW, const float* mean,
+                     const float* std, gdl_stream_t stream);
+/* x[o, :inner] *= s[o]  (per-sample DropPath scaling, timm DropPath) */
+int gdl_scale_outer(void* x, int dtype, const float* s, int64_t outer, int64_t inner,
+                    gdl_stream_t stream);
+
+/* ---- classifier tail -------------------------------------------------------------------
+ * 1x1 conv to K<=8 classes (+bias) on NHWC features -> f32 NHWC logits [P][K]
+ * (segmentation_head.py:22-26, fcn_head.py:73): */
+int gdl_head_1x1(const void* feat, int dtype, int64_t P, int C, int64_t f_sP, const float* w,
+                 const float* bias, const float* chan_scale, int64_t pix_per_img, float* out, int K,
+                 gdl_stream_t stream);
+/* its backward: dfeat (may be NULL), dw [K][C], db [K] (may be NULL) */
+int64_t gdl_head_1x1_bwd_workspace(int64_t P, int C, int K);
+int gdl_head_1x1_bwd(const void* feat, int dtype, const float* dlog, int64_t P, int C, int64_t f_sP,
+                     const float* w, const float* chan_scale, int64_t pix_per_img, void* dfeat,
+                     int64_t d_sP, float* dw, float* db, int K, float* workspace,
+                     int64_t workspace_bytes, gdl_stream_t stream);
+/* bilinear (align_corners=False) NHWC [B,Hi,Wi,K] -> NCHW f32 [B,K,Ho,Wo] logits (dofa.py:89-105) */
+int gdl_upsample_logits(const float* in, int B, int Hi, int Wi, int K, float* out, int Ho, int Wo,
+                        gdl_stream_t stream);
+int gdl_upsample_logits_bwd(const float* dout, int B, int Ho, int Wo, int K, float* din, int Hi,
+                            int Wi, gdl_stream_t stream);
+/* softmax(dim=1).argmax(dim=1) on NCHW f32 logits -> int64 mask (segmentation_dofa.py:281) */
+int gdl_softmax_argmax(const float* logits, int B, int K, int64_t HW, int64_t* mask,
+                       gdl_stream_t stream);
+/* smp DiceLoss(mode="multiclass", smooth=0, eps=1e-7) forward+backward on NCHW f32 logits
+ * (configs/dofa_config_RGB.yaml:58-61).  sums [3*K] = (intersection, sum p, count y)
+ * is produced by fwd and consumed by bwd.  dlogits = upstream[0]*grad_scale*dL/dlogits. */
+int64_t gdl_dice_loss_workspace(int B, int K, int64_t HW);
+int gdl_dice_loss_fwd(const float* logits, const int64_t* target, int B, int K, int64_t HW, float eps,
+                      float* sums, float* loss, float* workspace, int64_t workspace_bytes,
+                      gdl_stream_t stream);
+int gdl_dice_loss_bwd(const float* logits, const int64_t* target, int B, int K, int64_t HW, float eps,
+                      const float* sums, const float* upstream, float grad_scale, float* dlogits,
+                      int accumulate, gdl_stream_t stream);
+
+/* ---- optimizer -------------------------------------------------------------------------
+ * torch.optim.Adam step (configs/dofa_config_RGB.yaml:62-65) on one flat f32 tensor, with the
+ * global-norm clip coefficient read from device memory (gradient_clip_val 1.0, :11). */
+int gdl_sumsq(const float* x, int64_t n, float* out_accum, gdl_stream_t stream);
+/* coef = min(1, max_norm / (sqrt(sumsq) + 1e-6))  (torch.nn.utils.clip_grad_norm_) */
+int gdl_clip_coef(const float* sumsq, float max_norm, float* coef, gdl_stream_t stream);
+int gdl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, float bc1, float bc2,
+                  const float* clip_coef, gdl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDLHIP_H_ */

@@ -1,0 +1,110 @@
+"""CPU-only tests: the C-ABI library builds/loads and exports every symbol include/gdlhip.h
+declares (no compute calls without a GPU), and the host-side mirror of the reference's
+interface (class names, constructor arguments, state-dict keys, error behaviour)."""
+
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+import oracle
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gdlhip import _lib
+    if not _lib.LIB_PATH.exists():
+        import __graft_entry__ as ge
+        ge.build()
+    return _lib.load()
+
+
+def _declared():
+    text = (ROOT / "include" / "gdlhip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gdl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from gdlhip import _lib
+    names = _declared()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/gdlhip.h but not exported by libgdlhip.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names, "binding and header disagree"
+    assert lib.gdl_version() >= 100
+    assert lib.gdl_last_error() is not None
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirrors must have the header's field order and count."""
+    from gdlhip import _lib
+    text = (ROOT / "include" / "gdlhip.h").read_text()
+    for cname, struct in (("gdl_conv_args", _lib.ConvArgs), ("gdl_wgrad_args", _lib.WgradArgs)):
+        body = re.search(r"typedef struct \{([^}]*)\} " + cname + ";", text).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(None, 1)[1] if not decl.startswith("const") else decl.split(None, 2)[2]
+            fields += [x.strip().lstrip("*").strip() for x in names.split(",")]
+        mine = [f[0] for f in struct._fields_]
+        assert len(mine) == len(fields), (cname, mine, fields)
+        assert [m.replace("inp", "in") for m in mine] == fields
+
+
+def test_ops_refuse_cpu_tensors(lib):
+    from gdlhip import ops
+    with pytest.raises(ValueError):
+        ops.conv_gemm(torch.zeros(1, 2, 2, 64), torch.zeros(64, 64))
+    with pytest.raises(ValueError):
+        ops.layernorm(torch.zeros(2, 64), torch.ones(64), torch.zeros(64), 1e-5, torch.float32)
+
+
+def test_state_dict_and_ctor_contract():
+    """Same keys/shapes as the reference (332 tensors for DOFA-base)."""
+    from geo_deep_learning.models.segmentation.dofa import DOFASegmentationModel
+    from geo_deep_learning.models.heads.segmentation_head import SegmentationOutput
+    m = DOFASegmentationModel(encoder="dofa_base", image_size=(512, 512), freeze_layers=["encoder"],
+                              num_classes=5, pretrained=False)
+    ref = oracle.DOFASegmentationModel("dofa_base", (512, 512), num_classes=5)
+    sd, rsd = m.state_dict(), ref.state_dict()
+    assert len(sd) == 332 and list(sd) == list(rsd)
+    for k in sd:
+        assert sd[k].shape == rsd[k].shape, k
+    assert sum(p.numel() for p in m.parameters()) == 141_254_922
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 35_023_882
+    # conv weights are stored channels-last but load/save with the logical OIHW shape
+    w = m.neck.convs[0].conv.weight
+    assert w.shape == (768, 768, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()
+    m.load_state_dict(oracle.procedural_state_dict(ref, 1))
+    assert m.neck.convs[0].conv.weight.permute(0, 2, 3, 1).is_contiguous()
+    assert torch.equal(m.state_dict()["neck.convs.0.conv.weight"], oracle.procedural_state_dict(ref, 1)["neck.convs.0.conv.weight"])
+    assert SegmentationOutput._fields == ("out", "aux")
+    with pytest.raises(ValueError):
+        DOFASegmentationModel(encoder="nope", pretrained=False)
+    with pytest.raises(RuntimeError):
+        DOFASegmentationModel(encoder="dofa_base", pretrained=True)  # no network: fails loudly
+
+
+def test_neck_argument_errors():
+    from geo_deep_learning.models.necks.multilevel_neck import MultiLevelNeck
+    with pytest.raises(TypeError):
+        MultiLevelNeck(64, [64], scales=[1], norm_cfg={"type": "BN"}, act_cfg={"type": "ReLU"})
+    neck = MultiLevelNeck([64] * 2, [64] * 2, scales=[2, 1], norm_cfg={"type": "BN"}, act_cfg={"type": "ReLU"})
+    with pytest.raises(ValueError, match="len\\(inputs\\)"):
+        neck([torch.zeros(1, 64, 4, 4)])
+
+
+def test_pos_embed_matches_reference_init():
+    from geo_deep_learning.models.encoders.dofa_v2 import DOFAv2
+    from oracle.encoder import get_2d_sincos_pos_embed
+    e = DOFAv2(img_size=56, embed_dim=64, depth=1, num_heads=1, pretrained=False)
+    assert torch.equal(e.pos_embed[0], get_2d_sincos_pos_embed(64, 4, cls_token=True))
+    assert not e.pos_embed.requires_grad

@@ -1,0 +1,364 @@
+"""GPU parity tests, op level: every HIP kernel (through the C-ABI) vs a plain PyTorch f32/f64
+CPU reference of the same op on seeded inputs.  f32 tolerance 1e-4 (relative to the output
+scale), bf16 tolerance 2e-2."""
+
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+gdlhip = pytest.importorskip("gdlhip")
+from gdlhip import nn as gnn  # noqa: E402
+from gdlhip import ops  # noqa: E402
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return 1e-4 if dtype == torch.float32 else 2e-2
+
+
+def close(got, ref, dtype, what="", scale=None):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    s = ref.abs().max().item() if scale is None else scale
+    err = (got - ref).abs().max().item()
+    assert err <= tol(dtype) * max(s, 1e-6), f"{what}: max err {err:.3e} vs scale {s:.3e}"
+
+
+def rnd(*shape, seed=0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g).to(dtype)
+
+
+def q(t, dtype):
+    """quantise a f32 CPU tensor to the compute dtype (reference sees the same operand values)."""
+    return t.to(dtype).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,K,N", [(300, 128, 192), (64, 64, 64), (1297, 768, 256), (3, 128, 1024)])
+def test_linear_plain(dtype, M, K, N):
+    x, w = q(rnd(M, K), dtype), q(rnd(N, K, seed=1), dtype)
+    y = ops.linear(x.to(DEV, dtype), w.to(DEV, dtype), out_dtype=torch.float32)
+    close(y, x @ w.t(), dtype, "linear")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_epilogues(dtype):
+    B, T, K, N = 2, 150, 128, 256
+    x, w = q(rnd(B, T, K), dtype), q(rnd(N, K, seed=1), dtype) * 0.1
+    bias, scale, shift = rnd(N, seed=2), rnd(N, seed=3), rnd(N, seed=4)
+    resid, bs = rnd(B, T, N, seed=5), torch.tensor([0.0, 1.25])
+    xd, wd = x.to(DEV, dtype), w.to(DEV, dtype)
+    base = x @ w.t()
+    y = ops.linear(xd, wd, bias.to(DEV), act=ops.ACT_GELU, out_dtype=torch.float32)
+    close(y, F.gelu(base + bias), dtype, "gelu")
+    y = ops.linear(xd, wd, bias.to(DEV), scale=scale.to(DEV), shift=shift.to(DEV), act=ops.ACT_RELU,
+                   out_dtype=torch.float32)
+    close(y, F.relu((base + bias) * scale + shift), dtype, "bn-fold relu")
+    out = torch.empty(B, 1, T, N, device=DEV)
+    ops.conv_gemm(xd.view(B, 1, T, K), wd, bias=bias.to(DEV), scale=scale.to(DEV), batch_scale=bs.to(DEV),
+                  resid=resid.to(DEV).view(B, 1, T, N), out=out)
+    ref = resid + ((base + bias) * scale) * bs.view(B, 1, 1)
+    close(out.view(B, T, N), ref, dtype, "layerscale+droppath+residual")
+    y = ops.linear(xd, wd, out_dtype=dtype, alpha=0.5)
+    close(y, 0.5 * base, dtype if dtype == torch.float32 else torch.bfloat16, "alpha / out dtype")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,N,R", [(2, 10, 12, 64, 96, 3), (1, 18, 18, 128, 256, 3), (2, 7, 5, 64, 64, 1),
+                                         (3, 36, 36, 64, 128, 3)])
+def test_conv_nhwc(dtype, B, H, W, C, N, R):
+    x, w = q(rnd(B, C, H, W), dtype), q(rnd(N, C, R, R, seed=1) * 0.1, dtype)
+    bias = rnd(N, seed=2)
+    ref = F.conv2d(x, w, bias, padding=R // 2)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    wq = w.permute(0, 2, 3, 1).reshape(N, -1).contiguous().to(DEV, dtype)
+    y = ops.conv_gemm(xn, wq, R=R, S=R, pad=R // 2, bias=bias.to(DEV), out_dtype=torch.float32)
+    close(y.permute(0, 3, 1, 2), ref, dtype, "conv")
+
+
+def test_conv_strided_views():
+    """channel-sliced input and output buffers (concat-free decoder), tokens with a cls row."""
+    dtype = torch.float32
+    B, H, W = 2, 6, 6
+    big_in = rnd(B, H, W, 160).to(DEV)
+    x = big_in[..., 32:96]                     # 64 channels inside a 160-channel buffer
+    w = rnd(64, 64 * 9, seed=1).to(DEV) * 0.1
+    big_out = torch.zeros(B, H, W, 192, device=DEV)
+    ops.conv_gemm(x, w, R=3, S=3, pad=1, out=big_out[..., 64:128])
+    ref = F.conv2d(x.permute(0, 3, 1, 2).cpu(), w.cpu().view(64, 3, 3, 64).permute(0, 3, 1, 2), padding=1)
+    close(big_out[..., 64:128].permute(0, 3, 1, 2), ref, dtype, "sliced conv")
+    assert big_out[..., :64].abs().max().item() == 0 and big_out[..., 128:].abs().max().item() == 0
+    tok = rnd(B, 37, 64).to(DEV)               # taps: drop the cls token, view as 6x6 NHWC
+    tap = tok[:, 1:, :].unflatten(1, (6, 6))
+    y = ops.conv_gemm(tap, w[:, :64].contiguous(), out_dtype=torch.float32)
+    close(y.reshape(B, 36, 64), tok[:, 1:, :].cpu() @ w[:, :64].cpu().t(), dtype, "tap 1x1")
+
+
+def test_conv_arg_validation():
+    x = torch.zeros(1, 4, 4, 48, device=DEV)
+    w = torch.zeros(64, 48, device=DEV)
+    with pytest.raises(ValueError):
+        ops.conv_gemm(x, w)  # C not a multiple of 32
+    with pytest.raises(ValueError):
+        ops.conv_gemm(torch.zeros(1, 4, 4, 64), torch.zeros(64, 64))  # CPU tensors
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,H,hd", [(2, 70, 2, 64), (1, 197, 3, 64), (1, 132, 4, 32)])
+def test_attention_unfused(dtype, B, N, H, hd):
+    if dtype == torch.bfloat16 and hd % 64:
+        pytest.skip("bf16 needs head_dim % 64 == 0")
+    D = H * hd
+    qkv = q(rnd(B, N, 3 * D), dtype)
+    o = ops.attention_unfused(qkv.to(DEV, dtype), H)
+    qq, kk, vv = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, N, D)
+    close(o, ref, dtype, "attention_unfused")
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 70, 2), (1, 1297, 2), (2, 128, 3), (1, 65, 1)])
+def test_attention_flash(B, N, H):
+    dtype, hd = torch.bfloat16, 64
+    D = H * hd
+    qkv = q(rnd(B, N, 3 * D) * 1.5, dtype)
+    o = ops.attention_flash(qkv.to(DEV, dtype), H)
+    qq, kk, vv = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, N, D)
+    close(o, ref, dtype, "attention_flash")
+
+
+def test_attention_flash_spike():
+    """one dominant key late in the sequence forces the online-softmax rescale branch."""
+    B, N, H, hd = 1, 300, 1, 64
+    qkv = rnd(B, N, 3 * hd) * 0.5
+    qkv[0, 5, :hd] = 4.0            # query 5
+    qkv[0, 260, hd:2 * hd] = 4.0    # key 260 aligned with it -> score 1024/8 = 128
+    qkv = q(qkv, torch.bfloat16)
+    o = ops.attention_flash(qkv.to(DEV, torch.bfloat16), H)
+    qq, kk, vv = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, N, hd)
+    close(o, ref, torch.bfloat16, "attention_flash spike")
+
+
+@pytest.mark.parametrize("out_dtype", DTYPES)
+@pytest.mark.parametrize("D", [128, 768, 1024])
+def test_layernorm(out_dtype, D):
+    x, g, b = rnd(5, 33, D) * 3 + 1, rnd(D, seed=1), rnd(D, seed=2)
+    y = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, out_dtype)
+    close(y, F.layer_norm(x, (D,), g, b, 1e-5), out_dtype, "layernorm")
+    xs = rnd(4, 10, D).to(DEV)[:, 1:, :]   # strided rows
+    y = ops.layernorm(xs, g.to(DEV), b.to(DEV), 1e-5, torch.float32)
+    close(y, F.layer_norm(xs.cpu(), (D,), g, b, 1e-5), torch.float32, "layernorm strided")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 7, 64), (2, 1, 1, 256), (3, 24, 24, 128)])
+def test_batchnorm_train(dtype, B, H, W, C):
+    x = q(rnd(B, H, W, C) * 2 + 0.5, dtype)
+    g, b = rnd(C, seed=1), rnd(C, seed=2)
+    rm, rv = rnd(C, seed=3) * 0.1, rnd(C, seed=4).abs() + 0.5
+    dy = q(rnd(B, H, W, C, seed=5), dtype)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    yr = F.relu(F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5))
+    yr.backward(dy.permute(0, 3, 1, 2))
+    xd = x.to(DEV, dtype)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    mean, var = ops.bn_stats(xd, rmd, rvd, 0.1)
+    close(rmd, rm_ref, torch.float32, "running_mean")
+    close(rvd, rv_ref, torch.float32, "running_var")
+    y = ops.bn_apply(xd, mean, var, g.to(DEV), b.to(DEV), 1e-5, True)
+    close(y.permute(0, 3, 1, 2), yr, dtype, "bn fwd")
+    dyd = dy.to(DEV, dtype)
+    dg, db = ops.bn_bwd_reduce(xd, dyd, mean, var, g.to(DEV), b.to(DEV), 1e-5, True)
+    if B * H * W > 2:  # with 2 samples xhat = +-1 and the reference itself is ill-conditioned
+        close(dg, gr.grad, dtype, "dgamma")
+        close(db, br.grad, dtype, "dbeta")
+        dx = ops.bn_bwd_dx(xd, dyd, mean, var, g.to(DEV), b.to(DEV), 1e-5, True, dg, db, B * H * W)
+        close(dx.permute(0, 3, 1, 2), xr.grad, dtype, "bn dx", scale=xr.grad.abs().max().item() + 1e-3)
+
+
+def test_bn_fold_matches_eval_bn():
+    C = 96
+    g, b, rm, rv = rnd(C), rnd(C, seed=1), rnd(C, seed=2), rnd(C, seed=3).abs() + 0.3
+    x = rnd(2, C, 5, 5)
+    scale, shift = ops.bn_fold(g.to(DEV), b.to(DEV), rm.to(DEV), rv.to(DEV), 1e-5)
+    ref = F.batch_norm(x, rm, rv, g, b, False, 0.1, 1e-5)
+    close(x * scale.cpu().view(1, C, 1, 1) + shift.cpu().view(1, C, 1, 1), ref, torch.float32, "bn_fold")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hi,ho", [(9, 36), (18, 36), (36, 18), (9, 32), (5, 5), (1, 6), (36, 128)])
+def test_bilinear(dtype, hi, ho):
+    B, C = 2, 64
+    x = q(rnd(B, hi, hi, C), dtype)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ref = F.interpolate(xr, size=(ho, ho), mode="bilinear", align_corners=False)
+    y = ops.bilinear(x.to(DEV, dtype), (ho, ho))
+    close(y.permute(0, 3, 1, 2), ref, dtype, "bilinear fwd")
+    dy = q(rnd(B, ho, ho, C, seed=3), dtype)
+    ref.backward(dy.permute(0, 3, 1, 2))
+    dx = ops.bilinear_bwd(dy.to(DEV, dtype), (hi, hi))
+    close(dx.permute(0, 3, 1, 2), xr.grad, dtype, "bilinear bwd")
+    # accumulate into a channel slice
+    buf = torch.ones(B, ho, ho, 2 * C, device=DEV, dtype=dtype)
+    ops.bilinear(x.to(DEV, dtype), (ho, ho), out=buf[..., C:], accumulate=True)
+    close(buf[..., C:].permute(0, 3, 1, 2), ref + 1, dtype, "bilinear accumulate")
+    assert (buf[..., :C] == 1).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hi,s", [(18, 1), (18, 2), (18, 3), (18, 6), (4, 6), (4, 3), (36, 6)])
+def test_adaptive_avgpool(dtype, hi, s):
+    B, C = 2, 64
+    x = q(rnd(B, hi, hi, C), dtype)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ref = F.adaptive_avg_pool2d(xr, s)
+    y = ops.adaptive_avgpool(x.to(DEV, dtype), s)
+    close(y.permute(0, 3, 1, 2), ref, dtype, "avgpool fwd")
+    dy = q(rnd(B, s, s, C, seed=2), dtype)
+    ref.backward(dy.permute(0, 3, 1, 2))
+    dx = ops.adaptive_avgpool_bwd(dy.to(DEV, dtype), (hi, hi))
+    close(dx.permute(0, 3, 1, 2), xr.grad, dtype, "avgpool bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,N,R", [(2, 12, 12, 64, 64, 3), (2, 9, 11, 128, 256, 3), (4, 8, 8, 256, 128, 1),
+                                         (2, 1, 1, 128, 256, 1), (1, 40, 40, 64, 64, 3)])
+def test_conv_backward(dtype, B, H, W, C, N, R):
+    x = q(rnd(B, C, H, W), dtype).requires_grad_(True)
+    w = q(rnd(N, C, R, R, seed=1) * 0.1, dtype).requires_grad_(True)
+    dy = q(rnd(B, N, H, W, seed=2), dtype)
+    F.conv2d(x, w, padding=R // 2).backward(dy)
+    xn = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    dw = ops.conv_wgrad(xn, dyn, R=R, S=R, pad=R // 2)
+    close(dw.view(N, R, R, C).permute(0, 3, 1, 2), w.grad, dtype, "wgrad")
+    wq = w.detach().permute(0, 2, 3, 1).reshape(N, -1).contiguous().to(DEV)
+    wd = ops.pack_dgrad(wq, N, R * R, C, dtype)
+    dx = ops.conv_gemm(dyn, wd, R=R, S=R, pad=R - 1 - R // 2, out_dtype=torch.float32)
+    close(dx.permute(0, 3, 1, 2), x.grad, dtype, "dgrad")
+
+
+def test_wgrad_strided_dy():
+    """dy as a channel slice of a wider gradient buffer (concat backward)."""
+    B, H, W, C, N = 2, 10, 10, 64, 64
+    x = rnd(B, H, W, C).to(DEV)
+    big = rnd(B, H, W, 3 * N, seed=1).to(DEV)
+    dy = big[..., N:2 * N]
+    dw = ops.conv_wgrad(x, dy, R=3, S=3, pad=1)
+    xr = x.cpu().permute(0, 3, 1, 2)
+    w = torch.zeros(N, C, 3, 3, requires_grad=True)
+    F.conv2d(xr, w, padding=1).backward(dy.cpu().permute(0, 3, 1, 2))
+    close(dw.view(N, 3, 3, C).permute(0, 3, 1, 2), w.grad, torch.float32, "wgrad strided dy")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_head_and_logit_upsample(dtype):
+    B, H, W, C, K, HO = 2, 9, 9, 256, 5, 32
+    feat = q(rnd(B, H, W, C), dtype)
+    w, bias = rnd(K, C, seed=1) * 0.1, rnd(K, seed=2)
+    cs = (torch.rand(B, C, generator=torch.Generator().manual_seed(3)) < 0.9).float() / 0.9
+    fr = feat.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    low = F.conv2d(fr * cs[:, :, None, None], wr.view(K, C, 1, 1), br)
+    ref = F.interpolate(low, size=(HO, HO), mode="bilinear", align_corners=False)
+    got_low = ops.head_1x1(feat.to(DEV, dtype), w.to(DEV), bias.to(DEV), cs.to(DEV))
+    close(got_low.permute(0, 3, 1, 2), low, torch.float32 if dtype == torch.float32 else dtype, "head 1x1")
+    got = ops.upsample_logits(got_low, (HO, HO))
+    close(got, ref, dtype, "upsample logits")
+    g = rnd(B, K, HO, HO, seed=4)
+    ref.backward(g)
+    dlow = ops.upsample_logits_bwd(g.to(DEV), (H, W))
+    dfeat, dw, db = ops.head_1x1_bwd(feat.to(DEV, dtype), dlow, w.to(DEV), cs.to(DEV))
+    close(dfeat.permute(0, 3, 1, 2), fr.grad, dtype, "head dfeat")
+    close(dw, wr.grad, dtype, "head dw")
+    close(db, br.grad, dtype, "head db")
+
+
+def test_softmax_argmax_bit_exact():
+    logits = rnd(2, 5, 64, 64) * 4
+    logits[0, 1, :8] = logits[0, 3, :8]          # exact ties -> first index must win
+    got = ops.softmax_argmax(logits.to(DEV)).cpu()
+    ref = logits.softmax(dim=1).argmax(dim=1)
+    assert got.dtype == torch.int64 and torch.equal(got, ref)
+
+
+def test_dice_loss():
+    import oracle
+    B, K, H = 2, 5, 48
+    logits = (rnd(B, K, H, H) * 2).requires_grad_(True)
+    y = torch.randint(0, 4, (B, H, H), generator=torch.Generator().manual_seed(1))  # class 4 absent
+    ref = oracle.model.dice_loss_multiclass(logits, y)
+    (ref * 0.4).backward()
+    ld = logits.detach().to(DEV).requires_grad_(True)
+    loss = gnn.DiceLoss()(ld, y.to(DEV))
+    (loss * 0.4).backward()
+    assert abs(loss.item() - ref.item()) < 1e-6
+    close(ld.grad, logits.grad, torch.float32, "dice grad")
+
+
+def test_adam_and_clip():
+    torch.manual_seed(0)
+    ps = [torch.randn(1000, 3), torch.randn(64, 32, 3, 3).contiguous(memory_format=torch.channels_last)]
+    gs = [torch.randn_like(p) * 3 for p in ps]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    mine = [p.clone().to(DEV).requires_grad_(True) for p in ps]
+    o_ref = torch.optim.Adam(ref, lr=6e-5)
+    o_mine = gnn.FusedAdam(mine, lr=6e-5, max_grad_norm=1.0)
+    for step in range(3):
+        for r, m, g in zip(ref, mine, gs):
+            r.grad = g.clone() * (step + 1)
+            m.grad = (g.clone() * (step + 1)).to(DEV)
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        o_ref.step()
+        o_mine.step()
+    for r, m in zip(ref, mine):
+        assert (m.detach().cpu() - r.detach()).abs().max().item() < 2e-6
+
+
+def test_patch_embed_pieces():
+    B, C, H, P, D = 2, 3, 56, 14, 64
+    img = rnd(B, C, H, H)
+    g = rnd(C, P * P * D, seed=1)
+    w_ref = (g.view(C, P, P, D).permute(3, 0, 1, 2) * 0.01)
+    ref = F.conv2d(img, w_ref, stride=P, padding=1).flatten(2).transpose(1, 2)
+    gh = (H + 2 - P) // P + 1
+    kpad = (C * P * P + 31) // 32 * 32
+    cols = ops.patchify(img.to(DEV), P, 1, gh, gh, kpad, torch.float32)
+    wq = ops.dofa_pack_kernel(g.to(DEV), C, P * P, D, 0.01, kpad, torch.float32)
+    y = ops.linear(cols, wq).view(B, gh * gh, D)
+    close(y, ref, torch.float32, "patch embed")
+
+
+def test_normalize_u8_golden(golden_dir):
+    import numpy as np
+    g = np.load(golden_dir / "tensors_preprocess.npz")
+    out = ops.normalize_u8(torch.from_numpy(g["u8"]).to(DEV), torch.from_numpy(g["mean"]).flatten().to(DEV),
+                           torch.from_numpy(g["std"]).flatten().to(DEV))
+    assert (out.cpu() - torch.from_numpy(g["out"])).abs().max().item() < 1e-6
+
+
+def test_sincos_embed():
+    from oracle.encoder import position_embedding
+    wv = torch.tensor([0.665, 0.549, 0.481, 2.19])
+    got = ops.sincos_embed((wv * 1000).to(DEV), 128)
+    close(got, position_embedding(128, wv * 1000), torch.float32, "sincos", scale=1.0)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from gdlhip import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_lib.GdlHipError):
+        ops.cast(torch.zeros(4, device=DEV), torch.bfloat16)
+    assert not math.isnan(0.0)
