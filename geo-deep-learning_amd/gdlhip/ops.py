@@ -64,9 +64,17 @@ def as_nchw(x: Tensor) -> Tensor:
 def _nhwc4(x: Tensor, name: str) -> Tensor:
     if x.dim() == 2:
         x = x.unsqueeze(0).unsqueeze(0)
-    if x.dim() != 4 or x.stride(-1) != 1:
+    if x.dim() != 4 or (x.stride(-1) != 1 and x.shape[-1] != 1):
         raise ValueError(f"{name}: expected NHWC tensor with unit channel stride, got "
                          f"shape {tuple(x.shape)} strides {x.stride()}")
+    # strides of size-1 dims are arbitrary in torch: canonicalise them (alignment checks, "dense" tests)
+    B, H, W, Cc = x.shape
+    sB, sH, sW, _ = x.stride()
+    nW = sW if W > 1 else Cc
+    nH = sH if H > 1 else W * nW
+    nB = sB if B > 1 else H * nH
+    if (nB, nH, nW) != (sB, sH, sW) or x.stride(-1) != 1:
+        x = x.as_strided((B, H, W, Cc), (nB, nH, nW, 1))
     return x
 
 

