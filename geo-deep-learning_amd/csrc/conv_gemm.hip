@@ -282,12 +282,22 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   k.out_dense = (a.out_sH == (int64_t)a.Wo * a.out_sW && a.out_sB == (int64_t)a.Ho * a.out_sH);
   k.res_dense = !a.resid || (a.res_sH == (int64_t)a.Wo * a.res_sW && a.res_sB == (int64_t)a.Ho * a.res_sH);
   hipStream_t s = (hipStream_t)stream;
-  // Tile selection: big tiles when there is enough work to fill 256 CUs, else smaller.
-  const int64_t big_tiles = (int64_t)((k.M + 127) / 128) * ((a.N + 127) / 128) * a.nz;
+  const int variant = gdl_conv_gemm_plan(ap, nullptr);
   if (a.dtype == GDL_BF16) {
-    if (big_tiles >= 256 && a.N >= 128) return launch<bf16_tag, 2, 2, 2, 2>(k, s);
+    if (variant == 1) return launch<bf16_tag, 2, 2, 2, 2>(k, s);
     return launch<bf16_tag, 2, 2, 1, 1>(k, s);
   }
-  if (big_tiles >= 256 && a.N >= 128) return launch<float, 2, 2, 2, 2>(k, s);
+  if (variant == 1) return launch<float, 2, 2, 2, 2>(k, s);
   return launch<float, 2, 2, 1, 1>(k, s);
+}
+
+// Tile selection: 128x128 tiles (variant 1) when there is enough work to fill 256 CUs, else 64x64
+// (variant 0).  Also reports the ALGORITHMIC flops of the call (2*M*N*K, no padding counted).
+extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
+  if (!ap) return -1;
+  const gdl_conv_args& a = *ap;
+  const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
+  if (flops) *flops = 2 * M * a.N * ((int64_t)a.R * a.S * a.C) * a.nz;
+  const int64_t big_tiles = ((M + 127) / 128) * ((a.N + 127) / 128) * a.nz;
+  return (big_tiles >= 256 && a.N >= 128) ? 1 : 0;
 }

@@ -54,6 +54,7 @@ SIGNATURES = {
     "gdl_version": (c_i, []),
     "gdl_last_error": (C.c_char_p, []),
     "gdl_conv_gemm": (c_i, [C.POINTER(ConvArgs), c_p]),
+    "gdl_conv_gemm_plan": (c_i, [C.POINTER(ConvArgs), C.POINTER(c_l)]),
     "gdl_conv_wgrad_workspace": (c_l, [C.POINTER(WgradArgs)]),
     "gdl_conv_wgrad": (c_i, [C.POINTER(WgradArgs), c_p]),
     "gdl_layernorm_fwd": (c_i, [c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_i, c_f, c_p]),

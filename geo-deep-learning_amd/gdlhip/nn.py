@@ -88,6 +88,36 @@ def _world(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+# ------------------------------------------------------------------ SyncBatchNorm exchange
+def sync_batch_stats(mean: Tensor, var: Tensor, group=None) -> tuple[Tensor, Tensor]:
+    """Merge per-rank batch statistics into global ones (nn.SyncBatchNorm forward).
+
+    Every rank holds the same pixel count (fixed per-GPU batch, weak scaling), so the global mean
+    is the average of means and the global E[x^2] the average of (var + mean^2): ONE small
+    all-reduce of 2C floats per layer instead of torch's all_gather of [mean, invstd, count].
+    """
+    world = dist.get_world_size(group)
+    packed = torch.stack([mean, var + mean * mean])
+    dist.all_reduce(packed, group=group)
+    packed /= world
+    gmean = packed[0].contiguous()
+    gvar = (packed[1] - gmean * gmean).clamp_min_(0).contiguous()
+    return gmean, gvar
+
+
+def update_running_stats(running_mean, running_var, mean, var, momentum: float, count: int) -> None:
+    """nn.BatchNorm2d running-stat update with the UNBIASED variance."""
+    running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+    running_var.mul_(1 - momentum).add_(var, alpha=momentum * count / max(count - 1, 1))
+
+
+def sync_sum_pair(a: Tensor, b: Tensor, group=None) -> tuple[Tensor, Tensor]:
+    """all-reduce(SUM) of the two BN-backward reductions in one message (SyncBatchNorm backward)."""
+    packed = torch.stack([a, b])
+    dist.all_reduce(packed, group=group)
+    return packed[0].contiguous(), packed[1].contiguous()
+
+
 # ------------------------------------------------------------------ conv -> BN -> ReLU
 class _ConvBNActTrain(Function):
     """Training-mode ConvModule: conv(+bias) -> BatchNorm(batch stats) -> ReLU.
@@ -106,15 +136,9 @@ class _ConvBNActTrain(Function):
         world = _world(sync_group) if sync_group is not False else 1
         if world > 1:
             mean, var = ops.bn_stats(y)
-            # equal per-rank pixel counts (fixed per-GPU batch): average mean and E[x^2]
-            packed = torch.stack([mean, var + mean * mean])
-            dist.all_reduce(packed, group=sync_group or None)
-            packed /= world
-            mean, var = packed[0].contiguous(), (packed[1] - packed[0] * packed[0]).clamp_min_(0).contiguous()
+            mean, var = sync_batch_stats(mean, var, sync_group or None)
             if running_mean is not None:
-                p_tot = y.numel() // n * world
-                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var, alpha=momentum * p_tot / max(p_tot - 1, 1))
+                update_running_stats(running_mean, running_var, mean, var, momentum, y.numel() // n * world)
         else:
             mean, var = ops.bn_stats(y, running_mean, running_var, momentum)
         out = ops.bn_apply(y, mean, var, gamma.detach(), beta.detach(), eps, relu)
@@ -134,9 +158,7 @@ class _ConvBNActTrain(Function):
         p_local = y.numel() // n
         sg, sb = dgamma, dbeta
         if world > 1:
-            packed = torch.stack([dgamma, dbeta])
-            dist.all_reduce(packed, group=sync_group or None)
-            sg, sb = packed[0].contiguous(), packed[1].contiguous()
+            sg, sb = sync_sum_pair(dgamma, dbeta, sync_group or None)
         dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, p_local * world, out=y)
         dw = None
         if ctx.needs_input_grad[1]:

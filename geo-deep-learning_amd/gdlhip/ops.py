@@ -124,10 +124,52 @@ def conv_gemm(x: Tensor, w: Tensor, *, R: int = 1, S: int = 1, stride: int = 1, 
         a.res_sB = r4.stride(0) if r4.shape[0] == B else 0
         a.res_sH, a.res_sW = r4.stride(1), r4.stride(2)
     a.nz, a.nz_inner = 1, 1
-    check(_lib.load().gdl_conv_gemm(C.byref(a), _stream()), "gdl_conv_gemm")
+    _launch_conv_gemm(a, "gdl_conv_gemm")
     if two_d and out4 is out:
         return out.view(Wo, N)
     return out
+
+
+class KernelTimer:
+    """HIP-event timing of every gdl_conv_gemm launch (bench.py's roofline leg).  Events are
+    recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    VARIANT = {0: "conv_gemm_kernel<{dt},2,2,1,1> (64x64 tiles)", 1: "conv_gemm_kernel<{dt},2,2,2,2> (128x128 tiles)"}
+
+    def __init__(self) -> None:
+        self.records: list = []
+
+    def launch(self, a: ConvArgs, what: str) -> None:
+        lib = _lib.load()
+        fl = C.c_int64()
+        variant = lib.gdl_conv_gemm_plan(C.byref(a), C.byref(fl))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        status = lib.gdl_conv_gemm(C.byref(a), _stream())
+        e1.record()
+        check(status, what)
+        key = self.VARIANT[variant].format(dt="bf16" if a.dtype == BF16 else "f32")
+        self.records.append((key, fl.value, e0, e1))
+
+    def summary(self) -> dict:
+        torch.cuda.synchronize()
+        out: dict = {}
+        for key, flops, e0, e1 in self.records:
+            s = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0})
+            s["launches"] += 1
+            s["ms"] += e0.elapsed_time(e1)
+            s["flops"] += flops
+        return out
+
+
+TIMER: KernelTimer | None = None
+
+
+def _launch_conv_gemm(a: ConvArgs, what: str) -> None:
+    if TIMER is not None:
+        TIMER.launch(a, what)
+    else:
+        check(_lib.load().gdl_conv_gemm(C.byref(a), _stream()), what)
 
 
 def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, **kw) -> Tensor:
@@ -144,7 +186,7 @@ def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, **kw) -> Tensor:
 
 
 def batched_gemm_raw(a: ConvArgs) -> None:
-    check(_lib.load().gdl_conv_gemm(C.byref(a), _stream()), "gdl_conv_gemm(batched)")
+    _launch_conv_gemm(a, "gdl_conv_gemm(batched)")
 
 
 def conv_wgrad(x: Tensor, dy: Tensor, *, R: int, S: int, stride: int = 1, pad: int = 0,

@@ -77,6 +77,9 @@ typedef struct {
 } gdl_conv_args;
 
 int gdl_conv_gemm(const gdl_conv_args* a, gdl_stream_t stream);
+/* Which kernel variant the call above will launch (1 = 128x128 tiles, 0 = 64x64 tiles) and its
+ * algorithmic flops 2*M*N*K (for roofline accounting in bench.py). */
+int gdl_conv_gemm_plan(const gdl_conv_args* a, int64_t* flops);
 
 /* Weight gradient of the same convolution:
  * dw[n, (r*S+s)*C + c] (+)= sum_{b,oy,ox} dy[b,oy,ox,n] * in[b, oy*stride+r-pad, ox*stride+s-pad, c]
