@@ -3,21 +3,33 @@
 //   out[m, n] = epi( alpha * sum_{tap, c} in[pixel(m) + tap, c] * w[n, tap*C + c] )
 //
 // * NHWC activations, [N][R*S*C] weights: both operands are K-contiguous, so an operand
-//   tile is ROWS x 128 bytes of K (64 bf16 or 32 f32) -- im2col never exists in memory;
-//   the 3x3 halo/zero padding is resolved per 16-byte chunk while staging.
-// * Staging: global -> VGPR (16 B/lane, issued BEFORE the MFMA phase of the current tile)
-//   -> LDS (written AFTER it), two LDS stages, one barrier per K-step.
-// * LDS tile rows are 128 B; 16-byte chunk c of row r lives at chunk (c ^ ((r>>1)&7)), which
-//   makes the 4 x 16-lane groups of a ds_read_b128 fragment fetch conflict-free.
+//   tile is ROWS x 128 bytes of K (64 bf16 or 32 f32) -- im2col never exists in memory.
+// * Staging is direct global -> LDS DMA (global_load_lds_dwordx4, 1 KiB = 8 tile rows per
+//   wave-instruction, no VGPR round trip, no ds_write).  The 3x3 halo / zero padding / M and N
+//   tails need no predication: a lane whose 16-byte chunk is out of range simply points its
+//   (per-lane) SOURCE address at a zero page.
+// * The DMA writes LDS lane-linearly, so the bank swizzle lives on the source side: LDS slot s
+//   of row r receives source chunk s ^ ((r>>1)&7), and fragment reads apply the same involution
+//   (ds_read_b128 of chunk c at slot c ^ ((r>>1)&7)): the 4 x 16-lane groups of a fragment fetch
+//   hit 16 distinct 16-byte slots -> conflict-free.
+// * Two LDS stages; per K-step: wait own DMA (vmcnt 0) -> barrier -> issue next tile's DMA ->
+//   MFMA phase of the current tile (DMA in flight underneath).  One barrier per K-step.
 // * MFMA: v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (exact f32 -- the parity
-//   path); a wave owns TM x TN tiles of 32x32, f32 accumulators stay in registers.
-// * K order inside a 32-byte chunk pair is permuted identically for both operands (legal for
-//   a reduction), so both dtypes fetch fragments with the same ds_read_b128.
+//   path); a wave owns TM x TN tiles of 32x32, f32 accumulators stay in registers.  K order
+//   inside a 32-byte chunk pair is permuted identically for both operands (legal for a
+//   reduction), so both dtypes fetch fragments with the same ds_read_b128.
 // * blockIdx -> tile mapping is XCD-aware: the blocks of one XCD walk neighbouring N tiles of
 //   the same M rows so the activation rows are re-read from that XCD's L2.
+#include <type_traits>
+
 #include "gdl_common.h"
 
 namespace {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ uint4 g_zero_page[8];  // 128 bytes of zeros: source of every out-of-range chunk
 
 struct KArgs {
   gdl_conv_args a;
@@ -43,17 +55,16 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   constexpr int ES = TileTraits<T>::ES;
   constexpr int BKE = TileTraits<T>::BKE;
   constexpr int BM = WARPS_M * TM * 32, BN = WARPS_N * TN * 32;
-  constexpr int NT = 64 * WARPS_M * WARPS_N;
-  constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;  // 16-B chunks per thread per tile
-  constexpr int ROWSTEP = NT / 8;
-  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+  constexpr int NW = WARPS_M * WARPS_N;
+  constexpr int CA = BM / (8 * NW), CB = BN / (8 * NW);  // DMA instructions per wave per tile
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/waves mismatch");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // layout: [stage][A: BM*128 | B: BN*128]
-  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;  // [A: BM rows | B: BN rows] x 128 B
 
   const gdl_conv_args& a = k.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
   const int lid = xcd_remap(blockIdx.x, k.tiles_m * k.tiles_n);
@@ -61,75 +72,69 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.y;
   const int z0 = z / a.nz_inner, z1 = z % a.nz_inner;
-  const unsigned char* in_base =
-      (const unsigned char*)a.in + (z0 * a.in_sZ0 + z1 * a.in_sZ1) * ES;
+  const unsigned char* in_base = (const unsigned char*)a.in + (z0 * a.in_sZ0 + z1 * a.in_sZ1) * ES;
   const unsigned char* w_base = (const unsigned char*)a.w + (z0 * a.w_sZ0 + z1 * a.w_sZ1) * ES;
   const int64_t out_zoff = z0 * a.out_sZ0 + z1 * a.out_sZ1;
+  const unsigned char* zero = (const unsigned char*)g_zero_page;
 
-  // ---- per-thread staging geometry ----
-  const int cchunk = tid & 7;        // which 16-B chunk of the 128-B row
-  const int crow = tid >> 3;         // first row handled
-  int64_t a_off[CA];                 // element offset of (iy0, ix0, c=0) for the row
+  // ---- DMA geometry: wave w, instruction i covers tile rows (i*NW + w)*8 .. +7; lane l writes
+  //      LDS slot (l & 7) of row +(l >> 3) and therefore fetches source chunk slot ^ swz(row).
+  const int lrow = lane >> 3, lslot = lane & 7;
+  int64_t a_off[CA];   // byte offset of (iy0, ix0, chunk) for the row, tap (0,0), cc = 0
   int a_iy0[CA], a_ix0[CA];
   bool a_ok[CA];
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int i = 0; i < CA; ++i) {
-    const int m = m0 + crow + i * ROWSTEP;
+    const int r = (i * NW + wave) * 8 + lrow;
+    const int chunk = lslot ^ ((r >> 1) & 7);
+    const int m = m0 + r;
     a_ok[i] = m < k.M;
     const int mm = a_ok[i] ? m : 0;
-    int b, oy, ox;
-    if (k.in_dense) { b = 0; oy = 0; ox = mm; }
-    else { b = mm / HoWo; const int rem = mm - b * HoWo; oy = rem / a.Wo; ox = rem - oy * a.Wo; }
+    int64_t off;
     if (k.in_dense) {  // 1x1, stride 1, dense rows: offset is linear in m, nothing to clip
       a_iy0[i] = 0; a_ix0[i] = 0;
-      a_off[i] = (int64_t)mm * a.in_sW;
+      off = (int64_t)mm * a.in_sW;
     } else {
+      const int b = mm / HoWo, rem = mm - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
       a_iy0[i] = oy * a.stride - a.pad;
       a_ix0[i] = ox * a.stride - a.pad;
-      a_off[i] = (int64_t)b * a.in_sB + (int64_t)a_iy0[i] * a.in_sH + (int64_t)a_ix0[i] * a.in_sW;
+      off = (int64_t)b * a.in_sB + (int64_t)a_iy0[i] * a.in_sH + (int64_t)a_ix0[i] * a.in_sW;
     }
+    a_off[i] = (off + chunk * (16 / ES)) * ES;
   }
-  int64_t b_off[CB];
+  const unsigned char* b_ptr[CB];  // weight row + chunk (k = 0); nullptr-free: tails use zero page
   bool b_ok[CB];
 #pragma unroll
   for (int i = 0; i < CB; ++i) {
-    const int n = n0 + crow + i * ROWSTEP;
+    const int r = (i * NW + wave) * 8 + lrow;
+    const int chunk = lslot ^ ((r >> 1) & 7);
+    const int n = n0 + r;
     b_ok[i] = n < a.N;
-    b_off[i] = (int64_t)(b_ok[i] ? n : 0) * a.w_sN;
+    b_ptr[i] = w_base + ((int64_t)(b_ok[i] ? n : 0) * a.w_sN + chunk * (16 / ES)) * ES;
   }
 
-  uint4 ra[CA], rb[CB];
   int tap_r = 0, tap_s = 0, cc = 0;  // position of the NEXT tile to fetch
+  int64_t wk = 0;                    // its byte offset along the weight rows
 
-  auto fetch = [&]() {
-    const int64_t tap_off = (int64_t)tap_r * a.in_sH + (int64_t)tap_s * a.in_sW +
-                            (int64_t)cc * BKE + cchunk * (16 / ES);
-    const int64_t wk = ((int64_t)(tap_r * a.S + tap_s) * a.C) + (int64_t)cc * BKE + cchunk * (16 / ES);
+  auto issue = [&](int stage) {
+    unsigned char* sa = smem + stage * STAGE_BYTES;
+    unsigned char* sb = sa + BM * 128;
+    const int64_t tap_off = ((int64_t)tap_r * a.in_sH + (int64_t)tap_s * a.in_sW + (int64_t)cc * BKE) * ES;
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
       const bool ok = a_ok[i] && (unsigned)(a_iy0[i] + tap_r) < (unsigned)a.H &&
                       (unsigned)(a_ix0[i] + tap_s) < (unsigned)a.W;
-      ra[i] = ok ? *(const uint4*)(in_base + (a_off[i] + tap_off) * ES) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < CB; ++i)
-      rb[i] = b_ok[i] ? *(const uint4*)(w_base + (b_off[i] + wk) * ES) : make_uint4(0, 0, 0, 0);
-    if (++cc == k.kc) { cc = 0; if (++tap_s == a.S) { tap_s = 0; ++tap_r; } }
-  };
-  auto stash = [&](int stage) {
-    unsigned char* sa = smem + stage * STAGE_BYTES;
-    unsigned char* sb = sa + BM * 128;
-#pragma unroll
-    for (int i = 0; i < CA; ++i) {
-      const int r = crow + i * ROWSTEP;
-      *(uint4*)(sa + r * 128 + ((cchunk ^ ((r >> 1) & 7)) << 4)) = ra[i];
+      const unsigned char* src = ok ? in_base + a_off[i] + tap_off : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (i * NW + wave) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
-      const int r = crow + i * ROWSTEP;
-      *(uint4*)(sb + r * 128 + ((cchunk ^ ((r >> 1) & 7)) << 4)) = rb[i];
+      const unsigned char* src = b_ok[i] ? b_ptr[i] + wk : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (i * NW + wave) * 1024), 16, 0, 0);
     }
+    wk += 128;
+    if (++cc == k.kc) { cc = 0; if (++tap_s == a.S) { tap_s = 0; ++tap_r; } }
   };
 
   f32x16_t acc[TM][TN];
@@ -145,13 +150,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   const int a_lds0 = (wm * TM * 32 + frow) * 128;
   const int b_lds0 = BM * 128 + (wn * TN * 32 + frow) * 128;
 
-  fetch();
-  stash(0);
-  __syncthreads();
-
+  issue(0);
   for (int kt = 0; kt < k.KT; ++kt) {
-    const bool more = kt + 1 < k.KT;
-    if (more) fetch();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for tile kt has landed
+    __syncthreads();                                   // ... and everyone's; everyone left tile kt-1
+    if (kt + 1 < k.KT) issue((kt + 1) & 1);            // DMA of tile kt+1 flies under the MFMAs
     const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -181,8 +184,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
           }
         }
     }
-    if (more) stash((kt + 1) & 1);
-    __syncthreads();
   }
 
   // ---- epilogue: lane holds column n = lane&31 of each tile, rows (r&3)+8(r>>2)+4*fhalf ----
@@ -197,38 +198,91 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
     e_scale[j] = a.scale ? a.scale[nn] : 1.f;
     e_shift[j] = a.shift ? a.shift[nn] : 0.f;
   }
+  // Phase 1 (per 32-row slab i): apply the per-column epilogue in registers and park the slab in a
+  // wave-private LDS region as [32 rows][TN*32 cols] in the OUTPUT dtype.  Phase 2: every lane
+  // picks up 16 contiguous bytes of one row, applies the per-row terms (DropPath scale, residual)
+  // and issues ONE coalesced 16-byte store -- instead of 16*TN scattered 2/4-byte stores.
+  __syncthreads();  // all waves are done with the operand stages: LDS is free for the transposes
+  auto run = [&](auto oes_c) {
+    constexpr int OES = decltype(oes_c)::value;        // output element size
+    constexpr int COLS = TN * 32;
+    constexpr int ROWB = COLS * OES + 16;              // +16 B pad: the two half-waves hit different banks
+    constexpr int CPR = COLS * OES / 16;               // 16-byte chunks per row
+    constexpr int PER = 16 / OES;                      // elements per chunk
+    constexpr int PASSES = 32 * CPR / 64;
+    unsigned char* reg = smem + wave * (32 * ROWB);
+    const int prow = lane / CPR, pchunk = lane % CPR;
+    const bool vec_ok = ((uintptr_t)a.out % 16 == 0) && (a.out_sW % PER == 0) && (a.out_sH % PER == 0) &&
+                        (a.out_sB % PER == 0) && (out_zoff % PER == 0);
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-      if (m >= k.M) continue;
-      int64_t ooff, roff = 0;
-      float bscale = 1.f;
-      if (k.out_dense && k.res_dense && !a.batch_scale) {
-        ooff = (int64_t)m * a.out_sW;
-        roff = (int64_t)m * a.res_sW;
-      } else {
-        const int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
-        ooff = (int64_t)b * a.out_sB + (int64_t)oy * a.out_sH + (int64_t)ox * a.out_sW;
-        roff = (int64_t)b * a.res_sB + (int64_t)oy * a.res_sH + (int64_t)ox * a.res_sW;
-        if (a.batch_scale) bscale = a.batch_scale[b];
-      }
-      ooff += out_zoff;
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (!n_ok[j]) continue;
-        const int n = n0 + (wn * TN + j) * 32 + frow;
-        float v = acc[i][j][r] * a.alpha + e_bias[j];
-        if (a.scale) v = v * e_scale[j] + e_shift[j];
-        if (a.act == GDL_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (a.act == GDL_ACT_GELU) v = gelu_erf(v);
-        v *= bscale;
-        if (a.resid) v += load_as_f32(a.resid, roff + n, a.resid_dtype);
-        store_from_f32(a.out, ooff + n, v, a.out_dtype);
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] * a.alpha + e_bias[j];
+          if (a.scale) v = v * e_scale[j] + e_shift[j];
+          if (a.act == GDL_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (a.act == GDL_ACT_GELU) v = gelu_erf(v);
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+          unsigned char* q = reg + row * ROWB + (j * 32 + frow) * OES;
+          if constexpr (OES == 2) *(uint16_t*)q = f32_to_bf16(v);
+          else *(float*)q = v;
+        }
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const int row = ps * (64 / CPR) + prow;
+        const int m = m0 + (wm * TM + i) * 32 + row;
+        const int n = n0 + wn * COLS + pchunk * PER;
+        if (m >= k.M || n >= a.N) continue;
+        const uint4 raw = *(const uint4*)(reg + row * ROWB + pchunk * 16);
+        int64_t ooff, roff = 0;
+        float bscale = 1.f;
+        if (k.out_dense && k.res_dense && !a.batch_scale) {
+          ooff = (int64_t)m * a.out_sW;
+          roff = (int64_t)m * a.res_sW;
+        } else {
+          const int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+          ooff = (int64_t)b * a.out_sB + (int64_t)oy * a.out_sH + (int64_t)ox * a.out_sW;
+          roff = (int64_t)b * a.res_sB + (int64_t)oy * a.res_sH + (int64_t)ox * a.res_sW;
+          if (a.batch_scale) bscale = a.batch_scale[b];
+        }
+        ooff += out_zoff + n;
+        roff += n;
+        const bool full = n + PER <= a.N;
+        if (full && vec_ok && !a.resid && !a.batch_scale) {
+          *(uint4*)((unsigned char*)a.out + ooff * OES) = raw;
+          continue;
+        }
+        float v[PER];
+        if constexpr (OES == 2) {
+          const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w4[e] << 16); v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u); }
+        } else {
+          v[0] = __uint_as_float(raw.x); v[1] = __uint_as_float(raw.y); v[2] = __uint_as_float(raw.z); v[3] = __uint_as_float(raw.w);
+        }
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+          v[e] *= bscale;
+          if (a.resid && n + e < a.N) v[e] += load_as_f32(a.resid, roff + e, a.resid_dtype);
+        }
+        if (full && vec_ok) {
+          if constexpr (OES == 2)
+            *(uint4*)((unsigned char*)a.out + ooff * 2) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                                       pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+          else
+            *(float4*)((float*)a.out + ooff) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < PER; ++e)
+            if (n + e < a.N) store_from_f32(a.out, ooff + e, v[e], a.out_dtype);
+        }
       }
     }
-  }
+  };
+  if (a.out_dtype == GDL_BF16) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 4>{});
 }
 
 template <typename T, int WARPS_M, int WARPS_N, int TM, int TN>
@@ -284,20 +338,33 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int variant = gdl_conv_gemm_plan(ap, nullptr);
   if (a.dtype == GDL_BF16) {
+    if (variant == 2) return launch<bf16_tag, 2, 4, 4, 2>(k, s);
     if (variant == 1) return launch<bf16_tag, 2, 2, 2, 2>(k, s);
     return launch<bf16_tag, 2, 2, 1, 1>(k, s);
   }
+  if (variant == 2) return launch<float, 2, 4, 4, 2>(k, s);
   if (variant == 1) return launch<float, 2, 2, 2, 2>(k, s);
   return launch<float, 2, 2, 1, 1>(k, s);
 }
 
-// Tile selection: 128x128 tiles (variant 1) when there is enough work to fill 256 CUs, else 64x64
-// (variant 0).  Also reports the ALGORITHMIC flops of the call (2*M*N*K, no padding counted).
+// Tile selection by available parallelism (256 CUs): 256x256 tiles / 8 waves (variant 2) when
+// they still give >= 512 blocks, 128x128 / 4 waves (variant 1) when that gives >= 256 blocks,
+// else 64x64 (variant 0).  Also reports the ALGORITHMIC flops of the call (2*M*N*K, no padding).
+static int g_forced_variant = -1;
+extern "C" void gdl_debug_force_conv_variant(int v) { g_forced_variant = v; }  // tuning hook (-1 = auto)
+
 extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   if (!ap) return -1;
   const gdl_conv_args& a = *ap;
   const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
   if (flops) *flops = 2 * M * a.N * ((int64_t)a.R * a.S * a.C) * a.nz;
-  const int64_t big_tiles = ((M + 127) / 128) * ((a.N + 127) / 128) * a.nz;
-  return (big_tiles >= 256 && a.N >= 128) ? 1 : 0;
+  if (g_forced_variant >= 0) return g_forced_variant;
+  const int64_t t256 = ((M + 255) / 256) * ((a.N + 255) / 256) * a.nz;
+  const int64_t t128 = ((M + 127) / 128) * ((a.N + 127) / 128) * a.nz;
+  const int64_t ksteps = (int64_t)a.R * a.S * a.C * (int64_t)gdl_elem_size(a.dtype) / 128;
+  // measured (tools/bench_conv.py): 256^2 tiles win whenever K is deep, even at ~1 block per CU;
+  // for shallow K (ViT linears, 12 K-steps) the 128^2 tile's shorter prologue/epilogue wins
+  if (a.N % 256 == 0 && (t256 >= 512 || (t256 >= 256 && ksteps >= 32))) return 2;
+  if (t128 >= 256 && a.N >= 128) return 1;
+  return 0;
 }

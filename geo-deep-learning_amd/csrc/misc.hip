@@ -321,39 +321,60 @@ __global__ __launch_bounds__(256) void upsample_logits_kernel(const float* __res
   }
 }
 
-template <int K>
-__global__ __launch_bounds__(256) void upsample_logits_bwd_kernel(const float* __restrict__ dout, int B, int Ho, int Wo,
-                                                                  float* __restrict__ din, int Hi, int Wi) {
-  const int64_t total = (int64_t)B * Hi * Wi;
-  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+// Backward of the logit upsample, separable (bilinear weights factor as wy*wx), gather form:
+//   pass 1: tmp[b,k,iy,ox] = sum_oy wy(oy->iy) * dout[b,k,oy,ox]      (coalesced along ox)
+//   pass 2: din[b,iy,ix,k] = sum_ox wx(ox->ix) * tmp[b,k,iy,ox]
+__device__ __forceinline__ void cand_range(int i, float ratio, int out_size, int& lo, int& hi) {
+  lo = (int)floorf(((float)i - 0.5f) / ratio - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 1.5f) / ratio - 0.5f) + 1;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > out_size - 1 ? out_size - 1 : hi;
+}
+
+__global__ __launch_bounds__(256) void upsample_logits_bwd_pass1(const float* __restrict__ dout, int BK, int Ho, int Wo,
+                                                                 float* __restrict__ tmp, int Hi) {
+  const int64_t total = (int64_t)BK * Hi * Wo;
+  const float ry = (float)Hi / (float)Ho;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int ix = (int)(i % Wi);
-    const int64_t t = i / Wi;
-    const int iy = (int)(t % Hi), b = (int)(t / Hi);
-    int oy_lo = (int)floorf(((float)iy - 0.5f) / ry - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / ry - 0.5f) + 1;
-    int ox_lo = (int)floorf(((float)ix - 0.5f) / rx - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / rx - 0.5f) + 1;
-    oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
-    oy_hi = oy_hi > Ho - 1 ? Ho - 1 : oy_hi; ox_hi = ox_hi > Wo - 1 ? Wo - 1 : ox_hi;
-    float acc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0.f;
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    const int ox = (int)(i % Wo);
+    const int64_t t = i / Wo;
+    const int iy = (int)(t % Hi);
+    const int64_t bk = t / Hi;
+    int lo, hi;
+    cand_range(iy, ry, Ho, lo, hi);
+    float acc = 0.f;
+    for (int oy = lo; oy <= hi; ++oy) {
       int y0, y1; float ly;
       src_index2(ry, oy, Hi, y0, y1, ly);
       const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
-      if (wy == 0.f) continue;
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        int x0, x1; float lx;
-        src_index2(rx, ox, Wi, x0, x1, lx);
-        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
-        if (wx == 0.f) continue;
-        const float w = wy * wx;
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] += w * dout[(((int64_t)b * K + k) * Ho + oy) * Wo + ox];
-      }
+      if (wy != 0.f) acc += wy * dout[(bk * Ho + oy) * Wo + ox];
     }
-#pragma unroll
-    for (int k = 0; k < K; ++k) din[i * K + k] = acc[k];
+    tmp[i] = acc;
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void upsample_logits_bwd_pass2(const float* __restrict__ tmp, int B, int Wo,
+                                                                 float* __restrict__ din, int Hi, int Wi) {
+  const int64_t total = (int64_t)B * Hi * Wi * K;
+  const float rx = (float)Wi / (float)Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % K);
+    int64_t t = i / K;
+    const int ix = (int)(t % Wi); t /= Wi;
+    const int iy = (int)(t % Hi);
+    const int b = (int)(t / Hi);
+    int lo, hi;
+    cand_range(ix, rx, Wo, lo, hi);
+    const float* row = tmp + (((int64_t)b * K + k) * Hi + iy) * Wo;
+    float acc = 0.f;
+    for (int ox = lo; ox <= hi; ++ox) {
+      int x0, x1; float lx;
+      src_index2(rx, ox, Wi, x0, x1, lx);
+      const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+      if (wx != 0.f) acc += wx * row[ox];
+    }
+    din[i] = acc;
   }
 }
 
@@ -417,15 +438,21 @@ __global__ __launch_bounds__(256) void dice_partial_kernel(const float* __restri
 }
 
 template <int K>
-__global__ void dice_final_kernel(const float* __restrict__ ws, int nblk, float eps, float* __restrict__ sums,
-                                  float* __restrict__ loss) {
-  __shared__ double tot[3 * K];
-  const int t = threadIdx.x;
+__global__ __launch_bounds__(256) void dice_final_kernel(const float* __restrict__ ws, int nblk, float eps,
+                                                         float* __restrict__ sums, float* __restrict__ loss) {
+  __shared__ double part[8][32];
+  __shared__ double tot[32];
+  const int t = threadIdx.x, v = t & 31, grp = t >> 5;   // 8 groups of 32 value slots (3K <= 24)
+  double s = 0;
+  if (v < 3 * K)
+    for (int i = grp; i < nblk; i += 8) s += ws[(int64_t)i * 3 * K + v];
+  part[grp][v] = s;
+  __syncthreads();
   if (t < 3 * K) {
-    double s = 0;
-    for (int i = 0; i < nblk; ++i) s += ws[(int64_t)i * 3 * K + t];
-    tot[t] = s;
-    sums[t] = (float)s;
+    double r = 0;
+    for (int g = 0; g < 8; ++g) r += part[g][t];
+    tot[t] = r;
+    sums[t] = (float)r;
   }
   __syncthreads();
   if (t == 0) {
@@ -767,11 +794,17 @@ extern "C" int gdl_upsample_logits(const float* in, int B, int Hi, int Wi, int K
   return GDL_OK;
 }
 
+extern "C" int64_t gdl_upsample_logits_bwd_workspace(int B, int K, int Hi, int Wo) {
+  return (int64_t)B * K * Hi * Wo * (int64_t)sizeof(float);
+}
+
 extern "C" int gdl_upsample_logits_bwd(const float* dout, int B, int Ho, int Wo, int K, float* din, int Hi, int Wi,
-                                       gdl_stream_t stream) {
-  GDL_CHECK_ARG(dout && din, "gdl_upsample_logits_bwd: null pointer");
-  const int64_t total = (int64_t)B * Hi * Wi;
-  K_SWITCH(K, hipLaunchKernelGGL((upsample_logits_bwd_kernel<KK>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout, B, Ho, Wo, din, Hi, Wi));
+                                       float* ws, int64_t ws_bytes, gdl_stream_t stream) {
+  GDL_CHECK_ARG(dout && din && ws, "gdl_upsample_logits_bwd: null pointer");
+  GDL_CHECK_ARG(ws_bytes >= gdl_upsample_logits_bwd_workspace(B, K, Hi, Wo), "gdl_upsample_logits_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(upsample_logits_bwd_pass1, dim3(grid_for((int64_t)B * K * Hi * Wo)), dim3(256), 0, s, dout, B * K, Ho, Wo, ws, Hi);
+  K_SWITCH(K, hipLaunchKernelGGL((upsample_logits_bwd_pass2<KK>), dim3(grid_for((int64_t)B * Hi * Wi * K)), dim3(256), 0, s, ws, B, Wo, din, Hi, Wi));
   GDL_CHECK_LAUNCH("gdl_upsample_logits_bwd");
   return GDL_OK;
 }
@@ -785,8 +818,8 @@ extern "C" int gdl_softmax_argmax(const float* logits, int B, int K, int64_t HW,
 }
 
 static int dice_blocks(int64_t total) {
-  int64_t g = (total + 1023) / 1024;
-  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+  int64_t g = (total + 2047) / 2048;
+  return (int)(g < 1 ? 1 : (g > 512 ? 512 : g));
 }
 
 extern "C" int64_t gdl_dice_loss_workspace(int B, int K, int64_t HW) {
@@ -800,7 +833,7 @@ extern "C" int gdl_dice_loss_fwd(const float* logits, const int64_t* target, int
   const int nblk = dice_blocks((int64_t)B * HW);
   hipStream_t s = (hipStream_t)stream;
   K_SWITCH(K, hipLaunchKernelGGL((dice_partial_kernel<KK>), dim3(nblk), dim3(256), 0, s, logits, target, B, HW, ws);
-              hipLaunchKernelGGL((dice_final_kernel<KK>), dim3(1), dim3(64), 0, s, ws, nblk, eps, sums, loss));
+              hipLaunchKernelGGL((dice_final_kernel<KK>), dim3(1), dim3(256), 0, s, ws, nblk, eps, sums, loss));
   GDL_CHECK_LAUNCH("gdl_dice_loss_fwd");
   return GDL_OK;
 }

@@ -213,6 +213,180 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs k) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 production kernel (v2): no register staging at all.
+//  * dy / x tiles are DMA'd (global_load_lds_dwordx4) as they lie in memory, [pixel][channel]:
+//    per operand 2 panels of [64 pixels][64 channels] = 128-byte rows; out-of-range chunks (halo,
+//    pixel tail, channel tail) are sourced from a zero page.
+//  * MFMA fragments need 8 consecutive PIXELS per lane: the transpose is done by the LDS itself,
+//    ds_read_b64_tr_b16.  Probed semantics (tools/probes/tr_read_probe.hip): within a 16-lane
+//    group, result[lane L][j] = the 8-byte piece supplied by lane (4j + L/4), element L%4.  So
+//    lane s pointing at LDS[pixel k0 + s/4][channel c0 + 4(s%4)] gives lane L channel c0+L for
+//    pixels k0..k0+3; two such reads build one 32x16 fragment row.
+//  * Swizzle (source side, because the DMA writes lane-linearly): slot = chunk ^ swz(row) with
+//    swz(row) = ((row>>1)&1)<<2 | (row>>2)&3 -- the 4 rows x 64 bytes a half-wave touches per
+//    read land in 16 distinct 16-byte slots of the 256-byte bank line.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+__device__ uint4 g_wgrad_zero_page[8];
+
+__device__ __forceinline__ int tr_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const WArgs k) {
+  constexpr int BKP = 64, TM = 2, TN = 2;
+  constexpr int PANEL = 64 * 128;             // one [64 pixels][64 channels] panel
+  constexpr int STAGE_BYTES = 4 * PANEL;      // dy panels 0,1 | x panels 0,1
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const gdl_wgrad_args& a = k.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int n0 = blockIdx.x * 128;
+  const int tap = blockIdx.y / k.ctiles, c0 = (blockIdx.y % k.ctiles) * 128;
+  const int tap_r = tap / a.S, tap_s = tap % a.S;
+  const int split = blockIdx.z;
+  const int64_t p_begin = (int64_t)split * k.p_per_split;
+  int64_t p_end = p_begin + k.p_per_split;
+  if (p_end > k.P) p_end = k.P;
+  const int HoWo = a.Ho * a.Wo;
+  const unsigned char* zero = (const unsigned char*)g_wgrad_zero_page;
+
+  // ---- DMA geometry: this lane feeds tile rows rr[0], rr[1] (pixels) of all four panels
+  const int lrow = lane >> 3, lslot = lane & 7;
+  int rr[2], chunk[2], pb[2], py[2], px[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    rr[u] = (wave + 4 * u) * 8 + lrow;
+    chunk[u] = lslot ^ tr_swz(rr[u]);
+    const int64_t p = p_begin + rr[u];
+    const int b = (int)(p / HoWo);
+    const int rem = (int)(p - (int64_t)b * HoWo);
+    pb[u] = b; py[u] = rem / a.Wo; px[u] = rem - py[u] * a.Wo;
+  }
+
+  auto issue = [&](int stage, int64_t pbase) {
+    unsigned char* st = smem + stage * STAGE_BYTES;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t p = pbase + rr[u];
+      const bool pv = p < p_end;
+      const int64_t dyo = k.dy_dense ? p * a.dy_sW
+                                     : (int64_t)pb[u] * a.dy_sB + (int64_t)py[u] * a.dy_sH + (int64_t)px[u] * a.dy_sW;
+      bool xv = pv;
+      int64_t xo;
+      if (k.x_dense) {
+        xo = p * a.in_sW;
+      } else {
+        const int iy = py[u] * a.stride + tap_r - a.pad, ix = px[u] * a.stride + tap_s - a.pad;
+        xv = xv && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        xo = (int64_t)pb[u] * a.in_sB + (int64_t)iy * a.in_sH + (int64_t)ix * a.in_sW;
+      }
+      const int rowgroup = wave + 4 * u;
+#pragma unroll
+      for (int pn = 0; pn < 2; ++pn) {
+        const int nn = n0 + pn * 64 + chunk[u] * 8;
+        const unsigned char* sa = (pv && nn < a.N) ? (const unsigned char*)a.dy + (dyo + nn) * 2 : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(st + pn * PANEL + rowgroup * 1024), 16, 0, 0);
+        const int cc = c0 + pn * 64 + chunk[u] * 8;
+        const unsigned char* sb = (xv && cc < a.C) ? (const unsigned char*)a.in + (xo + cc) * 2 : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(st + (2 + pn) * PANEL + rowgroup * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      px[u] += BKP;
+      while (px[u] >= a.Wo) { px[u] -= a.Wo; ++py[u]; }
+      while (py[u] >= a.Ho) { py[u] -= a.Ho; ++pb[u]; }
+    }
+  };
+
+  // ---- fragment addressing (ds_read_b64_tr_b16); see header comment
+  const int g = lane >> 4, s = lane & 15;
+  const int R0 = 8 * (g >> 1) + (s >> 2);
+  int foff[2][2];  // [tile i][read t] byte offset inside a panel (kk adds kk*16*128)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 4 * t + R0;
+      const int channel = i * 32 + 16 * (g & 1) + 4 * (s & 3);
+      foff[i][t] = row * 128 + (((channel >> 3) ^ tr_swz(row)) << 4) + (channel & 7) * 2;
+    }
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int KT = (int)((p_end - p_begin + BKP - 1) / BKP);
+  if (KT > 0) issue(0, p_begin);
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) { advance(); issue((kt + 1) & 1, p_begin + (int64_t)(kt + 1) * BKP); }
+    const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
+    const unsigned char* pa = st + wm * PANEL;         // this wave's 64 n-channels = dy panel wm
+    const unsigned char* pbx = st + (2 + wn) * PANEL;  // and its 64 c-channels = x panel wn
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa + kk * 2048 + foff[i][0]));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pa + kk * 2048 + foff[i][1]));
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        fa[i] = __builtin_bit_cast(bf16x8_t, v);
+        const s16x4_t lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pbx + kk * 2048 + foff[i][0]));
+        const s16x4_t hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pbx + kk * 2048 + foff[i][1]));
+        const s16x8_t v2 = {lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+        fb[i] = __builtin_bit_cast(bf16x8_t, v2);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: rows = n, cols = c (coalesced along c) ----
+  const int frow = lane & 31, fhalf = lane >> 5;
+  float* dst;
+  int64_t ld;
+  if (k.splits > 1) {
+    ld = (int64_t)a.R * a.S * a.C;
+    dst = a.workspace + (int64_t)split * a.N * ld;
+  } else {
+    ld = a.dw_sN;
+    dst = a.dw;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int c = c0 + (wn * TN + j) * 32 + frow;
+        if (c >= a.C) continue;
+        float* q = dst + (int64_t)n * ld + (int64_t)tap * a.C + c;
+        const float v = acc[i][j][r];
+        *q = (k.splits == 1 && a.accumulate) ? *q + v : v;
+      }
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int N,
                                                            int64_t K, float* dw, int64_t dw_sN, int accumulate) {
   const int64_t total = (int64_t)N * K;
@@ -236,6 +410,9 @@ int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
 }
 
 }  // namespace
+
+static int g_wgrad_force_v1 = 0;
+extern "C" void gdl_debug_force_wgrad_v1(int on) { g_wgrad_force_v1 = on; }  // A/B hook: register-transpose kernel
 
 extern "C" int64_t gdl_conv_wgrad_workspace(const gdl_wgrad_args* ap) {
   if (!ap) return 0;
@@ -276,7 +453,8 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((a.N + 127) / 128, a.R * a.S * k.ctiles, k.splits);
   const size_t lds = 2 * (128 + 128) * 128;
-  if (a.dtype == GDL_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_tag>, grid, dim3(256), lds, s, k);
+  if (a.dtype == GDL_BF16 && !g_wgrad_force_v1) hipLaunchKernelGGL(wgrad_tr_kernel, grid, dim3(256), lds, s, k);
+  else if (a.dtype == GDL_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_tag>, grid, dim3(256), lds, s, k);
   else hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), lds, s, k);
   if (k.splits > 1) {
     const int64_t K = (int64_t)a.R * a.S * a.C;

@@ -91,7 +91,8 @@ SIGNATURES = {
     "gdl_head_1x1_bwd": (c_i, [c_p, c_i, c_p, c_l, c_i, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i,
                                c_p, c_l, c_p]),
     "gdl_upsample_logits": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
-    "gdl_upsample_logits_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "gdl_upsample_logits_bwd_workspace": (c_l, [c_i, c_i, c_i, c_i]),
+    "gdl_upsample_logits_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_l, c_p]),
     "gdl_softmax_argmax": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p]),
     "gdl_dice_loss_workspace": (c_l, [c_i, c_i, c_l]),
     "gdl_dice_loss_fwd": (c_i, [c_p, c_p, c_i, c_i, c_l, c_f, c_p, c_p, c_p, c_l, c_p]),

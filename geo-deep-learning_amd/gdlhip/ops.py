@@ -134,7 +134,8 @@ class KernelTimer:
     """HIP-event timing of every gdl_conv_gemm launch (bench.py's roofline leg).  Events are
     recorded on the stream the kernels are launched on (torch's current stream)."""
 
-    VARIANT = {0: "conv_gemm_kernel<{dt},2,2,1,1> (64x64 tiles)", 1: "conv_gemm_kernel<{dt},2,2,2,2> (128x128 tiles)"}
+    VARIANT = {0: "conv_gemm_kernel<{dt},2,2,1,1> (64x64 tiles)", 1: "conv_gemm_kernel<{dt},2,2,2,2> (128x128 tiles)",
+               2: "conv_gemm_kernel<{dt},2,4,4,2> (256x256 tiles)"}
 
     def __init__(self) -> None:
         self.records: list = []
@@ -591,8 +592,11 @@ def upsample_logits_bwd(dout: Tensor, in_size: tuple[int, int]) -> Tensor:
         raise ValueError("upsample_logits_bwd: contiguous f32 NCHW grad expected")
     B, K, Ho, Wo = dout.shape
     din = torch.empty((B, in_size[0], in_size[1], K), device=dout.device, dtype=torch.float32)
-    check(_lib.load().gdl_upsample_logits_bwd(_p(dout), B, Ho, Wo, K, _p(din), in_size[0],
-                                              in_size[1], _stream()), "gdl_upsample_logits_bwd")
+    lib = _lib.load()
+    nbytes = lib.gdl_upsample_logits_bwd_workspace(B, K, in_size[0], Wo)
+    ws = torch.empty(nbytes // 4, device=dout.device, dtype=torch.float32)
+    check(lib.gdl_upsample_logits_bwd(_p(dout), B, Ho, Wo, K, _p(din), in_size[0], in_size[1], _p(ws),
+                                      nbytes, _stream()), "gdl_upsample_logits_bwd")
     return din
 
 

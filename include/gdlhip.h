@@ -217,8 +217,9 @@ int gdl_head_1x1_bwd(const void* feat, int dtype, const float* dlog, int64_t P, 
 /* bilinear (align_corners=False) NHWC [B,Hi,Wi,K] -> NCHW f32 [B,K,Ho,Wo] logits (dofa.py:89-105) */
 int gdl_upsample_logits(const float* in, int B, int Hi, int Wi, int K, float* out, int Ho, int Wo,
                         gdl_stream_t stream);
+int64_t gdl_upsample_logits_bwd_workspace(int B, int K, int Hi, int Wo);
 int gdl_upsample_logits_bwd(const float* dout, int B, int Ho, int Wo, int K, float* din, int Hi,
-                            int Wi, gdl_stream_t stream);
+                            int Wi, float* workspace, int64_t workspace_bytes, gdl_stream_t stream);
 /* softmax(dim=1).argmax(dim=1) on NCHW f32 logits -> int64 mask (segmentation_dofa.py:281) */
 int gdl_softmax_argmax(const float* logits, int B, int K, int64_t HW, int64_t* mask,
                        gdl_stream_t stream);
