@@ -14,6 +14,10 @@
 
 namespace {
 
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ uint4 g_attn_zero_page[8];
+
 struct FArgs {
   const uint16_t* qkv;  // [B, N, 3, H, 64]
   const uint16_t* vt;   // [B, H, 64, Npad]
@@ -46,27 +50,26 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FArgs f) {
       qf[kk] = ok ? *(const uint4*)(qbase + (int64_t)q * row_stride + kk * 16 + fhalf * 8) : make_uint4(0, 0, 0, 0);
   }
 
-  // ---- staging: 512 chunks (K) + 512 chunks (V^T) per tile, 4 chunk loads per thread
-  const int cchunk = tid & 7, crow = tid >> 3;  // rows crow, crow+32
-  uint4 rk[2], rv[2];
-  auto fetch = [&](int kv0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = crow + i * 32;
-      const int key = kv0 + r;
-      rk[i] = key < f.N ? *(const uint4*)(kbase + (int64_t)key * row_stride + cchunk * 8) : make_uint4(0, 0, 0, 0);
-      rv[i] = *(const uint4*)(vtbase + (int64_t)r * f.Npad + kv0 + cchunk * 8);  // keys >= N are zero in vt
-    }
-  };
-  auto stash = [&](int stage) {
+  // ---- staging by DMA (global_load_lds_dwordx4): per tile 8 KiB of K rows + 8 KiB of V^T rows =
+  //      16 wave-instructions of 1 KiB (8 rows); wave w issues row groups w and w+4 of each.  The LDS
+  //      image is lane-linear, so the swizzle is applied to the per-lane SOURCE chunk; keys >= N read
+  //      a zero page (V^T is zero-padded in memory already).
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const unsigned char* zero = (const unsigned char*)g_attn_zero_page;
+  auto issue = [&](int stage, int kv0) {
     unsigned char* sk = smem + stage * STAGE_BYTES;
     unsigned char* sv = sk + KV * 128;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int r = crow + i * 32;
-      const int off = r * 128 + ((cchunk ^ ((r >> 1) & 7)) << 4);
-      *(uint4*)(sk + off) = rk[i];
-      *(uint4*)(sv + off) = rv[i];
+      const int rg = uwave + 4 * i;
+      const int r = rg * 8 + lrow;
+      const int chunk = lslot ^ ((r >> 1) & 7);
+      const int key = kv0 + r;
+      const unsigned char* srck = key < f.N ? (const unsigned char*)(kbase + (int64_t)key * row_stride + chunk * 8) : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)srck, (lptr_t)(sk + rg * 1024), 16, 0, 0);
+      const unsigned char* srcv = (const unsigned char*)(vtbase + (int64_t)r * f.Npad + kv0 + chunk * 8);
+      __builtin_amdgcn_global_load_lds((gptr_t)srcv, (lptr_t)(sv + rg * 1024), 16, 0, 0);
     }
   };
 
@@ -78,13 +81,11 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FArgs f) {
   float m_run = -INFINITY, l_run = 0.f;  // running max (log2 domain, shared by the lane pair), own partial sum
 
   const int ntiles = (f.N + KV - 1) / KV;
-  fetch(0);
-  stash(0);
-  __syncthreads();
-
+  issue(0, 0);
   for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) fetch((t + 1) * KV);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA of tile t landed
+    __syncthreads();                                   // everyone's did; everyone left tile t-1
+    if (t + 1 < ntiles) issue((t + 1) & 1, (t + 1) * KV);
     const unsigned char* sk = smem + (t & 1) * STAGE_BYTES;
     const unsigned char* sv = sk + KV * 128;
 
@@ -103,35 +104,41 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FArgs f) {
     }
     // ---- online softmax for query = frow (this lane holds 32 of the 64 keys, partner the rest)
     const int kv0 = t * KV;
-    float mx = -INFINITY;
+    if (t == ntiles - 1) {  // only the last tile can contain keys >= N (wave-uniform branch)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+          st[kt][r] = key < f.N ? st[kt][r] : -INFINITY;
+        }
+    }
+    float mx = -INFINITY;   // running max is tracked on the RAW scores (scale > 0 commutes with max)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-        float s = st[kt][r] * f.scale_log2e;
-        s = key < f.N ? s : -INFINITY;
-        st[kt][r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 valid key
-    const float alpha = exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * f.scale_log2e);  // first tile: exp2(-inf) = 0
     m_run = m_new;
+    const float mc = m_new * f.scale_log2e;
     float lsum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(st[kt][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], f.scale_log2e, -mc));  // one FMA + v_exp_f32
         st[kt][r] = p;
         lsum += p;
       }
     l_run = l_run * alpha + lsum;
+    if (!__all(alpha == 1.f)) {  // no running max moved in this wave: skip the O rescale
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) ot[dt][r] *= alpha;
+    }
 
     // ---- O^T += V^T · P^T ; MFMA step (kt, s): B = P regs [kt][8s..8s+7] of this lane,
     //      A lane (d, half') = V^T[d][keys 32kt + 16s + 4half' + {0..3}, +8 + {0..3}]
@@ -153,8 +160,6 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FArgs f) {
         }
       }
 
-    if (more) stash((t + 1) & 1);
-    __syncthreads();
   }
 
   // ---- finalize: l = own + partner; O = O^T / l ; lane holds query frow, 32 of the 64 d's

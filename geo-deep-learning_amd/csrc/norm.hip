@@ -140,17 +140,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ 
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps,
                                                        int relu) {
-  const int cv = C / 4;
-  const int64_t total = P * cv;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t p = i / cv;
-    const int c = (int)(i - p * cv) * 4;
+  // lane owns 4 fixed channels (params live in registers); grid = (C/256, pixel splits)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  if (c >= C) return;
+  float mu[4], sc[4], be[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; sc[j] = rsqrtf(var[c + j] + eps) * gamma[c + j]; be[j] = beta[c + j]; }
+  const int64_t per = (P + gridDim.y - 1) / gridDim.y;
+  const int64_t p0 = per * blockIdx.y, p1 = p0 + per < P ? p0 + per : P;
+  for (int64_t p = p0 + w; p < p1; p += 4) {
     float v[4];
     load4<T>(x, p * x_sP + c, v);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float sc = rsqrtf(var[c + j] + eps) * gamma[c + j];
-      float o = (v[j] - mean[c + j]) * sc + beta[c + j];
+      const float o = (v[j] - mu[j]) * sc[j] + be[j];
       v[j] = relu ? fmaxf(o, 0.f) : o;
     }
     store4<T>(y, p * y_sP + c, v);
@@ -229,24 +233,39 @@ __global__ __launch_bounds__(256) void bn_bwd_dx(const void* __restrict__ x, con
                                                  const float* __restrict__ beta, float eps, int relu,
                                                  const float* __restrict__ dgamma,
                                                  const float* __restrict__ dbeta) {
-  const int cv = C / 4;
-  const int64_t total = P * cv;
   const float invP = 1.0f / (float)P_total;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t p = i / cv;
-    const int c = (int)(i - p * cv) * 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  if (c >= C) return;
+  float mu[4], rs[4], ga[4], be[4], k1[4], k2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mu[j] = mean[c + j]; rs[j] = rsqrtf(var[c + j] + eps); ga[j] = gamma[c + j]; be[j] = beta[c + j];
+    k1[j] = dbeta[c + j] * invP; k2[j] = dgamma[c + j] * invP;
+  }
+  const int64_t per = (P + gridDim.y - 1) / gridDim.y;
+  const int64_t p0 = per * blockIdx.y, p1 = p0 + per < P ? p0 + per : P;
+  for (int64_t p = p0 + w; p < p1; p += 4) {
     float v[4], g[4];
     load4<T>(x, p * x_sP + c, v);
     load4<T>(dy, p * dy_sP + c, g);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float rs = rsqrtf(var[c + j] + eps), ga = gamma[c + j];
-      const float xh = (v[j] - mean[c + j]) * rs;
-      const float gg = (relu && !(xh * ga + beta[c + j] > 0.f)) ? 0.f : g[j];
-      v[j] = ga * rs * (gg - dbeta[c + j] * invP - xh * dgamma[c + j] * invP);
+      const float xh = (v[j] - mu[j]) * rs[j];
+      const float gg = (relu && !(xh * ga[j] + be[j] > 0.f)) ? 0.f : g[j];
+      v[j] = ga[j] * rs[j] * (gg - k1[j] - xh * k2[j]);
     }
     store4<T>(dx, p * dx_sP + c, v);
   }
+}
+
+// pixel splits of the elementwise BN kernels: ~4096 blocks in total, >= 16 pixels per wave
+int bn_ew_splits(int64_t P, int C) {
+  const int cg = (C + 255) / 256;
+  int64_t n = 4096 / cg;
+  if (n > P / 64) n = P / 64;
+  if (n < 1) n = 1;
+  return (int)n;
 }
 
 int bn_nsplit(int64_t P) {
@@ -305,11 +324,12 @@ extern "C" int gdl_bn_apply(const void* x, void* y, int dtype, int64_t P, int C,
   GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && y_sP % 4 == 0, "gdl_bn_apply: C/strides must be multiples of 4");
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = P * (C / 4);
-  const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  (void)total;
+  const dim3 grid((C + 255) / 256, bn_ew_splits(P, C));
   if (dtype == GDL_BF16)
-    hipLaunchKernelGGL(bn_apply_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, x, y, P, C, x_sP, y_sP, mean, var, gamma, beta, eps, relu);
+    hipLaunchKernelGGL(bn_apply_kernel<uint16_t>, grid, dim3(256), 0, s, x, y, P, C, x_sP, y_sP, mean, var, gamma, beta, eps, relu);
   else
-    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, s, x, y, P, C, x_sP, y_sP, mean, var, gamma, beta, eps, relu);
+    hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, s, x, y, P, C, x_sP, y_sP, mean, var, gamma, beta, eps, relu);
   GDL_CHECK_LAUNCH("gdl_bn_apply");
   return GDL_OK;
 }
@@ -341,11 +361,12 @@ extern "C" int gdl_bn_bwd_dx(const void* x, const void* dy, void* dx, int dtype,
   GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && dy_sP % 4 == 0 && dx_sP % 4 == 0 && P_total > 0, "gdl_bn_bwd_dx: C/strides % 4");
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = P * (C / 4);
-  const unsigned g2 = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  (void)total;
+  const dim3 g2((C + 255) / 256, bn_ew_splits(P, C));
   if (dtype == GDL_BF16)
-    hipLaunchKernelGGL(bn_bwd_dx<uint16_t>, dim3(g2), dim3(256), 0, s, x, dy, dx, P, P_total, C, x_sP, dy_sP, dx_sP, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum);
+    hipLaunchKernelGGL(bn_bwd_dx<uint16_t>, g2, dim3(256), 0, s, x, dy, dx, P, P_total, C, x_sP, dy_sP, dx_sP, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum);
   else
-    hipLaunchKernelGGL(bn_bwd_dx<float>, dim3(g2), dim3(256), 0, s, x, dy, dx, P, P_total, C, x_sP, dy_sP, dx_sP, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum);
+    hipLaunchKernelGGL(bn_bwd_dx<float>, g2, dim3(256), 0, s, x, dy, dx, P, P_total, C, x_sP, dy_sP, dx_sP, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum);
   GDL_CHECK_LAUNCH("gdl_bn_bwd_dx");
   return GDL_OK;
 }

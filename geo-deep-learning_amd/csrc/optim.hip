@@ -1,0 +1,68 @@
+// Multi-tensor optimizer kernels: ONE launch covers every parameter tensor of the step.
+// The host passes a device table of chunks; row = {param, grad, exp_avg, exp_avg_sq, count} with the
+// pointers already offset to the chunk (<= 65536 elements each), all f32, dense.
+#include "gdl_common.h"
+
+namespace {
+
+constexpr int ROW = 5;
+
+__global__ __launch_bounds__(256) void multi_sumsq_kernel(const int64_t* __restrict__ table, float* __restrict__ acc) {
+  __shared__ float red[4];
+  const int64_t* row = table + (int64_t)blockIdx.x * ROW;
+  const float* g = (const float*)row[1];
+  const int n = (int)row[4];
+  float s = 0.f;
+  const int n4 = n >> 2;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const float4 v = ((const float4*)g)[i];
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void multi_adam_kernel(const int64_t* __restrict__ table, float lr, float b1, float b2,
+                                                         float eps, float wd, float bc1, float bc2,
+                                                         const float* __restrict__ clip_coef) {
+  const int64_t* row = table + (int64_t)blockIdx.x * ROW;
+  float* p = (float*)row[0];
+  const float* g = (const float*)row[1];
+  float* m = (float*)row[2];
+  float* v = (float*)row[3];
+  const int n = (int)row[4];
+  const float cc = clip_coef ? clip_coef[0] : 1.f;
+  const float step = lr / bc1, rs = 1.f / sqrtf(bc2);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float gi = g[i] * cc;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = pi - step * mi / (sqrtf(vi) * rs + eps);
+  }
+}
+
+}  // namespace
+
+extern "C" int gdl_multi_sumsq(const int64_t* table, int nchunks, float* acc, gdl_stream_t stream) {
+  GDL_CHECK_ARG(table && acc && nchunks >= 0, "gdl_multi_sumsq: bad args");
+  if (nchunks == 0) return GDL_OK;
+  hipLaunchKernelGGL(multi_sumsq_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, acc);
+  GDL_CHECK_LAUNCH("gdl_multi_sumsq");
+  return GDL_OK;
+}
+
+extern "C" int gdl_multi_adam(const int64_t* table, int nchunks, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, float bc1, float bc2, const float* clip_coef, gdl_stream_t stream) {
+  GDL_CHECK_ARG(table && nchunks >= 0, "gdl_multi_adam: bad args");
+  if (nchunks == 0) return GDL_OK;
+  hipLaunchKernelGGL(multi_adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2, clip_coef);
+  GDL_CHECK_LAUNCH("gdl_multi_adam");
+  return GDL_OK;
+}

@@ -29,20 +29,21 @@ def compute_dtype() -> torch.dtype:
 
 
 # ------------------------------------------------------------------ packed-weight cache
-_EPOCH = 0
+_RAW_WRITES: dict = {}   # id(param) -> number of raw-pointer updates (tensor._version does not see them)
 _CACHE: dict = {}
 
 
-def bump_weights_epoch() -> None:
-    """Called by the fused optimizer after it rewrites parameters through raw pointers."""
-    global _EPOCH
-    _EPOCH += 1
+def mark_updated(p: Tensor) -> None:
+    """Called by the fused optimizer for every parameter it rewrites through a raw pointer."""
+    _RAW_WRITES[id(p)] = _RAW_WRITES.get(id(p), 0) + 1
 
 
 def cached(params: tuple, kind: str, builder):
-    """Memoise ``builder()`` on the identity + version of ``params`` (tensors)."""
+    """Memoise ``builder()`` on the identity + version of ``params`` (tensors).  Frozen
+    parameters never change version, so e.g. the DOFA dynamic patch-embed kernel of a frozen
+    encoder is generated once per sensor, not once per step."""
     key = (kind, *[id(p) for p in params])
-    ver = (_EPOCH, *[(p._version, p.data_ptr()) for p in params])
+    ver = tuple((p._version, _RAW_WRITES.get(id(p), 0), p.data_ptr()) for p in params)
     hit = _CACHE.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
@@ -369,16 +370,9 @@ class FusedAdam(torch.optim.Optimizer):
         todo = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
         if not todo:
             return loss
-        clip = None
-        if self.max_grad_norm is not None:
-            dev = todo[0][1].device
-            if self._acc is None:
-                self._acc = torch.zeros(2, device=dev, dtype=torch.float32)
-            self._acc.zero_()
-            for _, p in todo:
-                ops.sumsq_accum(_flat(p.grad), self._acc[0:1])
-            ops.clip_coef(self._acc[0:1], float(self.max_grad_norm), self._acc[1:2])
-            clip = self._acc[1:2]
+        dev = todo[0][1].device
+        # one chunk table per hyper-parameter set (lr, betas, eps, wd, step) -> one launch each
+        buckets: dict = {}
         for group, p in todo:
             st = self.state[p]
             if not st:
@@ -386,13 +380,31 @@ class FusedAdam(torch.optim.Optimizer):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["step"] += 1
-            b1, b2 = group["betas"]
             if p.grad.stride() != p.stride():
                 p.grad = _restride(p.grad, p)
-            ops.adam_step(_flat(p), _flat(p.grad), _flat(st["exp_avg"]), _flat(st["exp_avg_sq"]),
-                          group["lr"], b1, b2, group["eps"], group["weight_decay"], st["step"], clip)
-        bump_weights_epoch()
+            _flat(p), _flat(p.grad)  # layout check (dense storage)
+            key = (group["lr"], *group["betas"], group["eps"], group["weight_decay"], st["step"])
+            rows = buckets.setdefault(key, [])
+            n, pp, gp = p.numel(), p.data_ptr(), p.grad.data_ptr()
+            mp, vp = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            for off in range(0, n, self.CHUNK):
+                rows.append((pp + 4 * off, gp + 4 * off, mp + 4 * off, vp + 4 * off, min(self.CHUNK, n - off)))
+            mark_updated(p)
+        tables = {k: torch.tensor(v, dtype=torch.int64).to(dev, non_blocking=True) for k, v in buckets.items()}
+        clip = None
+        if self.max_grad_norm is not None:
+            if self._acc is None:
+                self._acc = torch.zeros(2, device=dev, dtype=torch.float32)
+            self._acc.zero_()
+            for t in tables.values():
+                ops.multi_sumsq(t, self._acc[0:1])
+            ops.clip_coef(self._acc[0:1], float(self.max_grad_norm), self._acc[1:2])
+            clip = self._acc[1:2]
+        for (lr, b1, b2, eps, wd, step), t in tables.items():
+            ops.multi_adam(t, lr, b1, b2, eps, wd, step, clip)
         return loss
+
+    CHUNK = 65536
 
 
 def _flat(t: Tensor) -> Tensor:

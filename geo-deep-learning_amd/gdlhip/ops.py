@@ -650,6 +650,18 @@ def clip_coef(sumsq: Tensor, max_norm: float, coef: Tensor) -> None:
     check(_lib.load().gdl_clip_coef(_p(sumsq), max_norm, _p(coef), _stream()), "gdl_clip_coef")
 
 
+def multi_sumsq(table: Tensor, acc: Tensor) -> None:
+    """acc += sum of squares of every gradient chunk listed in the device table [nchunks, 5]."""
+    check(_lib.load().gdl_multi_sumsq(_p(table), table.shape[0], _p(acc), _stream()), "gdl_multi_sumsq")
+
+
+def multi_adam(table: Tensor, lr: float, b1: float, b2: float, eps: float, wd: float, step: int,
+               clip: Tensor | None) -> None:
+    bc1, bc2 = 1.0 - b1**step, 1.0 - b2**step
+    check(_lib.load().gdl_multi_adam(_p(table), table.shape[0], lr, b1, b2, eps, wd, bc1, bc2, _p(clip),
+                                     _stream()), "gdl_multi_adam")
+
+
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, b1: float, b2: float,
               eps: float, wd: float, step: int, clip: Tensor | None) -> None:
     bc1, bc2 = 1.0 - b1**step, 1.0 - b2**step
