@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mode", default="both", choices=["both", "train", "infer"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -67,9 +67,9 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FArgs f) {
       const int chunk = lslot ^ ((r >> 1) & 7);
       const int key = kv0 + r;
       const unsigned char* srck = key < f.N ? (const unsigned char*)(kbase + (int64_t)key * row_stride + chunk * 8) : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)srck, (lptr_t)(sk + rg * 1024), 16, 0, 0);
+      dma16_to_lds(srck, sk + rg * 1024);
       const unsigned char* srcv = (const unsigned char*)(vtbase + (int64_t)r * f.Npad + kv0 + chunk * 8);
-      __builtin_amdgcn_global_load_lds((gptr_t)srcv, (lptr_t)(sv + rg * 1024), 16, 0, 0);
+      dma16_to_lds(srcv, sv + rg * 1024);
     }
   };
 

@@ -126,12 +126,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
       const bool ok = a_ok[i] && (unsigned)(a_iy0[i] + tap_r) < (unsigned)a.H &&
                       (unsigned)(a_ix0[i] + tap_s) < (unsigned)a.W;
       const unsigned char* src = ok ? in_base + a_off[i] + tap_off : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + (i * NW + wave) * 1024), 16, 0, 0);
+      dma16_to_lds(src, sa + (i * NW + wave) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
       const unsigned char* src = b_ok[i] ? b_ptr[i] + wk : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (i * NW + wave) * 1024), 16, 0, 0);
+      dma16_to_lds(src, sb + (i * NW + wave) * 1024);
     }
     wk += 128;
     if (++cc == k.kc) { cc = 0; if (++tap_s == a.S) { tap_s = 0; ++tap_r; } }

@@ -79,6 +79,30 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// 16-byte global -> LDS DMA (global_load_lds_dwordx4) issued through inline asm.
+// Why asm and not __builtin_amdgcn_global_load_lds: hipcc (ROCm 7.2) treats the builtin as a
+// pending LDS write that may alias ANY later ds_read and emits `s_waitcnt vmcnt(0)` in front of
+// the first fragment read of the MFMA phase -- i.e. it waits for the NEXT tile's DMA before
+// computing the current one and the copy/compute overlap is gone (seen in the .s: vmcnt(0) ->
+// ds_read_b128).  The asm form is invisible to that bookkeeping; the kernels wait by hand
+// (`s_waitcnt vmcnt(0)` + barrier) before a stage is read.  M0 (LDS base of the wave's 1 KiB
+// piece, wave-uniform) is saved/restored inside the same statement (compiler-reserved register);
+// `s_nop 0` covers the s_mov m0 -> LDS-DMA hazard.  Lane l lands at lds_base + 16*l.
+__device__ __forceinline__ void dma16_to_lds(const void* gsrc, void* lds_wave_base) {
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

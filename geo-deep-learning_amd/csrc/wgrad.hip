@@ -290,10 +290,10 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WArgs k) {
       for (int pn = 0; pn < 2; ++pn) {
         const int nn = n0 + pn * 64 + chunk[u] * 8;
         const unsigned char* sa = (pv && nn < a.N) ? (const unsigned char*)a.dy + (dyo + nn) * 2 : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(st + pn * PANEL + rowgroup * 1024), 16, 0, 0);
+        dma16_to_lds(sa, st + pn * PANEL + rowgroup * 1024);
         const int cc = c0 + pn * 64 + chunk[u] * 8;
         const unsigned char* sb = (xv && cc < a.C) ? (const unsigned char*)a.in + (xo + cc) * 2 : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(st + (2 + pn) * PANEL + rowgroup * 1024), 16, 0, 0);
+        dma16_to_lds(sb, st + (2 + pn) * PANEL + rowgroup * 1024);
       }
     }
   };
