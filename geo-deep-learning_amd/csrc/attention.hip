@@ -2,8 +2,10 @@
 //
 //   O[b, q, h*64 + d] = sum_k softmax_k( scale * Q[q]·K[k] ) V[k, d]
 //
-// Work split: block = 4 waves x 32 queries; KV tile = 64 keys, staged global -> VGPR -> LDS
+// Work split: block = 4 waves x 32 queries; KV tile = 64 keys, staged by global -> LDS DMA
 // (two stages, one barrier per tile) in the same swizzled 128-byte-row format as the GEMM.
+// Q and K/V may live in different tensors with different lengths (SegFormer's spatial-reduction
+// attention, mix_transformer.py:120-157) or in one packed qkv tensor (timm Attention).
 // Both MFMAs are issued "transposed" so that every softmax quantity of a query lives in ONE lane
 // (plus its partner lane+32), i.e. no cross-lane traffic besides one xor-32 shuffle per tile:
 //   S^T[key, q] = K · Q^T        A = K rows (LDS),  B = Q (registers, loaded once)
@@ -19,10 +21,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ uint4 g_attn_zero_page[8];
 
 struct FArgs {
-  const uint16_t* qkv;  // [B, N, 3, H, 64]
+  const uint16_t* q;    // query rows: q + b*q_sB + n*q_sN + h*64
+  const uint16_t* k;    // key rows:   k + b*k_sB + n*k_sN + h*64
+  int64_t q_sB, q_sN, k_sB, k_sN;
   const uint16_t* vt;   // [B, H, 64, Npad]
-  uint16_t* o;          // [B, N, H*64]
-  int B, H, N, Npad;
+  uint16_t* o;          // [B, Nq, H*64]
+  int B, H, Nq, N, Npad;  // N = number of keys
   float scale_log2e;    // scale * log2(e)
 };
 
@@ -35,19 +39,19 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FArgs f) {
   const int bh = blockIdx.y, b = bh / f.H, h = bh % f.H;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int frow = lane & 31, fhalf = lane >> 5, fswz = (frow >> 1) & 7;
-  const int64_t row_stride = (int64_t)3 * f.H * HD;  // elements between tokens in qkv
-  const uint16_t* qbase = f.qkv + (int64_t)b * f.N * row_stride + (int64_t)h * HD;
-  const uint16_t* kbase = qbase + (int64_t)f.H * HD;
+  const int64_t row_stride = f.k_sN;  // elements between key tokens
+  const uint16_t* qbase = f.q + (int64_t)b * f.q_sB + (int64_t)h * HD;
+  const uint16_t* kbase = f.k + (int64_t)b * f.k_sB + (int64_t)h * HD;
   const uint16_t* vtbase = f.vt + (int64_t)bh * HD * f.Npad;
 
   // ---- Q fragments (B operand of S^T): lane (query = frow, half) holds d = 16*kk + 8*half + 0..7
   uint4 qf[4];
   {
     const int q = q0 + frow;
-    const bool ok = q < f.N;
+    const bool ok = q < f.Nq;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
-      qf[kk] = ok ? *(const uint4*)(qbase + (int64_t)q * row_stride + kk * 16 + fhalf * 8) : make_uint4(0, 0, 0, 0);
+      qf[kk] = ok ? *(const uint4*)(qbase + (int64_t)q * f.q_sN + kk * 16 + fhalf * 8) : make_uint4(0, 0, 0, 0);
   }
 
   // ---- staging by DMA (global_load_lds_dwordx4): per tile 8 KiB of K rows + 8 KiB of V^T rows =
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FArgs f) {
   const float l = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l;
   const int q = q0 + frow;
-  if (q < f.N) {
-    uint16_t* orow = f.o + ((int64_t)b * f.N + q) * ((int64_t)f.H * HD) + (int64_t)h * HD;
+  if (q < f.Nq) {
+    uint16_t* orow = f.o + ((int64_t)b * f.Nq + q) * ((int64_t)f.H * HD) + (int64_t)h * HD;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -182,19 +186,22 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FArgs f) {
 
 }  // namespace
 
-extern "C" int gdl_flash_attn_fwd(const void* qkv, const void* vt, void* o, int B, int H, int N, int Npad,
-                                  float scale, gdl_stream_t stream) {
-  GDL_CHECK_ARG(qkv && vt && o, "gdl_flash_attn_fwd: null pointer");
-  GDL_CHECK_ARG(B > 0 && H > 0 && N > 0 && Npad >= N && Npad % 64 == 0, "gdl_flash_attn_fwd: bad dims (Npad %% 64)");
-  GDL_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)vt % 16 == 0) && ((uintptr_t)o % 8 == 0),
-                "gdl_flash_attn_fwd: pointers must be 16-byte aligned");
+extern "C" int gdl_flash_attn_fwd(const void* q, int64_t q_sB, int64_t q_sN, const void* k, int64_t k_sB, int64_t k_sN,
+                                  const void* vt, void* o, int B, int H, int Nq, int Nkv, int Npad, float scale,
+                                  gdl_stream_t stream) {
+  GDL_CHECK_ARG(q && k && vt && o, "gdl_flash_attn_fwd: null pointer");
+  GDL_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nkv > 0 && Npad >= Nkv && Npad % 64 == 0, "gdl_flash_attn_fwd: bad dims (Npad %% 64)");
+  GDL_CHECK_ARG(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)vt % 16 == 0) && ((uintptr_t)o % 8 == 0) &&
+                    q_sB % 8 == 0 && q_sN % 8 == 0 && k_sB % 8 == 0 && k_sN % 8 == 0,
+                "gdl_flash_attn_fwd: pointers / strides must keep 16-byte alignment");
   FArgs f;
-  f.qkv = (const uint16_t*)qkv;
+  f.q = (const uint16_t*)q; f.k = (const uint16_t*)k;
+  f.q_sB = q_sB; f.q_sN = q_sN; f.k_sB = k_sB; f.k_sN = k_sN;
   f.vt = (const uint16_t*)vt;
   f.o = (uint16_t*)o;
-  f.B = B; f.H = H; f.N = N; f.Npad = Npad;
+  f.B = B; f.H = H; f.Nq = Nq; f.N = Nkv; f.Npad = Npad;
   f.scale_log2e = scale * 1.4426950408889634f;
-  dim3 grid((N + 127) / 128, B * H);
+  dim3 grid((Nq + 127) / 128, B * H);
   hipLaunchKernelGGL(flash_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, f);
   GDL_CHECK_LAUNCH("gdl_flash_attn_fwd");
   return GDL_OK;

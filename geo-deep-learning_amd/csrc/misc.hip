@@ -10,16 +10,17 @@ inline unsigned grid_for(int64_t total, int per_block = 256) {
 }
 
 // ------------------------------------------------------------------ V^T for attention
-// qkv [B,N,3,H,hd] -> vt [B,H,hd,Npad] (keys >= N zero).  32x32 LDS tile transpose.
+// V rows (token n, head h at v + b*v_sB + n*v_sN + h*hd) -> vt [B,H,hd,Npad] (keys >= N zero).
+// 32x32 LDS tile transpose.
 template <typename T>
-__global__ __launch_bounds__(256) void v_transpose_kernel(const T* __restrict__ qkv, int N, int H, int hd,
-                                                          T* __restrict__ vt, int Npad) {
+__global__ __launch_bounds__(256) void v_transpose_kernel(const T* __restrict__ v, int N, int H, int hd,
+                                                          int64_t v_sB, int64_t v_sN, T* __restrict__ vt, int Npad) {
   __shared__ T tile[32][33];
   const int bh = blockIdx.z, b = bh / H, h = bh % H;
   const int n0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int64_t rowstride = (int64_t)3 * H * hd;
-  const T* src = qkv + (int64_t)b * N * rowstride + (int64_t)2 * H * hd + (int64_t)h * hd;
+  const int64_t rowstride = v_sN;
+  const T* src = v + (int64_t)b * v_sB + (int64_t)h * hd;
   for (int j = ty; j < 32; j += 8) {
     const int n = n0 + j, d = d0 + tx;
     tile[j][tx] = (n < N && d < hd) ? src[(int64_t)n * rowstride + d] : (T)0;
@@ -65,10 +66,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const void* __restric
 }
 
 // ------------------------------------------------------------------ DOFA patch embed helpers
-// im2col for conv2d(kernel P, stride P, padding pad) on NCHW f32 -> [B*Gh*Gw][Kpad]
+// im2col for conv2d(kernel P, stride, padding pad) on NCHW f32 -> [B*Gh*Gw][Kpad]; only used where the
+// input has too few channels for the implicit-GEMM kernel (C = 3..10 bands: DOFA patch embed, MiT stem)
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, int C, int H, int W,
-                                                       int P, int pad, int Gh, int Gw, void* cols, int Kpad) {
+                                                       int P, int stride, int pad, int Gh, int Gw, void* cols, int Kpad) {
   const int64_t total = (int64_t)B * Gh * Gw * Kpad;
   const int K = C * P * P;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     float v = 0.f;
     if (kk < K) {
       const int s = kk % P, r = (kk / P) % P, c = kk / (P * P);
-      const int y = gy * P + r - pad, x = gx * P + s - pad;
+      const int y = gy * stride + r - pad, x = gx * stride + s - pad;
       if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
         v = img[(((int64_t)b * C + c) * H + y) * W + x];
     }
@@ -626,14 +628,14 @@ extern "C" int gdl_pack_dgrad(const void* w, int w_dtype, int N, int T, int C, v
   return GDL_OK;
 }
 
-extern "C" int gdl_v_transpose(const void* qkv, int dtype, int B, int N, int H, int hd, void* vt, int Npad,
-                               gdl_stream_t stream) {
-  GDL_CHECK_ARG(qkv && vt && Npad >= N, "gdl_v_transpose: bad args");
+extern "C" int gdl_v_transpose(const void* v, int dtype, int B, int N, int H, int hd, int64_t v_sB, int64_t v_sN,
+                               void* vt, int Npad, gdl_stream_t stream) {
+  GDL_CHECK_ARG(v && vt && Npad >= N, "gdl_v_transpose: bad args");
   dim3 grid((Npad + 31) / 32, (hd + 31) / 32, B * H);
   if (dtype == GDL_BF16)
-    hipLaunchKernelGGL(v_transpose_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, N, H, hd, (uint16_t*)vt, Npad);
+    hipLaunchKernelGGL(v_transpose_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)v, N, H, hd, v_sB, v_sN, (uint16_t*)vt, Npad);
   else
-    hipLaunchKernelGGL(v_transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, N, H, hd, (float*)vt, Npad);
+    hipLaunchKernelGGL(v_transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)v, N, H, hd, v_sB, v_sN, (float*)vt, Npad);
   GDL_CHECK_LAUNCH("gdl_v_transpose");
   return GDL_OK;
 }
@@ -656,14 +658,14 @@ extern "C" int gdl_softmax_rows(const void* in, void* out, int dtype, int64_t ro
   return GDL_OK;
 }
 
-extern "C" int gdl_patchify(const float* img, int B, int C, int H, int W, int P, int pad, int Gh, int Gw, void* cols,
-                            int out_dtype, int Kpad, gdl_stream_t stream) {
+extern "C" int gdl_patchify(const float* img, int B, int C, int H, int W, int P, int stride, int pad, int Gh, int Gw,
+                            void* cols, int out_dtype, int Kpad, gdl_stream_t stream) {
   GDL_CHECK_ARG(img && cols && Kpad >= C * P * P, "gdl_patchify: bad args");
   const int64_t total = (int64_t)B * Gh * Gw * Kpad;
   if (out_dtype == GDL_BF16)
-    hipLaunchKernelGGL(patchify_kernel<bf16_tag>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, B, C, H, W, P, pad, Gh, Gw, cols, Kpad);
+    hipLaunchKernelGGL(patchify_kernel<bf16_tag>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, B, C, H, W, P, stride, pad, Gh, Gw, cols, Kpad);
   else
-    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, B, C, H, W, P, pad, Gh, Gw, cols, Kpad);
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, img, B, C, H, W, P, stride, pad, Gh, Gw, cols, Kpad);
   GDL_CHECK_LAUNCH("gdl_patchify");
   return GDL_OK;
 }

@@ -73,10 +73,11 @@ SIGNATURES = {
                                        c_p]),
     "gdl_adaptive_avgpool_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_l, c_l, c_l,
                                        c_i, c_p]),
-    "gdl_v_transpose": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "gdl_v_transpose": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_p, c_i, c_p]),
     "gdl_softmax_rows": (c_i, [c_p, c_p, c_i, c_l, c_i, c_i, c_p]),
-    "gdl_flash_attn_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
-    "gdl_patchify": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "gdl_flash_attn_fwd": (c_i, [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "gdl_patchify": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "gdl_dwconv3x3": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "gdl_dofa_pack_kernel": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p]),
     "gdl_sincos_embed": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "gdl_bn_fold": (c_i, [c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),

@@ -363,88 +363,122 @@ def adaptive_avgpool_bwd(dout: Tensor, in_size: tuple[int, int], din: Tensor | N
 
 
 # ------------------------------------------------------------------ attention (unfused + fused)
-def attention_unfused(qkv: Tensor, num_heads: int) -> Tensor:
-    """softmax(q k^T / sqrt(hd)) v with materialised scores: the exact-f32 parity path.
+def _attn_check(q: Tensor, k: Tensor, v: Tensor, num_heads: int):
+    _need_cuda(q, k, v)
+    if q.dim() != 3 or k.dim() != 3 or v.shape != k.shape or q.shape[0] != k.shape[0] or q.shape[2] != k.shape[2]:
+        raise ValueError("attention: expected q [B,Nq,D], k/v [B,Nkv,D]")
+    if not (q.dtype == k.dtype == v.dtype) or q.stride(2) != 1 or k.stride(2) != 1 or v.stride(2) != 1:
+        raise ValueError("attention: q/k/v must share a dtype and have unit channel stride")
+    B, Nq, D = q.shape
+    return B, Nq, k.shape[1], D, D // num_heads
 
-    qkv: [B, N, 3*H*hd] (timm Attention.qkv output).  Returns [B, N, H*hd].
-    """
-    _need_cuda(qkv)
-    B, N, three_d = qkv.shape
-    D = three_d // 3
-    hd = D // num_heads
-    es = 4 if qkv.dtype == torch.float32 else 2
+
+def _v_transposed(v: Tensor, num_heads: int, hd: int, npad: int) -> Tensor:
+    B, Nkv, _ = v.shape
+    vt = torch.empty((B, num_heads, hd, npad), device=v.device, dtype=v.dtype)
+    check(_lib.load().gdl_v_transpose(_p(v), dt(v), B, Nkv, num_heads, hd, v.stride(0), v.stride(1), _p(vt),
+                                      npad, _stream()), "gdl_v_transpose")
+    return vt
+
+
+def attention_unfused(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
+    """softmax(q k^T / sqrt(hd)) v with materialised scores: the exact-f32 parity path (and the
+    small / odd-head-dim cases).  q [B,Nq,D], k,v [B,Nkv,D] (strided views allowed, e.g. slices of
+    a packed qkv or kv tensor).  Returns [B,Nq,D]."""
+    B, Nq, Nkv, D, hd = _attn_check(q, k, v, num_heads)
+    es = 4 if q.dtype == torch.float32 else 2
     bke = 128 // es
-    if hd % bke != 0 or not qkv.is_contiguous():
-        raise ValueError(f"attention: head_dim {hd} must be a multiple of {bke}; qkv contiguous")
-    npad = (N + 63) // 64 * 64
+    if hd % bke != 0:
+        raise ValueError(f"attention: head_dim {hd} must be a multiple of {bke} for {q.dtype}")
+    npad = (Nkv + 63) // 64 * 64
     lib = _lib.load()
-    vt = torch.empty((B, num_heads, hd, npad), device=qkv.device, dtype=qkv.dtype)
-    check(lib.gdl_v_transpose(_p(qkv), dt(qkv), B, N, num_heads, hd, _p(vt), npad, _stream()),
-          "gdl_v_transpose")
-    scores = torch.empty((B, num_heads, N, npad), device=qkv.device, dtype=qkv.dtype)
+    vt = _v_transposed(v, num_heads, hd, npad)
+    scores = torch.empty((B, num_heads, Nq, npad), device=q.device, dtype=q.dtype)
     a = ConvArgs()
-    a.inp, a.dtype = qkv.data_ptr(), dt(qkv)
-    a.B, a.H, a.W, a.C = 1, 1, N, hd
-    a.in_sB, a.in_sH, a.in_sW = N * 3 * D, N * 3 * D, 3 * D
-    a.Ho, a.Wo, a.R, a.S, a.stride, a.pad = 1, N, 1, 1, 1, 0
-    a.w, a.w_sN, a.N = qkv.data_ptr() + D * es, 3 * D, N
+    a.inp, a.dtype = q.data_ptr(), dt(q)
+    a.B, a.H, a.W, a.C = 1, 1, Nq, hd
+    a.in_sB, a.in_sH, a.in_sW = Nq * q.stride(1), Nq * q.stride(1), q.stride(1)
+    a.Ho, a.Wo, a.R, a.S, a.stride, a.pad = 1, Nq, 1, 1, 1, 0
+    a.w, a.w_sN, a.N = k.data_ptr(), k.stride(1), Nkv
     a.out, a.out_dtype = scores.data_ptr(), dt(scores)
-    a.out_sB, a.out_sH, a.out_sW = N * npad, N * npad, npad
+    a.out_sB, a.out_sH, a.out_sW = Nq * npad, Nq * npad, npad
     a.alpha, a.act = float(hd) ** -0.5, ACT_NONE
     a.nz, a.nz_inner = B * num_heads, num_heads
-    a.in_sZ0, a.in_sZ1 = N * 3 * D, hd
-    a.w_sZ0, a.w_sZ1 = N * 3 * D, hd
-    a.out_sZ0, a.out_sZ1 = num_heads * N * npad, N * npad
+    a.in_sZ0, a.in_sZ1 = q.stride(0), hd
+    a.w_sZ0, a.w_sZ1 = k.stride(0), hd
+    a.out_sZ0, a.out_sZ1 = num_heads * Nq * npad, Nq * npad
     batched_gemm_raw(a)
-    check(lib.gdl_softmax_rows(_p(scores), _p(scores), dt(scores), B * num_heads * N, N, npad,
+    check(lib.gdl_softmax_rows(_p(scores), _p(scores), dt(scores), B * num_heads * Nq, Nkv, npad,
                                _stream()), "gdl_softmax_rows")
-    out = torch.empty((B, N, D), device=qkv.device, dtype=qkv.dtype)
+    out = torch.empty((B, Nq, D), device=q.device, dtype=q.dtype)
     a = ConvArgs()
     a.inp, a.dtype = scores.data_ptr(), dt(scores)
-    a.B, a.H, a.W, a.C = 1, 1, N, npad
-    a.in_sB, a.in_sH, a.in_sW = N * npad, N * npad, npad
-    a.Ho, a.Wo, a.R, a.S, a.stride, a.pad = 1, N, 1, 1, 1, 0
+    a.B, a.H, a.W, a.C = 1, 1, Nq, npad
+    a.in_sB, a.in_sH, a.in_sW = Nq * npad, Nq * npad, npad
+    a.Ho, a.Wo, a.R, a.S, a.stride, a.pad = 1, Nq, 1, 1, 1, 0
     a.w, a.w_sN, a.N = vt.data_ptr(), npad, hd
     a.out, a.out_dtype = out.data_ptr(), dt(out)
-    a.out_sB, a.out_sH, a.out_sW = N * D, N * D, D
+    a.out_sB, a.out_sH, a.out_sW = Nq * D, Nq * D, D
     a.alpha, a.act = 1.0, ACT_NONE
     a.nz, a.nz_inner = B * num_heads, num_heads
-    a.in_sZ0, a.in_sZ1 = num_heads * N * npad, N * npad
+    a.in_sZ0, a.in_sZ1 = num_heads * Nq * npad, Nq * npad
     a.w_sZ0, a.w_sZ1 = num_heads * hd * npad, hd * npad
-    a.out_sZ0, a.out_sZ1 = N * D, hd
+    a.out_sZ0, a.out_sZ1 = Nq * D, hd
     batched_gemm_raw(a)
     return out
 
 
-def attention_flash(qkv: Tensor, num_heads: int) -> Tensor:
-    """Fused flash attention forward (bf16, head_dim 64)."""
-    _need_cuda(qkv)
-    B, N, three_d = qkv.shape
-    D = three_d // 3
-    hd = D // num_heads
-    if qkv.dtype != torch.bfloat16 or hd != 64 or not qkv.is_contiguous():
-        raise ValueError("attention_flash: needs contiguous bf16 qkv with head_dim 64")
-    npad = (N + 63) // 64 * 64
-    lib = _lib.load()
-    vt = torch.empty((B, num_heads, hd, npad), device=qkv.device, dtype=qkv.dtype)
-    check(lib.gdl_v_transpose(_p(qkv), dt(qkv), B, N, num_heads, hd, _p(vt), npad, _stream()),
-          "gdl_v_transpose")
-    out = torch.empty((B, N, D), device=qkv.device, dtype=qkv.dtype)
-    check(lib.gdl_flash_attn_fwd(_p(qkv), _p(vt), _p(out), B, num_heads, N, npad,
-                                 float(hd) ** -0.5, _stream()), "gdl_flash_attn_fwd")
+def attention_flash(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
+    """Fused flash attention forward (bf16, head_dim 64); same argument convention."""
+    B, Nq, Nkv, D, hd = _attn_check(q, k, v, num_heads)
+    if q.dtype != torch.bfloat16 or hd != 64:
+        raise ValueError("attention_flash: needs bf16 and head_dim 64")
+    npad = (Nkv + 63) // 64 * 64
+    vt = _v_transposed(v, num_heads, hd, npad)
+    out = torch.empty((B, Nq, D), device=q.device, dtype=q.dtype)
+    check(_lib.load().gdl_flash_attn_fwd(_p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1),
+                                         _p(vt), _p(out), B, num_heads, Nq, Nkv, npad, float(hd) ** -0.5,
+                                         _stream()), "gdl_flash_attn_fwd")
+    return out
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
+    """Dispatch: flash kernel for bf16 / head_dim 64, materialised-score path otherwise."""
+    if q.dtype == torch.bfloat16 and q.shape[2] // num_heads == 64:
+        return attention_flash(q, k, v, num_heads)
+    return attention_unfused(q, k, v, num_heads)
+
+
+def split_qkv(qkv: Tensor):
+    """[B,N,3D] packed timm qkv -> three strided views [B,N,D] (no copy)."""
+    D = qkv.shape[-1] // 3
+    return qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+
+
+def dwconv3x3(x: Tensor, w9: Tensor, bias: Tensor, gelu: bool, out_dtype: torch.dtype | None = None) -> Tensor:
+    """Depthwise 3x3 (pad 1) + bias (+GELU) on a contiguous NHWC tensor; w9 is [9, C] f32."""
+    _need_cuda(x)
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("dwconv3x3: contiguous NHWC input expected")
+    B, H, W, Cc = x.shape
+    if w9.shape != (9, Cc) or w9.dtype != torch.float32 or not w9.is_contiguous():
+        raise ValueError("dwconv3x3: w9 must be contiguous f32 [9, C]")
+    out = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
+    check(_lib.load().gdl_dwconv3x3(_p(x), dt(x), B, H, W, Cc, _p(w9), _p(_f32vec(bias, Cc, "bias")), int(gelu),
+                                    _p(out), dt(out), _stream()), "gdl_dwconv3x3")
     return out
 
 
 # ------------------------------------------------------------------ DOFA patch embed helpers
 def patchify(img: Tensor, P: int, pad: int, gh: int, gw: int, kpad: int,
-             out_dtype: torch.dtype) -> Tensor:
+             out_dtype: torch.dtype, stride: int | None = None) -> Tensor:
     _need_cuda(img)
     if img.dtype != torch.float32 or not img.is_contiguous():
         raise ValueError("patchify: image must be contiguous f32 NCHW")
     B, Cc, H, W = img.shape
     cols = torch.empty((B * gh * gw, kpad), device=img.device, dtype=out_dtype)
-    check(_lib.load().gdl_patchify(_p(img), B, Cc, H, W, P, pad, gh, gw, _p(cols), dt(cols), kpad,
-                                   _stream()), "gdl_patchify")
+    check(_lib.load().gdl_patchify(_p(img), B, Cc, H, W, P, P if stride is None else stride, pad, gh, gw,
+                                   _p(cols), dt(cols), kpad, _stream()), "gdl_patchify")
     return cols
 
 

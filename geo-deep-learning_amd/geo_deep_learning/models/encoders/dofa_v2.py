@@ -76,7 +76,7 @@ class _PostNormLayer(nn.Module):
         f32 = torch.float32
         sa = self.self_attn
         qkv = ops.linear(x, gnn.gemm_weight(sa.in_proj_weight, f32), sa.in_proj_bias.detach())
-        att = ops.attention_unfused(qkv.unsqueeze(0), sa.num_heads)[0]
+        att = ops.attention_unfused(*ops.split_qkv(qkv.unsqueeze(0)), sa.num_heads)[0]
         h = ops.linear(att, gnn.gemm_weight(sa.out_proj.weight, f32), sa.out_proj.bias.detach(), resid=x)
         x = ops.layernorm(h, self.norm1.weight.detach(), self.norm1.bias.detach(), self.norm1.eps, f32)
         f = ops.linear(x, gnn.gemm_weight(self.linear1.weight, f32), self.linear1.bias.detach(),
@@ -244,10 +244,7 @@ class Block(nn.Module):
         s2 = self._drop_scale(b, x.device, None if masks is None else masks[1])
         h = ops.layernorm(x, self.norm1.weight.detach(), self.norm1.bias.detach(), self.norm1.eps, cd)
         qkv = ops.linear(h, gnn.gemm_weight(self.attn.qkv.weight, cd), self.attn.qkv.bias.detach())
-        if cd == torch.bfloat16 and qkv.shape[-1] // 3 // self.attn.num_heads == 64:
-            a = ops.attention_flash(qkv, self.attn.num_heads)
-        else:
-            a = ops.attention_unfused(qkv, self.attn.num_heads)
+        a = ops.attention(*ops.split_qkv(qkv), self.attn.num_heads)
         x = self._residual(a, self.attn.proj, self.ls1.gamma, s1, x)
         h = ops.layernorm(x, self.norm2.weight.detach(), self.norm2.bias.detach(), self.norm2.eps, cd)
         h = ops.linear(h, gnn.gemm_weight(self.mlp.fc1.weight, cd), self.mlp.fc1.bias.detach(),

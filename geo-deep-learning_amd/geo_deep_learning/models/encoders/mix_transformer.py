@@ -1,0 +1,318 @@
+"""SegFormer MixVisionTransformer (MiT-B0..B5) on MI355X.
+
+Drop-in for the reference's models/encoders/mix_transformer.py (same class names, constructor
+arguments, ``get_encoder`` factory and state-dict keys); arithmetic in HIP kernels:
+
+* OverlapPatchEmbed: 7x7/s4 stem on the raw bands via a strided patchify + MFMA GEMM (3..10 input
+  channels are too few for the implicit-GEMM kernel), 3x3/s2 stages 2-4 as implicit-GEMM convs
+  straight from the previous stage's NHWC feature; LayerNorm (eps 1e-5) -> f32 token stream.
+* Attention (spatial reduction): q GEMM; K/V from ``LN(sr-conv(x))`` (k=stride=sr implicit-GEMM
+  conv) -> kv GEMM; fused flash attention with Nq != Nkv reading Q and K in place (strided), V
+  re-laid as V^T; proj GEMM with DropPath scale + residual fused.
+* Mix-FFN: fc1 GEMM -> depthwise 3x3 + bias + erf-GELU in ONE HBM-bound kernel -> fc2 GEMM with
+  DropPath scale + residual fused.
+
+This round builds the forward (inference) path; training through the MiT encoder needs the
+attention / LayerNorm / depthwise backward kernels and raises NotImplementedError.
+"""
+
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+from torch import Tensor, nn
+
+from geo_deep_learning.models.segmentation.base import EncoderMixin
+from geo_deep_learning.models.utils import _cl_conv
+from gdlhip import nn as gnn
+from gdlhip import ops
+
+
+def _ln(x: Tensor, norm: nn.LayerNorm, out_dtype: torch.dtype) -> Tensor:
+    return ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), norm.eps, out_dtype)
+
+
+def _drop_scale(prob: float, training: bool, batch: int, device, mask: Tensor | None) -> Tensor | None:
+    if prob == 0.0 or not training:
+        return None
+    keep = 1.0 - prob
+    if mask is None:
+        mask = torch.empty(batch, device=device, dtype=torch.float32).bernoulli_(keep)
+    return (mask.to(device=device, dtype=torch.float32) / keep).contiguous()
+
+
+def _residual_linear(h: Tensor, lin: nn.Linear, drop_scale: Tensor | None, x: Tensor) -> Tensor:
+    """x + drop_path(lin(h)) in one GEMM epilogue; x is the f32 token stream [B,N,C]."""
+    b, n, c = x.shape
+    out = torch.empty_like(x)
+    ops.conv_gemm(h.reshape(b, 1, n, h.shape[-1]), gnn.gemm_weight(lin.weight, h.dtype), bias=lin.bias.detach(),
+                  batch_scale=drop_scale, resid=x.view(b, 1, n, c), out=out.view(b, 1, n, c))
+    return out
+
+
+class DWConv(nn.Module):
+    """Depthwise 3x3 conv parameter container (mix_transformer.py:533-546)."""
+
+    def __init__(self, dim: int = 768) -> None:
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
+
+    def taps(self) -> Tensor:
+        """[9, C] f32 tap-major weights (cached repack of the [C,1,3,3] parameter)."""
+        w = self.dwconv.weight
+        return gnn.cached((w,), "dw9", lambda: w.detach().reshape(w.shape[0], 9).t().contiguous())
+
+
+class Mlp(nn.Module):
+    """Mix-FFN (mix_transformer.py:17-63)."""
+
+    def __init__(self, in_features: int, hidden_features: int | None = None, out_features: int | None = None,
+                 act_layer: nn.Module = nn.GELU, drop: float = 0.0) -> None:
+        super().__init__()
+        if drop or act_layer is not nn.GELU:
+            msg = "gdlhip Mix-FFN: GELU, drop=0 (every MiT variant)"
+            raise NotImplementedError(msg)
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.dwconv = DWConv(hidden_features)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+    def forward_fused(self, h: Tensor, hh: int, ww: int, x: Tensor, drop_scale: Tensor | None) -> Tensor:
+        b, n, _ = h.shape
+        u = ops.linear(h, gnn.gemm_weight(self.fc1.weight, h.dtype), self.fc1.bias.detach())
+        g = ops.dwconv3x3(u.view(b, hh, ww, u.shape[-1]), self.dwconv.taps(), self.dwconv.dwconv.bias.detach(), True)
+        return _residual_linear(g.view(b, n, -1), self.fc2, drop_scale, x)
+
+
+class Attention(nn.Module):
+    """Spatial-reduction attention (mix_transformer.py:66-157)."""
+
+    def __init__(self, dim: int, num_heads: int = 8, qk_scale: float | None = None, attn_drop: float = 0.0,
+                 proj_drop: float = 0.0, sr_ratio: int = 1, *, qkv_bias: bool = False) -> None:
+        super().__init__()
+        if dim % num_heads != 0:
+            msg = f"dim {dim} should be divided by num_heads {num_heads}."
+            raise ValueError(msg)
+        if qk_scale is not None or attn_drop or proj_drop or not qkv_bias:
+            msg = "gdlhip MiT Attention: qkv_bias=True, default scale, no dropout (every MiT variant)"
+            raise NotImplementedError(msg)
+        self.dim = dim
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.sr_ratio = sr_ratio
+        if sr_ratio > 1:
+            self.sr = _cl_conv(dim, dim, sr_ratio, padding=0, bias=True)
+            self.sr.stride = (sr_ratio, sr_ratio)
+            self.norm = nn.LayerNorm(dim)
+
+    def forward_fused(self, h: Tensor, hh: int, ww: int, x: Tensor, drop_scale: Tensor | None) -> Tensor:
+        b, n, c = h.shape
+        cd = h.dtype
+        q = ops.linear(h, gnn.gemm_weight(self.q.weight, cd), self.q.bias.detach())
+        if self.sr_ratio > 1:
+            r = self.sr_ratio
+            red = ops.conv_gemm(h.view(b, hh, ww, c), gnn.gemm_weight(self.sr.weight, cd), R=r, S=r, stride=r,
+                                bias=self.sr.bias.detach(), out_dtype=torch.float32)
+            x_ = _ln(red.view(b, -1, c), self.norm, cd)
+        else:
+            x_ = h
+        kv = ops.linear(x_, gnn.gemm_weight(self.kv.weight, cd), self.kv.bias.detach())   # [B,Nkv,2C] = (k | v)
+        a = ops.attention(q, kv[..., :c], kv[..., c:], self.num_heads)
+        return _residual_linear(a, self.proj, drop_scale, x)
+
+
+class Block(nn.Module):
+    """mix_transformer.py:160-221."""
+
+    def __init__(self, dim: int, num_heads: int, mlp_ratio: float = 4.0, qk_scale: float | None = None,
+                 drop: float = 0.0, attn_drop: float = 0.0, drop_path: float = 0.0, act_layer: nn.Module = nn.GELU,
+                 norm_layer: nn.Module = nn.LayerNorm, sr_ratio: int = 1, *, qkv_bias: bool = False) -> None:
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop, sr_ratio=sr_ratio)
+        self.drop_prob = float(drop_path)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward(self, x: Tensor, h: int, w: int, masks=None) -> Tensor:
+        """x: f32 token stream [B, N, C]; ``masks`` pins the two DropPath draws (tests)."""
+        cd = gnn.compute_dtype()
+        b = x.shape[0]
+        s1 = _drop_scale(self.drop_prob, self.training, b, x.device, None if masks is None else masks[0])
+        s2 = _drop_scale(self.drop_prob, self.training, b, x.device, None if masks is None else masks[1])
+        x = self.attn.forward_fused(_ln(x, self.norm1, cd), h, w, x, s1)
+        return self.mlp.forward_fused(_ln(x, self.norm2, cd), h, w, x, s2)
+
+
+class OverlapPatchEmbed(nn.Module):
+    """Overlapped patch embedding: conv(k, stride, pad k//2) + LayerNorm (mix_transformer.py:224-276)."""
+
+    def __init__(self, img_size: int = 224, patch_size: int = 7, stride: int = 4, in_chans: int = 3,
+                 embed_dim: int = 768) -> None:
+        super().__init__()
+        self.patch_size = (patch_size, patch_size)
+        self.stride = stride
+        self.is_stem = in_chans < 32   # raw bands (NCHW image) vs an NHWC feature of the previous stage
+        self.proj = _cl_conv(in_chans, embed_dim, patch_size, padding=patch_size // 2, bias=True)
+        self.proj.stride = (stride, stride)
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def _stem_weight(self, cd: torch.dtype, kpad: int) -> Tensor:
+        """[N, Kpad] GEMM operand of the image stem, k = (c, r, s) like the patchify kernel."""
+        w = self.proj.weight
+
+        def build():
+            n = w.shape[0]
+            flat = w.detach().reshape(n, -1)  # logical OIHW flatten -> (c, r, s)
+            out = torch.zeros((n, kpad), device=w.device, dtype=torch.float32)
+            out[:, : flat.shape[1]] = flat
+            return out if cd == torch.float32 else ops.cast(out, cd)
+        return gnn.cached((w,), f"stem:{cd}:{kpad}", build)
+
+    def forward(self, x: Tensor) -> tuple[Tensor, int, int]:
+        """NCHW f32 image (stage 1) or NHWC feature in the compute dtype (stages 2-4) ->
+        (f32 tokens [B, h*w, C], h, w)."""
+        cd = gnn.compute_dtype()
+        k, s, p = self.patch_size[0], self.stride, self.patch_size[0] // 2
+        n = self.proj.weight.shape[0]
+        if self.is_stem:
+            b, c, hi, wi = x.shape  # raw bands, NCHW: im2col-free is impossible with C < one K chunk
+            h, w = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
+            bke = 32 if cd == torch.float32 else 64
+            kpad = (c * k * k + bke - 1) // bke * bke
+            cols = ops.patchify(x.float().contiguous(), k, p, h, w, kpad, cd, stride=s)
+            y = ops.linear(cols, self._stem_weight(cd, kpad), self.proj.bias.detach(), out_dtype=torch.float32)
+        else:
+            b, hi, wi, c = x.shape  # NHWC feature of the previous stage
+            y = ops.conv_gemm(x, gnn.gemm_weight(self.proj.weight, cd), R=k, S=k, stride=s, pad=p,
+                              bias=self.proj.bias.detach(), out_dtype=torch.float32)
+            h, w = y.shape[1], y.shape[2]
+        return _ln(y.view(b, h * w, n), self.norm, torch.float32), h, w
+
+
+class MixVisionTransformer(nn.Module):
+    """mix_transformer.py:279-530."""
+
+    def __init__(self, img_size: int = 224, in_chans: int = 3, num_classes: int = 1000,
+                 embed_dims: list[int] | None = None, num_heads: list[int] | None = None,
+                 mlp_ratios: list[float] | None = None, qk_scale: float | None = None, drop_rate: float = 0.0,
+                 attn_drop_rate: float = 0.0, drop_path_rate: float = 0.0, norm_layer: nn.Module = nn.LayerNorm,
+                 depths: list[int] | None = None, sr_ratios: list[int] | None = None, *,
+                 qkv_bias: bool = False) -> None:
+        super().__init__()
+        self.num_classes = num_classes
+        embed_dims = embed_dims or [64, 128, 256, 512]
+        num_heads = num_heads or [1, 2, 4, 8]
+        mlp_ratios = mlp_ratios or [4, 4, 4, 4]
+        depths = depths or [3, 4, 6, 3]
+        sr_ratios = sr_ratios or [8, 4, 2, 1]
+        self.depths = depths
+        self.embed_dims = embed_dims
+        for i in range(4):
+            setattr(self, f"patch_embed{i + 1}", OverlapPatchEmbed(
+                img_size=img_size // (1 if i == 0 else 2 ** (i + 1)), patch_size=7 if i == 0 else 3,
+                stride=4 if i == 0 else 2, in_chans=in_chans if i == 0 else embed_dims[i - 1],
+                embed_dim=embed_dims[i]))
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        cur = 0
+        for i in range(4):
+            setattr(self, f"block{i + 1}", nn.ModuleList([
+                Block(dim=embed_dims[i], num_heads=num_heads[i], mlp_ratio=mlp_ratios[i], qkv_bias=qkv_bias,
+                      qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[cur + j],
+                      norm_layer=norm_layer, sr_ratio=sr_ratios[i]) for j in range(depths[i])]))
+            setattr(self, f"norm{i + 1}", norm_layer(embed_dims[i]))
+            cur += depths[i]
+
+    def forward_features_nhwc(self, x: Tensor, drop_masks=None) -> list[Tensor]:
+        """-> 4 NHWC features in the compute dtype ([B,128,128,64] ... [B,16,16,512] for B2 @512^2)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            msg = ("gdlhip MixVisionTransformer: the MiT backward (attention / LayerNorm / depthwise) is not "
+                   "built yet -- run under torch.no_grad() (inference) or freeze the encoder")
+            raise NotImplementedError(msg)
+        with torch.no_grad():
+            cd = gnn.compute_dtype()
+            b = x.shape[0]
+            outs, bi = [], 0
+            for i in range(4):
+                tok, h, w = getattr(self, f"patch_embed{i + 1}")(x)
+                for blk in getattr(self, f"block{i + 1}"):
+                    tok = blk(tok, h, w, None if drop_masks is None else drop_masks[bi])
+                    bi += 1
+                x = _ln(tok, getattr(self, f"norm{i + 1}"), cd).view(b, h, w, -1)
+                outs.append(x)
+            return outs
+
+    def forward_features(self, x: Tensor) -> list[Tensor]:
+        return [ops.as_nchw(f) for f in self.forward_features_nhwc(x)]
+
+    def forward(self, x: Tensor) -> list[Tensor]:
+        return self.forward_features(x)
+
+
+class MixVisionTransformerEncoder(MixVisionTransformer, EncoderMixin):
+    """mix_transformer.py:550-584."""
+
+    def __init__(self, in_channels: int, out_channels: int, depth: int = 5, **kwargs: object) -> None:
+        super().__init__(in_chans=in_channels, **kwargs)
+        self._out_channels = out_channels
+        self._depth = depth
+
+    def make_dilated(self) -> None:
+        msg = "MixVisionTransformer encoder does not support dilated mode"
+        raise ValueError(msg)
+
+    def set_in_channels(self, in_channels: int) -> None:  # noqa: ARG002 (reference: a no-op, :570-574)
+        return
+
+    def forward(self, x: Tensor) -> list[Tensor]:
+        return self.forward_features(x)[: self._depth - 1]
+
+    def forward_nhwc(self, x: Tensor, drop_masks=None) -> list[Tensor]:
+        return self.forward_features_nhwc(x, drop_masks)[: self._depth - 1]
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        state_dict = dict(state_dict)
+        state_dict.pop("head.weight", None)
+        state_dict.pop("head.bias", None)
+        return super().load_state_dict(state_dict, *args, **kwargs)
+
+
+def _variant(embed_dims, depths):
+    return {"encoder": MixVisionTransformerEncoder,
+            "params": {"out_channels": (3, 0, *embed_dims), "embed_dims": embed_dims, "num_heads": [1, 2, 5, 8],
+                       "mlp_ratios": [4, 4, 4, 4], "qkv_bias": True, "norm_layer": partial(nn.LayerNorm, eps=1e-6),
+                       "depths": depths, "sr_ratios": [8, 4, 2, 1], "drop_rate": 0.0, "drop_path_rate": 0.1}}
+
+
+# mix_transformer.py:599-708
+mix_transformer_encoders = {
+    "mit_b0": _variant([32, 64, 160, 256], [2, 2, 2, 2]),
+    "mit_b1": _variant([64, 128, 320, 512], [2, 2, 2, 2]),
+    "mit_b2": _variant([64, 128, 320, 512], [3, 4, 6, 3]),
+    "mit_b3": _variant([64, 128, 320, 512], [3, 4, 18, 3]),
+    "mit_b4": _variant([64, 128, 320, 512], [3, 8, 27, 3]),
+    "mit_b5": _variant([64, 128, 320, 512], [3, 6, 40, 3]),
+}
+
+
+def get_encoder(name: str, in_channels: int = 3, depth: int = 5, weights: str | None = None,
+                output_stride: int = 32) -> MixVisionTransformerEncoder:  # noqa: ARG001
+    """mix_transformer.py:711-759 (pretrained weights need network access: load a checkpoint instead)."""
+    try:
+        entry = mix_transformer_encoders[name]
+    except KeyError as err:
+        msg = f"Wrong encoder name `{name}`, supported encoders: {list(mix_transformer_encoders.keys())}"
+        raise KeyError(msg) from err
+    if weights is not None:
+        msg = ("pretrained MiT weights are downloaded from github.com in the reference; this build has no "
+               "network: pass weights=None and load a checkpoint with load_state_dict")
+        raise RuntimeError(msg)
+    params = dict(entry["params"])
+    params.update(in_channels=in_channels, depth=depth)
+    return entry["encoder"](**params)

@@ -30,3 +30,24 @@ class BaseSegmentationModel(nn.Module):
         for name, param in self.named_parameters():
             if any(layer in name for layer in layers):
                 param.requires_grad = False
+
+
+class EncoderMixin:
+    """Encoder mixin (base.py:47-73): channel bookkeeping shared with smp-style encoders."""
+
+    _output_stride = 32
+
+    @property
+    def out_channels(self) -> list[int]:
+        return self._out_channels[: self._depth + 1]
+
+    @property
+    def output_stride(self) -> int:
+        return min(self._output_stride, 2**self._depth)
+
+    def set_in_channels(self, in_channels: int, *, pretrained: bool = True) -> None:  # noqa: ARG002
+        if in_channels == 3:
+            return
+        self._in_channels = in_channels
+        if self._out_channels[0] == 3:
+            self._out_channels = (in_channels, *self._out_channels[1:])

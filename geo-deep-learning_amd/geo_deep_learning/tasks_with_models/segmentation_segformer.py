@@ -1,0 +1,73 @@
+"""Segmentation SegFormer task (drop-in for the reference's tasks_with_models/segmentation_segformer.py:32-384)."""
+
+from __future__ import annotations
+
+from collections.abc import Callable
+from typing import Any
+
+import torch
+from torch import Tensor
+
+from geo_deep_learning.models.segmentation.segformer import SegFormerSegmentationModel
+from geo_deep_learning.tasks_with_models.segmentation_dofa import LightningModule
+from geo_deep_learning.utils.models import load_weights_from_checkpoint
+from gdlhip import nn as gnn
+
+
+class SegmentationSegformer(LightningModule):
+    """Same constructor keywords / hooks as the reference (segmentation_segformer.py:35-54,202-316)."""
+
+    def __init__(self, encoder: str, in_channels: int, num_classes: int, max_samples: int, loss: Callable,
+                 image_size: tuple[int, int] = (512, 512), weights: str | None = None,
+                 optimizer: Callable = torch.optim.Adam,
+                 scheduler: Callable = torch.optim.lr_scheduler.ConstantLR,
+                 scheduler_config: dict[str, Any] | None = None, freeze_layers: list[str] | None = None,
+                 class_labels: list[str] | None = None, class_colors: list[str] | None = None,
+                 weights_from_checkpoint_path: str | None = None, *, use_dynamic_encoder: bool = False,
+                 **kwargs: object) -> None:
+        super().__init__()
+        self.save_hyperparameters(encoder=encoder, in_channels=in_channels, num_classes=num_classes, **kwargs)
+        self.encoder, self.in_channels, self.weights = encoder, in_channels, weights
+        self.image_size = tuple(image_size)
+        self.use_dynamic_encoder = use_dynamic_encoder
+        self.freeze_layers = freeze_layers
+        self.weights_from_checkpoint_path = weights_from_checkpoint_path
+        self.optimizer, self.scheduler = optimizer, scheduler
+        self.scheduler_config = scheduler_config or {"interval": "epoch"}
+        self.class_colors, self.max_samples, self.num_classes = class_colors, max_samples, num_classes
+        self.threshold = 0.5
+        self.loss = loss
+        n = num_classes + 1 if num_classes == 1 else num_classes
+        self.labels = [str(i) for i in range(n)] if class_labels is None else class_labels
+
+    def configure_model(self) -> None:
+        if getattr(self, "model", None) is not None:
+            return
+        self.model = SegFormerSegmentationModel(encoder=self.encoder, in_channels=self.in_channels,
+                                                weights=self.weights, freeze_layers=self.freeze_layers,
+                                                num_classes=self.num_classes,
+                                                use_dynamic_encoder=self.use_dynamic_encoder)
+        if self.weights_from_checkpoint_path:
+            load_weights_from_checkpoint(self.model, self.weights_from_checkpoint_path,
+                                         load_parts=self.hparams.get("load_parts"), map_location=self.device)
+
+    def configure_optimizers(self):
+        optimizer = self.optimizer(self.parameters())
+        return [optimizer], [{"scheduler": self.scheduler(optimizer), **self.scheduler_config}]
+
+    def forward(self, image: Tensor) -> Tensor:
+        return self.model(image)
+
+    def training_step(self, batch: dict[str, Any], batch_idx: int) -> Tensor:  # noqa: ARG002
+        y_hat = self(batch["image"])
+        loss = self.loss(y_hat, batch["mask"].squeeze(1).long())
+        self.log("train_loss", loss, batch_size=batch["image"].shape[0], on_step=False, on_epoch=True, sync_dist=True)
+        return loss
+
+    def validation_step(self, batch: dict[str, Any], batch_idx: int) -> Tensor:  # noqa: ARG002
+        y_hat = self(batch["image"])
+        loss = self.loss(y_hat, batch["mask"].squeeze(1).long())
+        self.log("val_loss", loss, batch_size=batch["image"].shape[0], on_step=False, on_epoch=True, sync_dist=True)
+        if self.num_classes == 1:
+            return (y_hat.sigmoid().squeeze(1) > self.threshold).long()
+        return gnn.predict_mask(y_hat)

@@ -157,21 +157,26 @@ int gdl_adaptive_avgpool_bwd(const void* dout, int dtype, int B, int So, int C, 
 /* ---- attention -----------------------------------------------------------------------
  * qkv [B,N,3,H,hd] (output of timm Attention.qkv).  Q and K are consumed in place
  * (strided GEMM operands); only V is re-laid out: vt [B,H,hd,Npad] (keys >= N zero). */
-int gdl_v_transpose(const void* qkv, int dtype, int B, int N, int H, int hd, void* vt, int Npad,
-                    gdl_stream_t stream);
+int gdl_v_transpose(const void* v, int dtype, int B, int N, int H, int hd, int64_t v_sB, int64_t v_sN,
+                    void* vt, int Npad, gdl_stream_t stream);
 /* row softmax over the first n_valid of n_cols columns; pad columns written as 0 */
 int gdl_softmax_rows(const void* in, void* out, int dtype, int64_t rows, int n_valid, int n_cols,
                      gdl_stream_t stream);
 /* fused flash attention forward (bf16, hd = 64): F.scaled_dot_product_attention inside timm
  * Attention.  Reads q,k straight from qkv [B,N,3,H,64], v from vt; o[b, n, h*64 + d]. */
-int gdl_flash_attn_fwd(const void* qkv, const void* vt, void* o, int B, int H, int N, int Npad,
+int gdl_flash_attn_fwd(const void* q, int64_t q_sB, int64_t q_sN, const void* k, int64_t k_sB,
+                       int64_t k_sN, const void* vt, void* o, int B, int H, int Nq, int Nkv, int Npad,
                        float scale, gdl_stream_t stream);
 
 /* ---- DOFA patch embed (dofa_v2.py:157-181) --------------------------------------------
  * im2col of conv2d(stride=P, padding=1, kernel P): in NCHW f32 [B,C,H,W] ->
  * cols [B*Gh*Gw][Kpad] (k = (c*P + r)*P + s, zero padded to Kpad), dtype out_dtype. */
-int gdl_patchify(const float* img, int B, int C, int H, int W, int P, int pad, int Gh, int Gw,
-                 void* cols, int out_dtype, int Kpad, gdl_stream_t stream);
+int gdl_patchify(const float* img, int B, int C, int H, int W, int P, int stride, int pad, int Gh,
+                 int Gw, void* cols, int out_dtype, int Kpad, gdl_stream_t stream);
+/* depthwise 3x3 conv (pad 1, stride 1) + bias (+ exact-erf GELU) on NHWC -- the Mix-FFN DWConv of
+ * SegFormer (mix_transformer.py:533-546 + :56-63).  w9 is [9][C] f32 (tap-major), bias [C]. */
+int gdl_dwconv3x3(const void* in, int dtype, int B, int H, int W, int C, const float* w9,
+                  const float* bias, int gelu, void* out, int out_dtype, gdl_stream_t stream);
 /* generated kernel G [C][P*P][D] f32 (TransformerWeightGenerator.fc_weight output viewed as at
  * dofa_v2.py:157-166) -> GEMM weight [D][Kpad], k = c*P*P + r*P + s, times `scaler` (0.01) */
 int gdl_dofa_pack_kernel(const float* g, int C, int PP, int D, float scaler, void* out,

@@ -136,7 +136,7 @@ def procedural_state_dict(model: nn.Module, seed: int = 42) -> dict[str, Tensor]
             v = g.uniform(0.5, 1.5, shape)
         elif leaf == "running_mean":
             v = g.normal(0.0, 0.1, shape)
-        elif is_norm and leaf == "weight":
+        elif leaf == "weight" and (is_norm or len(shape) == 1):   # every 1-D "weight" is a norm scale
             v = g.uniform(0.8, 1.2, shape)
         elif leaf == "gamma":
             v = g.uniform(0.05, 0.2, shape) * np.where(g.uniform(size=shape) < 0.5, -1.0, 1.0)

@@ -118,7 +118,7 @@ def test_attention_unfused(dtype, B, N, H, hd):
         pytest.skip("bf16 needs head_dim % 64 == 0")
     D = H * hd
     qkv = q(rnd(B, N, 3 * D), dtype)
-    o = ops.attention_unfused(qkv.to(DEV, dtype), H)
+    o = ops.attention_unfused(*ops.split_qkv(qkv.to(DEV, dtype)), H)
     qq, kk, vv = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
     ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, N, D)
     close(o, ref, dtype, "attention_unfused")
@@ -129,7 +129,7 @@ def test_attention_flash(B, N, H):
     dtype, hd = torch.bfloat16, 64
     D = H * hd
     qkv = q(rnd(B, N, 3 * D) * 1.5, dtype)
-    o = ops.attention_flash(qkv.to(DEV, dtype), H)
+    o = ops.attention_flash(*ops.split_qkv(qkv.to(DEV, dtype)), H)
     qq, kk, vv = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
     ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, N, D)
     close(o, ref, dtype, "attention_flash")
@@ -142,7 +142,7 @@ def test_attention_flash_spike():
     qkv[0, 5, :hd] = 4.0            # query 5
     qkv[0, 260, hd:2 * hd] = 4.0    # key 260 aligned with it -> score 1024/8 = 128
     qkv = q(qkv, torch.bfloat16)
-    o = ops.attention_flash(qkv.to(DEV, torch.bfloat16), H)
+    o = ops.attention_flash(*ops.split_qkv(qkv.to(DEV, torch.bfloat16)), H)
     qq, kk, vv = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
     ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B, N, hd)
     close(o, ref, torch.bfloat16, "attention_flash spike")
@@ -362,3 +362,54 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     with pytest.raises(_lib.GdlHipError):
         ops.cast(torch.zeros(4, device=DEV), torch.bfloat16)
     assert not math.isnan(0.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 256), (1, 9, 7, 64)])
+def test_dwconv3x3_gelu(dtype, B, H, W, C):
+    x = q(rnd(B, C, H, W), dtype)
+    w, b = rnd(C, 1, 3, 3, seed=1) * 0.3, rnd(C, seed=2)
+    ref = F.gelu(F.conv2d(x, w, b, padding=1, groups=C))
+    w9 = w.reshape(C, 9).t().contiguous().to(DEV)
+    y = ops.dwconv3x3(x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype), w9, b.to(DEV), True)
+    close(y.permute(0, 3, 1, 2), ref, dtype, "dwconv+gelu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_separate_kv(dtype):
+    """SegFormer SR attention: Nq != Nkv, K/V packed in one [B,Nkv,2C] tensor."""
+    B, Nq, Nkv, H, hd = 2, 200, 64, 2, 64
+    C = H * hd
+    qq, kv = q(rnd(B, Nq, C), dtype), q(rnd(B, Nkv, 2 * C, seed=1), dtype)
+    qd, kvd = qq.to(DEV, dtype), kv.to(DEV, dtype)
+    o = ops.attention(qd, kvd[..., :C], kvd[..., C:], H)
+    k, v = kv[..., :C], kv[..., C:]
+    ref = F.scaled_dot_product_attention(qq.view(B, Nq, H, hd).transpose(1, 2), k.reshape(B, Nkv, H, hd).transpose(1, 2),
+                                         v.reshape(B, Nkv, H, hd).transpose(1, 2)).transpose(1, 2).reshape(B, Nq, C)
+    close(o, ref, dtype, "attention q/kv")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,s,p,C,N", [(3, 2, 1, 64, 128), (8, 8, 0, 64, 64), (2, 2, 0, 320, 320)])
+def test_conv_strided(dtype, k, s, p, C, N):
+    """MiT patch-embed (3x3/s2) and spatial-reduction (k = stride) convs."""
+    B, H = 2, 16
+    x, w = q(rnd(B, C, H, H), dtype), q(rnd(N, C, k, k, seed=1) * 0.05, dtype)
+    ref = F.conv2d(x, w, stride=s, padding=p)
+    y = ops.conv_gemm(x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype),
+                      w.permute(0, 2, 3, 1).reshape(N, -1).contiguous().to(DEV, dtype), R=k, S=k, stride=s, pad=p,
+                      out_dtype=torch.float32)
+    close(y.permute(0, 3, 1, 2), ref, dtype, "strided conv")
+
+
+def test_patchify_strided_stem():
+    B, C, H, P, S, N = 2, 3, 32, 7, 4, 64
+    img, w = rnd(B, C, H, H), rnd(N, C, P, P, seed=1) * 0.1
+    ref = F.conv2d(img, w, stride=S, padding=3)
+    g = (H + 6 - P) // S + 1
+    kpad = (C * P * P + 31) // 32 * 32
+    cols = ops.patchify(img.to(DEV), P, 3, g, g, kpad, torch.float32, stride=S)
+    wq = torch.zeros(N, kpad)
+    wq[:, : C * P * P] = w.reshape(N, -1)
+    y = ops.linear(cols, wq.to(DEV)).view(B, g, g, N)
+    close(y.permute(0, 3, 1, 2), ref, torch.float32, "7x7/s4 stem")

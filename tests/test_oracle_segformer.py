@@ -1,0 +1,42 @@
+"""Pin the SegFormer oracle against outputs of the REAL reference (tests/golden/segformer.npz,
+produced by tools/make_goldens.py --only segformer)."""
+
+import json
+
+import numpy as np
+import torch
+
+from oracle import procedural_state_dict, synthetic_batch
+from oracle.segformer import SegFormerSegmentationModel
+
+
+def _sub(t, sc, sp, off=1):
+    return t.detach()[:, ::sc, off::sp, off::sp].numpy()
+
+
+def test_segformer_oracle_matches_reference(golden_dir):
+    g = np.load(golden_dir / "segformer.npz")
+    seed = json.loads(str(g["meta"]))["seed"]
+    m = SegFormerSegmentationModel("mit_b1", 3, 5).eval()
+    m.load_state_dict(procedural_state_dict(m, seed))
+    batch = synthetic_batch(2, 3, 64, 5, seed)
+    with torch.no_grad():
+        feats = m.encoder(batch["image"])
+        y = m(batch["image"])
+    for i, f in enumerate(feats):
+        np.testing.assert_allclose(f.numpy(), g[f"b1_feat{i}"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(y.numpy(), g["b1_out"], atol=1e-4, rtol=0)
+
+    m = SegFormerSegmentationModel("mit_b2", 3, 5).eval()
+    m.load_state_dict(procedural_state_dict(m, seed))
+    batch = synthetic_batch(1, 3, 512, 5, seed)
+    with torch.no_grad():
+        feats = m.encoder(batch["image"])
+        y = m(batch["image"])
+    for i, f in enumerate(feats):
+        np.testing.assert_allclose(_sub(f, 8, 3), g[f"b2_feat{i}_s"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(_sub(y, 1, 8, 3), g["b2_out_s8"], atol=2e-4, rtol=0)
+    mask = y.softmax(1).argmax(1).numpy()
+    top2 = y.topk(2, dim=1).values
+    decided = ((top2[:, 0] - top2[:, 1]) > 1e-3).numpy()
+    assert (mask == g["b2_mask"])[decided].all()

@@ -73,7 +73,7 @@ def main():
         print(f"wgrad     {name:14s} GF {flops / 1e9:8.1f}  TF/s {flops / med / 1e9:7.1f}  ({med * 1e3:.0f} us)")
     qkv = torch.randn(B, 1297, 2304, device=DEV).to(bf)
     flops = 4 * 1297 * 1297 * 768 * B
-    med, mn = timeit(lambda: ops.attention_flash(qkv, 12))
+    med, mn = timeit(lambda: ops.attention_flash(*ops.split_qkv(qkv), 12))
     print(f"flash_attn B{B} N1297 H12     GF {flops / 1e9:8.1f}  TF/s {flops / med / 1e9:7.1f}  ({med * 1e3:.0f} us)")
 
 
