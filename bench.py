@@ -43,9 +43,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mode", default="both", choices=["both", "train", "infer"])
+    ap.add_argument("--model", default="dofa", choices=["dofa", "segformer"],
+                    help="dofa = DOFA-base+UperNet (headline, configs[1]); segformer = SegFormer-B2 (configs[2], inference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     return ap.parse_args()
@@ -129,12 +131,18 @@ def main() -> None:
     from gdlhip import ops
     from gdlhip.nn import DiceLoss, FusedAdam
     from tasks_with_models.segmentation_dofa import SegmentationDOFA
+    from tasks_with_models.segmentation_segformer import SegmentationSegformer
 
     torch.manual_seed(42 + rank)  # train.py:67 seeds 42
-    task = SegmentationDOFA(
-        encoder="dofa_base", pretrained=False, image_size=(512, 512), num_classes=5, max_samples=6,
-        loss=DiceLoss(mode="multiclass"), freeze_layers=["encoder"],
-        optimizer=lambda params: FusedAdam(params, lr=6e-5, max_grad_norm=1.0))
+    if args.model == "segformer":
+        args.mode = "infer"  # the MiT backward kernels are not built yet (forward path only)
+        task = SegmentationSegformer(encoder="mit_b2", in_channels=3, num_classes=5, max_samples=6,
+                                     loss=DiceLoss(mode="multiclass"))
+    else:
+        task = SegmentationDOFA(
+            encoder="dofa_base", pretrained=False, image_size=(512, 512), num_classes=5, max_samples=6,
+            loss=DiceLoss(mode="multiclass"), freeze_layers=["encoder"],
+            optimizer=lambda params: FusedAdam(params, lr=6e-5, max_grad_norm=1.0))
     task.configure_model()
     task.to(device)
     if world > 1:
@@ -182,8 +190,9 @@ def main() -> None:
 
     tiles = args.batch * world * args.steps
     head = "train" if "train" in res else "infer"
+    model_name = "SegFormer-B2 (MiT-B2 + MLP decoder)" if args.model == "segformer" else "DOFA-base + UperNet"
     out = {
-        "metric": f"512x512 tiles/s, DOFA-base+UperNet, {head} step",
+        "metric": f"512x512 tiles/s, {model_name}, {head} step",
         "value": round(tiles / res[head], 3),
         "unit": "tiles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -191,7 +200,7 @@ def main() -> None:
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {
-            "workload": ("DOFA-base + UperNet, 3-band RGB 512x512 (configs[1]): "
+            "workload": (f"{model_name}, 3-band RGB 512x512 ({'configs[2]' if args.model == 'segformer' else 'configs[1]'}): "
                          + ("training step = fwd + Dice(main)+0.4*Dice(aux) + bwd + clip 1.0 + Adam 6e-5, "
                             "encoder frozen, DropPath/Dropout2d active" if head == "train"
                             else "inference = fwd + softmax/argmax")),
@@ -204,7 +213,7 @@ def main() -> None:
         out["inference_tiles_per_s"] = round(tiles / res["infer"], 3)
         out["inference_ms_per_step"] = round(1e3 * res["infer"] / args.steps, 3)
     # whole-model algorithmic flops: 1606.7 GF/tile train (frozen encoder), 726.7 fwd
-    gf = {"train": 1606.7, "infer": 726.7}
+    gf = {"train": 1606.7, "infer": 726.7} if args.model == "dofa" else {"infer": 121.0}
     peak = PEAK_BF16_TFLOPS if use_bf16 else PEAK_F32_TFLOPS
     out["model_flops_utilisation"] = {
         k: round(gf[k] * 1e-3 * tiles / res[k] / world / peak, 4) for k in res}
