@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mode", default="both", choices=["both", "train", "infer"])
     ap.add_argument("--model", default="dofa", choices=["dofa", "segformer"],
-                    help="dofa = DOFA-base+UperNet (headline, configs[1]); segformer = SegFormer-B2 (configs[2], inference)")
+                    help="dofa = DOFA-base+UperNet (headline, configs[1]); segformer = SegFormer-B2 (configs[2], all parameters trainable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     return ap.parse_args()
@@ -135,9 +135,9 @@ def main() -> None:
 
     torch.manual_seed(42 + rank)  # train.py:67 seeds 42
     if args.model == "segformer":
-        args.mode = "infer"  # the MiT backward kernels are not built yet (forward path only)
         task = SegmentationSegformer(encoder="mit_b2", in_channels=3, num_classes=5, max_samples=6,
-                                     loss=DiceLoss(mode="multiclass"))
+                                     loss=DiceLoss(mode="multiclass"),
+                                     optimizer=lambda params: FusedAdam(params, lr=6e-5, max_grad_norm=1.0))
     else:
         task = SegmentationDOFA(
             encoder="dofa_base", pretrained=False, image_size=(512, 512), num_classes=5, max_samples=6,
@@ -201,8 +201,10 @@ def main() -> None:
         "dtype": args.dtype, "data": "synthetic",
         "config": {
             "workload": (f"{model_name}, 3-band RGB 512x512 ({'configs[2]' if args.model == 'segformer' else 'configs[1]'}): "
-                         + ("training step = fwd + Dice(main)+0.4*Dice(aux) + bwd + clip 1.0 + Adam 6e-5, "
-                            "encoder frozen, DropPath/Dropout2d active" if head == "train"
+                         + (("training step = fwd + Dice + bwd (every parameter) + clip 1.0 + Adam 6e-5, "
+                             "DropPath/Dropout2d active" if args.model == "segformer" else
+                             "training step = fwd + Dice(main)+0.4*Dice(aux) + bwd + clip 1.0 + Adam 6e-5, "
+                             "encoder frozen, DropPath/Dropout2d active") if head == "train"
                             else "inference = fwd + softmax/argmax")),
             "per_gpu_batch": args.batch, "global_batch": args.batch * world, "num_classes": 5,
             "parallelism": f"dp{world}" + (" (DDP over RCCL + SyncBatchNorm)" if world > 1 else ""),
@@ -213,7 +215,7 @@ def main() -> None:
         out["inference_tiles_per_s"] = round(tiles / res["infer"], 3)
         out["inference_ms_per_step"] = round(1e3 * res["infer"] / args.steps, 3)
     # whole-model algorithmic flops: 1606.7 GF/tile train (frozen encoder), 726.7 fwd
-    gf = {"train": 1606.7, "infer": 726.7} if args.model == "dofa" else {"infer": 121.0}
+    gf = {"train": 1606.7, "infer": 726.7} if args.model == "dofa" else {"train": 3 * 121.0, "infer": 121.0}
     peak = PEAK_BF16_TFLOPS if use_bf16 else PEAK_F32_TFLOPS
     out["model_flops_utilisation"] = {
         k: round(gf[k] * 1e-3 * tiles / res[k] / world / peak, 4) for k in res}

@@ -212,71 +212,85 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
     constexpr int PASSES = 32 * CPR / 64;
     unsigned char* reg = smem + wave * (32 * ROWB);
     const int prow = lane / CPR, pchunk = lane % CPR;
-    const bool vec_ok = ((uintptr_t)a.out % 16 == 0) && (a.out_sW % PER == 0) && (a.out_sH % PER == 0) &&
+    const bool vec_ok = ((uintptr_t)a.out % 16 == 0) && ((uintptr_t)a.aux_out % 16 == 0) && (a.out_sW % PER == 0) && (a.out_sH % PER == 0) &&
                         (a.out_sB % PER == 0) && (out_zoff % PER == 0);
+    const bool mulgrad = a.act == GDL_ACT_MUL_GELU_GRAD;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      // pass 0 (only with aux_out): acc*alpha + bias, before scale/shift/act; pass 1: the final output
+      for (int pass = a.aux_out ? 0 : 1; pass < 2; ++pass) {
+        const bool is_aux = pass == 0;
+        unsigned char* dst_base = (unsigned char*)(is_aux ? a.aux_out : a.out);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r] * a.alpha + e_bias[j];
-          if (a.scale) v = v * e_scale[j] + e_shift[j];
-          if (a.act == GDL_ACT_RELU) v = fmaxf(v, 0.f);
-          else if (a.act == GDL_ACT_GELU) v = gelu_erf(v);
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-          unsigned char* q = reg + row * ROWB + (j * 32 + frow) * OES;
-          if constexpr (OES == 2) *(uint16_t*)q = f32_to_bf16(v);
-          else *(float*)q = v;
-        }
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][j][r] * a.alpha + e_bias[j];
+            if (!is_aux) {
+              if (a.scale) v = v * e_scale[j] + e_shift[j];
+              if (a.act == GDL_ACT_RELU) v = fmaxf(v, 0.f);
+              else if (a.act == GDL_ACT_GELU) v = gelu_erf(v);
+            }
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+            unsigned char* q = reg + row * ROWB + (j * 32 + frow) * OES;
+            if constexpr (OES == 2) *(uint16_t*)q = f32_to_bf16(v);
+            else *(float*)q = v;
+          }
 #pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) {
-        const int row = ps * (64 / CPR) + prow;
-        const int m = m0 + (wm * TM + i) * 32 + row;
-        const int n = n0 + wn * COLS + pchunk * PER;
-        if (m >= k.M || n >= a.N) continue;
-        const uint4 raw = *(const uint4*)(reg + row * ROWB + pchunk * 16);
-        int64_t ooff, roff = 0;
-        float bscale = 1.f;
-        if (k.out_dense && k.res_dense && !a.batch_scale) {
-          ooff = (int64_t)m * a.out_sW;
-          roff = (int64_t)m * a.res_sW;
-        } else {
-          const int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
-          ooff = (int64_t)b * a.out_sB + (int64_t)oy * a.out_sH + (int64_t)ox * a.out_sW;
-          roff = (int64_t)b * a.res_sB + (int64_t)oy * a.res_sH + (int64_t)ox * a.res_sW;
-          if (a.batch_scale) bscale = a.batch_scale[b];
-        }
-        ooff += out_zoff + n;
-        roff += n;
-        const bool full = n + PER <= a.N;
-        if (full && vec_ok && !a.resid && !a.batch_scale) {
-          *(uint4*)((unsigned char*)a.out + ooff * OES) = raw;
-          continue;
-        }
-        float v[PER];
-        if constexpr (OES == 2) {
-          const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int row = ps * (64 / CPR) + prow;
+          const int m = m0 + (wm * TM + i) * 32 + row;
+          const int n = n0 + wn * COLS + pchunk * PER;
+          if (m >= k.M || n >= a.N) continue;
+          const uint4 raw = *(const uint4*)(reg + row * ROWB + pchunk * 16);
+          int64_t ooff, roff = 0;
+          float bscale = 1.f;
+          if (k.out_dense && k.res_dense && !a.batch_scale) {
+            ooff = (int64_t)m * a.out_sW;
+            roff = (int64_t)m * a.res_sW;
+          } else {
+            const int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            ooff = (int64_t)b * a.out_sB + (int64_t)oy * a.out_sH + (int64_t)ox * a.out_sW;
+            roff = (int64_t)b * a.res_sB + (int64_t)oy * a.res_sH + (int64_t)ox * a.res_sW;
+            if (a.batch_scale) bscale = a.batch_scale[b];
+          }
+          ooff += out_zoff + n;
+          roff += n;
+          const bool full = n + PER <= a.N;
+          const bool plain = is_aux || (!a.resid && !a.batch_scale);
+          if (full && vec_ok && plain) {
+            *(uint4*)(dst_base + ooff * OES) = raw;
+            continue;
+          }
+          float v[PER];
+          if constexpr (OES == 2) {
+            const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w4[e] << 16); v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u); }
-        } else {
-          v[0] = __uint_as_float(raw.x); v[1] = __uint_as_float(raw.y); v[2] = __uint_as_float(raw.z); v[3] = __uint_as_float(raw.w);
-        }
+            for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w4[e] << 16); v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u); }
+          } else {
+            v[0] = __uint_as_float(raw.x); v[1] = __uint_as_float(raw.y); v[2] = __uint_as_float(raw.z); v[3] = __uint_as_float(raw.w);
+          }
+          if (!plain) {
 #pragma unroll
-        for (int e = 0; e < PER; ++e) {
-          v[e] *= bscale;
-          if (a.resid && n + e < a.N) v[e] += load_as_f32(a.resid, roff + e, a.resid_dtype);
-        }
-        if (full && vec_ok) {
-          if constexpr (OES == 2)
-            *(uint4*)((unsigned char*)a.out + ooff * 2) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
-                                                                       pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-          else
-            *(float4*)((float*)a.out + ooff) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
+            for (int e = 0; e < PER; ++e) {
+              v[e] *= bscale;
+              if (a.resid && n + e < a.N) {
+                const float rv = load_as_f32(a.resid, roff + e, a.resid_dtype);
+                v[e] = mulgrad ? v[e] * gelu_erf_grad(rv) : v[e] + rv;
+              }
+            }
+          }
+          if (full && vec_ok) {
+            if constexpr (OES == 2)
+              *(uint4*)(dst_base + ooff * 2) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                          pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+            else
+              *(float4*)((float*)dst_base + ooff) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
 #pragma unroll
-          for (int e = 0; e < PER; ++e)
-            if (n + e < a.N) store_from_f32(a.out, ooff + e, v[e], a.out_dtype);
+            for (int e = 0; e < PER; ++e)
+              if (n + e < a.N) store_from_f32(dst_base, ooff + e, v[e], a.out_dtype);
+          }
         }
       }
     }
@@ -324,6 +338,9 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   GDL_CHECK_ARG(((uintptr_t)a.in % 16 == 0) && ((uintptr_t)a.w % 16 == 0),
                 "gdl_conv_gemm: operand pointers must be 16-byte aligned");
   GDL_CHECK_ARG(a.nz >= 1 && a.nz_inner >= 1, "gdl_conv_gemm: nz/nz_inner must be >= 1");
+  GDL_CHECK_ARG(a.act >= GDL_ACT_NONE && a.act <= GDL_ACT_MUL_GELU_GRAD, "gdl_conv_gemm: bad act %d", a.act);
+  GDL_CHECK_ARG(a.act != GDL_ACT_MUL_GELU_GRAD || (a.resid && !a.aux_out),
+                "gdl_conv_gemm: GDL_ACT_MUL_GELU_GRAD takes the pre-activation tensor in `resid`");
   GDL_CHECK_ARG((int64_t)a.B * a.Ho * a.Wo < (1ll << 31), "gdl_conv_gemm: M too large");
   KArgs k;
   k.a = a;

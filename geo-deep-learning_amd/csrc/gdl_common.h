@@ -106,3 +106,7 @@ __device__ __forceinline__ void dma16_to_lds(const void* gsrc, void* lds_wave_ba
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
+// d/dx of gelu_erf: Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}

@@ -64,7 +64,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs k) {
   const int n0 = blockIdx.x * BM;
   const int tap = blockIdx.y / k.ctiles, c0 = (blockIdx.y % k.ctiles) * BN;
   const int tap_r = tap / a.S, tap_s = tap % a.S;
-  const int split = blockIdx.z;
+  // grid.z = (batch index zb -> (z0, z1)) * splits + split-K index
+  const int zb = blockIdx.z / k.splits;
+  const int split = blockIdx.z - zb * k.splits;
+  const int z0 = zb / a.nz_inner, z1 = zb % a.nz_inner;
+  const unsigned char* in_p = (const unsigned char*)a.in + (z0 * a.in_sZ0 + z1 * a.in_sZ1) * ES;
+  const unsigned char* dy_p = (const unsigned char*)a.dy + (z0 * a.dy_sZ0 + z1 * a.dy_sZ1) * ES;
+  float* dw_p = a.dw + z0 * a.dw_sZ0 + z1 * a.dw_sZ1;
   const int64_t p_begin = (int64_t)split * k.p_per_split;
   int64_t p_end = p_begin + k.p_per_split;
   if (p_end > k.P) p_end = k.P;
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs k) {
         const int n = n0 + cg * BLK;
         const int64_t off = k.dy_dense ? pp * a.dy_sW
                                        : (int64_t)b * a.dy_sB + (int64_t)oy * a.dy_sH + (int64_t)ox * a.dy_sW;
-        ra[i] = (pv && n < a.N) ? *(const uint4*)((const unsigned char*)a.dy + (off + n) * ES)
+        ra[i] = (pv && n < a.N) ? *(const uint4*)(dy_p + (off + n) * ES)
                                 : make_uint4(0, 0, 0, 0);
       }
       if (do_b) {
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs k) {
           ok = ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
           off = (int64_t)b * a.in_sB + (int64_t)iy * a.in_sH + (int64_t)ix * a.in_sW;
         }
-        rb[i] = ok ? *(const uint4*)((const unsigned char*)a.in + (off + c) * ES) : make_uint4(0, 0, 0, 0);
+        rb[i] = ok ? *(const uint4*)(in_p + (off + c) * ES) : make_uint4(0, 0, 0, 0);
       }
     }
   };
@@ -191,10 +197,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs k) {
   int64_t ld;
   if (k.splits > 1) {
     ld = (int64_t)a.R * a.S * a.C;
-    dst = a.workspace + (int64_t)split * a.N * ld;
+    dst = a.workspace + ((int64_t)zb * k.splits + split) * a.N * ld;
   } else {
     ld = a.dw_sN;
-    dst = a.dw;
+    dst = dw_p;
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -248,7 +254,12 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WArgs k) {
   const int n0 = blockIdx.x * 128;
   const int tap = blockIdx.y / k.ctiles, c0 = (blockIdx.y % k.ctiles) * 128;
   const int tap_r = tap / a.S, tap_s = tap % a.S;
-  const int split = blockIdx.z;
+  const int zb = blockIdx.z / k.splits;
+  const int split = blockIdx.z - zb * k.splits;
+  const int z0 = zb / a.nz_inner, z1 = zb % a.nz_inner;
+  const unsigned char* in_p = (const unsigned char*)a.in + (z0 * a.in_sZ0 + z1 * a.in_sZ1) * 2;
+  const unsigned char* dy_p = (const unsigned char*)a.dy + (z0 * a.dy_sZ0 + z1 * a.dy_sZ1) * 2;
+  float* dw_p = a.dw + z0 * a.dw_sZ0 + z1 * a.dw_sZ1;
   const int64_t p_begin = (int64_t)split * k.p_per_split;
   int64_t p_end = p_begin + k.p_per_split;
   if (p_end > k.P) p_end = k.P;
@@ -289,10 +300,10 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WArgs k) {
 #pragma unroll
       for (int pn = 0; pn < 2; ++pn) {
         const int nn = n0 + pn * 64 + chunk[u] * 8;
-        const unsigned char* sa = (pv && nn < a.N) ? (const unsigned char*)a.dy + (dyo + nn) * 2 : zero;
+        const unsigned char* sa = (pv && nn < a.N) ? dy_p + (dyo + nn) * 2 : zero;
         dma16_to_lds(sa, st + pn * PANEL + rowgroup * 1024);
         const int cc = c0 + pn * 64 + chunk[u] * 8;
-        const unsigned char* sb = (xv && cc < a.C) ? (const unsigned char*)a.in + (xo + cc) * 2 : zero;
+        const unsigned char* sb = (xv && cc < a.C) ? in_p + (xo + cc) * 2 : zero;
         dma16_to_lds(sb, st + (2 + pn) * PANEL + rowgroup * 1024);
       }
     }
@@ -365,10 +376,10 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WArgs k) {
   int64_t ld;
   if (k.splits > 1) {
     ld = (int64_t)a.R * a.S * a.C;
-    dst = a.workspace + (int64_t)split * a.N * ld;
+    dst = a.workspace + ((int64_t)zb * k.splits + split) * a.N * ld;
   } else {
     ld = a.dw_sN;
-    dst = a.dw;
+    dst = dw_p;
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -388,8 +399,12 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WArgs k) {
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int N,
-                                                           int64_t K, float* dw, int64_t dw_sN, int accumulate) {
+                                                           int64_t K, float* dw, int64_t dw_sN, int accumulate,
+                                                           int nz_inner, int64_t dw_sZ0, int64_t dw_sZ1) {
   const int64_t total = (int64_t)N * K;
+  const int zb = blockIdx.y;
+  ws += (int64_t)zb * splits * total;
+  dw += (zb / nz_inner) * dw_sZ0 + (zb % nz_inner) * dw_sZ1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     float s = 0.f;
     for (int sp = 0; sp < splits; ++sp) s += ws[(int64_t)sp * total + i];
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
-  const int64_t tiles = (int64_t)((a.N + 127) / 128) * a.R * a.S * ((a.C + 127) / 128);
+  const int64_t tiles = (int64_t)((a.N + 127) / 128) * a.R * a.S * ((a.C + 127) / 128) * (a.nz > 1 ? a.nz : 1);
   int64_t want = (1024 + tiles - 1) / tiles;           // aim for ~1024 blocks
   const int64_t max_by_k = P / (8 * bkp);              // keep >= 8 K-steps per split
   if (want > max_by_k) want = max_by_k;
@@ -421,7 +436,7 @@ extern "C" int64_t gdl_conv_wgrad_workspace(const gdl_wgrad_args* ap) {
   const int bkp = a.dtype == GDL_BF16 ? 64 : 32;
   const int splits = choose_splits(a, P, bkp);
   if (splits <= 1) return 0;
-  return (int64_t)splits * a.N * a.R * a.S * a.C * (int64_t)sizeof(float);
+  return (int64_t)splits * (a.nz > 1 ? a.nz : 1) * a.N * a.R * a.S * a.C * (int64_t)sizeof(float);
 }
 
 extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
@@ -434,6 +449,9 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
   GDL_CHECK_ARG(a.in_sB % al == 0 && a.in_sH % al == 0 && a.in_sW % al == 0 && a.dy_sB % al == 0 &&
                     a.dy_sH % al == 0 && a.dy_sW % al == 0, "gdl_conv_wgrad: strides must keep 16-byte alignment");
   GDL_CHECK_ARG(((uintptr_t)a.in % 16 == 0) && ((uintptr_t)a.dy % 16 == 0), "gdl_conv_wgrad: pointers must be 16-byte aligned");
+  GDL_CHECK_ARG(a.nz >= 1 && a.nz_inner >= 1 && a.nz <= 65535, "gdl_conv_wgrad: nz/nz_inner must be >= 1");
+  GDL_CHECK_ARG(a.in_sZ0 % al == 0 && a.in_sZ1 % al == 0 && a.dy_sZ0 % al == 0 && a.dy_sZ1 % al == 0,
+                "gdl_conv_wgrad: batch strides must keep 16-byte alignment");
   WArgs k;
   k.a = a;
   k.P = (int64_t)a.B * a.Ho * a.Wo;
@@ -441,7 +459,7 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
   const int bkp = a.dtype == GDL_BF16 ? 64 : 32;
   k.splits = choose_splits(a, k.P, bkp);
   if (k.splits > 1) {
-    const int64_t need = (int64_t)k.splits * a.N * a.R * a.S * a.C * (int64_t)sizeof(float);
+    const int64_t need = (int64_t)k.splits * a.nz * a.N * a.R * a.S * a.C * (int64_t)sizeof(float);
     GDL_CHECK_ARG(a.workspace && a.workspace_bytes >= need, "gdl_conv_wgrad: workspace too small (%lld needed)", (long long)need);
   }
   int64_t per = (k.P + k.splits - 1) / k.splits;
@@ -451,7 +469,8 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
                a.in_sH == (int64_t)a.W * a.in_sW && a.in_sB == (int64_t)a.H * a.in_sH);
   k.dy_dense = (a.dy_sH == (int64_t)a.Wo * a.dy_sW && a.dy_sB == (int64_t)a.Ho * a.dy_sH);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((a.N + 127) / 128, a.R * a.S * k.ctiles, k.splits);
+  GDL_CHECK_ARG((int64_t)a.nz * k.splits <= 65535, "gdl_conv_wgrad: nz * splits too large");
+  dim3 grid((a.N + 127) / 128, a.R * a.S * k.ctiles, a.nz * k.splits);
   const size_t lds = 2 * (128 + 128) * 128;
   if (a.dtype == GDL_BF16 && !g_wgrad_force_v1) hipLaunchKernelGGL(wgrad_tr_kernel, grid, dim3(256), lds, s, k);
   else if (a.dtype == GDL_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_tag>, grid, dim3(256), lds, s, k);
@@ -460,8 +479,8 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
     const int64_t K = (int64_t)a.R * a.S * a.C;
     int64_t g = ((int64_t)a.N * K + 255) / 256;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, a.workspace, k.splits, a.N, K, a.dw,
-                       a.dw_sN, a.accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g, a.nz), dim3(256), 0, s, a.workspace, k.splits, a.N, K,
+                       a.dw, a.dw_sN, a.accumulate, a.nz_inner, a.dw_sZ0, a.dw_sZ1);
   }
   GDL_CHECK_LAUNCH("gdl_conv_wgrad");
   return GDL_OK;

@@ -13,7 +13,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libgdlhip.so"
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_MUL_GELU_GRAD = 0, 1, 2, 3
 
 c_i, c_l, c_f, c_p = C.c_int, C.c_int64, C.c_float, C.c_void_p
 
@@ -33,6 +33,7 @@ class ConvArgs(C.Structure):
         ("nz", c_i), ("nz_inner", c_i),
         ("in_sZ0", c_l), ("in_sZ1", c_l), ("w_sZ0", c_l), ("w_sZ1", c_l),
         ("out_sZ0", c_l), ("out_sZ1", c_l),
+        ("aux_out", c_p),
     ]
 
 
@@ -46,6 +47,8 @@ class WgradArgs(C.Structure):
         ("N", c_i), ("dy_sB", c_l), ("dy_sH", c_l), ("dy_sW", c_l),
         ("dw", c_p), ("dw_sN", c_l), ("accumulate", c_i),
         ("workspace", c_p), ("workspace_bytes", c_l),
+        ("nz", c_i), ("nz_inner", c_i),
+        ("in_sZ0", c_l), ("in_sZ1", c_l), ("dy_sZ0", c_l), ("dy_sZ1", c_l), ("dw_sZ0", c_l), ("dw_sZ1", c_l),
     ]
 
 
@@ -58,6 +61,15 @@ SIGNATURES = {
     "gdl_conv_wgrad_workspace": (c_l, [C.POINTER(WgradArgs)]),
     "gdl_conv_wgrad": (c_i, [C.POINTER(WgradArgs), c_p]),
     "gdl_layernorm_fwd": (c_i, [c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_i, c_f, c_p]),
+    "gdl_colreduce_workspace": (c_l, [c_l, c_i, c_i]),
+    "gdl_layernorm_bwd": (c_i, [c_p, c_l, c_p, c_i, c_p, c_p, c_l, c_p, c_l, c_l, c_i, c_f, c_p, c_p, c_i, c_p, c_l,
+                                c_p]),
+    "gdl_colsum": (c_i, [c_p, c_i, c_l, c_i, c_l, c_p, c_i, c_p, c_l, c_p]),
+    "gdl_layerscale_bwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_l, c_p]),
+    "gdl_softmax_bwd_rows": (c_i, [c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_f, c_p]),
+    "gdl_dwconv3x3_gelu_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l,
+                                     c_p]),
+    "gdl_col2im": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_l, c_l, c_l, c_p]),
     "gdl_bn_stats": (c_i, [c_p, c_i, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_f, c_p, c_l, c_p]),
     "gdl_bn_stats_workspace": (c_l, [c_l, c_i]),
     "gdl_bn_apply": (c_i, [c_p, c_p, c_i, c_l, c_i, c_l, c_l, c_p, c_p, c_p, c_p, c_f, c_i, c_p]),

@@ -78,10 +78,23 @@ def dgrad_weight(weight: Tensor, cd: torch.dtype) -> Tensor:
     return cached((weight,), f"dgrad:{cd}", build)
 
 
+class _ToCompute(Function):
+    @staticmethod
+    def forward(ctx, x, cd):
+        ctx.in_dtype = x.dtype
+        return ops.bilinear(x, (x.shape[1], x.shape[2]), out_dtype=cd)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.bilinear(g, (g.shape[1], g.shape[2]), out_dtype=ctx.in_dtype), None
+
+
 def to_compute(x: Tensor, cd: torch.dtype) -> Tensor:
     """NHWC tensor in the compute dtype (strided copy+cast through the identity resize)."""
     if x.dtype == cd:
         return x
+    if x.requires_grad and torch.is_grad_enabled():
+        return _ToCompute.apply(x, cd)
     return ops.bilinear(x, (x.shape[1], x.shape[2]), out_dtype=cd)
 
 

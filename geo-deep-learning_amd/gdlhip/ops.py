@@ -15,7 +15,8 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, ConvArgs, WgradArgs, check  # noqa: F401
+from ._lib import (ACT_GELU, ACT_MUL_GELU_GRAD, ACT_NONE, ACT_RELU, BF16, F32, ConvArgs, WgradArgs,  # noqa: F401
+                   check)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -83,8 +84,9 @@ def conv_gemm(x: Tensor, w: Tensor, *, R: int = 1, S: int = 1, stride: int = 1, 
               bias: Tensor | None = None, scale: Tensor | None = None, shift: Tensor | None = None,
               act: int = ACT_NONE, batch_scale: Tensor | None = None, resid: Tensor | None = None,
               out: Tensor | None = None, out_dtype: torch.dtype | None = None,
-              alpha: float = 1.0) -> Tensor:
-    """out = epilogue(conv(x, w)); x NHWC [B,H,W,C], w [N, R*S*C] (K order r,s,c)."""
+              alpha: float = 1.0, aux_out: Tensor | None = None) -> Tensor:
+    """out = epilogue(conv(x, w)); x NHWC [B,H,W,C], w [N, R*S*C] (K order r,s,c).
+    ``aux_out`` (same shape / dtype / strides as out) receives the pre-activation values."""
     _need_cuda(x, w)
     two_d = x.dim() == 2
     x4 = _nhwc4(x, "conv_gemm input")
@@ -123,6 +125,11 @@ def conv_gemm(x: Tensor, w: Tensor, *, R: int = 1, S: int = 1, stride: int = 1, 
         a.resid, a.resid_dtype = r4.data_ptr(), dt(r4)
         a.res_sB = r4.stride(0) if r4.shape[0] == B else 0
         a.res_sH, a.res_sW = r4.stride(1), r4.stride(2)
+    if aux_out is not None:
+        x4a = _nhwc4(aux_out, "conv_gemm aux_out")
+        if x4a.shape != out4.shape or x4a.stride() != out4.stride() or x4a.dtype != out4.dtype:
+            raise ValueError("conv_gemm: aux_out must match out in shape, strides and dtype")
+        a.aux_out = x4a.data_ptr()
     a.nz, a.nz_inner = 1, 1
     _launch_conv_gemm(a, "gdl_conv_gemm")
     if two_d and out4 is out:
@@ -180,8 +187,9 @@ def linear(x: Tensor, w: Tensor, bias: Tensor | None = None, **kw) -> Tensor:
     x2 = x.reshape(-1, K)
     if "resid" in kw and kw["resid"] is not None:
         kw["resid"] = kw["resid"].reshape(-1, w.shape[0])
-    if kw.get("out") is not None:
-        kw["out"] = kw["out"].reshape(-1, w.shape[0])
+    for key in ("out", "aux_out"):
+        if kw.get(key) is not None:
+            kw[key] = kw[key].reshape(-1, w.shape[0])
     y = conv_gemm(x2, w, bias=bias, **kw)
     return y.reshape(*lead, w.shape[0])
 
@@ -208,6 +216,7 @@ def conv_wgrad(x: Tensor, dy: Tensor, *, R: int, S: int, stride: int = 1, pad: i
     a.Ho, a.Wo, a.R, a.S, a.stride, a.pad, a.N = Ho, Wo, R, S, stride, pad, N
     a.dy_sB, a.dy_sH, a.dy_sW = dy4.stride(0), dy4.stride(1), dy4.stride(2)
     a.dw, a.dw_sN, a.accumulate = dw.data_ptr(), dw.stride(0), int(accumulate)
+    a.nz, a.nz_inner = 1, 1
     lib = _lib.load()
     nbytes = lib.gdl_conv_wgrad_workspace(C.byref(a))
     ws = torch.empty(max(nbytes, 4) // 4, device=x.device, dtype=torch.float32)
@@ -467,6 +476,187 @@ def dwconv3x3(x: Tensor, w9: Tensor, bias: Tensor, gelu: bool, out_dtype: torch.
     check(_lib.load().gdl_dwconv3x3(_p(x), dt(x), B, H, W, Cc, _p(w9), _p(_f32vec(bias, Cc, "bias")), int(gelu),
                                     _p(out), dt(out), _stream()), "gdl_dwconv3x3")
     return out
+
+
+# ------------------------------------------------------------------ transformer-block backward
+def _colreduce_ws(rows: int, Cc: int, planes: int, device) -> tuple[Tensor, int]:
+    nbytes = _lib.load().gdl_colreduce_workspace(rows, Cc, planes)
+    return torch.empty(max(nbytes, 4) // 4, device=device, dtype=torch.float32), nbytes
+
+
+def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Tensor, eps: float, dres: Tensor | None = None,
+                  dgamma: Tensor | None = None, dbeta: Tensor | None = None, accumulate: bool = False):
+    """-> (dx f32 like x, dgamma, dbeta); ``dres`` (f32, x's shape) is added into dx."""
+    _need_cuda(x, dy)
+    D = x.shape[-1]
+    if x.dtype != torch.float32 or x.stride(-1) != 1 or not dy.is_contiguous() or dy.shape != x.shape:
+        raise ValueError("layernorm_bwd: x f32 with unit last stride, dy contiguous of the same shape")
+    x2 = x.reshape(-1, D)
+    rows = x2.shape[0]
+    dx = torch.empty((rows, D), device=x.device, dtype=torch.float32)
+    r2 = None
+    if dres is not None:
+        if dres.dtype != torch.float32 or dres.shape != x.shape or dres.stride(-1) != 1:
+            raise ValueError("layernorm_bwd: dres must be f32 of x's shape")
+        r2 = dres.reshape(-1, D)
+    dgamma = torch.empty(D, device=x.device, dtype=torch.float32) if dgamma is None else dgamma
+    dbeta = torch.empty(D, device=x.device, dtype=torch.float32) if dbeta is None else dbeta
+    ws, nbytes = _colreduce_ws(rows, D, 2, x.device)
+    check(_lib.load().gdl_layernorm_bwd(_p(x2), x2.stride(0), _p(dy), dt(dy), _p(_f32vec(gamma, D, "gamma")), _p(r2),
+                                        0 if r2 is None else r2.stride(0), _p(dx), D, rows, D, eps, _p(dgamma),
+                                        _p(dbeta), int(accumulate), _p(ws), nbytes, _stream()), "gdl_layernorm_bwd")
+    return dx.reshape(x.shape), dgamma, dbeta
+
+
+def colsum(x: Tensor, out: Tensor | None = None, accumulate: bool = False) -> Tensor:
+    """out[c] (+)= sum over all leading dims of x[..., c] (bias gradients)."""
+    _need_cuda(x)
+    Cc = x.shape[-1]
+    x2 = x.reshape(-1, Cc)
+    if x2.stride(1) != 1:
+        raise ValueError("colsum: unit channel stride expected")
+    if out is None:
+        out = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    ws, nbytes = _colreduce_ws(x2.shape[0], Cc, 1, x.device)
+    check(_lib.load().gdl_colsum(_p(x2), dt(x2), x2.shape[0], Cc, x2.stride(0), _p(out), int(accumulate), _p(ws),
+                                 nbytes, _stream()), "gdl_colsum")
+    return out
+
+
+def layerscale_bwd(g: Tensor, z: Tensor | None, gamma: Tensor | None, batch_scale: Tensor | None,
+                   out_dtype: torch.dtype, dgamma: Tensor | None = None, accumulate: bool = False):
+    """g f32 [B,N,C] -> (dz [B,N,C] in out_dtype = g*batch_scale*gamma, dgamma = sum g*batch_scale*z or None)."""
+    _need_cuda(g)
+    B, N, Cc = g.shape
+    if g.dtype != torch.float32 or not g.is_contiguous():
+        raise ValueError("layerscale_bwd: contiguous f32 gradient expected")
+    dz = torch.empty((B, N, Cc), device=g.device, dtype=out_dtype)
+    ws, nbytes = (None, 0)
+    if gamma is not None:
+        if z is None or not z.is_contiguous() or z.shape != g.shape:
+            raise ValueError("layerscale_bwd: z must be contiguous and of g's shape")
+        dgamma = torch.empty(Cc, device=g.device, dtype=torch.float32) if dgamma is None else dgamma
+        ws, nbytes = _colreduce_ws(B * N, Cc, 1, g.device)
+    zz = z if gamma is not None else None
+    check(_lib.load().gdl_layerscale_bwd(_p(g), _p(zz), F32 if zz is None else dt(zz),
+                                         _p(None if gamma is None else _f32vec(gamma, Cc, "gamma")),
+                                         _p(None if batch_scale is None else _f32vec(batch_scale, B, "batch_scale")),
+                                         B * N, N, Cc, _p(dz), dt(dz), _p(dgamma if gamma is not None else None),
+                                         int(accumulate), _p(ws), nbytes, _stream()), "gdl_layerscale_bwd")
+    return dz, (dgamma if gamma is not None else None)
+
+
+def dwconv3x3_gelu_bwd(u: Tensor, dy: Tensor, w9: Tensor, bias: Tensor):
+    """backward of gelu(dwconv3x3(u)+bias): -> (du like u, dw9 [9,C] f32, dbias [C] f32)."""
+    _need_cuda(u, dy)
+    if u.dim() != 4 or not u.is_contiguous() or not dy.is_contiguous() or dy.shape != u.shape or dy.dtype != u.dtype:
+        raise ValueError("dwconv3x3_gelu_bwd: contiguous NHWC u and dy of one dtype expected")
+    B, H, W, Cc = u.shape
+    dpre = torch.empty_like(u)
+    dw9 = torch.empty((9, Cc), device=u.device, dtype=torch.float32)
+    db = torch.empty(Cc, device=u.device, dtype=torch.float32)
+    ws, nbytes = _colreduce_ws(B * H * W, Cc, 10, u.device)
+    check(_lib.load().gdl_dwconv3x3_gelu_bwd(_p(u), _p(dy), dt(u), B, H, W, Cc, _p(w9), _p(_f32vec(bias, Cc, "bias")),
+                                             _p(dpre), _p(dw9), _p(db), 0, _p(ws), nbytes, _stream()),
+          "gdl_dwconv3x3_gelu_bwd")
+    zero_b = torch.zeros(Cc, device=u.device, dtype=torch.float32)
+    du = dwconv3x3(dpre, w9.flip(0).contiguous(), zero_b, False)
+    return du, dw9, db
+
+
+def col2im(cols: Tensor, B: int, Ho: int, Wo: int, R: int, S: int, Cc: int, stride: int, pad: int, H: int, W: int,
+           out_dtype: torch.dtype) -> Tensor:
+    """cols [B*Ho*Wo, R*S*C] -> dx NHWC [B,H,W,C] (data gradient of a strided conv)."""
+    _need_cuda(cols)
+    if not cols.is_contiguous() or cols.numel() != B * Ho * Wo * R * S * Cc:
+        raise ValueError("col2im: contiguous [B*Ho*Wo, R*S*C] expected")
+    dx = torch.empty((B, H, W, Cc), device=cols.device, dtype=out_dtype)
+    check(_lib.load().gdl_col2im(_p(cols), dt(cols), B, Ho, Wo, R, S, Cc, stride, pad, H, W, _p(dx), dt(dx),
+                                 dx.stride(0), dx.stride(1), dx.stride(2), _stream()), "gdl_col2im")
+    return dx
+
+
+def _bgemm(inp: Tensor, in_sW: int, in_sZ: tuple[int, int], w: Tensor, w_sN: int, w_sZ: tuple[int, int], out: Tensor,
+           out_sW: int, out_sZ: tuple[int, int], M: int, K: int, N: int, nz: int, nz_inner: int, alpha: float) -> None:
+    """out[z][m, n] = alpha * sum_k in[z][m, k] * w[z][n, k] over nz = (z0, z1) problems."""
+    a = ConvArgs()
+    a.inp, a.dtype = inp.data_ptr(), dt(inp)
+    a.B, a.H, a.W, a.C = 1, 1, M, K
+    a.in_sB, a.in_sH, a.in_sW = M * in_sW, M * in_sW, in_sW
+    a.Ho, a.Wo, a.R, a.S, a.stride, a.pad = 1, M, 1, 1, 1, 0
+    a.w, a.w_sN, a.N = w.data_ptr(), w_sN, N
+    a.out, a.out_dtype = out.data_ptr(), dt(out)
+    a.out_sB, a.out_sH, a.out_sW = M * out_sW, M * out_sW, out_sW
+    a.alpha, a.act = alpha, ACT_NONE
+    a.nz, a.nz_inner = nz, nz_inner
+    a.in_sZ0, a.in_sZ1 = in_sZ
+    a.w_sZ0, a.w_sZ1 = w_sZ
+    a.out_sZ0, a.out_sZ1 = out_sZ
+    batched_gemm_raw(a)
+
+
+def _bwgrad(x: Tensor, x_sW: int, x_sZ: tuple[int, int], dy: Tensor, dy_sW: int, dy_sZ: tuple[int, int], dw: Tensor,
+            P: int, Cc: int, N: int, nz: int, nz_inner: int) -> None:
+    """dw[z][n, c] = sum_p dy[z][p, n] * x[z][p, c] (f32), dw dense [nz, N, C]."""
+    a = WgradArgs()
+    a.inp, a.dy, a.dtype = x.data_ptr(), dy.data_ptr(), dt(x)
+    a.B, a.H, a.W, a.C = 1, 1, P, Cc
+    a.in_sB, a.in_sH, a.in_sW = P * x_sW, P * x_sW, x_sW
+    a.Ho, a.Wo, a.R, a.S, a.stride, a.pad, a.N = 1, P, 1, 1, 1, 0, N
+    a.dy_sB, a.dy_sH, a.dy_sW = P * dy_sW, P * dy_sW, dy_sW
+    a.dw, a.dw_sN, a.accumulate = dw.data_ptr(), Cc, 0
+    a.nz, a.nz_inner = nz, nz_inner
+    a.in_sZ0, a.in_sZ1 = x_sZ
+    a.dy_sZ0, a.dy_sZ1 = dy_sZ
+    a.dw_sZ0, a.dw_sZ1 = nz_inner * N * Cc, N * Cc
+    lib = _lib.load()
+    nbytes = lib.gdl_conv_wgrad_workspace(C.byref(a))      # non-zero only for nz == 1 (split-K)
+    ws = torch.empty(max(nbytes, 4) // 4, device=x.device, dtype=torch.float32)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    check(lib.gdl_conv_wgrad(C.byref(a), _stream()), "gdl_conv_wgrad(batched)")
+
+
+def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, num_heads: int, dq: Tensor, dk: Tensor,
+                  dv: Tensor) -> None:
+    """Backward of softmax(q k^T / sqrt(hd)) v.  q/do/dq [B,Nq,D], k/v/dk/dv [B,Nkv,D]; all may be strided
+    slices of packed qkv / kv tensors (unit channel stride); dq/dk/dv are written in place.
+
+    The probabilities are recomputed (the forward is the fused flash kernel and keeps none):
+    S = scale q k^T -> P = softmax(S); dP = dO V^T; dS = P*(dP - rowsum(dP*P))*scale;
+    dQ = dS K (batched GEMM against K^T); dK = dS^T Q, dV = P^T dO (batched weight-gradient kernels)."""
+    B, Nq, Nkv, D, hd = _attn_check(q, k, v, num_heads)
+    cdt = q.dtype
+    bke = 32 if cdt == torch.float32 else 64
+    if hd % bke != 0:
+        raise ValueError(f"attention_bwd: head_dim {hd} must be a multiple of {bke} for {cdt}")
+    for t, n in ((do, Nq), (dq, Nq), (dk, Nkv), (dv, Nkv)):
+        if t.shape != (B, n, D) or t.dtype != cdt or t.stride(2) != 1:
+            raise ValueError("attention_bwd: gradient tensor shape / dtype / stride mismatch")
+    Hh = num_heads
+    npad = (Nkv + 63) // 64 * 64
+    lib = _lib.load()
+    nz = B * Hh
+    sc_z = (Hh * Nq * npad, Nq * npad)
+    scale = float(hd) ** -0.5
+    P = torch.empty((B, Hh, Nq, npad), device=q.device, dtype=cdt)
+    _bgemm(q, q.stride(1), (q.stride(0), hd), k, k.stride(1), (k.stride(0), hd), P, npad, sc_z, Nq, hd, Nkv, nz, Hh,
+           scale)
+    check(lib.gdl_softmax_rows(_p(P), _p(P), dt(P), nz * Nq, Nkv, npad, _stream()), "gdl_softmax_rows")
+    dS = torch.empty_like(P)
+    _bgemm(do, do.stride(1), (do.stride(0), hd), v, v.stride(1), (v.stride(0), hd), dS, npad, sc_z, Nq, hd, Nkv, nz, Hh,
+           1.0)
+    check(lib.gdl_softmax_bwd_rows(_p(P), _p(dS), _p(dS), dt(P), nz * Nq, Nkv, npad, scale, _stream()),
+          "gdl_softmax_bwd_rows")
+    kt = _v_transposed(k, Hh, hd, npad)                                    # K^T [B,H,hd,npad]
+    _bgemm(dS, npad, sc_z, kt, npad, (Hh * hd * npad, hd * npad), dq, dq.stride(1), (dq.stride(0), hd), Nq, npad, hd,
+           nz, Hh, 1.0)
+    dkv32 = torch.empty((2, B, Hh, npad, hd), device=q.device, dtype=torch.float32)
+    _bwgrad(q, q.stride(1), (q.stride(0), hd), dS, npad, sc_z, dkv32[0], Nq, hd, npad, nz, Hh)
+    _bwgrad(do, do.stride(1), (do.stride(0), hd), P, npad, sc_z, dkv32[1], Nq, hd, npad, nz, Hh)
+    for src, dst in ((dkv32[0], dk), (dkv32[1], dv)):
+        # [B,H,n,hd] f32 -> [B,n,H*hd] slice in the compute dtype: a strided copy-cast (identity resample)
+        bilinear(src.permute(0, 2, 1, 3)[:, :Nkv], (Nkv, Hh),
+                 out=dst.as_strided((B, Nkv, Hh, hd), (dst.stride(0), dst.stride(1), hd, 1)))
 
 
 # ------------------------------------------------------------------ DOFA patch embed helpers

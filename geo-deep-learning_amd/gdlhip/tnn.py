@@ -1,0 +1,403 @@
+"""Trainable transformer building blocks: conv / linear, LayerNorm, and whole MiT / ViT blocks as
+single autograd nodes whose forward AND backward are sequences of libgdlhip.so kernels.
+
+A block-level ``torch.autograd.Function`` (instead of one node per op) lets the backward fuse the
+residual-stream gradient adds into the LayerNorm-backward kernel and the two data-gradient
+contributions of the attention input into one GEMM epilogue, and keeps autograd bookkeeping to one
+node per transformer block.
+
+Reference semantics: MiT Block mix_transformer.py:160-221 (Attention :66-157, Mix-FFN :17-63,
+DWConv :533-546, OverlapPatchEmbed :224-276); timm ViT Block as used by dofa_v2.py:248-263.
+"""
+
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import ops
+from .nn import cached, conv_weight_matrix, gemm_weight, to_compute
+from .ops import ACT_GELU, ACT_MUL_GELU_GRAD, ACT_NONE
+
+
+# ------------------------------------------------------------------ operand helpers
+def _wmat32(weight: Tensor) -> Tensor:
+    """f32 [N, K] GEMM view of a Linear ([N,K]) or conv ([N,C,R,S] -> K = (r,s,c)) parameter."""
+    w = weight.detach() if weight.dim() == 2 else conv_weight_matrix(weight)
+    return w if w.is_contiguous() else w.contiguous()
+
+
+def t_weight(weight: Tensor, cd: torch.dtype) -> Tensor:
+    """[K, N] transposed operand (compute dtype) for the data gradient of a Linear / strided conv:
+    dx_cols[m, k] = sum_n dy[m, n] * w[n, k]."""
+    def build():
+        wm = _wmat32(weight)
+        return ops.pack_dgrad(wm, wm.shape[0], 1, wm.shape[1], cd)
+    return cached((weight,), f"wT:{cd}", build)
+
+
+def flipped_weight(weight: Tensor, cd: torch.dtype) -> Tensor:
+    """[C, (R*S flipped)*N] operand for the data gradient of a stride-1 conv."""
+    def build():
+        n, c, r, s = weight.shape
+        return ops.pack_dgrad(conv_weight_matrix(weight), n, r * s, c, cd)
+    return cached((weight,), f"dgrad:{cd}", build)
+
+
+def _dense(g: Tensor) -> Tensor:
+    """Contiguous version of a (possibly strided, unit channel stride) gradient; copy through the
+    identity-resample kernel when needed."""
+    if g.is_contiguous():
+        return g
+    shape = g.shape
+    g4 = g if g.dim() == 4 else g.reshape(shape[0], 1, -1, shape[-1]) if g.dim() == 3 else g.unsqueeze(0).unsqueeze(0)
+    out = ops.bilinear(g4, (g4.shape[1], g4.shape[2]), out_dtype=g.dtype)
+    return out.view(shape)
+
+
+def _to_cd(g: Tensor, cd: torch.dtype) -> Tensor:
+    """Dense tensor in the compute dtype (one kernel: cast, or strided copy+cast)."""
+    if g.dtype == cd:
+        return _dense(g)
+    if g.is_contiguous():
+        return ops.cast(g, cd)
+    shape = g.shape
+    g4 = g if g.dim() == 4 else g.reshape(shape[0], 1, -1, shape[-1])
+    return ops.bilinear(g4, (g4.shape[1], g4.shape[2]), out_dtype=cd).view(shape)
+
+
+def _conv_shape(weight: Tensor) -> tuple[int, int, int, int]:
+    if weight.dim() == 2:
+        return weight.shape[0], weight.shape[1], 1, 1
+    return tuple(weight.shape)  # n, c, r, s
+
+
+def _as_param_grad(dw: Tensor, weight: Tensor) -> Tensor:
+    """f32 [N, (r,s,c)] weight gradient -> a tensor of the parameter's logical shape."""
+    if weight.dim() == 2:
+        return dw
+    n, c, r, s = weight.shape
+    return dw.view(n, r, s, c).permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------ raw backward pieces (no autograd)
+def linear_dx(dz: Tensor, weight: Tensor, *, resid: Tensor | None = None, act: int = ACT_NONE,
+              out_dtype: torch.dtype | None = None) -> Tensor:
+    """dz [..., N] (compute dtype) -> dz @ W [..., K]; ``resid`` is added (or, with
+    ACT_MUL_GELU_GRAD, multiplied as gelu'(resid)) in the GEMM epilogue."""
+    return ops.linear(dz, t_weight(weight, dz.dtype), None, resid=resid, act=act, out_dtype=out_dtype)
+
+
+def linear_dw(x: Tensor, dz: Tensor) -> tuple[Tensor, Tensor]:
+    """(dW [N,K] f32, db [N] f32) of y = x W^T + b from x [..., K], dz [..., N]."""
+    x2, d2 = x.reshape(-1, x.shape[-1]), dz.reshape(-1, dz.shape[-1])
+    return ops.conv_wgrad(x2, d2, R=1, S=1), ops.colsum(d2)
+
+
+def conv_dx(dy: Tensor, weight: Tensor, stride: int, pad: int, in_hw: tuple[int, int]) -> Tensor:
+    """Data gradient of conv(x NHWC, weight, stride, pad) given dense dy NHWC (compute dtype)."""
+    n, c, r, s = _conv_shape(weight)
+    if stride == 1:
+        if r == 1 and s == 1:
+            return linear_dx(dy, weight)
+        return ops.conv_gemm(dy, flipped_weight(weight, dy.dtype), R=r, S=s, pad=r - 1 - pad)
+    b, ho, wo, _ = dy.shape
+    cols = ops.linear(dy.reshape(-1, n), t_weight(weight, dy.dtype), None)       # [B*Ho*Wo, (r,s,c)]
+    return ops.col2im(cols, b, ho, wo, r, s, c, stride, pad, in_hw[0], in_hw[1], dy.dtype)
+
+
+# ------------------------------------------------------------------ conv / linear node
+class _Conv(Function):
+    """y = conv(x, weight) + bias on NHWC (Linear = 1x1 on [B,1,N,K]); output dtype selectable."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, out_dtype):
+        n, c, r, s = _conv_shape(weight)
+        y = ops.conv_gemm(x, gemm_weight(weight, x.dtype), R=r, S=s, stride=stride, pad=pad,
+                          bias=None if bias is None else bias.detach(), out_dtype=out_dtype)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        stride, pad, has_bias = ctx.cfg
+        n, c, r, s = _conv_shape(weight)
+        dy = _to_cd(g, x.dtype)
+        dw = db = dx = None
+        if ctx.needs_input_grad[1]:
+            dw = _as_param_grad(ops.conv_wgrad(x, dy, R=r, S=s, stride=stride, pad=pad), weight)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy)
+        if ctx.needs_input_grad[0]:
+            dx = conv_dx(dy, weight, stride, pad, (x.shape[1], x.shape[2]))
+        return dx, dw, db, None, None, None
+
+
+def conv(x: Tensor, weight: Tensor, bias: Tensor | None, *, stride: int = 1, pad: int = 0,
+         out_dtype: torch.dtype | None = None) -> Tensor:
+    """Differentiable conv / 1x1 on an NHWC tensor in the compute dtype."""
+    return _Conv.apply(x, weight, bias, stride, pad, out_dtype)
+
+
+def linear(x: Tensor, weight: Tensor, bias: Tensor | None, out_dtype: torch.dtype | None = None) -> Tensor:
+    """Differentiable nn.Linear on [..., K] (compute dtype)."""
+    lead = x.shape[:-1]
+    x4 = x.reshape(1, 1, -1, x.shape[-1]) if x.dim() != 4 else x
+    y = _Conv.apply(x4, weight, bias, 1, 0, out_dtype)
+    return y.reshape(*lead, weight.shape[0])
+
+
+class _StemLinear(Function):
+    """Patchified image stem: y = cols @ pad(W.reshape(N, c*k*k))^T + b (raw bands carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, cols, weight, bias, wq, out_dtype):
+        y = ops.linear(cols, wq, bias.detach(), out_dtype=out_dtype)
+        ctx.save_for_backward(cols, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        cols, weight = ctx.saved_tensors
+        dy = _to_cd(g, cols.dtype)
+        dwp, db = linear_dw(cols, dy)                                  # [N, kpad]
+        n = weight.shape[0]
+        k = weight[0].numel()
+        dw = dwp[:, :k].reshape(weight.shape)                          # (c, r, s) order = logical OIHW
+        return None, dw, db, None, None
+
+
+def stem_linear(cols: Tensor, weight: Tensor, bias: Tensor, wq: Tensor, out_dtype: torch.dtype) -> Tensor:
+    return _StemLinear.apply(cols, weight, bias, wq, out_dtype)
+
+
+# ------------------------------------------------------------------ LayerNorm node
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        ctx.save_for_backward(x, weight)
+        ctx.eps = eps
+        return ops.layernorm(x, weight.detach(), bias.detach(), eps, out_dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(x, _dense(g), weight.detach(), ctx.eps)
+        return dx, dg, db, None, None
+
+
+def layernorm(x: Tensor, norm: torch.nn.LayerNorm, out_dtype: torch.dtype) -> Tensor:
+    """Differentiable F.layer_norm on the f32 token stream."""
+    return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps, out_dtype)
+
+
+# ------------------------------------------------------------------ MiT block
+class _MitBlock(Function):
+    """SegFormer block: x + dp(proj(SRA(LN1 x))) then + dp(fc2(gelu(dw3x3(fc1(LN2 .))))).
+
+    inputs: x f32 [B,N,C]; s1, s2 DropPath batch scales ([B] f32 or None); then the parameters
+    n1w n1b qw qb kvw kvb pw pb n2w n2b f1w f1b dww dwb f2w f2b [srw srb nsw nsb].
+    """
+
+    @staticmethod
+    def forward(ctx, x, s1, s2, hh, ww, heads, sr, eps1, eps_sr, cd, *prm):
+        n1w, n1b, qw, qb, kvw, kvb, pw, pb, n2w, n2b, f1w, f1b, dww, dwb, f2w, f2b = prm[:16]
+        b, n, c = x.shape
+        d = [p.detach() for p in prm]
+        h1 = ops.layernorm(x, d[0], d[1], eps1, cd)
+        q = ops.linear(h1, gemm_weight(qw, cd), d[3])
+        red = None
+        if sr > 1:
+            srw, srb, nsw, nsb = prm[16:20]
+            red = ops.conv_gemm(h1.view(b, hh, ww, c), gemm_weight(srw, cd), R=sr, S=sr, stride=sr, bias=d[17],
+                                out_dtype=torch.float32)
+            xn = ops.layernorm(red.view(b, -1, c), d[18], d[19], eps_sr, cd)
+        else:
+            xn = h1
+        kv = ops.linear(xn, gemm_weight(kvw, cd), d[5])
+        a = ops.attention(q, kv[..., :c], kv[..., c:], heads)
+        x1 = torch.empty_like(x)
+        ops.conv_gemm(a.view(b, 1, n, c), gemm_weight(pw, cd), bias=d[7], batch_scale=s1, resid=x.view(b, 1, n, c),
+                      out=x1.view(b, 1, n, c))
+        h2 = ops.layernorm(x1, d[8], d[9], eps1, cd)
+        u = ops.linear(h2, gemm_weight(f1w, cd), d[11])
+        w9 = cached((dww,), "dw9", lambda: dww.detach().reshape(dww.shape[0], 9).t().contiguous())
+        g = ops.dwconv3x3(u.view(b, hh, ww, -1), w9, d[13], True)
+        x2 = torch.empty_like(x)
+        ops.conv_gemm(g.view(b, 1, n, -1), gemm_weight(f2w, cd), bias=d[15], batch_scale=s2,
+                      resid=x1.view(b, 1, n, c), out=x2.view(b, 1, n, c))
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, s1, s2, h1, q, red, xn if sr > 1 else None, kv, a, x1, h2, u, g, w9, *prm)
+            ctx.cfg = (hh, ww, heads, sr, eps1, eps_sr, cd)
+        return x2
+
+    @staticmethod
+    def backward(ctx, gx2):
+        x, s1, s2, h1, q, red, xn, kv, a, x1, h2, u, g, w9, *prm = ctx.saved_tensors
+        hh, ww, heads, sr, eps1, eps_sr, cd = ctx.cfg
+        n1w, n1b, qw, qb, kvw, kvb, pw, pb, n2w, n2b, f1w, f1b, dww, dwb, f2w, f2b = prm[:16]
+        b, n, c = x.shape
+        gx2 = _dense(gx2)
+        # ---- Mix-FFN branch
+        dz2, _ = ops.layerscale_bwd(gx2, None, None, s2, cd)
+        df2w, df2b = linear_dw(g, dz2)
+        dg = linear_dx(dz2, f2w)
+        du, dw9, ddwb = ops.dwconv3x3_gelu_bwd(u.view(b, hh, ww, -1), dg.view(b, hh, ww, -1), w9, dwb.detach())
+        du = du.view(b, n, -1)
+        df1w, df1b = linear_dw(h2, du)
+        dh2 = linear_dx(du, f1w)
+        gx1, dn2w, dn2b = ops.layernorm_bwd(x1, dh2, n2w.detach(), eps1, dres=gx2)
+        # ---- attention branch
+        dz1, _ = ops.layerscale_bwd(gx1, None, None, s1, cd)
+        dpw, dpb = linear_dw(a, dz1)
+        da = linear_dx(dz1, pw)
+        dq = torch.empty((b, n, c), device=x.device, dtype=cd)
+        dkv = torch.empty_like(kv)
+        ops.attention_bwd(q, kv[..., :c], kv[..., c:], da, heads, dq, dkv[..., :c], dkv[..., c:])
+        kv_in = xn if sr > 1 else h1
+        dkvw, dkvb = linear_dw(kv_in, dkv)
+        dxn = linear_dx(dkv, kvw)
+        dqw, dqb = linear_dw(h1, dq)
+        extra = ()
+        if sr > 1:
+            srw, srb, nsw, nsb = prm[16:20]
+            dred, dnsw, dnsb = ops.layernorm_bwd(red.view(b, -1, c), dxn, nsw.detach(), eps_sr)
+            dred = (dred if cd == torch.float32 else ops.cast(dred, cd)).view(red.shape)
+            h1_img = h1.view(b, hh, ww, c)
+            dsrw = _as_param_grad(ops.conv_wgrad(h1_img, dred, R=sr, S=sr, stride=sr), srw)
+            dsrb = ops.colsum(dred)
+            side = conv_dx(dred, srw, sr, 0, (hh, ww)).view(b, n, c)
+            extra = (dsrw, dsrb, dnsw, dnsb)
+        else:
+            side = dxn
+        dh1 = linear_dx(dq, qw, resid=side)
+        gx, dn1w, dn1b = ops.layernorm_bwd(x, dh1, n1w.detach(), eps1, dres=gx1)
+        ddww = dw9.t().reshape(dww.shape)
+        return (gx, None, None, None, None, None, None, None, None, None,
+                dn1w, dn1b, dqw, dqb, dkvw, dkvb, dpw, dpb, dn2w, dn2b, df1w, df1b, ddww, ddwb, df2w, df2b, *extra)
+
+
+def mit_block(x: Tensor, s1, s2, hh: int, ww: int, heads: int, sr: int, eps1: float, eps_sr: float,
+              cd: torch.dtype, params: tuple) -> Tensor:
+    return _MitBlock.apply(x, s1, s2, hh, ww, heads, sr, eps1, eps_sr, cd, *params)
+
+
+# ------------------------------------------------------------------ timm ViT block (DOFA)
+class _VitBlock(Function):
+    """timm Block with LayerScale + DropPath: x + s1*g1*proj(MHA(LN1 x)); + s2*g2*fc2(gelu(fc1(LN2 .))).
+
+    inputs: x f32 [B,N,C]; s1, s2; parameters n1w n1b qkvw qkvb pw pb g1 n2w n2b f1w f1b f2w f2b g2
+    (g1 / g2 may be None when the block has no LayerScale).
+    """
+
+    @staticmethod
+    def forward(ctx, x, s1, s2, heads, eps, cd, *prm):
+        n1w, n1b, qkvw, qkvb, pw, pb, g1, n2w, n2b, f1w, f1b, f2w, f2b, g2 = prm
+        b, n, c = x.shape
+        d = [None if p is None else p.detach() for p in prm]
+        h1 = ops.layernorm(x, d[0], d[1], eps, cd)
+        qkv = ops.linear(h1, gemm_weight(qkvw, cd), d[3])
+        qv, kv_, vv = ops.split_qkv(qkv)
+        a = ops.attention(qv, kv_, vv, heads)
+        # the backward needs the branch outputs before LayerScale (z) and the GELU input (u): extra epilogue
+        # stores that are skipped when nothing upstream or in the block wants a gradient (inference, frozen)
+        train = any(ctx.needs_input_grad)
+        x1, z1 = torch.empty_like(x), (torch.empty_like(x) if train else None)
+        ops.conv_gemm(a.view(b, 1, n, c), gemm_weight(pw, cd), bias=d[5], scale=d[6], batch_scale=s1,
+                      resid=x.view(b, 1, n, c), out=x1.view(b, 1, n, c),
+                      aux_out=z1.view(b, 1, n, c) if train else None)
+        h2 = ops.layernorm(x1, d[7], d[8], eps, cd)
+        u = torch.empty((b, n, f1w.shape[0]), device=x.device, dtype=cd) if train else None
+        f = ops.linear(h2, gemm_weight(f1w, cd), d[10], act=ACT_GELU, aux_out=u)
+        x2, z2 = torch.empty_like(x), (torch.empty_like(x) if train else None)
+        ops.conv_gemm(f.view(b, 1, n, -1), gemm_weight(f2w, cd), bias=d[12], scale=d[13], batch_scale=s2,
+                      resid=x1.view(b, 1, n, c), out=x2.view(b, 1, n, c),
+                      aux_out=z2.view(b, 1, n, c) if train else None)
+        if train:
+            ctx.save_for_backward(x, s1, s2, h1, qkv, a, z1, x1, h2, u, f, z2, *prm)
+            ctx.cfg = (heads, eps, cd)
+        return x2
+
+    @staticmethod
+    def backward(ctx, gx2):
+        x, s1, s2, h1, qkv, a, z1, x1, h2, u, f, z2, *prm = ctx.saved_tensors
+        n1w, n1b, qkvw, qkvb, pw, pb, g1, n2w, n2b, f1w, f1b, f2w, f2b, g2 = prm
+        heads, eps, cd = ctx.cfg
+        b, n, c = x.shape
+        gx2 = _dense(gx2)
+        dz2, dg2 = ops.layerscale_bwd(gx2, z2, None if g2 is None else g2.detach(), s2, cd)
+        df2w, df2b = linear_dw(f, dz2)
+        du = linear_dx(dz2, f2w, resid=u, act=ACT_MUL_GELU_GRAD)
+        df1w, df1b = linear_dw(h2, du)
+        dh2 = linear_dx(du, f1w)
+        gx1, dn2w, dn2b = ops.layernorm_bwd(x1, dh2, n2w.detach(), eps, dres=gx2)
+        dz1, dg1 = ops.layerscale_bwd(gx1, z1, None if g1 is None else g1.detach(), s1, cd)
+        dpw, dpb = linear_dw(a, dz1)
+        da = linear_dx(dz1, pw)
+        dqkv = torch.empty_like(qkv)
+        qv, kv_, vv = ops.split_qkv(qkv)
+        dq_, dk_, dv_ = ops.split_qkv(dqkv)
+        ops.attention_bwd(qv, kv_, vv, da, heads, dq_, dk_, dv_)
+        dqkvw, dqkvb = linear_dw(h1, dqkv)
+        dh1 = linear_dx(dqkv, qkvw)
+        gx, dn1w, dn1b = ops.layernorm_bwd(x, dh1, n1w.detach(), eps, dres=gx1)
+        return (gx, None, None, None, None, None,
+                dn1w, dn1b, dqkvw, dqkvb, dpw, dpb, dg1, dn2w, dn2b, df1w, df1b, df2w, df2b, dg2)
+
+
+def vit_block(x: Tensor, s1, s2, heads: int, eps: float, cd: torch.dtype, params: tuple) -> Tensor:
+    return _VitBlock.apply(x, s1, s2, heads, eps, cd, *params)
+
+
+# ------------------------------------------------------------------ DOFA token assembly / feature taps
+class _DofaTokens(Function):
+    """tok = [cls ; cols @ wq^T + bias + pos_embed[1:]] as f32 [B, 1+n, D] (dofa_v2.py:444-452)."""
+
+    @staticmethod
+    def forward(ctx, cols, wq, bias, cls_token, pos_embed):
+        b, n, kp = cols.shape
+        d = wq.shape[0]
+        tok = torch.empty((b, n + 1, d), device=cols.device, dtype=torch.float32)
+        ops.add_rows(cls_token.detach().view(1, d), None, tok[:, 0, :], b)
+        ops.conv_gemm(cols.view(b, 1, n, kp), wq.detach(), bias=bias.detach(),
+                      resid=pos_embed.detach()[0, 1:, :].view(1, 1, n, d), out=tok[:, 1:, :].unsqueeze(1))
+        ctx.save_for_backward(cols)
+        return tok
+
+    @staticmethod
+    def backward(ctx, g):
+        (cols,) = ctx.saved_tensors
+        g = _dense(g)
+        d = g.shape[-1]
+        dcls = ops.colsum(g[:, 0, :]).view(1, 1, d) if ctx.needs_input_grad[3] else None
+        dwq = dbias = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dwq, dbias = linear_dw(cols, _to_cd(g[:, 1:, :], cols.dtype))
+        return None, dwq, dbias, dcls, None
+
+
+def dofa_tokens(cols: Tensor, wq: Tensor, bias: Tensor, cls_token: Tensor, pos_embed: Tensor) -> Tensor:
+    return _DofaTokens.apply(cols, wq, bias, cls_token, pos_embed)
+
+
+class _Tap(Function):
+    """f32 token stream [B, 1+hw*hw, D] -> NHWC feature [B, hw, hw, D] in the compute dtype (cls row dropped)."""
+
+    @staticmethod
+    def forward(ctx, tok, hw, cd):
+        ctx.shape = tok.shape
+        return ops.bilinear(tok[:, 1:, :].unflatten(1, (hw, hw)), (hw, hw), out_dtype=cd)
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = torch.zeros(ctx.shape, device=g.device, dtype=torch.float32)
+        hw = g.shape[1]
+        ops.bilinear(g, (hw, hw), out=gx[:, 1:, :].unflatten(1, (hw, hw)))
+        return gx, None, None
+
+
+def tap(tok: Tensor, hw: int, cd: torch.dtype) -> Tensor:
+    return _Tap.apply(tok, hw, cd)

@@ -7,7 +7,7 @@ from torch import nn
 
 from geo_deep_learning.models.utils import _cl_conv
 from gdlhip import nn as gnn
-from gdlhip import ops
+from gdlhip import ops, tnn
 
 
 class MLP(nn.Module):
@@ -19,7 +19,7 @@ class MLP(nn.Module):
 
     def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
         """[B,h,w,C] -> [B,h,w,E] (the reference's flatten/transpose is a no-op in NHWC)."""
-        return ops.linear(x, gnn.gemm_weight(self.proj.weight, x.dtype), self.proj.bias.detach())
+        return tnn.conv(x, self.proj.weight, self.proj.bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         xn = gnn.to_compute(ops.as_nhwc(x), gnn.compute_dtype())

@@ -22,7 +22,7 @@ import torch
 from torch import Tensor, nn
 
 from gdlhip import nn as gnn
-from gdlhip import ops
+from gdlhip import ops, tnn
 
 
 def position_embedding(embed_dim: int, pos: Tensor) -> Tensor:
@@ -236,30 +236,16 @@ class Block(nn.Module):
         return (mask.to(device=device, dtype=torch.float32) / keep).contiguous()
 
     def forward(self, x: Tensor, masks: tuple[Tensor, Tensor] | None = None) -> Tensor:
-        """x: f32 [B, N, D] token stream.  ``masks`` pins the two DropPath draws (tests)."""
-        cd = gnn.compute_dtype()
-        f32 = torch.float32
+        """x: f32 [B, N, D] token stream.  ``masks`` pins the two DropPath draws (tests).
+        One autograd node per block (gdlhip.tnn._VitBlock): forward and backward are HIP kernels."""
         b = x.shape[0]
         s1 = self._drop_scale(b, x.device, None if masks is None else masks[0])
         s2 = self._drop_scale(b, x.device, None if masks is None else masks[1])
-        h = ops.layernorm(x, self.norm1.weight.detach(), self.norm1.bias.detach(), self.norm1.eps, cd)
-        qkv = ops.linear(h, gnn.gemm_weight(self.attn.qkv.weight, cd), self.attn.qkv.bias.detach())
-        a = ops.attention(*ops.split_qkv(qkv), self.attn.num_heads)
-        x = self._residual(a, self.attn.proj, self.ls1.gamma, s1, x)
-        h = ops.layernorm(x, self.norm2.weight.detach(), self.norm2.bias.detach(), self.norm2.eps, cd)
-        h = ops.linear(h, gnn.gemm_weight(self.mlp.fc1.weight, cd), self.mlp.fc1.bias.detach(),
-                       act=ops.ACT_GELU)
-        return self._residual(h, self.mlp.fc2, self.ls2.gamma, s2, x)
-
-    @staticmethod
-    def _residual(h: Tensor, lin: nn.Linear, gamma: Tensor, drop_scale: Tensor | None, x: Tensor) -> Tensor:
-        """x + drop_path(gamma * lin(h)) in ONE GEMM epilogue."""
-        b, n, d = x.shape
-        out = torch.empty_like(x)
-        ops.conv_gemm(h.view(b, 1, n, h.shape[-1]), gnn.gemm_weight(lin.weight, h.dtype),
-                      bias=lin.bias.detach(), scale=gamma.detach(), batch_scale=drop_scale,
-                      resid=x.view(b, 1, n, d), out=out.view(b, 1, n, d))
-        return out
+        at, m = self.attn, self.mlp
+        prm = (self.norm1.weight, self.norm1.bias, at.qkv.weight, at.qkv.bias, at.proj.weight, at.proj.bias,
+               self.ls1.gamma, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+               self.ls2.gamma)
+        return tnn.vit_block(x, s1, s2, at.num_heads, self.norm1.eps, gnn.compute_dtype(), prm)
 
 
 class DOFAv2(nn.Module):
@@ -411,29 +397,24 @@ class DOFAv2(nn.Module):
     def _dynamic_operands(self, wavelengths: Tensor, device, cd: torch.dtype):
         host, key = self._check_wavelengths(wavelengths)
         params = tuple(self.patch_embed.parameters())
-        frozen = not torch.is_grad_enabled() or not any(p.requires_grad for p in params)
 
         def build():
-            return self.patch_embed.dynamic_gemm_operands(host, cd)
+            with torch.no_grad():
+                return self.patch_embed.dynamic_gemm_operands(host, cd)
 
-        if frozen:  # depends only on the wavelengths + frozen weights: generate once per sensor
-            return gnn.cached(params, f"dofa_dyn:{key}:{cd}", build)
-        return build()
+        # depends only on the wavelengths + the generator weights: regenerated when those change
+        return gnn.cached(params, f"dofa_dyn:{key}:{cd}", build)
 
-    def forward_features(self, x: Tensor, wavelengths: Tensor,
-                         drop_masks: list[tuple[Tensor, Tensor]] | None = None) -> list[Tensor]:
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            msg = ("gdlhip DOFAv2: the encoder backward (unfrozen ViT) is not built yet -- freeze the "
-                   "encoder (freeze_layers=['encoder'], the reference's default config) or run "
-                   "under torch.no_grad()")
+    def _tokens(self, x: Tensor, wavelengths: Tensor, drop_masks):
+        """Generator of (block index, f32 token stream [B, 1+n, D]) after every block."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.patch_embed.parameters()):
+            msg = ("gdlhip DOFAv2: the backward of the dynamic weight generator (patch_embed.*) is not built -- "
+                   "freeze it (freeze_layers=['encoder.patch_embed'] or the reference default ['encoder']); the "
+                   "ViT blocks and cls_token train with HIP kernels")
             raise NotImplementedError(msg)
-        with torch.no_grad():
-            return self._forward_features(x, wavelengths, drop_masks)
-
-    def _forward_features(self, x: Tensor, wavelengths: Tensor, drop_masks) -> list[Tensor]:
         cd = gnn.compute_dtype()
         b, c, h, w_ = x.shape
-        k, d = self.patch_size, self.embed_dim
+        k = self.patch_size
         gh, gw = (h + 2 - k) // k + 1, (w_ + 2 - k) // k + 1
         n = gh * gw
         if n + 1 != self.pos_embed.shape[1]:
@@ -441,20 +422,29 @@ class DOFAv2(nn.Module):
             raise ValueError(msg)
         wq, bias = self._dynamic_operands(wavelengths, x.device, cd)
         cols = ops.patchify(x.float().contiguous(), k, 1, gh, gw, wq.shape[1], cd)
-        tok = torch.empty((b, n + 1, d), device=x.device, dtype=torch.float32)
         # cls token rows (no pos-embed: dofa_v2.py:447-452), then patch GEMM + bias + pos_embed[1:]
-        ops.add_rows(self.cls_token.detach().view(1, d), None, tok[:, 0, :], b)
-        ops.conv_gemm(cols.view(b, 1, n, cols.shape[1]), wq, bias=bias,
-                      resid=self.pos_embed.detach()[0, 1:, :].view(1, 1, n, d),
-                      out=tok[:, 1:, :].unsqueeze(1))
-        feats = []
+        tok = tnn.dofa_tokens(cols.view(b, n, -1), wq, bias, self.cls_token, self.pos_embed)
         for i, blk in enumerate(self.blocks):
             tok = blk(tok, None if drop_masks is None else drop_masks[i])
+            yield i, tok
+
+    def forward_features_nhwc(self, x: Tensor, wavelengths: Tensor, drop_masks=None) -> list[Tensor]:
+        """Feature taps as NHWC tensors in the compute dtype (what the neck kernels consume)."""
+        cd = gnn.compute_dtype()
+        feats = []
+        for i, tok in self._tokens(x, wavelengths, drop_masks):
             if i in self.out_indices:
-                f = tok[:, 1:, :]
-                hw = int(n**0.5)
-                feats.append(f.reshape(b, hw, hw, d).permute(0, 3, 1, 2) if f.is_contiguous()
-                             else f.unflatten(1, (hw, hw)).permute(0, 3, 1, 2))
+                feats.append(tnn.tap(tok, int((tok.shape[1] - 1) ** 0.5), cd))
+        return feats
+
+    def forward_features(self, x: Tensor, wavelengths: Tensor,
+                         drop_masks: list[tuple[Tensor, Tensor]] | None = None) -> list[Tensor]:
+        """Reference API: f32 NCHW taps, zero-copy channels-last views of the token stream."""
+        feats = []
+        for i, tok in self._tokens(x, wavelengths, drop_masks):
+            if i in self.out_indices:
+                hw = int((tok.shape[1] - 1) ** 0.5)
+                feats.append(tok[:, 1:, :].unflatten(1, (hw, hw)).permute(0, 3, 1, 2))
         return feats
 
     def forward(self, x: Tensor, wavelengths: Tensor, drop_masks=None) -> list[Tensor]:

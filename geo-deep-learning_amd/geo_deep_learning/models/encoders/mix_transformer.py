@@ -12,8 +12,10 @@ arguments, ``get_encoder`` factory and state-dict keys); arithmetic in HIP kerne
 * Mix-FFN: fc1 GEMM -> depthwise 3x3 + bias + erf-GELU in ONE HBM-bound kernel -> fc2 GEMM with
   DropPath scale + residual fused.
 
-This round builds the forward (inference) path; training through the MiT encoder needs the
-attention / LayerNorm / depthwise backward kernels and raises NotImplementedError.
+Every block is ONE autograd node (gdlhip.tnn._MitBlock): its backward recomputes the attention
+probabilities, runs the dS/dQ GEMMs and batched dK/dV weight-gradient kernels, the depthwise /
+LayerNorm / bias reductions, and fuses the residual-stream gradient adds into the LayerNorm-backward
+kernel -- so ``loss.backward()`` trains the encoder with HIP kernels only.
 """
 
 from __future__ import annotations
@@ -26,11 +28,7 @@ from torch import Tensor, nn
 from geo_deep_learning.models.segmentation.base import EncoderMixin
 from geo_deep_learning.models.utils import _cl_conv
 from gdlhip import nn as gnn
-from gdlhip import ops
-
-
-def _ln(x: Tensor, norm: nn.LayerNorm, out_dtype: torch.dtype) -> Tensor:
-    return ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), norm.eps, out_dtype)
+from gdlhip import ops, tnn
 
 
 def _drop_scale(prob: float, training: bool, batch: int, device, mask: Tensor | None) -> Tensor | None:
@@ -40,15 +38,6 @@ def _drop_scale(prob: float, training: bool, batch: int, device, mask: Tensor | 
     if mask is None:
         mask = torch.empty(batch, device=device, dtype=torch.float32).bernoulli_(keep)
     return (mask.to(device=device, dtype=torch.float32) / keep).contiguous()
-
-
-def _residual_linear(h: Tensor, lin: nn.Linear, drop_scale: Tensor | None, x: Tensor) -> Tensor:
-    """x + drop_path(lin(h)) in one GEMM epilogue; x is the f32 token stream [B,N,C]."""
-    b, n, c = x.shape
-    out = torch.empty_like(x)
-    ops.conv_gemm(h.reshape(b, 1, n, h.shape[-1]), gnn.gemm_weight(lin.weight, h.dtype), bias=lin.bias.detach(),
-                  batch_scale=drop_scale, resid=x.view(b, 1, n, c), out=out.view(b, 1, n, c))
-    return out
 
 
 class DWConv(nn.Module):
@@ -79,12 +68,6 @@ class Mlp(nn.Module):
         self.dwconv = DWConv(hidden_features)
         self.fc2 = nn.Linear(hidden_features, out_features)
 
-    def forward_fused(self, h: Tensor, hh: int, ww: int, x: Tensor, drop_scale: Tensor | None) -> Tensor:
-        b, n, _ = h.shape
-        u = ops.linear(h, gnn.gemm_weight(self.fc1.weight, h.dtype), self.fc1.bias.detach())
-        g = ops.dwconv3x3(u.view(b, hh, ww, u.shape[-1]), self.dwconv.taps(), self.dwconv.dwconv.bias.detach(), True)
-        return _residual_linear(g.view(b, n, -1), self.fc2, drop_scale, x)
-
 
 class Attention(nn.Module):
     """Spatial-reduction attention (mix_transformer.py:66-157)."""
@@ -110,21 +93,6 @@ class Attention(nn.Module):
             self.sr.stride = (sr_ratio, sr_ratio)
             self.norm = nn.LayerNorm(dim)
 
-    def forward_fused(self, h: Tensor, hh: int, ww: int, x: Tensor, drop_scale: Tensor | None) -> Tensor:
-        b, n, c = h.shape
-        cd = h.dtype
-        q = ops.linear(h, gnn.gemm_weight(self.q.weight, cd), self.q.bias.detach())
-        if self.sr_ratio > 1:
-            r = self.sr_ratio
-            red = ops.conv_gemm(h.view(b, hh, ww, c), gnn.gemm_weight(self.sr.weight, cd), R=r, S=r, stride=r,
-                                bias=self.sr.bias.detach(), out_dtype=torch.float32)
-            x_ = _ln(red.view(b, -1, c), self.norm, cd)
-        else:
-            x_ = h
-        kv = ops.linear(x_, gnn.gemm_weight(self.kv.weight, cd), self.kv.bias.detach())   # [B,Nkv,2C] = (k | v)
-        a = ops.attention(q, kv[..., :c], kv[..., c:], self.num_heads)
-        return _residual_linear(a, self.proj, drop_scale, x)
-
 
 class Block(nn.Module):
     """mix_transformer.py:160-221."""
@@ -140,14 +108,24 @@ class Block(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
+    def _params(self) -> tuple:
+        at, m = self.attn, self.mlp
+        prm = [self.norm1.weight, self.norm1.bias, at.q.weight, at.q.bias, at.kv.weight, at.kv.bias, at.proj.weight,
+               at.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.dwconv.dwconv.weight,
+               m.dwconv.dwconv.bias, m.fc2.weight, m.fc2.bias]
+        if at.sr_ratio > 1:
+            prm += [at.sr.weight, at.sr.bias, at.norm.weight, at.norm.bias]
+        return tuple(prm)
+
     def forward(self, x: Tensor, h: int, w: int, masks=None) -> Tensor:
         """x: f32 token stream [B, N, C]; ``masks`` pins the two DropPath draws (tests)."""
-        cd = gnn.compute_dtype()
         b = x.shape[0]
         s1 = _drop_scale(self.drop_prob, self.training, b, x.device, None if masks is None else masks[0])
         s2 = _drop_scale(self.drop_prob, self.training, b, x.device, None if masks is None else masks[1])
-        x = self.attn.forward_fused(_ln(x, self.norm1, cd), h, w, x, s1)
-        return self.mlp.forward_fused(_ln(x, self.norm2, cd), h, w, x, s2)
+        at = self.attn
+        eps_sr = at.norm.eps if at.sr_ratio > 1 else 0.0
+        return tnn.mit_block(x, s1, s2, h, w, at.num_heads, at.sr_ratio, self.norm1.eps, eps_sr, gnn.compute_dtype(),
+                             self._params())
 
 
 class OverlapPatchEmbed(nn.Module):
@@ -187,13 +165,12 @@ class OverlapPatchEmbed(nn.Module):
             bke = 32 if cd == torch.float32 else 64
             kpad = (c * k * k + bke - 1) // bke * bke
             cols = ops.patchify(x.float().contiguous(), k, p, h, w, kpad, cd, stride=s)
-            y = ops.linear(cols, self._stem_weight(cd, kpad), self.proj.bias.detach(), out_dtype=torch.float32)
+            y = tnn.stem_linear(cols, self.proj.weight, self.proj.bias, self._stem_weight(cd, kpad), torch.float32)
         else:
             b, hi, wi, c = x.shape  # NHWC feature of the previous stage
-            y = ops.conv_gemm(x, gnn.gemm_weight(self.proj.weight, cd), R=k, S=k, stride=s, pad=p,
-                              bias=self.proj.bias.detach(), out_dtype=torch.float32)
+            y = tnn.conv(x, self.proj.weight, self.proj.bias, stride=s, pad=p, out_dtype=torch.float32)
             h, w = y.shape[1], y.shape[2]
-        return _ln(y.view(b, h * w, n), self.norm, torch.float32), h, w
+        return tnn.layernorm(y.view(b, h * w, n), self.norm, torch.float32), h, w
 
 
 class MixVisionTransformer(nn.Module):
@@ -231,22 +208,17 @@ class MixVisionTransformer(nn.Module):
 
     def forward_features_nhwc(self, x: Tensor, drop_masks=None) -> list[Tensor]:
         """-> 4 NHWC features in the compute dtype ([B,128,128,64] ... [B,16,16,512] for B2 @512^2)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            msg = ("gdlhip MixVisionTransformer: the MiT backward (attention / LayerNorm / depthwise) is not "
-                   "built yet -- run under torch.no_grad() (inference) or freeze the encoder")
-            raise NotImplementedError(msg)
-        with torch.no_grad():
-            cd = gnn.compute_dtype()
-            b = x.shape[0]
-            outs, bi = [], 0
-            for i in range(4):
-                tok, h, w = getattr(self, f"patch_embed{i + 1}")(x)
-                for blk in getattr(self, f"block{i + 1}"):
-                    tok = blk(tok, h, w, None if drop_masks is None else drop_masks[bi])
-                    bi += 1
-                x = _ln(tok, getattr(self, f"norm{i + 1}"), cd).view(b, h, w, -1)
-                outs.append(x)
-            return outs
+        cd = gnn.compute_dtype()
+        b = x.shape[0]
+        outs, bi = [], 0
+        for i in range(4):
+            tok, h, w = getattr(self, f"patch_embed{i + 1}")(x)
+            for blk in getattr(self, f"block{i + 1}"):
+                tok = blk(tok, h, w, None if drop_masks is None else drop_masks[bi])
+                bi += 1
+            x = tnn.layernorm(tok, getattr(self, f"norm{i + 1}"), cd).view(b, h, w, -1)
+            outs.append(x)
+        return outs
 
     def forward_features(self, x: Tensor) -> list[Tensor]:
         return [ops.as_nchw(f) for f in self.forward_features_nhwc(x)]

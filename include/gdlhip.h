@@ -24,7 +24,12 @@ extern "C" {
 typedef void* gdl_stream_t; /* hipStream_t */
 
 enum { GDL_F32 = 0, GDL_BF16 = 1 };
-enum { GDL_ACT_NONE = 0, GDL_ACT_RELU = 1, GDL_ACT_GELU = 2 };
+enum {
+  GDL_ACT_NONE = 0,
+  GDL_ACT_RELU = 1,
+  GDL_ACT_GELU = 2,         /* erf GELU */
+  GDL_ACT_MUL_GELU_GRAD = 3 /* backward of a fused Linear+GELU: v *= gelu'(u), u passed in `resid` */
+};
 enum {
   GDL_OK = 0,
   GDL_ERR_INVALID = -1, /* bad argument (shape / alignment / dtype) */
@@ -74,6 +79,8 @@ typedef struct {
   /* batching over grid.z: z -> (z / nz_inner, z % nz_inner) */
   int nz, nz_inner;
   int64_t in_sZ0, in_sZ1, w_sZ0, w_sZ1, out_sZ0, out_sZ1;
+  void* aux_out; /* optional: alpha*acc + bias, i.e. the value BEFORE scale/shift/act (same dtype and
+                    strides as out), saved for the backward pass (GELU input, LayerScale input) */
 } gdl_conv_args;
 
 int gdl_conv_gemm(const gdl_conv_args* a, gdl_stream_t stream);
@@ -98,6 +105,10 @@ typedef struct {
   int accumulate;
   float* workspace;       /* split-K partials, >= gdl_conv_wgrad_workspace() bytes, or NULL */
   int64_t workspace_bytes;
+  /* batched mode (nz > 1): grid.z -> (z / nz_inner, z % nz_inner) selects independent problems (the per-head
+   * dK = dS^T Q and dV = P^T dO of attention backward); gdl_conv_wgrad_workspace() covers nz * splits partials */
+  int nz, nz_inner;
+  int64_t in_sZ0, in_sZ1, dy_sZ0, dy_sZ1, dw_sZ0, dw_sZ1;
 } gdl_wgrad_args;
 
 int64_t gdl_conv_wgrad_workspace(const gdl_wgrad_args* a);
@@ -133,6 +144,39 @@ int gdl_bn_bwd_dx(const void* x, const void* dy, void* dx, int dtype, int64_t P,
                   const float* gamma, const float* beta, float eps, int relu,
                   const float* dgamma_sum, const float* dbeta_sum, int64_t P_total,
                   gdl_stream_t stream);
+
+/* ---- transformer-block backward (timm Block dofa_v2.py:248-263, MiT Block mix_transformer.py:160-221) ----
+ * Column reductions (parameter gradients) go through per-block partials in `ws`
+ * (>= gdl_colreduce_workspace(rows, C, planes) bytes) and a deterministic final pass; no atomics. */
+int64_t gdl_colreduce_workspace(int64_t rows, int C, int planes);
+/* autograd of F.layer_norm: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) [+ dres], g = dy*gamma;
+ * dgamma (+)= sum dy*xhat, dbeta (+)= sum dy.  x f32 rows (stride x_stride), dy dense [rows][D] of dy_dtype,
+ * dres optional f32 gradient of the residual stream added into dx.  planes = 2. */
+int gdl_layernorm_bwd(const float* x, int64_t x_stride, const void* dy, int dy_dtype, const float* gamma,
+                      const float* dres, int64_t dres_stride, float* dx, int64_t dx_stride, int64_t rows, int D,
+                      float eps, float* dgamma, float* dbeta, int accumulate_params, float* ws, int64_t ws_bytes,
+                      gdl_stream_t stream);
+/* out[c] (+)= sum_rows x[row, c]: bias gradient of nn.Linear / conv.  planes = 1. */
+int gdl_colsum(const void* x, int dtype, int64_t rows, int C, int64_t x_stride, float* out, int accumulate,
+               float* ws, int64_t ws_bytes, gdl_stream_t stream);
+/* backward of y = x + batch_scale[b] * gamma[c] * z (LayerScale + DropPath, dofa_v2.py:255-262):
+ * dz = g*batch_scale*gamma in dz_dtype; dgamma (+)= sum g*batch_scale*z.  gamma / batch_scale optional. */
+int gdl_layerscale_bwd(const float* g, const void* z, int z_dtype, const float* gamma, const float* batch_scale,
+                       int64_t rows, int64_t rows_per_batch, int C, void* dz, int dz_dtype, float* dgamma,
+                       int accumulate, float* ws, int64_t ws_bytes, gdl_stream_t stream);
+/* dS = P * (dP - sum_k dP*P) * scale on the first n_valid columns of each row, pad columns -> 0 (in place ok) */
+int gdl_softmax_bwd_rows(const void* p, const void* dp, void* ds, int dtype, int64_t rows, int n_valid, int n_cols,
+                         float scale, gdl_stream_t stream);
+/* backward of y = gelu(dwconv3x3(u) + bias) (Mix-FFN, mix_transformer.py:533-546 + :52-63):
+ * dpre = dy * gelu'(dwconv3x3(u)+bias); dw9[9][C] (+)= sum dpre * u@tap; dbias (+)= sum dpre.  planes = 10.
+ * (du is gdl_dwconv3x3 of dpre with the taps reversed.) */
+int gdl_dwconv3x3_gelu_bwd(const void* u, const void* dy, int dtype, int B, int H, int W, int C, const float* w9,
+                           const float* bias, void* dpre, float* dw9, float* dbias, int accumulate, float* ws,
+                           int64_t ws_bytes, gdl_stream_t stream);
+/* data gradient of a strided conv: cols[(b,oy,ox)][(r,s,c)] (= dy x W, a GEMM) gathered into dx[b,y,x,c]
+ * (autograd of F.conv2d wrt input for OverlapPatchEmbed / the sr conv, mix_transformer.py:224-276, :95-99) */
+int gdl_col2im(const void* cols, int dtype, int B, int Ho, int Wo, int R, int S, int C, int stride, int pad, int H,
+               int W, void* dx, int dx_dtype, int64_t dx_sB, int64_t dx_sH, int64_t dx_sW, gdl_stream_t stream);
 
 /* ---- resampling (NHWC) ---------------------------------------------------------------
  * F.interpolate(mode="bilinear", align_corners=False) (models/utils.py:96-137,

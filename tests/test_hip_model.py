@@ -20,6 +20,7 @@ import oracle  # noqa: E402
 from gdlhip import nn as gnn  # noqa: E402
 from geo_deep_learning.models.encoders.dofa_v2 import DOFAv2  # noqa: E402
 from geo_deep_learning.models.segmentation.dofa import DOFASegmentationModel  # noqa: E402
+from oracle.model import dice_loss_multiclass  # noqa: E402
 from oracle import procedural_state_dict, synthetic_batch  # noqa: E402
 
 DEV = "cuda"
@@ -171,6 +172,46 @@ def test_tiny_train_step_f32(tiny):
     for k in g.files:
         if k.startswith("buf/"):
             np.testing.assert_allclose(bufs[k[4:]].cpu().numpy(), g[k], atol=2e-5, rtol=1e-4, err_msg=k)
+
+
+def test_tiny_train_vit_blocks_unfrozen(tiny):
+    """Only the dynamic weight generator frozen: the ViT blocks + cls_token train through the HIP
+    block backward (attention / LayerNorm / LayerScale / GELU kernels).  Checked against the CPU oracle."""
+    g, meta, _, _, batch = tiny
+    nc, img, b, seed = meta["num_classes"], meta["img"], meta["batch"], meta["seed"]
+    freeze = ["encoder.patch_embed"]
+    ref = oracle.DOFASegmentationModel("dofa_tiny_test", (img,) * 2, num_classes=nc, _encoder_kwargs=meta["tiny"],
+                                       freeze_layers=freeze).train()
+    sd = procedural_state_dict(ref, seed)
+    ref.load_state_dict(sd)
+    enc = DOFAv2(img_size=img, pretrained=False, **meta["tiny"])
+    model = DOFASegmentationModel(enc, (img,) * 2, num_classes=nc, pretrained=False, freeze_layers=freeze)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    masks = _drop_masks(meta["tiny"]["depth"], 0.1, b, seed)
+    am = _aux_mask(b, 256, seed)
+    y = batch["mask"].squeeze(1).long()
+    ro = ref(batch["image"], batch["wavelengths"], masks, am)
+    lo = dice_loss_multiclass(ro.out, y) + 0.4 * dice_loss_multiclass(ro.aux, y)
+    lo.backward()
+    r = model(batch["image"].to(DEV), batch["wavelengths"], masks, am)
+    crit = gnn.DiceLoss(mode="multiclass")
+    loss = crit(r.out, y.to(DEV)) + 0.4 * crit(r.aux, y.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - lo.item()) < 1e-5
+    refp = dict(ref.named_parameters())
+    n_enc = 0
+    for n, p in model.named_parameters():
+        rg = refp[n].grad
+        assert (p.grad is None) == (rg is None), n
+        if rg is None or (n.endswith("conv.bias") and n.startswith("neck.")):
+            continue
+        n_enc += n.startswith("encoder.")
+        # absolute floor: the last block's fc2.bias shifts every token of a tap by a per-channel constant,
+        # which the neck's train-mode BN removes -> analytically zero gradient (rounding noise in both)
+        err, ref_n = (p.grad.cpu() - rg).norm().item(), rg.norm().item()
+        assert err <= 3e-2 * ref_n + 2e-6, (n, err, ref_n)
+    assert n_enc > 40
 
 
 def test_tiny_train_bf16_runs_and_descends(tiny):

@@ -6,8 +6,10 @@ import json
 import numpy as np
 import torch
 
+from _recipes import chan_mask, check_grads, mit_drop_masks
 from oracle import procedural_state_dict, synthetic_batch
-from oracle.segformer import SegFormerSegmentationModel
+from oracle.model import dice_loss_multiclass
+from oracle.segformer import MIT_VARIANTS, SegFormerSegmentationModel
 
 
 def _sub(t, sc, sp, off=1):
@@ -40,3 +42,25 @@ def test_segformer_oracle_matches_reference(golden_dir):
     top2 = y.topk(2, dim=1).values
     decided = ((top2[:, 0] - top2[:, 1]) > 1e-3).numpy()
     assert (mask == g["b2_mask"])[decided].all()
+
+
+def test_segformer_oracle_train_step_matches_reference(golden_dir):
+    """Full train step (DropPath / Dropout2d masks pinned, BN batch statistics) vs the real reference."""
+    g = np.load(golden_dir / "segformer_train.npz")
+    meta = json.loads(str(g["meta"]))
+    seed, b, nc = meta["seed"], meta["batch"], meta["num_classes"]
+    m = SegFormerSegmentationModel(meta["encoder"], 3, nc).train()
+    m.load_state_dict(procedural_state_dict(m, seed))
+    batch = synthetic_batch(b, 3, meta["size"], nc, seed)
+    depths = MIT_VARIANTS[meta["encoder"]]["depths"]
+    y = m(batch["image"], mit_drop_masks(depths, 0.1, b, seed), chan_mask(b, m.decoder.linear_pred.in_channels, seed))
+    np.testing.assert_allclose(y.detach().numpy(), g["train_out"], atol=2e-4, rtol=0)
+    loss = dice_loss_multiclass(y, batch["mask"].squeeze(1).long())
+    assert abs(loss.item() - float(g["train_loss"])) < 1e-5
+    loss.backward()
+    named = [(n, p.grad) for n, p in m.named_parameters()]
+    assert sorted(n for n, _ in named) == sorted(meta["grad_names"])
+    check_grads(named, g, tol=2e-3)
+    for n, buf in m.named_buffers():
+        if n.endswith(("running_mean", "running_var")):
+            np.testing.assert_allclose(buf.numpy(), g["buf/" + n], atol=1e-5, rtol=1e-5)
