@@ -50,7 +50,9 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <typename T, int WARPS_M, int WARPS_N, int TM, int TN>
+// EXTRA = the training-only epilogue features (aux_out store of the pre-activation, GDL_ACT_MUL_GELU_GRAD);
+// they live in separate instantiations so the inference / frozen-encoder kernels keep their register budget.
+template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const KArgs k) {
   constexpr int ES = TileTraits<T>::ES;
   constexpr int BKE = TileTraits<T>::BKE;
@@ -214,12 +216,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
     const int prow = lane / CPR, pchunk = lane % CPR;
     const bool vec_ok = ((uintptr_t)a.out % 16 == 0) && ((uintptr_t)a.aux_out % 16 == 0) && (a.out_sW % PER == 0) && (a.out_sH % PER == 0) &&
                         (a.out_sB % PER == 0) && (out_zoff % PER == 0);
-    const bool mulgrad = a.act == GDL_ACT_MUL_GELU_GRAD;
+    const bool mulgrad = EXTRA && a.act == GDL_ACT_MUL_GELU_GRAD;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       // pass 0 (only with aux_out): acc*alpha + bias, before scale/shift/act; pass 1: the final output
-      for (int pass = a.aux_out ? 0 : 1; pass < 2; ++pass) {
-        const bool is_aux = pass == 0;
+#pragma unroll
+      for (int pass = EXTRA ? 0 : 1; pass < 2; ++pass) {
+        const bool is_aux = EXTRA && pass == 0;
+        if (is_aux && !a.aux_out) continue;
         unsigned char* dst_base = (unsigned char*)(is_aux ? a.aux_out : a.out);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -299,14 +303,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   else run(std::integral_constant<int, 4>{});
 }
 
-template <typename T, int WARPS_M, int WARPS_N, int TM, int TN>
-int launch(const KArgs& k, hipStream_t stream) {
+template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA>
+int launch_x(const KArgs& k, hipStream_t stream) {
   constexpr int BM = WARPS_M * TM * 32, BN = WARPS_N * TN * 32;
   KArgs kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.a.N + BN - 1) / BN;
   const size_t lds = 2 * (BM + BN) * 128;
-  auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN>;
+  auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -316,6 +320,12 @@ int launch(const KArgs& k, hipStream_t stream) {
   hipLaunchKernelGGL(kern, grid, block, lds, stream, kk);
   GDL_CHECK_LAUNCH("gdl_conv_gemm");
   return GDL_OK;
+}
+
+template <typename T, int WARPS_M, int WARPS_N, int TM, int TN>
+int launch(const KArgs& k, hipStream_t stream) {
+  if (k.a.aux_out || k.a.act == GDL_ACT_MUL_GELU_GRAD) return launch_x<T, WARPS_M, WARPS_N, TM, TN, true>(k, stream);
+  return launch_x<T, WARPS_M, WARPS_N, TM, TN, false>(k, stream);
 }
 
 }  // namespace
@@ -355,11 +365,11 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int variant = gdl_conv_gemm_plan(ap, nullptr);
   if (a.dtype == GDL_BF16) {
-    if (variant == 2) return launch<bf16_tag, 2, 4, 4, 2>(k, s);
+    if (variant == 2) return launch_x<bf16_tag, 2, 4, 4, 2, false>(k, s);
     if (variant == 1) return launch<bf16_tag, 2, 2, 2, 2>(k, s);
     return launch<bf16_tag, 2, 2, 1, 1>(k, s);
   }
-  if (variant == 2) return launch<float, 2, 4, 4, 2>(k, s);
+  if (variant == 2) return launch_x<float, 2, 4, 4, 2, false>(k, s);
   if (variant == 1) return launch<float, 2, 2, 2, 2>(k, s);
   return launch<float, 2, 2, 1, 1>(k, s);
 }
@@ -375,13 +385,16 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   const gdl_conv_args& a = *ap;
   const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
   if (flops) *flops = 2 * M * a.N * ((int64_t)a.R * a.S * a.C) * a.nz;
-  if (g_forced_variant >= 0) return g_forced_variant;
+  if (g_forced_variant >= 0 && !(g_forced_variant == 2 && (a.aux_out || a.act == GDL_ACT_MUL_GELU_GRAD)))
+    return g_forced_variant;
   const int64_t t256 = ((M + 255) / 256) * ((a.N + 255) / 256) * a.nz;
   const int64_t t128 = ((M + 127) / 128) * ((a.N + 127) / 128) * a.nz;
   const int64_t ksteps = (int64_t)a.R * a.S * a.C * (int64_t)gdl_elem_size(a.dtype) / 128;
   // measured (tools/bench_conv.py): 256^2 tiles win whenever K is deep, even at ~1 block per CU;
   // for shallow K (ViT linears, 12 K-steps) the 128^2 tile's shorter prologue/epilogue wins
-  if (a.N % 256 == 0 && (t256 >= 512 || (t256 >= 256 && ksteps >= 32))) return 2;
+  // the training-only epilogue (aux_out / GELU-grad) does not fit the 256^2 tile's register budget
+  const bool extra = a.aux_out != nullptr || a.act == GDL_ACT_MUL_GELU_GRAD;
+  if (!extra && a.N % 256 == 0 && (t256 >= 512 || (t256 >= 256 && ksteps >= 32))) return 2;
   if (t128 >= 256 && a.N >= 128) return 1;
   return 0;
 }

@@ -108,3 +108,30 @@ def test_pos_embed_matches_reference_init():
     e = DOFAv2(img_size=56, embed_dim=64, depth=1, num_heads=1, pretrained=False)
     assert torch.equal(e.pos_embed[0], get_2d_sincos_pos_embed(64, 4, cls_token=True))
     assert not e.pos_embed.requires_grad
+
+
+def test_no_kernel_spills_to_scratch():
+    """The build keeps hipcc's per-kernel resource remarks (csrc/build/*.usage): no kernel of the library may
+    use scratch memory (a spilling MFMA kernel once cost 3x end to end), and the production conv / weight-
+    gradient / attention kernels must keep >= 2 waves per SIMD."""
+    import re
+    from pathlib import Path
+    build = Path(__file__).resolve().parents[1] / "geo-deep-learning_amd" / "csrc" / "build"
+    files = sorted(build.glob("*.usage"))
+    if not files:
+        pytest.skip("no build logs (run __graft_entry__.build() first)")
+    seen = 0
+    for f in files:
+        name = None
+        for line in f.read_text().splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                seen += 1
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m:
+                assert int(m.group(1)) == 0, f"{name} uses {m.group(1)} bytes/lane of scratch"
+            m = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", line)
+            if m and name and any(k in name for k in ("conv_gemm_kernel", "wgrad_tr_kernel", "flash_fwd_kernel")):
+                assert int(m.group(1)) >= 2, f"{name}: occupancy {m.group(1)}"
+    assert seen > 100
