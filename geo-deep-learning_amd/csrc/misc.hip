@@ -143,6 +143,17 @@ __global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __rest
   }
 }
 
+// same arithmetic for any raw sample dtype the reference's `.float()` accepts (uint8 / uint16 / int16 / f32)
+template <typename TI>
+__global__ __launch_bounds__(256) void normalize_raw_kernel(const TI* __restrict__ in, float* out, int C, int64_t HW,
+                                                            int64_t total, const float* __restrict__ mean,
+                                                            const float* __restrict__ stdv) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)((i / HW) % C);
+    out[i] = ((float)in[i] / 255.0f - mean[c]) / stdv[c];
+  }
+}
+
 // ------------------------------------------------------------------ classifier tail
 // 1x1 conv to K<=8 classes: one wave per pixel, 4 channels per lane per step.
 template <typename T, int K>
@@ -720,6 +731,24 @@ extern "C" int gdl_normalize_u8(const uint8_t* in, float* out, int B, int C, int
   const int64_t total4 = (int64_t)B * C * HW / 4;
   hipLaunchKernelGGL(normalize_u8_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, in, out, C, HW, total4, mean, stdv);
   GDL_CHECK_LAUNCH("gdl_normalize_u8");
+  return GDL_OK;
+}
+
+extern "C" int gdl_normalize_raw(const void* in, int kind, float* out, int B, int C, int64_t HW, const float* mean,
+                                 const float* stdv, gdl_stream_t stream) {
+  GDL_CHECK_ARG(in && out && mean && stdv, "gdl_normalize_raw: null pointer");
+  GDL_CHECK_ARG(kind >= GDL_RAW_U8 && kind <= GDL_RAW_F32, "gdl_normalize_raw: bad sample kind %d", kind);
+  if (kind == GDL_RAW_U8 && HW % 4 == 0 && (uintptr_t)in % 4 == 0)
+    return gdl_normalize_u8((const uint8_t*)in, out, B, C, HW, mean, stdv, stream);
+  const int64_t total = (int64_t)B * C * HW;
+  hipStream_t s = (hipStream_t)stream;
+#define NR(T) hipLaunchKernelGGL(normalize_raw_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, (const T*)in, out, C, HW, total, mean, stdv)
+  if (kind == GDL_RAW_U8) NR(uint8_t);
+  else if (kind == GDL_RAW_U16) NR(uint16_t);
+  else if (kind == GDL_RAW_I16) NR(int16_t);
+  else NR(float);
+#undef NR
+  GDL_CHECK_LAUNCH("gdl_normalize_raw");
   return GDL_OK;
 }
 

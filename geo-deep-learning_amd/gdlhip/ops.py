@@ -757,6 +757,23 @@ def normalize_u8(u8: Tensor, mean: Tensor, std: Tensor) -> Tensor:
     return out
 
 
+_RAW_KIND = {torch.uint8: 0, torch.uint16: 1, torch.int16: 2, torch.float32: 3}
+
+
+def normalize_raw(raw: Tensor, mean: Tensor, std: Tensor) -> Tensor:
+    """Raw NCHW samples (uint8 / uint16 / int16 / f32) -> (float(x)/255 - mean[c]) / std[c] f32
+    (datasets/wds_dataset.py:230-236 + utils/tensors.py:10-35)."""
+    _need_cuda(raw)
+    if raw.dtype not in _RAW_KIND or not raw.is_contiguous() or raw.dim() != 4:
+        raise ValueError(f"normalize_raw: contiguous NCHW uint8/uint16/int16/float32 expected, got {raw.dtype}")
+    B, Cc, H, W = raw.shape
+    out = torch.empty((B, Cc, H, W), device=raw.device, dtype=torch.float32)
+    check(_lib.load().gdl_normalize_raw(_p(raw), _RAW_KIND[raw.dtype], _p(out), B, Cc, H * W,
+                                        _p(_f32vec(mean, Cc, "mean")), _p(_f32vec(std, Cc, "std")), _stream()),
+          "gdl_normalize_raw")
+    return out
+
+
 def scale_outer(x: Tensor, s: Tensor) -> Tensor:
     """x[o, ...] *= s[o] in place."""
     if not x.is_contiguous():

@@ -1,0 +1,122 @@
+"""GPU-side input stage.
+
+The reference's loader (datamodules/wds_datamodule.py:104-111: ``WebLoader(pin_memory=True)``) hands Lightning
+f32 batches that were normalised by CPU workers; Lightning then copies them synchronously.  This stage sits
+between any iterable of host batch dicts and the training loop:
+
+* every host tensor is staged through a ring of **pinned** buffers and copied with ``non_blocking=True`` on a
+  dedicated HIP copy stream, ``depth`` batches ahead of the consumer -- the copy of batch k+1 overlaps the
+  compute of batch k;
+* raw tiles (``image`` in uint8 / uint16 / int16 / f32 as stored) are normalised **on the GPU** by one
+  HBM-bound kernel (``x/255 -> (x-mean)/std``, gdl_normalize_raw) on the compute stream, after it waited for the
+  copy event: uint8 tiles cross PCIe at 1 byte / sample instead of the reference's 4;
+* the yielded dict has the reference's keys and dtypes (``image`` f32 standardised, ``mask`` int64, ...), so
+  ``training_step`` / ``validation_step`` are unchanged.
+"""
+
+from __future__ import annotations
+
+from collections import deque
+from collections.abc import Iterable, Iterator
+from typing import Any
+
+import torch
+
+from gdlhip import ops
+
+
+class DeviceInputStage:
+    """Iterate device-resident, normalised batches ``depth`` copies ahead of the consumer."""
+
+    def __init__(self, batches: Iterable[dict[str, Any]], device: torch.device | str = "cuda", depth: int = 2,
+                 raw_key: str = "image") -> None:
+        self.batches = batches
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            msg = "DeviceInputStage needs a HIP device (no CPU fallback)"
+            raise ValueError(msg)
+        self.depth = max(1, int(depth))
+        self.raw_key = raw_key
+        self._copy_stream = torch.cuda.Stream(device=self.device)
+        self._pinned: dict = {}      # (key, shape, dtype) -> ring of pinned host buffers
+        self._slot = 0
+        self.bytes_h2d = 0
+
+    # ------------------------------------------------------------------ staging
+    def _pinned_buffer(self, key: str, t: torch.Tensor) -> torch.Tensor:
+        sig = (key, tuple(t.shape), t.dtype)
+        ring = self._pinned.get(sig)
+        if ring is None:
+            ring = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for _ in range(self.depth + 1)]
+            self._pinned[sig] = ring
+        return ring[self._slot % (self.depth + 1)]
+
+    def _stage(self, batch: dict[str, Any]):
+        """Enqueue the H2D copies of one batch on the copy stream; returns (device dict, event)."""
+        dev: dict[str, Any] = {}
+        with torch.cuda.stream(self._copy_stream):
+            for k, v in batch.items():
+                if isinstance(v, torch.Tensor) and not v.is_cuda and k != "wavelengths":
+                    if v.is_pinned():
+                        src = v
+                    else:
+                        src = self._pinned_buffer(k, v)
+                        src.copy_(v)
+                    dev[k] = src.to(self.device, non_blocking=True)
+                    self.bytes_h2d += v.numel() * v.element_size()
+                else:
+                    dev[k] = v        # wavelengths stay on the host (the encoder reads them there), strings, ...
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        self._slot += 1
+        return dev, ev
+
+    def _finish(self, dev: dict[str, Any], ev: torch.cuda.Event) -> dict[str, Any]:
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        for v in dev.values():
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                v.record_stream(cur)  # allocated on the copy stream, consumed on the compute stream
+        img = dev.get(self.raw_key)
+        if isinstance(img, torch.Tensor) and self._is_raw(img, dev):
+            mean, std = self._sensor_stats(dev)
+            dev[self.raw_key] = ops.normalize_raw(img.contiguous(), mean, std)
+        return dev
+
+    @staticmethod
+    def _is_raw(img: torch.Tensor, dev: dict[str, Any]) -> bool:
+        if img.dtype in (torch.uint8, torch.uint16, torch.int16):
+            return True
+        return bool(dev.get("image_is_raw", False))
+
+    @staticmethod
+    def _sensor_stats(dev: dict[str, Any]) -> tuple[torch.Tensor, torch.Tensor]:
+        """[C] f32 device vectors from the batch's ``mean`` / ``std`` ([C,1,1] or stacked [B,C,1,1]; one sensor
+        per batch, as the reference batches per sensor dataset)."""
+        out = []
+        for k in ("mean", "std"):
+            t = dev[k]
+            c = dev["image"].shape[1]
+            t = t.reshape(-1, c)[0] if t.numel() != c else t.reshape(c)
+            out.append(t.to(dtype=torch.float32).contiguous())
+        return out[0], out[1]
+
+    # ------------------------------------------------------------------ iteration
+    def __iter__(self) -> Iterator[dict[str, Any]]:
+        queue: deque = deque()
+        it = iter(self.batches)
+        for _ in range(self.depth):
+            try:
+                queue.append(self._stage(next(it)))
+            except StopIteration:
+                break
+        while queue:
+            dev, ev = queue.popleft()
+            try:
+                queue.append(self._stage(next(it)))     # keep the copy stream `depth` batches ahead
+            except StopIteration:
+                pass
+            yield self._finish(dev, ev)
+
+    def __len__(self) -> int:
+        return len(self.batches)  # type: ignore[arg-type]

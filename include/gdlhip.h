@@ -247,6 +247,10 @@ int gdl_add_rows(const float* a, int64_t a_rows, int64_t a_stride, const float* 
 /* u8 tile -> (x/255 - mean[c]) / std[c], NCHW f32 (utils/tensors.py:10-35, wds_dataset.py:230-236) */
 int gdl_normalize_u8(const uint8_t* in, float* out, int B, int C, int64_t HW, const float* mean,
                      const float* std, gdl_stream_t stream);
+/* the same for any raw sample dtype the reference's `.float()` accepts (wds_dataset.py:230-236) */
+enum { GDL_RAW_U8 = 0, GDL_RAW_U16 = 1, GDL_RAW_I16 = 2, GDL_RAW_F32 = 3 };
+int gdl_normalize_raw(const void* in, int kind, float* out, int B, int C, int64_t HW, const float* mean,
+                      const float* stdv, gdl_stream_t stream);
 /* x[o, :inner] *= s[o]  (per-sample DropPath scaling, timm DropPath) */
 int gdl_scale_outer(void* x, int dtype, const float* s, int64_t outer, int64_t inner,
                     gdl_stream_t stream);
