@@ -33,6 +33,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_F32_TFLOPS = 157.3
+UNETPP_R18_FWD_GF = 128.04  # sum over convs of 2*K*C*R*S*Hout*Wout at 512x512 (counted on oracle/unetpp.py)
 RGB_MEAN = [0.3992, 0.4283, 0.3998]   # configs/dofa_config_RGB.yaml:91-98
 RGB_STD = [0.1672, 0.1800, 0.1584]
 WAVELENGTHS = [0.665, 0.549, 0.481]   # configs/dofa_config_RGB.yaml:50
@@ -46,8 +47,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mode", default="both", choices=["both", "train", "infer"])
-    ap.add_argument("--model", default="dofa", choices=["dofa", "segformer"],
-                    help="dofa = DOFA-base+UperNet (headline, configs[1]); segformer = SegFormer-B2 (configs[2], all parameters trainable)")
+    ap.add_argument("--model", default="dofa", choices=["dofa", "segformer", "unetpp"],
+                    help="dofa = DOFA-base+UperNet (headline, configs[1]); segformer = SegFormer-B2 (configs[2], all parameters trainable); "
+                         "unetpp = UNet++/ResNet18 (configs[0], the reference's CPU smoke case)")
     ap.add_argument("--with-input-stage", action="store_true",
                     help="also time the train step fed by host uint8 tiles through DeviceInputStage (PCIe-inclusive; "
                          "reported beside `value`, never as `value`)")
@@ -137,7 +139,12 @@ def main() -> None:
     from tasks_with_models.segmentation_segformer import SegmentationSegformer
 
     torch.manual_seed(42 + rank)  # train.py:67 seeds 42
-    if args.model == "segformer":
+    if args.model == "unetpp":
+        from tasks_with_models.segmentation_unetplus import SegmentationUnetPlus
+        task = SegmentationUnetPlus(encoder="resnet18", image_size=(512, 512), in_channels=3, num_classes=5,
+                                    max_samples=6, loss=DiceLoss(mode="multiclass"),
+                                    optimizer=lambda params: FusedAdam(params, lr=6e-5, max_grad_norm=1.0))
+    elif args.model == "segformer":
         task = SegmentationSegformer(encoder="mit_b2", in_channels=3, num_classes=5, max_samples=6,
                                      loss=DiceLoss(mode="multiclass"),
                                      optimizer=lambda params: FusedAdam(params, lr=6e-5, max_grad_norm=1.0))
@@ -219,7 +226,9 @@ def main() -> None:
 
     tiles = args.batch * world * args.steps
     head = "train" if "train" in res else "infer"
-    model_name = "SegFormer-B2 (MiT-B2 + MLP decoder)" if args.model == "segformer" else "DOFA-base + UperNet"
+    model_name = {"segformer": "SegFormer-B2 (MiT-B2 + MLP decoder)", "unetpp": "UNet++ (ResNet18 encoder)",
+                  "dofa": "DOFA-base + UperNet"}[args.model]
+    cfg_name = {"segformer": "configs[2]", "unetpp": "configs[0]", "dofa": "configs[1]"}[args.model]
     out = {
         "metric": f"512x512 tiles/s, {model_name}, {head} step",
         "value": round(tiles / res[head], 3),
@@ -229,9 +238,9 @@ def main() -> None:
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {
-            "workload": (f"{model_name}, 3-band RGB 512x512 ({'configs[2]' if args.model == 'segformer' else 'configs[1]'}): "
+            "workload": (f"{model_name}, 3-band RGB 512x512 ({cfg_name}): "
                          + (("training step = fwd + Dice + bwd (every parameter) + clip 1.0 + Adam 6e-5, "
-                             "DropPath/Dropout2d active" if args.model == "segformer" else
+                             "DropPath/Dropout2d active" if args.model != "dofa" else
                              "training step = fwd + Dice(main)+0.4*Dice(aux) + bwd + clip 1.0 + Adam 6e-5, "
                              "encoder frozen, DropPath/Dropout2d active") if head == "train"
                             else "inference = fwd + softmax/argmax")),
@@ -244,7 +253,8 @@ def main() -> None:
         out["inference_tiles_per_s"] = round(tiles / res["infer"], 3)
         out["inference_ms_per_step"] = round(1e3 * res["infer"] / args.steps, 3)
     # whole-model algorithmic flops: 1606.7 GF/tile train (frozen encoder), 726.7 fwd
-    gf = {"train": 1606.7, "infer": 726.7} if args.model == "dofa" else {"train": 3 * 121.0, "infer": 121.0}
+    gf = {"dofa": {"train": 1606.7, "infer": 726.7}, "segformer": {"train": 3 * 121.0, "infer": 121.0},
+          "unetpp": {"train": 3 * UNETPP_R18_FWD_GF, "infer": UNETPP_R18_FWD_GF}}[args.model]
     peak = PEAK_BF16_TFLOPS if use_bf16 else PEAK_F32_TFLOPS
     out["model_flops_utilisation"] = {
         k: round(gf[k] * 1e-3 * tiles / res[k] / world / peak, 4) for k in res}

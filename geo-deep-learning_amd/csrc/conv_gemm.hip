@@ -282,6 +282,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
                 const float rv = load_as_f32(a.resid, roff + e, a.resid_dtype);
                 v[e] = mulgrad ? v[e] * gelu_erf_grad(rv) : v[e] + rv;
               }
+              if (a.act == GDL_ACT_RESID_RELU) v[e] = fmaxf(v[e], 0.f);
             }
           }
           if (full && vec_ok) {
@@ -348,7 +349,8 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   GDL_CHECK_ARG(((uintptr_t)a.in % 16 == 0) && ((uintptr_t)a.w % 16 == 0),
                 "gdl_conv_gemm: operand pointers must be 16-byte aligned");
   GDL_CHECK_ARG(a.nz >= 1 && a.nz_inner >= 1, "gdl_conv_gemm: nz/nz_inner must be >= 1");
-  GDL_CHECK_ARG(a.act >= GDL_ACT_NONE && a.act <= GDL_ACT_MUL_GELU_GRAD, "gdl_conv_gemm: bad act %d", a.act);
+  GDL_CHECK_ARG(a.act >= GDL_ACT_NONE && a.act <= GDL_ACT_RESID_RELU, "gdl_conv_gemm: bad act %d", a.act);
+  GDL_CHECK_ARG(a.act != GDL_ACT_RESID_RELU || a.resid, "gdl_conv_gemm: GDL_ACT_RESID_RELU needs `resid`");
   GDL_CHECK_ARG(a.act != GDL_ACT_MUL_GELU_GRAD || (a.resid && !a.aux_out),
                 "gdl_conv_gemm: GDL_ACT_MUL_GELU_GRAD takes the pre-activation tensor in `resid`");
   GDL_CHECK_ARG((int64_t)a.B * a.Ho * a.Wo < (1ll << 31), "gdl_conv_gemm: M too large");

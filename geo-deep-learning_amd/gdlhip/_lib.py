@@ -13,7 +13,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libgdlhip.so"
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_MUL_GELU_GRAD = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_MUL_GELU_GRAD, ACT_RESID_RELU = 0, 1, 2, 3, 4
 
 c_i, c_l, c_f, c_p = C.c_int, C.c_int64, C.c_float, C.c_void_p
 
@@ -70,6 +70,14 @@ SIGNATURES = {
     "gdl_dwconv3x3_gelu_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l,
                                      c_p]),
     "gdl_col2im": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_l, c_l, c_l, c_p]),
+    "gdl_maxpool3x3s2_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p]),
+    "gdl_maxpool3x3s2_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l,
+                                   c_p]),
+    "gdl_nearest2x_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p]),
+    "gdl_nearest2x_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p]),
+    "gdl_add_relu": (c_i, [c_p, c_p, c_p, c_i, c_l, c_p]),
+    "gdl_relu_bwd": (c_i, [c_p, c_p, c_p, c_i, c_l, c_p]),
+    "gdl_pad_channels": (c_i, [c_p, c_i, c_l, c_i, c_p, c_i, c_i, c_p]),
     "gdl_bn_stats": (c_i, [c_p, c_i, c_l, c_i, c_l, c_p, c_p, c_p, c_p, c_f, c_p, c_l, c_p]),
     "gdl_bn_stats_workspace": (c_l, [c_l, c_i]),
     "gdl_bn_apply": (c_i, [c_p, c_p, c_i, c_l, c_i, c_l, c_l, c_p, c_p, c_p, c_p, c_f, c_i, c_p]),

@@ -1,0 +1,298 @@
+"""Convolutional building blocks of the ResNet-encoder / UNet++ path (smp.UnetPlusPlus; reference call site
+tasks_with_models/segmentation_unetplus.py:126-131) as autograd nodes over libgdlhip.so kernels.
+
+Channel padding: the implicit-GEMM kernel consumes K in 128-byte chunks (64 bf16 / 32 f32 channels per filter
+tap), while UNet++'s last decoder stages have 32 and 16 channels.  Those tensors are simply carried with their
+channel dim zero-padded to the chunk size: a conv whose input has more channels than its weight treats the extra
+channels as zero-weight, a conv whose output count is not a chunk multiple pads it (zero weight rows, BN gamma =
+beta = 0 => exactly 0 after BN/ReLU), and every gradient is sliced back to the parameter's real shape.
+"""
+
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+from torch.autograd import Function
+
+from . import ops
+from .nn import (_world, cached, conv_weight_matrix, sync_batch_stats, sync_sum_pair, to_compute,
+                 update_running_stats)
+from .ops import ACT_NONE, ACT_RELU, ACT_RESID_RELU
+from .tnn import _dense
+
+
+def chunk(cd: torch.dtype) -> int:
+    return 32 if cd == torch.float32 else 64
+
+
+def pad_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+_FLAT: set = set()   # ids of conv parameters consumed as a flat [N, C*R*S] matrix (patchified image stems)
+
+
+def mark_flat(weight: Tensor) -> None:
+    """The image stem runs as patchify + GEMM: its [N,C,R,S] parameter is used as the [N, (c,r,s)] matrix."""
+    _FLAT.add(id(weight))
+
+
+def _wshape(weight: Tensor) -> tuple[int, int, int, int]:
+    if weight.dim() == 2 or id(weight) in _FLAT:
+        return weight.shape[0], weight[0].numel(), 1, 1
+    return tuple(weight.shape)
+
+
+def _matrix3(weight: Tensor) -> Tensor:
+    """f32 [N, R*S, C] view/copy of a conv parameter ([N,C,R,S]), a 2-D [N,K] matrix or a flat stem (taps = 1)."""
+    if weight.dim() == 2 or id(weight) in _FLAT:
+        return weight.detach().reshape(weight.shape[0], 1, -1)
+    n, c, r, s = weight.shape
+    return conv_weight_matrix(weight).view(n, r * s, c)
+
+
+def padded_operands(weight: Tensor, cd: torch.dtype, cpad: int, npad: int) -> tuple[Tensor, Tensor]:
+    """(forward operand [Npad, R*S*Cpad], data-gradient operand [Cpad, (R*S flipped)*Npad]) in the compute dtype."""
+    def build():
+        n, c, r, s = _wshape(weight)
+        m = torch.zeros((npad, r * s, cpad), device=weight.device, dtype=torch.float32)
+        m[:n, :, :c] = _matrix3(weight)
+        m = m.view(npad, r * s * cpad)
+        fwd = m if cd == torch.float32 else ops.cast(m, cd)
+        return fwd, ops.pack_dgrad(m, npad, r * s, cpad, cd)
+    return cached((weight,), f"padw:{cd}:{cpad}:{npad}", build)
+
+
+def padded_t_operand(weight: Tensor, cd: torch.dtype, cpad: int, npad: int) -> Tensor:
+    """[(R*S*Cpad), Npad] operand for the GEMM + col2im data gradient of a strided conv."""
+    def build():
+        n, c, r, s = _wshape(weight)
+        m = torch.zeros((npad, r * s, cpad), device=weight.device, dtype=torch.float32)
+        m[:n, :, :c] = _matrix3(weight)
+        return ops.pack_dgrad(m.view(npad, r * s * cpad), npad, 1, r * s * cpad, cd)
+    return cached((weight,), f"padwT:{cd}:{cpad}:{npad}", build)
+
+
+def _padvec(v: Tensor, npad: int, fill: float = 0.0) -> Tensor:
+    if v.numel() == npad:
+        return v.detach()
+    out = torch.full((npad,), fill, device=v.device, dtype=torch.float32)
+    out[: v.numel()] = v.detach()
+    return out
+
+
+def _param_grad(dw: Tensor, weight: Tensor, cpad: int) -> Tensor:
+    """[Npad, R*S*Cpad] f32 weight gradient -> the parameter's logical shape (real channels only)."""
+    n, c, r, s = _wshape(weight)
+    d = dw.view(-1, r * s, cpad)[:n, :, :c]
+    if weight.dim() == 2 or id(weight) in _FLAT:
+        return d.reshape(weight.shape)
+    return d.reshape(n, r, s, c).permute(0, 3, 1, 2)
+
+
+def _conv_dx(dy: Tensor, weight: Tensor, cd: torch.dtype, cpad: int, npad: int, stride: int, pad: int,
+             in_hw: tuple[int, int]) -> Tensor:
+    n, c, r, s = _wshape(weight)
+    if stride == 1:
+        return ops.conv_gemm(dy, padded_operands(weight, cd, cpad, npad)[1], R=r, S=s, pad=r - 1 - pad)
+    b, ho, wo, _ = dy.shape
+    cols = ops.linear(dy.reshape(-1, npad), padded_t_operand(weight, cd, cpad, npad), None)
+    return ops.col2im(cols, b, ho, wo, r, s, cpad, stride, pad, in_hw[0], in_hw[1], cd)
+
+
+# ------------------------------------------------------------------ conv -> BN(batch stats) -> [ReLU]
+class _ConvBNTrain(Function):
+    """Training-mode Conv2d(bias=False) + BatchNorm2d / SyncBatchNorm + optional ReLU with stride and channel
+    padding (torchvision resnet.py conv-bn-relu; smp base/modules.py Conv2dReLU)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, momentum, eps, stride, pad, relu, sync_group):
+        cd = x.dtype
+        n, c, r, s = _wshape(weight)
+        cpad, npad = x.shape[-1], pad_to(n, chunk(cd))
+        if cpad < c or cpad % chunk(cd):
+            raise ValueError(f"conv input has {cpad} channels, weight expects {c} (padded to a multiple of {chunk(cd)})")
+        wq, _ = padded_operands(weight, cd, cpad, npad)
+        y = ops.conv_gemm(x, wq, R=r, S=s, stride=stride, pad=pad)
+        world = _world(sync_group) if sync_group is not False else 1
+        mean, var = ops.bn_stats(y)
+        if world > 1:
+            mean, var = sync_batch_stats(mean, var, sync_group or None)
+        if running_mean is not None:
+            update_running_stats(running_mean, running_var, mean[:n], var[:n], momentum, y.numel() // npad * world)
+        g, b = _padvec(gamma, npad), _padvec(beta, npad)
+        out = ops.bn_apply(y, mean, var, g, b, eps, relu)
+        ctx.save_for_backward(x, weight, y, mean, var, g, b)
+        ctx.cfg = (stride, pad, relu, eps, sync_group, world, cpad, npad)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, weight, y, mean, var, g, b = ctx.saved_tensors
+        stride, pad, relu, eps, sync_group, world, cpad, npad = ctx.cfg
+        n, c, r, s = _wshape(weight)
+        gout = _dense(gout if gout.dtype == y.dtype else to_compute(gout, y.dtype))
+        dgamma, dbeta = ops.bn_bwd_reduce(y, gout, mean, var, g, b, eps, relu)
+        sg, sb = dgamma, dbeta
+        if world > 1:
+            sg, sb = sync_sum_pair(dgamma, dbeta, sync_group or None)
+        dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, y.numel() // npad * world, out=y)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = _param_grad(ops.conv_wgrad(x, dy, R=r, S=s, stride=stride, pad=pad), weight, cpad)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv_dx(dy, weight, x.dtype, cpad, npad, stride, pad, (x.shape[1], x.shape[2]))
+        return dx, dw, dgamma[:n], dbeta[:n], None, None, None, None, None, None, None, None
+
+
+def conv_bn(x: Tensor, weight: Tensor, norm: nn.Module, *, stride: int = 1, pad: int = 0, relu: bool = True,
+            resid: Tensor | None = None) -> Tensor:
+    """conv(bias=False) -> BN -> [+ resid] -> [ReLU] on NHWC (compute dtype); output channels padded to the
+    K-chunk.  Training: batch statistics (autograd node); eval: BN folded into the GEMM epilogue."""
+    cd = x.dtype
+    n, c, r, s = _wshape(weight)
+    if norm.training:
+        sync_group = norm.process_group if isinstance(norm, nn.SyncBatchNorm) else False
+        momentum = 0.1 if norm.momentum is None else norm.momentum
+        y = _ConvBNTrain.apply(x, weight, norm.weight, norm.bias, norm.running_mean, norm.running_var, momentum,
+                               norm.eps, stride, pad, relu and resid is None, sync_group)
+        if norm.num_batches_tracked is not None:
+            norm.num_batches_tracked.add_(1)
+        if resid is not None:
+            y = add_relu(y, resid) if relu else y + resid
+        return y
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        msg = ("gdlhip: autograd through eval-mode BatchNorm is not implemented; call under torch.no_grad() for "
+               "inference or model.train() for training")
+        raise NotImplementedError(msg)
+    cpad, npad = x.shape[-1], pad_to(n, chunk(cd))
+
+    def fold():
+        scale, shift = ops.bn_fold(norm.weight.detach(), norm.bias.detach(), norm.running_mean, norm.running_var,
+                                   norm.eps)
+        return _padvec(scale, npad), _padvec(shift, npad)
+    scale, shift = cached((norm.weight, norm.bias, norm.running_mean, norm.running_var), f"bnfold:{npad}", fold)
+    act = ACT_NONE if not relu else (ACT_RELU if resid is None else ACT_RESID_RELU)
+    return ops.conv_gemm(x, padded_operands(weight, cd, cpad, npad)[0], R=r, S=s, stride=stride, pad=pad, scale=scale,
+                         shift=shift, act=act, resid=resid)
+
+
+# ------------------------------------------------------------------ plain conv + bias (segmentation head)
+class _ConvBias(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad, out_dtype):
+        cd = x.dtype
+        n, c, r, s = _wshape(weight)
+        cpad = x.shape[-1]
+        wq = padded_operands(weight, cd, cpad, n)[0]
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (pad, cpad)
+        return ops.conv_gemm(x, wq, R=r, S=s, pad=pad, bias=bias.detach(), out_dtype=out_dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        pad, cpad = ctx.cfg
+        cd = x.dtype
+        n, c, r, s = _wshape(weight)
+        g = g.contiguous()                                  # dense NHWC [B,H,W,n] f32 (n = classes, any count)
+        npad = pad_to(n, 8)                                 # 16-byte rows for the weight-gradient kernel
+        dy = ops.pad_channels(g, npad, cd)
+        dw = _param_grad(ops.conv_wgrad(x, dy, R=r, S=s, pad=pad), weight, cpad) if ctx.needs_input_grad[1] else None
+        db = ops.colsum(dy)[:n] if ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            npk = pad_to(n, chunk(cd))                      # K of the data-gradient GEMM
+            dyk = dy if npk == npad else ops.pad_channels(g, npk, cd)
+            dx = ops.conv_gemm(dyk, padded_operands(weight, cd, cpad, npk)[1], R=r, S=s, pad=r - 1 - pad)
+        return dx, dw, db, None, None
+
+
+def conv_bias(x: Tensor, conv: nn.Conv2d, out_dtype: torch.dtype = torch.float32) -> Tensor:
+    """Conv2d(+bias) with few output channels (the 3x3 classifier): NHWC in, NHWC [B,H,W,N] out."""
+    return _ConvBias.apply(x, conv.weight, conv.bias, conv.padding[0], out_dtype)
+
+
+# ------------------------------------------------------------------ pooling / resampling / residual
+class _MaxPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.maxpool3x3s2(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool3x3s2_bwd(x, _dense(g))
+
+
+def maxpool3x3s2(x: Tensor) -> Tensor:
+    return _MaxPool.apply(x)
+
+
+class _UpCat(Function):
+    """cat([nearest2x(x), *skips], channel dim) written straight into one NHWC buffer
+    (smp decoders/unetplusplus/decoder.py DecoderBlock.forward + the dense-skip torch.cat)."""
+
+    @staticmethod
+    def forward(ctx, x, *skips):
+        b, h, w, c = x.shape
+        chans = [c] + [s.shape[3] for s in skips]
+        out = torch.empty((b, 2 * h, 2 * w, sum(chans)), device=x.device, dtype=x.dtype)
+        ops.nearest2x(x, out=out[..., :c])
+        off = c
+        for s in skips:
+            ops.bilinear(s, (2 * h, 2 * w), out=out[..., off:off + s.shape[3]])     # identity-size strided copy
+            off += s.shape[3]
+        ctx.chans = chans
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        chans = ctx.chans
+        grads = [ops.nearest2x_bwd(g[..., : chans[0]]) if ctx.needs_input_grad[0] else None]
+        off = chans[0]
+        for i, c in enumerate(chans[1:]):
+            grads.append(g[..., off:off + c] if ctx.needs_input_grad[i + 1] else None)
+            off += c
+        return tuple(grads)
+
+
+def up_cat(x: Tensor, skips: list[Tensor]) -> Tensor:
+    return _UpCat.apply(x, *skips)
+
+
+class _AddRelu(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out = ops.add_relu(a, b)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        d = ops.relu_bwd(out, _dense(g))
+        return d, d
+
+
+def add_relu(a: Tensor, b: Tensor) -> Tensor:
+    return _AddRelu.apply(a.contiguous(), b.contiguous())
+
+
+class _LogitsNCHW(Function):
+    """NHWC f32 logits [B,H,W,K] -> NCHW f32 (what the loss / argmax kernels consume)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (x.shape[1], x.shape[2])
+        return ops.upsample_logits(x, ctx.hw)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.upsample_logits_bwd(g.contiguous(), ctx.hw)
+
+
+def logits_nchw(x: Tensor) -> Tensor:
+    return _LogitsNCHW.apply(x)

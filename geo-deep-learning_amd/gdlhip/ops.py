@@ -15,8 +15,8 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_MUL_GELU_GRAD, ACT_NONE, ACT_RELU, BF16, F32, ConvArgs, WgradArgs,  # noqa: F401
-                   check)
+from ._lib import (ACT_GELU, ACT_MUL_GELU_GRAD, ACT_NONE, ACT_RELU, ACT_RESID_RELU, BF16, F32, ConvArgs,  # noqa: F401
+                   WgradArgs, check)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -657,6 +657,81 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, num_heads: int, d
         # [B,H,n,hd] f32 -> [B,n,H*hd] slice in the compute dtype: a strided copy-cast (identity resample)
         bilinear(src.permute(0, 2, 1, 3)[:, :Nkv], (Nkv, Hh),
                  out=dst.as_strided((B, Nkv, Hh, hd), (dst.stride(0), dst.stride(1), hd, 1)))
+
+
+# ------------------------------------------------------------------ ResNet / UNet++ pieces
+def maxpool3x3s2(x: Tensor) -> Tensor:
+    """F.max_pool2d(kernel 3, stride 2, padding 1) on NHWC."""
+    _need_cuda(x)
+    x4 = _nhwc4(x, "maxpool x")
+    B, H, W, Cc = x4.shape
+    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), device=x.device, dtype=x.dtype)
+    check(_lib.load().gdl_maxpool3x3s2_fwd(_p(x4), dt(x4), B, H, W, Cc, x4.stride(0), x4.stride(1), x4.stride(2), _p(out),
+                                           out.stride(0), out.stride(1), out.stride(2), _stream()), "gdl_maxpool3x3s2_fwd")
+    return out
+
+
+def maxpool3x3s2_bwd(x: Tensor, dout: Tensor) -> Tensor:
+    x4, d4 = _nhwc4(x, "maxpool_bwd x"), _nhwc4(dout, "maxpool_bwd dout")
+    B, H, W, Cc = x4.shape
+    din = torch.empty((B, H, W, Cc), device=x.device, dtype=x.dtype)
+    check(_lib.load().gdl_maxpool3x3s2_bwd(_p(x4), _p(d4), _p(din), dt(x4), B, H, W, Cc, x4.stride(0), x4.stride(1),
+                                           x4.stride(2), d4.stride(0), d4.stride(1), d4.stride(2), din.stride(0),
+                                           din.stride(1), din.stride(2), _stream()), "gdl_maxpool3x3s2_bwd")
+    return din
+
+
+def nearest2x(x: Tensor, out: Tensor | None = None) -> Tensor:
+    """F.interpolate(scale_factor=2, mode='nearest') on NHWC; ``out`` may be a channel slice of a concat buffer."""
+    _need_cuda(x)
+    x4 = _nhwc4(x, "nearest2x x")
+    B, H, W, Cc = x4.shape
+    if out is None:
+        out = torch.empty((B, 2 * H, 2 * W, Cc), device=x.device, dtype=x.dtype)
+    o4 = _nhwc4(out, "nearest2x out")
+    if tuple(o4.shape) != (B, 2 * H, 2 * W, Cc) or o4.dtype != x4.dtype:
+        raise ValueError("nearest2x: out shape / dtype mismatch")
+    check(_lib.load().gdl_nearest2x_fwd(_p(x4), dt(x4), B, H, W, Cc, x4.stride(0), x4.stride(1), x4.stride(2), _p(o4),
+                                        o4.stride(0), o4.stride(1), o4.stride(2), _stream()), "gdl_nearest2x_fwd")
+    return out
+
+
+def nearest2x_bwd(dout: Tensor) -> Tensor:
+    d4 = _nhwc4(dout, "nearest2x_bwd dout")
+    B, H2, W2, Cc = d4.shape
+    din = torch.empty((B, H2 // 2, W2 // 2, Cc), device=dout.device, dtype=dout.dtype)
+    check(_lib.load().gdl_nearest2x_bwd(_p(d4), dt(d4), B, H2 // 2, W2 // 2, Cc, d4.stride(0), d4.stride(1), d4.stride(2),
+                                        _p(din), din.stride(0), din.stride(1), din.stride(2), _stream()),
+          "gdl_nearest2x_bwd")
+    return din
+
+
+def add_relu(a: Tensor, b: Tensor) -> Tensor:
+    if a.shape != b.shape or a.dtype != b.dtype or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError("add_relu: two contiguous tensors of one shape / dtype expected")
+    out = torch.empty_like(a)
+    check(_lib.load().gdl_add_relu(_p(a), _p(b), _p(out), dt(a), a.numel(), _stream()), "gdl_add_relu")
+    return out
+
+
+def pad_channels(x: Tensor, cpad: int, out_dtype: torch.dtype) -> Tensor:
+    """Dense [..., C] -> [..., cpad] in out_dtype with zero-filled extra channels."""
+    _need_cuda(x)
+    if not x.is_contiguous():
+        raise ValueError("pad_channels: contiguous input expected")
+    Cc = x.shape[-1]
+    out = torch.empty((*x.shape[:-1], cpad), device=x.device, dtype=out_dtype)
+    check(_lib.load().gdl_pad_channels(_p(x), dt(x), x.numel() // Cc, Cc, _p(out), dt(out), cpad, _stream()),
+          "gdl_pad_channels")
+    return out
+
+
+def relu_bwd(y: Tensor, dy: Tensor) -> Tensor:
+    if y.shape != dy.shape or y.dtype != dy.dtype or not y.is_contiguous() or not dy.is_contiguous():
+        raise ValueError("relu_bwd: two contiguous tensors of one shape / dtype expected")
+    dx = torch.empty_like(y)
+    check(_lib.load().gdl_relu_bwd(_p(y), _p(dy), _p(dx), dt(y), y.numel(), _stream()), "gdl_relu_bwd")
+    return dx
 
 
 # ------------------------------------------------------------------ DOFA patch embed helpers

@@ -1,0 +1,180 @@
+"""UNet++ with a ResNet BasicBlock encoder on MI355X: drop-in for the ``smp.UnetPlusPlus`` instance the reference
+builds at tasks_with_models/segmentation_unetplus.py:126-131 (same constructor keywords, same state-dict keys as
+segmentation-models-pytorch 0.5.0 / torchvision, so its checkpoints load).
+
+Everything runs NHWC in the compute dtype on the implicit-GEMM MFMA kernel:
+* stem 7x7/2 on the raw bands = strided patchify + GEMM + BN + ReLU, then the 3x3/2 max-pool kernel;
+* BasicBlock = conv3x3-BN-ReLU, conv3x3-BN, (+ 1x1/s downsample-BN), residual add + ReLU (one kernel in
+  training; folded into the second conv's epilogue in eval);
+* DecoderBlock = nearest x2 of the input written straight into the dense-skip concat buffer, then two
+  conv3x3-BN-ReLU; the 32- and 16-channel stages are carried zero-padded to the kernel's K-chunk (gdlhip.cnn);
+* head = 3x3 conv to ``classes`` -> NCHW f32 logits.
+"""
+
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from geo_deep_learning.models.utils import _cl_conv
+from gdlhip import cnn, ops
+from gdlhip import nn as gnn
+
+RESNET_LAYERS = {"resnet18": [2, 2, 2, 2], "resnet34": [3, 4, 6, 3]}
+
+
+class BasicBlock(nn.Module):
+    """torchvision models/resnet.py BasicBlock (parameter names conv1/bn1/conv2/bn2/downsample.{0,1})."""
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1) -> None:
+        super().__init__()
+        self.stride = stride
+        self.conv1 = _cl_conv(inplanes, planes, 3, padding=1, bias=False)
+        self.conv1.stride = (stride, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = _cl_conv(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != planes:
+            ds = _cl_conv(inplanes, planes, 1, padding=0, bias=False)
+            ds.stride = (stride, stride)
+            self.downsample = nn.Sequential(ds, nn.BatchNorm2d(planes))
+
+    def forward_nhwc(self, x: Tensor) -> Tensor:
+        identity = x
+        if self.downsample is not None:
+            identity = cnn.conv_bn(x, self.downsample[0].weight, self.downsample[1], stride=self.stride, relu=False)
+        out = cnn.conv_bn(x, self.conv1.weight, self.bn1, stride=self.stride, pad=1)
+        return cnn.conv_bn(out, self.conv2.weight, self.bn2, pad=1, resid=identity)
+
+
+class ResNetEncoder(nn.Module):
+    """smp encoders/resnet.py ResNetEncoder (depth 5): features at strides 1, 2, 4, 8, 16, 32."""
+
+    def __init__(self, name: str = "resnet18", in_channels: int = 3) -> None:
+        super().__init__()
+        if name not in RESNET_LAYERS:
+            msg = f"gdlhip UnetPlusPlus: encoder {name!r} is not built (BasicBlock ResNets: {sorted(RESNET_LAYERS)})"
+            raise NotImplementedError(msg)
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)     # standard OIHW layout: consumed flat
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        for i, (planes, blocks) in enumerate(zip([64, 128, 256, 512], RESNET_LAYERS[name])):
+            layer = []
+            for j in range(blocks):
+                layer.append(BasicBlock(inplanes, planes, (1 if i == 0 else 2) if j == 0 else 1))
+                inplanes = planes
+            setattr(self, f"layer{i + 1}", nn.Sequential(*layer))
+        self.out_channels = (in_channels, 64, 64, 128, 256, 512)
+
+    def forward_nhwc(self, img: Tensor) -> list[Tensor]:
+        """NCHW f32 image -> the five NHWC feature maps (strides 2..32) in the compute dtype."""
+        cd = gnn.compute_dtype()
+        b, c, h, w = img.shape
+        gh, gw = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+        kpad = cnn.pad_to(c * 49, cnn.chunk(cd))
+        cols = ops.patchify(img.float().contiguous(), 7, 3, gh, gw, kpad, cd, stride=2).view(b, gh, gw, kpad)
+        cnn.mark_flat(self.conv1.weight)    # the stem parameter is the [64, (c,r,s)] matrix of the patch GEMM
+        x = cnn.conv_bn(cols, self.conv1.weight, self.bn1)
+        feats = [x]
+        x = cnn.maxpool3x3s2(x)
+        for i in (1, 2, 3, 4):
+            for blk in getattr(self, f"layer{i}"):
+                x = blk.forward_nhwc(x)
+            feats.append(x)
+        return feats
+
+    def forward(self, img: Tensor) -> list[Tensor]:
+        return [img, *[ops.as_nchw(f) for f in self.forward_nhwc(img)]]
+
+
+class Conv2dReLU(nn.Sequential):
+    """smp base/modules.py Conv2dReLU: Conv2d(bias=False) + BatchNorm2d + ReLU (keys ``0.weight``, ``1.*``)."""
+
+    def __init__(self, cin: int, cout: int) -> None:
+        super().__init__(_cl_conv(cin, cout, 3, padding=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+    def forward_nhwc(self, x: Tensor) -> Tensor:
+        return cnn.conv_bn(x, self[0].weight, self[1], pad=1)
+
+
+class DecoderBlock(nn.Module):
+    """smp decoders/unetplusplus/decoder.py DecoderBlock (attention type None)."""
+
+    def __init__(self, in_channels: int, skip_channels: int, out_channels: int) -> None:
+        super().__init__()
+        self.in_channels = in_channels
+        self.conv1 = Conv2dReLU(in_channels + skip_channels, out_channels)
+        self.conv2 = Conv2dReLU(out_channels, out_channels)
+
+    def forward_nhwc(self, x: Tensor, skips: list[Tensor]) -> Tensor:
+        if x.shape[-1] != self.in_channels and skips:
+            msg = "a channel-padded tensor cannot be concatenated with skips"   # only x_0_4 (no skips) sees padding
+            raise ValueError(msg)
+        return self.conv2.forward_nhwc(self.conv1.forward_nhwc(cnn.up_cat(x, skips)))
+
+
+class UnetPlusPlusDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels=(256, 128, 64, 32, 16)) -> None:
+        super().__init__()
+        enc = list(encoder_channels[1:])[::-1]
+        self.in_channels = [enc[0], *decoder_channels[:-1]]
+        self.skip_channels = [*enc[1:], 0]
+        self.out_channels = list(decoder_channels)
+        blocks = {}
+        for layer in range(len(self.in_channels) - 1):
+            for depth in range(layer + 1):
+                if depth == 0:
+                    cin, skip, cout = (self.in_channels[layer], self.skip_channels[layer] * (layer + 1),
+                                       self.out_channels[layer])
+                else:
+                    cout = self.skip_channels[layer]
+                    skip = self.skip_channels[layer] * (layer + 1 - depth)
+                    cin = self.skip_channels[layer - 1]
+                blocks[f"x_{depth}_{layer}"] = DecoderBlock(cin, skip, cout)
+        blocks[f"x_0_{len(self.in_channels) - 1}"] = DecoderBlock(self.in_channels[-1], 0, self.out_channels[-1])
+        self.blocks = nn.ModuleDict(blocks)
+        self.depth = len(self.in_channels) - 1
+
+    def forward_nhwc(self, feats: list[Tensor]) -> Tensor:
+        """feats: the encoder's five NHWC maps, shallow to deep."""
+        feats = feats[::-1]
+        dense: dict[str, Tensor] = {}
+        for layer in range(len(self.in_channels) - 1):
+            for depth in range(self.depth - layer):
+                if layer == 0:
+                    dense[f"x_{depth}_{depth}"] = self.blocks[f"x_{depth}_{depth}"].forward_nhwc(
+                        feats[depth], [feats[depth + 1]])
+                else:
+                    li = depth + layer
+                    skips = [dense[f"x_{idx}_{li}"] for idx in range(depth + 1, li + 1)] + [feats[li + 1]]
+                    dense[f"x_{depth}_{li}"] = self.blocks[f"x_{depth}_{li}"].forward_nhwc(
+                        dense[f"x_{depth}_{li - 1}"], skips)
+        return self.blocks[f"x_0_{self.depth}"].forward_nhwc(dense[f"x_0_{self.depth - 1}"], [])
+
+
+class UnetPlusPlus(nn.Module):
+    """``smp.UnetPlusPlus(encoder_name, in_channels, encoder_weights, classes)`` -> NCHW f32 logits."""
+
+    def __init__(self, encoder_name: str = "resnet34", encoder_depth: int = 5, encoder_weights: str | None = "imagenet",
+                 decoder_channels=(256, 128, 64, 32, 16), in_channels: int = 3, classes: int = 1,
+                 activation=None, aux_params=None, **kwargs: object) -> None:
+        super().__init__()
+        if encoder_weights is not None:
+            msg = ("pretrained encoder weights are downloaded by smp in the reference; this build has no network: "
+                   "pass encoder_weights=None and load a checkpoint with load_state_dict")
+            raise RuntimeError(msg)
+        if encoder_depth != 5 or activation is not None or aux_params is not None or kwargs:
+            msg = "gdlhip UnetPlusPlus implements the reference's configuration (depth 5, no activation / aux head)"
+            raise NotImplementedError(msg)
+        self.encoder = ResNetEncoder(encoder_name, in_channels)
+        self.decoder = UnetPlusPlusDecoder(self.encoder.out_channels, tuple(decoder_channels))
+        self.segmentation_head = nn.Sequential(_cl_conv(decoder_channels[-1], classes, 3, padding=1, bias=True),
+                                               nn.Identity(), nn.Identity())
+
+    def forward(self, x: Tensor) -> Tensor:
+        if x.shape[2] % 32 or x.shape[3] % 32:
+            msg = f"Wrong input shape height={x.shape[2]}, width={x.shape[3]}: must be divisible by 32"   # smp's check
+            raise RuntimeError(msg)
+        dec = self.decoder.forward_nhwc(self.encoder.forward_nhwc(x))
+        return cnn.logits_nchw(cnn.conv_bias(dec, self.segmentation_head[0]))

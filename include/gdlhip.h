@@ -28,7 +28,8 @@ enum {
   GDL_ACT_NONE = 0,
   GDL_ACT_RELU = 1,
   GDL_ACT_GELU = 2,         /* erf GELU */
-  GDL_ACT_MUL_GELU_GRAD = 3 /* backward of a fused Linear+GELU: v *= gelu'(u), u passed in `resid` */
+  GDL_ACT_MUL_GELU_GRAD = 3, /* backward of a fused Linear+GELU: v *= gelu'(u), u passed in `resid` */
+  GDL_ACT_RESID_RELU = 4     /* ReLU applied AFTER the residual add: ResNet BasicBlock tail relu(bn(conv) + identity) */
 };
 enum {
   GDL_OK = 0,
@@ -177,6 +178,27 @@ int gdl_dwconv3x3_gelu_bwd(const void* u, const void* dy, int dtype, int B, int 
  * (autograd of F.conv2d wrt input for OverlapPatchEmbed / the sr conv, mix_transformer.py:224-276, :95-99) */
 int gdl_col2im(const void* cols, int dtype, int B, int Ho, int Wo, int R, int S, int C, int stride, int pad, int H,
                int W, void* dx, int dx_dtype, int64_t dx_sB, int64_t dx_sH, int64_t dx_sW, gdl_stream_t stream);
+
+/* ---- ResNet encoder / UNet++ decoder pieces (smp.UnetPlusPlus, segmentation_unetplus.py:126-131; torchvision
+ * resnet.py BasicBlock / maxpool; smp decoders/unetplusplus/decoder.py DecoderBlock) ----------------------------
+ * NHWC, strides in elements, channels a multiple of 8 (bf16) / 4 (f32); tensors may be slices of a concat buffer. */
+/* F.max_pool2d(kernel 3, stride 2, padding 1); backward routes each window's gradient to its FIRST maximum */
+int gdl_maxpool3x3s2_fwd(const void* in, int dtype, int B, int H, int W, int C, int64_t in_sB, int64_t in_sH,
+                         int64_t in_sW, void* out, int64_t out_sB, int64_t out_sH, int64_t out_sW, gdl_stream_t stream);
+int gdl_maxpool3x3s2_bwd(const void* in, const void* dout, void* din, int dtype, int B, int H, int W, int C,
+                         int64_t in_sB, int64_t in_sH, int64_t in_sW, int64_t d_sB, int64_t d_sH, int64_t d_sW,
+                         int64_t g_sB, int64_t g_sH, int64_t g_sW, gdl_stream_t stream);
+/* F.interpolate(scale_factor=2, mode="nearest"): [B,H,W,C] -> [B,2H,2W,C]; backward sums each 2x2 block */
+int gdl_nearest2x_fwd(const void* in, int dtype, int B, int H, int W, int C, int64_t in_sB, int64_t in_sH,
+                      int64_t in_sW, void* out, int64_t out_sB, int64_t out_sH, int64_t out_sW, gdl_stream_t stream);
+int gdl_nearest2x_bwd(const void* dout, int dtype, int B, int H, int W, int C, int64_t d_sB, int64_t d_sH,
+                      int64_t d_sW, void* din, int64_t g_sB, int64_t g_sH, int64_t g_sW, gdl_stream_t stream);
+/* out = relu(a + b) on dense tensors of n elements; dx = dy * (y > 0) */
+int gdl_add_relu(const void* a, const void* b, void* out, int dtype, int64_t n, gdl_stream_t stream);
+int gdl_relu_bwd(const void* y, const void* dy, void* dx, int dtype, int64_t n, gdl_stream_t stream);
+/* dense [P][C] (any C, e.g. the 5-class logit gradient) -> [P][Cpad] in out_dtype, extra channels zero */
+int gdl_pad_channels(const void* in, int in_dtype, int64_t P, int C, void* out, int out_dtype, int Cpad,
+                     gdl_stream_t stream);
 
 /* ---- resampling (NHWC) ---------------------------------------------------------------
  * F.interpolate(mode="bilinear", align_corners=False) (models/utils.py:96-137,
