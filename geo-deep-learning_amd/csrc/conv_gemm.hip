@@ -29,8 +29,6 @@ namespace {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ uint4 g_zero_page[8];  // 128 bytes of zeros: source of every out-of-range chunk
-
 struct KArgs {
   gdl_conv_args a;
   int M;        // B*Ho*Wo
@@ -38,11 +36,25 @@ struct KArgs {
   int KT;       // R*S*kc
   int tiles_m, tiles_n;
   int in_dense, out_dense, res_dense;
+  unsigned in_span, w_span;   // bytes addressed from the (z-offset) operand base: buffer num_records
+  int tap_inner;              // K order: 1 = channel chunk outer / filter tap inner (default), 0 = tap outer
+  int dbg;                    // tuning experiments only: 1 = no DMA after the first tile, 2 = no MFMA
+  unsigned long long* probe;  // tuning only: per block {shader cycles, 100 MHz ticks} of the K loop
 };
 
 template <typename T> struct TileTraits;
 template <> struct TileTraits<float> { static constexpr int ES = 4; static constexpr int BKE = 32; };
 template <> struct TileTraits<bf16_tag> { static constexpr int ES = 2; static constexpr int BKE = 64; };
+
+// the transcendental activations are kept out of line: the epilogue is unrolled 32-fold (static accumulator
+// indexing) and would otherwise exceed the unroller's size budget
+__device__ __noinline__ float4 gelu4(float4 v) {
+  return make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+}
+__device__ __noinline__ float4 mul_gelu_grad4(float4 v, float4 u) {
+  return make_float4(v.x * gelu_erf_grad(u.x), v.y * gelu_erf_grad(u.y), v.z * gelu_erf_grad(u.z),
+                     v.w * gelu_erf_grad(u.w));
+}
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
   // bijective "XCD-major" remap (cdna guide T1): hardware places block id on XCD id % 8.
@@ -52,14 +64,19 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 
 // EXTRA = the training-only epilogue features (aux_out store of the pre-activation, GDL_ACT_MUL_GELU_GRAD);
 // they live in separate instantiations so the inference / frozen-encoder kernels keep their register budget.
-template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA>
+// PP ("ping-pong", 8-wave tile only): the two waves that share a SIMD (w and w+4) take turns being the LOADER of a
+// K-step: the loader half issues the whole next tile's DMA while its partners go straight to their MFMAs, so the
+// matrix pipe never idles behind a workgroup-wide DMA-issue phase; the halves swap roles every K-step.
+template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const KArgs k) {
   constexpr int ES = TileTraits<T>::ES;
   constexpr int BKE = TileTraits<T>::BKE;
   constexpr int BM = WARPS_M * TM * 32, BN = WARPS_N * TN * 32;
-  constexpr int NW = WARPS_M * WARPS_N;
-  constexpr int CA = BM / (8 * NW), CB = BN / (8 * NW);  // DMA instructions per wave per tile
+  constexpr int NWALL = WARPS_M * WARPS_N;
+  constexpr int NW = PP ? NWALL / 2 : NWALL;             // waves that share one tile's DMA
+  constexpr int CA = BM / (8 * NW), CB = BN / (8 * NW);  // DMA instructions per loading wave per tile
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/waves mismatch");
+  static_assert(!PP || NWALL == 8, "ping-pong needs two waves per SIMD");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE_BYTES = (BM + BN) * 128;  // [A: BM rows | B: BN rows] x 128 B
@@ -74,69 +91,92 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.y;
   const int z0 = z / a.nz_inner, z1 = z % a.nz_inner;
-  const unsigned char* in_base = (const unsigned char*)a.in + (z0 * a.in_sZ0 + z1 * a.in_sZ1) * ES;
-  const unsigned char* w_base = (const unsigned char*)a.w + (z0 * a.w_sZ0 + z1 * a.w_sZ1) * ES;
   const int64_t out_zoff = z0 * a.out_sZ0 + z1 * a.out_sZ1;
-  const unsigned char* zero = (const unsigned char*)g_zero_page;
+  // Operands are fetched through buffer descriptors (raw, num_records = the operand's span in bytes, < 2 GiB):
+  // a lane whose 16-byte chunk is out of range (halo / zero padding / M and N tails) gets voffset = kOob and the
+  // hardware writes ZEROS to its LDS slot (probed: tools/probes/buffer_lds_probe.hip) -- no predication, no zero
+  // page, and all address arithmetic is 32-bit.
+  constexpr unsigned kOob = 0x80000000u;
+  const srd_t srd_a = make_srd((const unsigned char*)a.in + (z0 * a.in_sZ0 + z1 * a.in_sZ1) * ES, k.in_span);
+  const srd_t srd_b = make_srd((const unsigned char*)a.w + (z0 * a.w_sZ0 + z1 * a.w_sZ1) * ES, k.w_span);
+  const unsigned lds_base =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
 
   // ---- DMA geometry: wave w, instruction i covers tile rows (i*NW + w)*8 .. +7; lane l writes
   //      LDS slot (l & 7) of row +(l >> 3) and therefore fetches source chunk slot ^ swz(row).
   const int lrow = lane >> 3, lslot = lane & 7;
-  int64_t a_off[CA];   // byte offset of (iy0, ix0, chunk) for the row, tap (0,0), cc = 0
-  int a_iy0[CA], a_ix0[CA];
-  bool a_ok[CA];
+  const int lwave = PP ? (wave & 3) : wave;   // index among the waves that load a tile together
+  const int half = PP ? (wave >> 2) : 0;      // waves w and w+4 share a SIMD
+  int a_voff[CA];        // byte offset of (b, iy0, ix0, chunk) for the row at tap (0,0), cc = 0 (may be negative)
+  unsigned a_mask[CA];   // bit t set <=> filter tap t of this row reads inside the image
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int i = 0; i < CA; ++i) {
-    const int r = (i * NW + wave) * 8 + lrow;
+    const int r = (i * NW + lwave) * 8 + lrow;
     const int chunk = lslot ^ ((r >> 1) & 7);
     const int m = m0 + r;
-    a_ok[i] = m < k.M;
-    const int mm = a_ok[i] ? m : 0;
-    int64_t off;
+    const bool ok = m < k.M;
+    const int mm = ok ? m : 0;
     if (k.in_dense) {  // 1x1, stride 1, dense rows: offset is linear in m, nothing to clip
-      a_iy0[i] = 0; a_ix0[i] = 0;
-      off = (int64_t)mm * a.in_sW;
+      a_voff[i] = ok ? (int)((mm * a.in_sW + chunk * (16 / ES)) * ES) : (int)kOob;
+      a_mask[i] = ok ? 1u : 0u;
     } else {
       const int b = mm / HoWo, rem = mm - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
-      a_iy0[i] = oy * a.stride - a.pad;
-      a_ix0[i] = ox * a.stride - a.pad;
-      off = (int64_t)b * a.in_sB + (int64_t)a_iy0[i] * a.in_sH + (int64_t)a_ix0[i] * a.in_sW;
+      const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+      a_voff[i] = (int)((b * a.in_sB + iy0 * a.in_sH + ix0 * a.in_sW + chunk * (16 / ES)) * ES);
+      unsigned mask = 0;
+      if (ok) {
+        if (a.pad == 0) {
+          mask = 0xffffffffu;                       // no halo: every tap of every valid row is inside
+        } else {
+          for (int tr = 0; tr < a.R; ++tr)
+            for (int ts = 0; ts < a.S; ++ts)
+              if ((unsigned)(iy0 + tr) < (unsigned)a.H && (unsigned)(ix0 + ts) < (unsigned)a.W)
+                mask |= 1u << (tr * a.S + ts);
+        }
+      }
+      a_mask[i] = mask;
     }
-    a_off[i] = (off + chunk * (16 / ES)) * ES;
   }
-  const unsigned char* b_ptr[CB];  // weight row + chunk (k = 0); nullptr-free: tails use zero page
-  bool b_ok[CB];
+  unsigned b_voff[CB];   // weight row + chunk (k = 0), or kOob for the N tail
 #pragma unroll
   for (int i = 0; i < CB; ++i) {
-    const int r = (i * NW + wave) * 8 + lrow;
+    const int r = (i * NW + lwave) * 8 + lrow;
     const int chunk = lslot ^ ((r >> 1) & 7);
     const int n = n0 + r;
-    b_ok[i] = n < a.N;
-    b_ptr[i] = w_base + ((int64_t)(b_ok[i] ? n : 0) * a.w_sN + chunk * (16 / ES)) * ES;
+    b_voff[i] = n < a.N ? (unsigned)((n * a.w_sN + chunk * (16 / ES)) * ES) : kOob;
   }
 
   int tap_r = 0, tap_s = 0, cc = 0;  // position of the NEXT tile to fetch
-  int64_t wk = 0;                    // its byte offset along the weight rows
+  unsigned wk = 0;                   // its byte offset along the weight rows
 
-  auto issue = [&](int stage) {
-    unsigned char* sa = smem + stage * STAGE_BYTES;
-    unsigned char* sb = sa + BM * 128;
-    const int64_t tap_off = ((int64_t)tap_r * a.in_sH + (int64_t)tap_s * a.in_sW + (int64_t)cc * BKE) * ES;
+  auto issue = [&](int stage, bool load) {
+    if (load) {
+      const unsigned lds_a = lds_base + stage * STAGE_BYTES + lwave * 1024;
+      const unsigned lds_b = lds_a + BM * 128;
+      if (k.in_dense) {
 #pragma unroll
-    for (int i = 0; i < CA; ++i) {
-      const bool ok = a_ok[i] && (unsigned)(a_iy0[i] + tap_r) < (unsigned)a.H &&
-                      (unsigned)(a_ix0[i] + tap_s) < (unsigned)a.W;
-      const unsigned char* src = ok ? in_base + a_off[i] + tap_off : zero;
-      dma16_to_lds(src, sa + (i * NW + wave) * 1024);
-    }
+        for (int i = 0; i < CA; ++i) dma16_buf((unsigned)a_voff[i], srd_a, wk, lds_a + i * NW * 1024);
+      } else {
+        const int tap_off = (int)((tap_r * a.in_sH + tap_s * a.in_sW + cc * BKE) * ES);
+        const unsigned bit = a.pad == 0 ? 1u : 1u << (tap_r * a.S + tap_s);
 #pragma unroll
-    for (int i = 0; i < CB; ++i) {
-      const unsigned char* src = b_ok[i] ? b_ptr[i] + wk : zero;
-      dma16_to_lds(src, sb + (i * NW + wave) * 1024);
+        for (int i = 0; i < CA; ++i) {
+          const unsigned v = (a_mask[i] & bit) ? (unsigned)(a_voff[i] + tap_off) : kOob;
+          dma16_buf(v, srd_a, 0u, lds_a + i * NW * 1024);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < CB; ++i) dma16_buf(b_voff[i], srd_b, wk, lds_b + i * NW * 1024);
     }
-    wk += 128;
-    if (++cc == k.kc) { cc = 0; if (++tap_s == a.S) { tap_s = 0; ++tap_r; } }
+    // every wave tracks the tile position, loader or not.  K order = channel chunk OUTER, filter tap INNER: the
+    // R*S taps of one chunk re-read (shifted) the same activation bytes back to back, while they are hot in L2
+    if (k.tap_inner) {
+      if (++tap_s == a.S) { tap_s = 0; if (++tap_r == a.R) { tap_r = 0; ++cc; } }
+    } else {
+      if (++cc == k.kc) { cc = 0; if (++tap_s == a.S) { tap_s = 0; ++tap_r; } }
+    }
+    wk = (unsigned)(((tap_r * a.S + tap_s) * a.C + cc * BKE) * ES);
   };
 
   f32x16_t acc[TM][TN];
@@ -152,166 +192,237 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   const int a_lds0 = (wm * TM * 32 + frow) * 128;
   const int b_lds0 = BM * 128 + (wn * TN * 32 + frow) * 128;
 
-  issue(0);
+  // ---- main loop.  Per K-step (tile kt in LDS stage kt&1, four k16 groups kk):
+  //   kk = 0..2 : fetch fragments of kk+1 (ds_read_b128, double-buffered registers), MFMAs of kk
+  //   then      : wait own DMA of tile kt+1 (vmcnt 0) -> barrier -> issue DMA of tile kt+2 into the stage tile kt
+  //               just vacated (every wave holds its kk=3 fragments in registers) -> fetch kk=0 of tile kt+1
+  //   kk = 3    : MFMAs, covering the barrier skew, the DMA issue and the first-fragment LDS latency.
+  // One barrier per K-step, a tile's DMA has a full K-step to land, and no MFMA ever waits on a just-issued read.
+  uint4 fa[2][TM], fb[2][TN];
+  auto fetch = [&](const unsigned char* st, int kk, int buf) {
+    const int coff = (((2 * kk + fhalf) ^ fswz) << 4);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[buf][i] = *(const uint4*)(st + a_lds0 + i * 32 * 128 + coff);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[buf][j] = *(const uint4*)(st + b_lds0 + j * 32 * 128 + coff);
+  };
+  auto mfmas = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (ES == 2) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8_t, fb[buf][j]), __builtin_bit_cast(bf16x8_t, fa[buf][i]), acc[i][j], 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fb[buf][j].x), __uint_as_float(fa[buf][i].x), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fb[buf][j].y), __uint_as_float(fa[buf][i].y), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fb[buf][j].z), __uint_as_float(fa[buf][i].z), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fb[buf][j].w), __uint_as_float(fa[buf][i].w), acc[i][j], 0, 0, 0);
+        }
+      }
+  };
+  const unsigned long long t0c = k.probe ? __builtin_readcyclecounter() : 0;
+  const unsigned long long t0r = k.probe ? __builtin_amdgcn_s_memrealtime() : 0;
+  // tile t is loaded by half (t & 1) in the ping-pong variant, by everyone otherwise
+  issue(0, !PP || half == 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (k.KT > 1) issue(1, !PP || half == 1);
+  fetch(smem, 0, 0);
   for (int kt = 0; kt < k.KT; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for tile kt has landed
-    __syncthreads();                                   // ... and everyone's; everyone left tile kt-1
-    if (kt + 1 < k.KT) issue((kt + 1) & 1);            // DMA of tile kt+1 flies under the MFMAs
     const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int coff = (((2 * kk + fhalf) ^ fswz) << 4);
-      uint4 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *(const uint4*)(st + a_lds0 + i * 32 * 128 + coff);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *(const uint4*)(st + b_lds0 + j * 32 * 128 + coff);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if constexpr (ES == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8_t, fa[i]), __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j],
-                0, 0, 0);
-          } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i].x),
-                                                              __uint_as_float(fb[j].x), acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i].y),
-                                                              __uint_as_float(fb[j].y), acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i].z),
-                                                              __uint_as_float(fb[j].z), acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i].w),
-                                                              __uint_as_float(fb[j].w), acc[i][j], 0, 0, 0);
-          }
-        }
+    for (int kk = 0; kk < 3; ++kk) {
+      fetch(st, kk + 1, (kk + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k.dbg != 2) mfmas(kk & 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (kt + 1 < k.KT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt+1 has landed
+      __syncthreads();                                   // ... and everyone's; nobody reads tile kt's stage any more
+      if (kt + 2 < k.KT) issue(kt & 1, (!PP || half == (kt & 1)) && k.dbg != 1);
+      fetch(smem + ((kt + 1) & 1) * STAGE_BYTES, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (k.dbg != 2) mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
-  // ---- epilogue: lane holds column n = lane&31 of each tile, rows (r&3)+8(r>>2)+4*fhalf ----
-  float e_bias[TN], e_scale[TN], e_shift[TN];
-  bool n_ok[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + frow;
-    n_ok[j] = n < a.N;
-    const int nn = n_ok[j] ? n : 0;
-    e_bias[j] = a.bias ? a.bias[nn] : 0.f;
-    e_scale[j] = a.scale ? a.scale[nn] : 1.f;
-    e_shift[j] = a.shift ? a.shift[nn] : 0.f;
+  if (k.probe && tid == 0 && blockIdx.x < 2048) {
+    k.probe[2 * blockIdx.x] = __builtin_readcyclecounter() - t0c;
+    k.probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
   }
-  // Phase 1 (per 32-row slab i): apply the per-column epilogue in registers and park the slab in a
-  // wave-private LDS region as [32 rows][TN*32 cols] in the OUTPUT dtype.  Phase 2: every lane
-  // picks up 16 contiguous bytes of one row, applies the per-row terms (DropPath scale, residual)
-  // and issues ONE coalesced 16-byte store -- instead of 16*TN scattered 2/4-byte stores.
-  __syncthreads();  // all waves are done with the operand stages: LDS is free for the transposes
-  auto run = [&](auto oes_c) {
-    constexpr int OES = decltype(oes_c)::value;        // output element size
-    constexpr int COLS = TN * 32;
-    constexpr int ROWB = COLS * OES + 16;              // +16 B pad: the two half-waves hit different banks
-    constexpr int CPR = COLS * OES / 16;               // 16-byte chunks per row
-    constexpr int PER = 16 / OES;                      // elements per chunk
-    constexpr int PASSES = 32 * CPR / 64;
-    unsigned char* reg = smem + wave * (32 * ROWB);
-    const int prow = lane / CPR, pchunk = lane % CPR;
-    const bool vec_ok = ((uintptr_t)a.out % 16 == 0) && ((uintptr_t)a.aux_out % 16 == 0) && (a.out_sW % PER == 0) && (a.out_sH % PER == 0) &&
-                        (a.out_sB % PER == 0) && (out_zoff % PER == 0);
-    const bool mulgrad = EXTRA && a.act == GDL_ACT_MUL_GELU_GRAD;
+  // ---- epilogue.  The MFMAs ran with swapped operands (D = W_tile x X_tile^T), so a lane owns ONE output row
+  // m = lane&31 of each 32x32 tile and its 16 accumulators are 4 groups of 4 CONSECUTIVE channels
+  // n = 8g + 4*(lane>>5) + e: per-channel terms are float4 loads, per-row terms (DropPath scale, residual) are
+  // per lane, and results leave as 8/16-byte pieces straight from registers -- no LDS round trip, no barrier.
+  // bf16: the two lanes that hold adjacent 8-byte pieces of a row trade one piece (v_permlane32_swap) so that each
+  // stores 16 contiguous bytes.
+  const bool out_bf16 = a.out_dtype == GDL_BF16;
+  const int oes = out_bf16 ? 2 : 4;
+  const bool mulgrad = EXTRA && a.act == GDL_ACT_MUL_GELU_GRAD;
+  const bool plain = !a.resid && !a.batch_scale;
+  const bool vec_ok = ((uintptr_t)a.out % 16 == 0) && ((uintptr_t)a.aux_out % 16 == 0) && (a.out_sW % 8 == 0) &&
+                      (a.out_sH % 8 == 0) && (a.out_sB % 8 == 0) && (out_zoff % 8 == 0) && (a.N % 16 == 0);
+  const bool res_vec = !a.resid || (((uintptr_t)a.resid % 16 == 0) && (a.res_sW % 4 == 0) && (a.res_sH % 4 == 0) &&
+                                    (a.res_sB % 4 == 0));
+  int64_t row_o[TM], row_r[TM];
+  float row_s[TM];
+  bool m_ok[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      // pass 0 (only with aux_out): acc*alpha + bias, before scale/shift/act; pass 1: the final output
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + (wm * TM + i) * 32 + frow;
+    m_ok[i] = m < k.M;
+    row_s[i] = 1.f;
+    if (k.out_dense && k.res_dense && !a.batch_scale) {
+      row_o[i] = (int64_t)m * a.out_sW + out_zoff;
+      row_r[i] = (int64_t)m * a.res_sW;
+    } else {
+      const int mm = m_ok[i] ? m : 0;
+      const int b = mm / HoWo, rem = mm - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+      row_o[i] = (int64_t)b * a.out_sB + (int64_t)oy * a.out_sH + (int64_t)ox * a.out_sW + out_zoff;
+      row_r[i] = (int64_t)b * a.res_sB + (int64_t)oy * a.res_sH + (int64_t)ox * a.res_sW;
+      if (a.batch_scale) row_s[i] = a.batch_scale[b];
+    }
+  }
+  auto load4 = [&](const float* p, int n, float dflt, float (&o)[4]) {
+    if (!p) { o[0] = o[1] = o[2] = o[3] = dflt; return; }
+    if (n + 3 < a.N && ((uintptr_t)p % 16 == 0)) {
+      const float4 t = *(const float4*)(p + n);
+      o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    } else {
 #pragma unroll
-      for (int pass = EXTRA ? 0 : 1; pass < 2; ++pass) {
-        const bool is_aux = EXTRA && pass == 0;
-        if (is_aux && !a.aux_out) continue;
-        unsigned char* dst_base = (unsigned char*)(is_aux ? a.aux_out : a.out);
+      for (int e = 0; e < 4; ++e) o[e] = n + e < a.N ? p[n + e] : dflt;
+    }
+  };
+  // values of one 4-channel group of row i after the whole epilogue; `pre` gets alpha*acc + bias
+  auto finish = [&](int i, int j, int g, int n, const float (&bias4)[4], const float (&sc4)[4], const float (&sh4)[4],
+                    float (&v)[4], float (&pre)[4]) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+    for (int e = 0; e < 4; ++e) {
+      float x = acc[i][j][4 * g + e] * a.alpha + bias4[e];
+      pre[e] = x;
+      if (a.scale) x = x * sc4[e] + sh4[e];
+      if (a.act == GDL_ACT_RELU) x = fmaxf(x, 0.f);
+      v[e] = x;
+    }
+    if (a.act == GDL_ACT_GELU) {
+      const float4 t = gelu4(make_float4(v[0], v[1], v[2], v[3]));
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    if (!plain && m_ok[i]) {
+      float rv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.resid) {
+        const int64_t ro = row_r[i] + n;
+        if (res_vec && n + 3 < a.N) {
+          if (a.resid_dtype == GDL_BF16) {
+            const uint2 t = *(const uint2*)((const uint16_t*)a.resid + ro);
+            rv[0] = __uint_as_float(t.x << 16); rv[1] = __uint_as_float(t.x & 0xffff0000u);
+            rv[2] = __uint_as_float(t.y << 16); rv[3] = __uint_as_float(t.y & 0xffff0000u);
+          } else {
+            const float4 t = *(const float4*)((const float*)a.resid + ro);
+            rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w;
+          }
+        } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = acc[i][j][r] * a.alpha + e_bias[j];
-            if (!is_aux) {
-              if (a.scale) v = v * e_scale[j] + e_shift[j];
-              if (a.act == GDL_ACT_RELU) v = fmaxf(v, 0.f);
-              else if (a.act == GDL_ACT_GELU) v = gelu_erf(v);
+          for (int e = 0; e < 4; ++e)
+            if (n + e < a.N) rv[e] = load_as_f32(a.resid, ro + e, a.resid_dtype);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= row_s[i];
+      if (EXTRA && mulgrad) {
+        const float4 t = mul_gelu_grad4(make_float4(v[0], v[1], v[2], v[3]), make_float4(rv[0], rv[1], rv[2], rv[3]));
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = v[e] + rv[e];
+          if (a.act == GDL_ACT_RESID_RELU) x = fmaxf(x, 0.f);
+          v[e] = x;
+        }
+      }
+    }
+  };
+  auto store4 = [&](void* base, int64_t off, int n, const float (&v)[4]) {   // 4 channels of one row, tail-safe
+    if (vec_ok && n + 3 < a.N) {
+      if (out_bf16) *(uint2*)((uint16_t*)base + off) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      else *(float4*)((float*)base + off) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < a.N) store_from_f32(base, off + e, v[e], a.out_dtype);
+    }
+  };
+  (void)oes;
+  auto tile_col = [&](auto jc) {   // static j (the unroller's size budget does not cover the 8-wave variant's body)
+    constexpr int j = decltype(jc)::value;
+    const int nt = n0 + (wn * TN + j) * 32;
+    if (out_bf16 && vec_ok) {
+      if (nt < a.N) {
+      // pairs of groups (2p, 2p+1): after the lane-pair swap the low half-wave stores channels [16p, 16p+8) of its
+      // row and the high half-wave channels [16p+8, 16p+16)
+#pragma unroll
+      for (int p2 = 0; p2 < 2; ++p2) {
+        const int na = nt + 16 * p2 + 4 * fhalf, nb = na + 8;
+        float ba[4], sa[4], ha[4], bb[4], sb[4], hb[4];
+        load4(a.bias, na, 0.f, ba); load4(a.scale, na, 1.f, sa); load4(a.shift, na, 0.f, ha);
+        load4(a.bias, nb, 0.f, bb); load4(a.scale, nb, 1.f, sb); load4(a.shift, nb, 0.f, hb);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          float va[4], vb[4], pa[4], pb[4];
+          finish(i, j, 2 * p2, na, ba, sa, ha, va, pa);
+          finish(i, j, 2 * p2 + 1, nb, bb, sb, hb, vb, pb);
+          const int ncol = nt + 16 * p2 + 8 * fhalf;
+          auto emit = [&](void* base, const float (&xa)[4], const float (&xb)[4]) {
+            unsigned a0 = pack_bf16x2(xa[0], xa[1]), a1 = pack_bf16x2(xa[2], xa[3]);
+            unsigned b0 = pack_bf16x2(xb[0], xb[1]), b1 = pack_bf16x2(xb[2], xb[3]);
+            // upper half of (a0,a1) <-> lower half of (b0,b1): low lanes end with (lowA, highA), high with (lowB, highB)
+            const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            if (m_ok[i]) *(uint4*)((uint16_t*)base + row_o[i] + ncol) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          };
+          if (EXTRA && a.aux_out) emit(a.aux_out, pa, pb);
+          emit(a.out, va, vb);
+        }
+      }
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nt + 8 * g + 4 * fhalf;
+        if (n < a.N) {
+          float b4[4], s4[4], h4[4];
+          load4(a.bias, n, 0.f, b4); load4(a.scale, n, 1.f, s4); load4(a.shift, n, 0.f, h4);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            float v[4], pre[4];
+            finish(i, j, g, n, b4, s4, h4, v, pre);
+            if (m_ok[i]) {
+              if (EXTRA && a.aux_out) store4(a.aux_out, row_o[i] + n, n, pre);
+              store4(a.out, row_o[i] + n, n, v);
             }
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-            unsigned char* q = reg + row * ROWB + (j * 32 + frow) * OES;
-            if constexpr (OES == 2) *(uint16_t*)q = f32_to_bf16(v);
-            else *(float*)q = v;
-          }
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-          const int row = ps * (64 / CPR) + prow;
-          const int m = m0 + (wm * TM + i) * 32 + row;
-          const int n = n0 + wn * COLS + pchunk * PER;
-          if (m >= k.M || n >= a.N) continue;
-          const uint4 raw = *(const uint4*)(reg + row * ROWB + pchunk * 16);
-          int64_t ooff, roff = 0;
-          float bscale = 1.f;
-          if (k.out_dense && k.res_dense && !a.batch_scale) {
-            ooff = (int64_t)m * a.out_sW;
-            roff = (int64_t)m * a.res_sW;
-          } else {
-            const int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            ooff = (int64_t)b * a.out_sB + (int64_t)oy * a.out_sH + (int64_t)ox * a.out_sW;
-            roff = (int64_t)b * a.res_sB + (int64_t)oy * a.res_sH + (int64_t)ox * a.res_sW;
-            if (a.batch_scale) bscale = a.batch_scale[b];
-          }
-          ooff += out_zoff + n;
-          roff += n;
-          const bool full = n + PER <= a.N;
-          const bool plain = is_aux || (!a.resid && !a.batch_scale);
-          if (full && vec_ok && plain) {
-            *(uint4*)(dst_base + ooff * OES) = raw;
-            continue;
-          }
-          float v[PER];
-          if constexpr (OES == 2) {
-            const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w4[e] << 16); v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u); }
-          } else {
-            v[0] = __uint_as_float(raw.x); v[1] = __uint_as_float(raw.y); v[2] = __uint_as_float(raw.z); v[3] = __uint_as_float(raw.w);
-          }
-          if (!plain) {
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {
-              v[e] *= bscale;
-              if (a.resid && n + e < a.N) {
-                const float rv = load_as_f32(a.resid, roff + e, a.resid_dtype);
-                v[e] = mulgrad ? v[e] * gelu_erf_grad(rv) : v[e] + rv;
-              }
-              if (a.act == GDL_ACT_RESID_RELU) v[e] = fmaxf(v[e], 0.f);
-            }
-          }
-          if (full && vec_ok) {
-            if constexpr (OES == 2)
-              *(uint4*)(dst_base + ooff * 2) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
-                                                          pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-            else
-              *(float4*)((float*)dst_base + ooff) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < PER; ++e)
-              if (n + e < a.N) store_from_f32(dst_base, ooff + e, v[e], a.out_dtype);
           }
         }
       }
     }
   };
-  if (a.out_dtype == GDL_BF16) run(std::integral_constant<int, 2>{});
-  else run(std::integral_constant<int, 4>{});
+  tile_col(std::integral_constant<int, 0>{});
+  if constexpr (TN > 1) tile_col(std::integral_constant<int, 1>{});
+  static_assert(TN <= 2, "epilogue is written for TN <= 2");
+  if (k.probe && tid == 0 && blockIdx.x < 2048) k.probe[4096 + blockIdx.x] = __builtin_readcyclecounter() - t0c;
 }
 
-template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA>
+template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false>
 int launch_x(const KArgs& k, hipStream_t stream) {
   constexpr int BM = WARPS_M * TM * 32, BN = WARPS_N * TN * 32;
   KArgs kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.a.N + BN - 1) / BN;
   const size_t lds = 2 * (BM + BN) * 128;
-  auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA>;
+  auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA, PP>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -330,6 +441,12 @@ int launch(const KArgs& k, hipStream_t stream) {
 }
 
 }  // namespace
+
+static int g_tap_inner = 1, g_dbg = 0;
+extern "C" void gdl_debug_set_conv_dbg(int mode) { g_dbg = mode; }
+static unsigned long long* g_probe = nullptr;
+extern "C" void gdl_debug_set_conv_probe(void* dev_buf_2048x2_u64) { g_probe = (unsigned long long*)dev_buf_2048x2_u64; }
+extern "C" void gdl_debug_set_conv_korder(int tap_inner) { g_tap_inner = tap_inner; }  // A/B hook
 
 extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   GDL_CHECK_ARG(ap != nullptr, "gdl_conv_gemm: null args");
@@ -354,12 +471,38 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   GDL_CHECK_ARG(a.act != GDL_ACT_MUL_GELU_GRAD || (a.resid && !a.aux_out),
                 "gdl_conv_gemm: GDL_ACT_MUL_GELU_GRAD takes the pre-activation tensor in `resid`");
   GDL_CHECK_ARG((int64_t)a.B * a.Ho * a.Wo < (1ll << 31), "gdl_conv_gemm: M too large");
+  GDL_CHECK_ARG(a.pad == 0 || a.R * a.S <= 32, "gdl_conv_gemm: padded filters are limited to 32 taps (got %dx%d)", a.R, a.S);
+  // operands are addressed through 32-bit buffer offsets: each must span < 2 GiB (split the batch otherwise)
+  const int64_t kSpanMax = 0x7ffffff0ll;
+  const int64_t in_span = (((int64_t)a.B - 1) * a.in_sB + ((int64_t)a.H - 1) * a.in_sH + ((int64_t)a.W - 1) * a.in_sW + a.C) * es;
+  const int64_t w_span = (((int64_t)a.N - 1) * a.w_sN + (int64_t)a.R * a.S * a.C) * es;
+  GDL_CHECK_ARG(w_span <= kSpanMax, "gdl_conv_gemm: weight matrix spans more than 2 GiB");
+  if (in_span > kSpanMax) {
+    GDL_CHECK_ARG(a.B > 1 && a.nz == 1, "gdl_conv_gemm: one image spans more than 2 GiB");
+    const int b1 = a.B / 2;
+    const int64_t oes = (int64_t)gdl_elem_size(a.out_dtype);
+    gdl_conv_args lo = a, hi = a;
+    lo.B = b1;
+    hi.B = a.B - b1;
+    hi.in = (const unsigned char*)a.in + (int64_t)b1 * a.in_sB * es;
+    hi.out = (unsigned char*)a.out + (int64_t)b1 * a.out_sB * oes;
+    if (a.aux_out) hi.aux_out = (unsigned char*)a.aux_out + (int64_t)b1 * a.out_sB * oes;
+    if (a.resid) hi.resid = (const unsigned char*)a.resid + (int64_t)b1 * a.res_sB * (int64_t)gdl_elem_size(a.resid_dtype);
+    if (a.batch_scale) hi.batch_scale = a.batch_scale + b1;
+    const int st = gdl_conv_gemm(&lo, stream);
+    return st != GDL_OK ? st : gdl_conv_gemm(&hi, stream);
+  }
   KArgs k;
   k.a = a;
   k.M = a.B * a.Ho * a.Wo;
   k.kc = a.C / bke;
   k.KT = a.R * a.S * k.kc;
   // "dense" = the (b,oy,ox) -> offset map is linear in m, so no divisions are needed
+  k.tap_inner = g_tap_inner;
+  k.dbg = g_dbg;
+  k.probe = g_probe;
+  k.in_span = (unsigned)in_span;
+  k.w_span = (unsigned)w_span;
   k.in_dense = (a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo &&
                 a.in_sH == (int64_t)a.W * a.in_sW && a.in_sB == (int64_t)a.H * a.in_sH);
   k.out_dense = (a.out_sH == (int64_t)a.Wo * a.out_sW && a.out_sB == (int64_t)a.Ho * a.out_sH);
@@ -367,10 +510,12 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int variant = gdl_conv_gemm_plan(ap, nullptr);
   if (a.dtype == GDL_BF16) {
+    if (variant == 3) return launch_x<bf16_tag, 2, 4, 4, 2, false, true>(k, s);
     if (variant == 2) return launch_x<bf16_tag, 2, 4, 4, 2, false>(k, s);
     if (variant == 1) return launch<bf16_tag, 2, 2, 2, 2>(k, s);
     return launch<bf16_tag, 2, 2, 1, 1>(k, s);
   }
+  if (variant == 3) return launch_x<float, 2, 4, 4, 2, false, true>(k, s);
   if (variant == 2) return launch_x<float, 2, 4, 4, 2, false>(k, s);
   if (variant == 1) return launch<float, 2, 2, 2, 2>(k, s);
   return launch<float, 2, 2, 1, 1>(k, s);
@@ -387,7 +532,7 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   const gdl_conv_args& a = *ap;
   const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
   if (flops) *flops = 2 * M * a.N * ((int64_t)a.R * a.S * a.C) * a.nz;
-  if (g_forced_variant >= 0 && !(g_forced_variant == 2 && (a.aux_out || a.act == GDL_ACT_MUL_GELU_GRAD)))
+  if (g_forced_variant >= 0 && !(g_forced_variant >= 2 && (a.aux_out || a.act == GDL_ACT_MUL_GELU_GRAD)))
     return g_forced_variant;
   const int64_t t256 = ((M + 255) / 256) * ((a.N + 255) / 256) * a.nz;
   const int64_t t128 = ((M + 127) / 128) * ((a.N + 127) / 128) * a.nz;
@@ -396,7 +541,7 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   // for shallow K (ViT linears, 12 K-steps) the 128^2 tile's shorter prologue/epilogue wins
   // the training-only epilogue (aux_out / GELU-grad) does not fit the 256^2 tile's register budget
   const bool extra = a.aux_out != nullptr || a.act == GDL_ACT_MUL_GELU_GRAD;
-  if (!extra && a.N % 256 == 0 && (t256 >= 512 || (t256 >= 256 && ksteps >= 32))) return 2;
+  if (!extra && a.N % 256 == 0 && (t256 >= 512 || (t256 >= 256 && ksteps >= 32))) return 3;   // ping-pong 256^2
   if (t128 >= 256 && a.N >= 128) return 1;
   return 0;
 }

@@ -35,15 +35,14 @@ static inline size_t gdl_elem_size(int dtype) { return dtype == GDL_BF16 ? 2 : 4
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
 }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
+typedef __attribute__((ext_vector_type(2))) float gdl_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 gdl_bf16x2_t;
+// hardware conversion (v_cvt_pk_bf16_f32 on gfx950): round-to-nearest-even, quiet NaN
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const gdl_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, gdl_bf16x2_t));
 }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct ElemIO;
 template <> struct ElemIO<float> {
@@ -101,6 +100,31 @@ __device__ __forceinline__ void dma16_to_lds(const void* gsrc, void* lds_wave_ba
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_addr)
       : "memory");
+}
+
+// ---- buffer-descriptor DMA (buffer_load_dwordx4 ... offen lds): 32-bit per-lane offsets, hardware range check.
+// Probed on gfx950 (tools/probes/buffer_lds_probe.hip): the LDS destination is M0 + lane*16; a lane is out of
+// range when voffset >= num_records OR voffset + soffset >= num_records, and then ZEROS are written to its slot.
+typedef __attribute__((ext_vector_type(4))) unsigned srd_t;
+
+__device__ __forceinline__ srd_t make_srd(const void* base, unsigned num_bytes) {
+  const unsigned long long p = (unsigned long long)base;
+  srd_t r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)p);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32) & 0xffffu);   // stride 0: raw buffer
+  r.z = __builtin_amdgcn_readfirstlane(num_bytes);
+  r.w = 0x00020000u;                                                     // gfx9-family raw-buffer word 3
+  return r;
+}
+
+// 64 lanes x 16 bytes: lane l fetches base + voffset[l] + soffset into LDS[lds_addr + 16*l]; lds_addr wave-uniform.
+// M0 is only ever used by these DMA helpers in this library (the compiler itself needs it for nothing on gfx9+).
+__device__ __forceinline__ void dma16_buf(unsigned voffset, srd_t srd, unsigned soffset, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :
+               : "v"(voffset), "s"(srd), "s"(__builtin_amdgcn_readfirstlane(soffset)),
+                 "s"(__builtin_amdgcn_readfirstlane(lds_addr))
+               : "memory", "m0");
 }
 
 __device__ __forceinline__ float gelu_erf(float x) {

@@ -142,7 +142,8 @@ class KernelTimer:
     recorded on the stream the kernels are launched on (torch's current stream)."""
 
     VARIANT = {0: "conv_gemm_kernel<{dt},2,2,1,1> (64x64 tiles)", 1: "conv_gemm_kernel<{dt},2,2,2,2> (128x128 tiles)",
-               2: "conv_gemm_kernel<{dt},2,4,4,2> (256x256 tiles)"}
+               2: "conv_gemm_kernel<{dt},2,4,4,2> (256x256 tiles)",
+               3: "conv_gemm_kernel<{dt},2,4,4,2,pingpong> (256x256 tiles, alternating loader halves)"}
 
     def __init__(self) -> None:
         self.records: list = []

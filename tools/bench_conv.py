@@ -50,21 +50,36 @@ CONVS = [  # name, (B,H,W,C), N, R
 def main():
     lib = _lib.load()
     lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
+    lib.gdl_debug_set_conv_korder.argtypes = [ctypes.c_int]
+    lib.gdl_debug_set_conv_dbg.argtypes = [ctypes.c_int]
     print(f"batch {B}")
     for name, shp, n, r in CONVS:
         x = torch.randn(shp, device=DEV).to(bf)
         w = (torch.randn(n, r * r * shp[3], device=DEV) * 0.05).to(bf)
         flops = 2 * shp[0] * shp[1] * shp[2] * n * r * r * shp[3]
-        row = []
-        for v in (1, 2, -1):
-            if v == 2 and n % 256:
+        row, outs = [], {}
+        lib.gdl_debug_set_conv_korder(0)
+        lib.gdl_debug_force_conv_variant(2 if n % 256 == 0 else 1)
+        med0, _ = timeit(lambda: ops.conv_gemm(x, w, R=r, S=r, pad=r // 2))
+        lib.gdl_debug_set_conv_korder(1)
+        lib.gdl_debug_set_conv_dbg(1)
+        med1, _ = timeit(lambda: ops.conv_gemm(x, w, R=r, S=r, pad=r // 2))
+        lib.gdl_debug_set_conv_dbg(2)
+        med2, _ = timeit(lambda: ops.conv_gemm(x, w, R=r, S=r, pad=r // 2))
+        lib.gdl_debug_set_conv_dbg(0)
+        print(f"   {name}: compute-only (no DMA) {flops / med1 / 1e9:7.1f} TF/s-equivalent, load-only (no MFMA) {flops / med2 / 1e9:7.1f}")
+        for v in (1, 2, 3, -1):
+            if v in (2, 3) and n % 256:
                 row.append("   -   ")
                 continue
             lib.gdl_debug_force_conv_variant(v)
             med, mn = timeit(lambda: ops.conv_gemm(x, w, R=r, S=r, pad=r // 2))
+            outs[v] = ops.conv_gemm(x, w, R=r, S=r, pad=r // 2)
             row.append(f"{flops / med / 1e9:7.1f}")
         lib.gdl_debug_force_conv_variant(-1)
-        print(f"conv_gemm {name:14s} GF {flops / 1e9:8.1f}  TF/s v1(128^2) {row[0]}  v2(256^2) {row[1]}  auto {row[2]}")
+        same = "" if 3 not in outs else f"  v3==v2: {torch.equal(outs[2], outs[3])}"
+        print(f"conv_gemm {name:14s} GF {flops / 1e9:8.1f}  TF/s v1(128^2) {row[0]}  v2(256^2) {row[1]}  "
+              f"v3(256^2 ping-pong) {row[2]}  auto {row[3]}{same}  [tap-outer K order: {flops / med0 / 1e9:7.1f}]")
     for name, shp, n, r in CONVS[:6]:
         x = torch.randn(shp, device=DEV).to(bf)
         dy = torch.randn((shp[0], shp[1], shp[2], n), device=DEV).to(bf)

@@ -6,7 +6,12 @@ import torch
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "geo-deep-learning_amd"))
 from gdlhip import ops  # noqa: E402
+import ctypes, os  # noqa: E401,E402
+from gdlhip import _lib  # noqa: E402
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+_l = _lib.load()
+_l.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
+_l.gdl_debug_force_conv_variant(int(os.environ.get("GDL_VARIANT", "-1")))
 B = 8
 x = torch.randn(B, 144, 144, 768, device="cuda").to(torch.bfloat16)
 if which == "fwd":
