@@ -119,12 +119,21 @@ __device__ __forceinline__ srd_t make_srd(const void* base, unsigned num_bytes) 
 
 // 64 lanes x 16 bytes: lane l fetches base + voffset[l] + soffset into LDS[lds_addr + 16*l]; lds_addr wave-uniform.
 // M0 is only ever used by these DMA helpers in this library (the compiler itself needs it for nothing on gfx9+).
+// POL selects the cache policy bits of the load: 0 default, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt
+template <int POL = 0>
 __device__ __forceinline__ void dma16_buf(unsigned voffset, srd_t srd, unsigned soffset, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-               :
-               : "v"(voffset), "s"(srd), "s"(__builtin_amdgcn_readfirstlane(soffset)),
-                 "s"(__builtin_amdgcn_readfirstlane(lds_addr))
-               : "memory", "m0");
+#define GDL_DMA_ASM(MODS)                                                                          \
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen" MODS " lds"   \
+               :                                                                                   \
+               : "v"(voffset), "s"(srd), "s"(__builtin_amdgcn_readfirstlane(soffset)),             \
+                 "s"(__builtin_amdgcn_readfirstlane(lds_addr))                                     \
+               : "memory", "m0")
+  if constexpr (POL == 1) GDL_DMA_ASM(" nt");
+  else if constexpr (POL == 2) GDL_DMA_ASM(" sc1");
+  else if constexpr (POL == 3) GDL_DMA_ASM(" sc0 sc1");
+  else if constexpr (POL == 4) GDL_DMA_ASM(" sc0 sc1 nt");
+  else GDL_DMA_ASM("");
+#undef GDL_DMA_ASM
 }
 
 __device__ __forceinline__ float gelu_erf(float x) {

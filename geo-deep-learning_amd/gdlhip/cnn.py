@@ -29,23 +29,25 @@ def pad_to(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
 
-_FLAT: set = set()   # ids of conv parameters consumed as a flat [N, C*R*S] matrix (patchified image stems)
-
-
 def mark_flat(weight: Tensor) -> None:
-    """The image stem runs as patchify + GEMM: its [N,C,R,S] parameter is used as the [N, (c,r,s)] matrix."""
-    _FLAT.add(id(weight))
+    """The image stem runs as patchify + GEMM: its [N,C,R,S] parameter is used as the [N, (c,r,s)] matrix.
+    The mark lives on the Parameter object itself (ids are recycled after garbage collection)."""
+    weight._gdl_flat = True
+
+
+def _is_flat(weight: Tensor) -> bool:
+    return weight.dim() == 2 or getattr(weight, "_gdl_flat", False)
 
 
 def _wshape(weight: Tensor) -> tuple[int, int, int, int]:
-    if weight.dim() == 2 or id(weight) in _FLAT:
+    if _is_flat(weight):
         return weight.shape[0], weight[0].numel(), 1, 1
     return tuple(weight.shape)
 
 
 def _matrix3(weight: Tensor) -> Tensor:
     """f32 [N, R*S, C] view/copy of a conv parameter ([N,C,R,S]), a 2-D [N,K] matrix or a flat stem (taps = 1)."""
-    if weight.dim() == 2 or id(weight) in _FLAT:
+    if _is_flat(weight):
         return weight.detach().reshape(weight.shape[0], 1, -1)
     n, c, r, s = weight.shape
     return conv_weight_matrix(weight).view(n, r * s, c)
@@ -85,7 +87,7 @@ def _param_grad(dw: Tensor, weight: Tensor, cpad: int) -> Tensor:
     """[Npad, R*S*Cpad] f32 weight gradient -> the parameter's logical shape (real channels only)."""
     n, c, r, s = _wshape(weight)
     d = dw.view(-1, r * s, cpad)[:n, :, :c]
-    if weight.dim() == 2 or id(weight) in _FLAT:
+    if _is_flat(weight):
         return d.reshape(weight.shape)
     return d.reshape(n, r, s, c).permute(0, 3, 1, 2)
 

@@ -7,6 +7,8 @@ reference's ``loss.backward()`` / DDP hooks keep working unchanged.
 
 from __future__ import annotations
 
+import weakref
+
 import torch
 import torch.distributed as dist
 from torch import Tensor, nn
@@ -45,10 +47,12 @@ def cached(params: tuple, kind: str, builder):
     key = (kind, *[id(p) for p in params])
     ver = tuple((p._version, _RAW_WRITES.get(id(p), 0), p.data_ptr()) for p in params)
     hit = _CACHE.get(key)
-    if hit is not None and hit[0] == ver:
+    # ids (and allocator addresses) are recycled once a model is garbage collected: an entry only counts when it
+    # was built from these very tensor objects
+    if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
         return hit[1]
     val = builder()
-    _CACHE[key] = (ver, val)
+    _CACHE[key] = (ver, val, tuple(weakref.ref(p) for p in params))
     return val
 
 

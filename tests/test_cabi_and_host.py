@@ -135,3 +135,20 @@ def test_no_kernel_spills_to_scratch():
             if m and name and any(k in name for k in ("conv_gemm_kernel", "wgrad_tr_kernel", "flash_fwd_kernel")):
                 assert int(m.group(1)) >= 2, f"{name}: occupancy {m.group(1)}"
     assert seen > 100
+
+
+def test_packed_weight_cache_rejects_recycled_ids():
+    """The packed-operand cache is keyed by id(): an entry built from a dead tensor whose id / address were
+    recycled must not be served for the new tensor."""
+    from gdlhip import nn as gnn
+    p1 = torch.nn.Parameter(torch.ones(4))
+    assert gnn.cached((p1,), "t_cache", lambda: "first") == "first"
+    assert gnn.cached((p1,), "t_cache", lambda: "again") == "first"          # same object, same version: hit
+    p2 = torch.nn.Parameter(torch.ones(4))
+    key1, key2 = ("t_cache", id(p1)), ("t_cache", id(p2))
+    ver, val, refs = gnn._CACHE[key1]
+    gnn._CACHE[key2] = ((ver[0][:2] + (p2.data_ptr(),),), val, refs)         # what a recycled id would find
+    assert gnn.cached((p2,), "t_cache", lambda: "second") == "second"
+    with torch.no_grad():
+        p2.add_(1)
+    assert gnn.cached((p2,), "t_cache", lambda: "third") == "third"          # in-place update bumps the version
