@@ -398,6 +398,199 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WArgs k) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 wide-layer kernel: 256 (n) x 256 (c) output tile, 8 waves (2 x 4), wave tile 128 x 64, K-step = 64 pixels.
+// Twice the arithmetic intensity of the 128^2 kernel per staged byte (the 128^2 kernel issues 8 KiB of LDS-DMA per
+// 16 MFMAs and is bound by DMA issue).  Operands arrive through buffer descriptors (32-bit offsets, out-of-range
+// chunk -> hardware zero fill), fragments through ds_read_b64_tr_b16 with double-buffered registers; the K loop is
+// the software-pipelined single-barrier loop of conv_gemm.hip.
+struct W256 {
+  WArgs w;
+  unsigned in_span, dy_span;   // bytes, < 2 GiB
+};
+
+__global__ __launch_bounds__(512) void wgrad_tr256_kernel(const W256 kk) {
+  constexpr int BKP = 64, TM = 4, TN = 2;
+  constexpr int PANEL = 64 * 128;             // one [64 pixels][64 channels] panel
+  constexpr int STAGE_BYTES = 8 * PANEL;      // dy panels 0..3 | x panels 0..3
+  constexpr unsigned kOob = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const WArgs& k = kk.w;
+  const gdl_wgrad_args& a = k.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int n0 = blockIdx.x * 256;
+  const int tap = blockIdx.y / k.ctiles, c0 = (blockIdx.y % k.ctiles) * 256;
+  const int tap_r = tap / a.S, tap_s = tap % a.S;
+  const int zb = blockIdx.z / k.splits;
+  const int split = blockIdx.z - zb * k.splits;
+  const int z0 = zb / a.nz_inner, z1 = zb % a.nz_inner;
+  const srd_t srd_x = make_srd((const unsigned char*)a.in + (z0 * a.in_sZ0 + z1 * a.in_sZ1) * 2, kk.in_span);
+  const srd_t srd_dy = make_srd((const unsigned char*)a.dy + (z0 * a.dy_sZ0 + z1 * a.dy_sZ1) * 2, kk.dy_span);
+  float* dw_p = a.dw + z0 * a.dw_sZ0 + z1 * a.dw_sZ1;
+  const int64_t p_begin = (int64_t)split * k.p_per_split;
+  int64_t p_end = p_begin + k.p_per_split;
+  if (p_end > k.P) p_end = k.P;
+  const int HoWo = a.Ho * a.Wo;
+  const unsigned lds_base =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+
+  // ---- DMA geometry: wave w feeds pixel rows 8w..8w+7 of all eight panels; lane l row (l>>3), slot (l&7)
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const int rr = wave * 8 + lrow;
+  const int chunk = lslot ^ tr_swz(rr);
+  int pb, py, px;   // (batch, oy, ox) of this lane's pixel in the NEXT tile to fetch
+  {
+    const int64_t p = p_begin + rr;
+    pb = (int)(p / HoWo);
+    const int rem = (int)(p - (int64_t)pb * HoWo);
+    py = rem / a.Wo;
+    px = rem - py * a.Wo;
+  }
+  unsigned n_off[4], c_off[4];   // byte offset of this lane's chunk inside a pixel row, or kOob past the N / C tail
+#pragma unroll
+  for (int pn = 0; pn < 4; ++pn) {
+    const int nn = n0 + pn * 64 + chunk * 8, cc = c0 + pn * 64 + chunk * 8;
+    n_off[pn] = nn < a.N ? (unsigned)nn * 2u : kOob;
+    c_off[pn] = cc < a.C ? (unsigned)cc * 2u : kOob;
+  }
+  int64_t pnext = p_begin;   // first pixel of the NEXT tile to fetch
+
+  auto issue = [&](int stage) {
+    const unsigned lds = lds_base + stage * STAGE_BYTES + wave * 1024;
+    const bool pv = pnext + rr < p_end;
+    unsigned dyo, xo;
+    bool xv = pv;
+    if (k.dy_dense) dyo = (unsigned)((pnext + rr) * a.dy_sW * 2);
+    else dyo = (unsigned)((pb * a.dy_sB + py * a.dy_sH + px * a.dy_sW) * 2);
+    if (k.x_dense) {
+      xo = (unsigned)((pnext + rr) * a.in_sW * 2);
+    } else {
+      const int iy = py * a.stride + tap_r - a.pad, ix = px * a.stride + tap_s - a.pad;
+      xv = xv && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      xo = (unsigned)((pb * a.in_sB + iy * a.in_sH + ix * a.in_sW) * 2);
+    }
+#pragma unroll
+    for (int pn = 0; pn < 4; ++pn) {
+      const unsigned vd = (pv && n_off[pn] != kOob) ? dyo + n_off[pn] : kOob;
+      dma16_buf(vd, srd_dy, 0u, lds + pn * PANEL);
+      const unsigned vx = (xv && c_off[pn] != kOob) ? xo + c_off[pn] : kOob;
+      dma16_buf(vx, srd_x, 0u, lds + (4 + pn) * PANEL);
+    }
+    pnext += BKP;
+    if (!(k.dy_dense && k.x_dense)) {
+      px += BKP;
+      while (px >= a.Wo) { px -= a.Wo; ++py; }
+      while (py >= a.Ho) { py -= a.Ho; ++pb; }
+    }
+  };
+
+  // ---- fragment addressing (ds_read_b64_tr_b16; see the 128^2 kernel's header comment)
+  const int g = lane >> 4, s = lane & 15;
+  const int R0 = 8 * (g >> 1) + (s >> 2);
+  int foff[2][2];   // [32-channel tile inside a 64-channel panel][read t]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 4 * t + R0;
+      const int channel = i * 32 + 16 * (g & 1) + 4 * (s & 3);
+      foff[i][t] = row * 128 + (((channel >> 3) ^ tr_swz(row)) << 4) + (channel & 7) * 2;
+    }
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  bf16x8_t fa[2][TM], fb[2][TN];
+  auto fetch = [&](const unsigned char* st, int kq, int buf) {
+    const unsigned char* pa = st + (wm * 2) * PANEL + kq * 2048;   // this wave's 128 n = dy panels 2wm, 2wm+1
+    const unsigned char* px_ = st + (4 + wn) * PANEL + kq * 2048;  // its 64 c = x panel wn
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const unsigned char* q = pa + (i >> 1) * PANEL;
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q + foff[i & 1][0]));
+      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q + foff[i & 1][1]));
+      const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      fa[buf][i] = __builtin_bit_cast(bf16x8_t, v);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(px_ + foff[j][0]));
+      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(px_ + foff[j][1]));
+      const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      fb[buf][j] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  };
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto mfmas = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);
+  };
+
+  const int KT = (int)((p_end - p_begin + BKP - 1) / BKP);
+  if (KT > 0) {
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (KT > 1) issue(1);
+    fetch(smem, 0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+      const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+      for (int kq = 0; kq < 3; ++kq) {
+        fetch(st, kq + 1, (kq + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(kq & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kt + 1 < KT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 2 < KT) issue(kt & 1);
+        fetch(smem + ((kt + 1) & 1) * STAGE_BYTES, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: rows = n (registers), cols = c (lane): 128-byte coalesced f32 rows
+  const int frow = lane & 31, fhalf = lane >> 5;
+  float* dst;
+  int64_t ld;
+  if (k.splits > 1) {
+    ld = (int64_t)a.R * a.S * a.C;
+    dst = a.workspace + ((int64_t)zb * k.splits + split) * a.N * ld;
+  } else {
+    ld = a.dw_sN;
+    dst = dw_p;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int c = c0 + (wn * TN + j) * 32 + frow;
+        if (c >= a.C) continue;
+        float* q = dst + (int64_t)n * ld + (int64_t)tap * a.C + c;
+        const float v = acc[i][j][r];
+        *q = (k.splits == 1 && a.accumulate) ? *q + v : v;
+      }
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int N,
                                                            int64_t K, float* dw, int64_t dw_sN, int accumulate,
                                                            int nz_inner, int64_t dw_sZ0, int64_t dw_sZ1) {
@@ -414,9 +607,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+int64_t span_bytes(int B, int H, int W, int C, int64_t sB, int64_t sH, int64_t sW, int es) {
+  return (((int64_t)B - 1) * sB + ((int64_t)H - 1) * sH + ((int64_t)W - 1) * sW + C) * es;
+}
+
+int g_wgrad_force_small = 0;   // A/B hook: 1 = never use the 256^2 kernel
+
+// 256^2 tiles for wide bf16 layers whose operands fit 32-bit buffer offsets
+int wgrad_tile(const gdl_wgrad_args& a) {
+  if (a.dtype != GDL_BF16 || g_wgrad_force_small || a.N < 256 || a.C < 256) return 128;
+  if (span_bytes(a.B, a.H, a.W, a.C, a.in_sB, a.in_sH, a.in_sW, 2) > 0x7ffffff0ll ||
+      span_bytes(a.B, a.Ho, a.Wo, a.N, a.dy_sB, a.dy_sH, a.dy_sW, 2) > 0x7ffffff0ll)
+    return 128;
+  return 256;
+}
+
 int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
-  const int64_t tiles = (int64_t)((a.N + 127) / 128) * a.R * a.S * ((a.C + 127) / 128) * (a.nz > 1 ? a.nz : 1);
-  int64_t want = (1024 + tiles - 1) / tiles;           // aim for ~1024 blocks
+  const int t = wgrad_tile(a);
+  const int64_t tiles = (int64_t)((a.N + t - 1) / t) * a.R * a.S * ((a.C + t - 1) / t) * (a.nz > 1 ? a.nz : 1);
+  int64_t want = ((t == 256 ? 512 : 1024) + tiles - 1) / tiles;   // aim for ~1024 (512 big-tile) blocks
   const int64_t max_by_k = P / (8 * bkp);              // keep >= 8 K-steps per split
   if (want > max_by_k) want = max_by_k;
   if (want > 64) want = 64;
@@ -427,6 +636,7 @@ int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
 }  // namespace
 
 static int g_wgrad_force_v1 = 0;
+extern "C" void gdl_debug_force_wgrad_small(int on) { g_wgrad_force_small = on; }  // A/B hook: 128^2 tiles only
 extern "C" void gdl_debug_force_wgrad_v1(int on) { g_wgrad_force_v1 = on; }  // A/B hook: register-transpose kernel
 
 extern "C" int64_t gdl_conv_wgrad_workspace(const gdl_wgrad_args* ap) {
@@ -472,7 +682,20 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
   GDL_CHECK_ARG((int64_t)a.nz * k.splits <= 65535, "gdl_conv_wgrad: nz * splits too large");
   dim3 grid((a.N + 127) / 128, a.R * a.S * k.ctiles, a.nz * k.splits);
   const size_t lds = 2 * (128 + 128) * 128;
-  if (a.dtype == GDL_BF16 && !g_wgrad_force_v1) hipLaunchKernelGGL(wgrad_tr_kernel, grid, dim3(256), lds, s, k);
+  if (wgrad_tile(a) == 256 && !g_wgrad_force_v1) {
+    W256 kb;
+    kb.w = k;
+    kb.w.ctiles = (a.C + 255) / 256;
+    kb.in_span = (unsigned)span_bytes(a.B, a.H, a.W, a.C, a.in_sB, a.in_sH, a.in_sW, 2);
+    kb.dy_span = (unsigned)span_bytes(a.B, a.Ho, a.Wo, a.N, a.dy_sB, a.dy_sH, a.dy_sW, 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)wgrad_tr256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr_set = true;
+    }
+    dim3 gridb((a.N + 255) / 256, a.R * a.S * kb.w.ctiles, a.nz * k.splits);
+    hipLaunchKernelGGL(wgrad_tr256_kernel, gridb, dim3(512), 128 * 1024, s, kb);
+  } else if (a.dtype == GDL_BF16 && !g_wgrad_force_v1) hipLaunchKernelGGL(wgrad_tr_kernel, grid, dim3(256), lds, s, k);
   else if (a.dtype == GDL_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_tag>, grid, dim3(256), lds, s, k);
   else hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), lds, s, k);
   if (k.splits > 1) {

@@ -233,7 +233,8 @@ def test_adaptive_avgpool(dtype, hi, s):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,C,N,R", [(2, 12, 12, 64, 64, 3), (2, 9, 11, 128, 256, 3), (4, 8, 8, 256, 128, 1),
-                                         (2, 1, 1, 128, 256, 1), (1, 40, 40, 64, 64, 3)])
+                                         (2, 1, 1, 128, 256, 1), (1, 40, 40, 64, 64, 3),
+                                         (2, 13, 11, 256, 512, 3), (3, 9, 9, 264, 320, 1), (1, 33, 35, 512, 256, 3)])
 def test_conv_backward(dtype, B, H, W, C, N, R):
     x = q(rnd(B, C, H, W), dtype).requires_grad_(True)
     w = q(rnd(N, C, R, R, seed=1) * 0.1, dtype).requires_grad_(True)
@@ -249,17 +250,18 @@ def test_conv_backward(dtype, B, H, W, C, N, R):
     close(dx.permute(0, 3, 1, 2), x.grad, dtype, "dgrad")
 
 
-def test_wgrad_strided_dy():
-    """dy as a channel slice of a wider gradient buffer (concat backward)."""
-    B, H, W, C, N = 2, 10, 10, 64, 64
-    x = rnd(B, H, W, C).to(DEV)
-    big = rnd(B, H, W, 3 * N, seed=1).to(DEV)
-    dy = big[..., N:2 * N]
-    dw = ops.conv_wgrad(x, dy, R=3, S=3, pad=1)
-    xr = x.cpu().permute(0, 3, 1, 2)
+@pytest.mark.parametrize("dtype,C,N", [(torch.float32, 64, 64), (torch.bfloat16, 256, 256)])
+def test_wgrad_strided_dy(dtype, C, N):
+    """dy as a channel slice of a wider gradient buffer (concat backward); the bf16 case runs the 256^2 kernel."""
+    B, H, W = 2, 10, 10
+    x = q(rnd(B, H, W, C), dtype)
+    big = q(rnd(B, H, W, 3 * N, seed=1), dtype)
+    dy = big.to(DEV, dtype)[..., N:2 * N]
+    dw = ops.conv_wgrad(x.to(DEV, dtype), dy, R=3, S=3, pad=1)
+    xr = x.permute(0, 3, 1, 2)
     w = torch.zeros(N, C, 3, 3, requires_grad=True)
-    F.conv2d(xr, w, padding=1).backward(dy.cpu().permute(0, 3, 1, 2))
-    close(dw.view(N, 3, 3, C).permute(0, 3, 1, 2), w.grad, torch.float32, "wgrad strided dy")
+    F.conv2d(xr, w, padding=1).backward(big[..., N:2 * N].permute(0, 3, 1, 2))
+    close(dw.view(N, 3, 3, C).permute(0, 3, 1, 2), w.grad, dtype, "wgrad strided dy")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -51,6 +51,7 @@ def main():
     lib = _lib.load()
     lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
     lib.gdl_debug_set_conv_korder.argtypes = [ctypes.c_int]
+    lib.gdl_debug_force_wgrad_small.argtypes = [ctypes.c_int]
     lib.gdl_debug_set_conv_dbg.argtypes = [ctypes.c_int]
     print(f"batch {B}")
     for name, shp, n, r in CONVS:
@@ -84,8 +85,15 @@ def main():
         x = torch.randn(shp, device=DEV).to(bf)
         dy = torch.randn((shp[0], shp[1], shp[2], n), device=DEV).to(bf)
         flops = 2 * shp[0] * shp[1] * shp[2] * n * r * r * shp[3]
+        lib.gdl_debug_force_wgrad_small(1)
+        med_s, _ = timeit(lambda: ops.conv_wgrad(x, dy, R=r, S=r, pad=r // 2), rounds=3, inner=2)
+        ref = ops.conv_wgrad(x, dy, R=r, S=r, pad=r // 2)
+        lib.gdl_debug_force_wgrad_small(0)
         med, mn = timeit(lambda: ops.conv_wgrad(x, dy, R=r, S=r, pad=r // 2), rounds=3, inner=2)
-        print(f"wgrad     {name:14s} GF {flops / 1e9:8.1f}  TF/s {flops / med / 1e9:7.1f}  ({med * 1e3:.0f} us)")
+        got = ops.conv_wgrad(x, dy, R=r, S=r, pad=r // 2)
+        err = ((got - ref).abs().max() / ref.abs().max()).item()
+        print(f"wgrad     {name:14s} GF {flops / 1e9:8.1f}  TF/s {flops / med / 1e9:7.1f}  ({med * 1e3:.0f} us)  "
+              f"[128^2 kernel only: {flops / med_s / 1e9:7.1f}; max rel diff {err:.1e}]")
     qkv = torch.randn(B, 1297, 2304, device=DEV).to(bf)
     flops = 4 * 1297 * 1297 * 768 * B
     med, mn = timeit(lambda: ops.attention_flash(*ops.split_qkv(qkv), 12))
