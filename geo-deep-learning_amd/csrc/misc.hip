@@ -103,6 +103,16 @@ __global__ __launch_bounds__(256) void dofa_pack_kernel(const float* __restrict_
   }
 }
 
+// backward of the pack: dG[kk][d] = scaler * dW[d][kk] for kk < C*P*P (f32)
+__global__ __launch_bounds__(256) void dofa_unpack_grad_kernel(const float* __restrict__ dw, int CPP, int D, float scaler,
+                                                               int Kpad, float* __restrict__ dg) {
+  const int64_t total = (int64_t)CPP * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int d = (int)(i % D), kk = (int)(i / D);
+    dg[i] = dw[(int64_t)d * Kpad + kk] * scaler;
+  }
+}
+
 // ------------------------------------------------------------------ elementwise
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void cast_kernel(const void* __restrict__ in, void* out, int64_t n) {
@@ -152,6 +162,30 @@ __global__ __launch_bounds__(256) void normalize_raw_kernel(const TI* __restrict
     const int c = (int)((i / HW) % C);
     out[i] = ((float)in[i] / 255.0f - mean[c]) / stdv[c];
   }
+}
+
+// ------------------------------------------------------------------ IoU counts (torchmetrics MeanIoU update)
+// per sample b and class k: intersection |pred==k & target==k|, |pred==k|, |target==k| as exact 64-bit counts.
+// LDS histogram per block, integer atomics only (deterministic).
+__global__ __launch_bounds__(256) void iou_counts_kernel(const int64_t* __restrict__ pred,
+                                                         const int64_t* __restrict__ target, int64_t P, int K,
+                                                         unsigned long long* __restrict__ counts) {
+  __shared__ unsigned h[3 * 64];
+  for (int i = threadIdx.x; i < 3 * K; i += 256) h[i] = 0;
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int64_t per = (P + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = per * blockIdx.x, p1 = p0 + per < P ? p0 + per : P;
+  for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
+    const int64_t a = pred[(int64_t)b * P + p], t = target[(int64_t)b * P + p];
+    const bool av = a >= 0 && a < K, tv = t >= 0 && t < K;
+    if (av) atomicAdd(&h[K + (int)a], 1u);
+    if (tv) atomicAdd(&h[2 * K + (int)t], 1u);
+    if (av && a == t) atomicAdd(&h[(int)a], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * K; i += 256)
+    if (h[i]) atomicAdd(&counts[((int64_t)b * 3 + i / K) * K + i % K], (unsigned long long)h[i]);
 }
 
 // ------------------------------------------------------------------ classifier tail
@@ -408,6 +442,28 @@ __global__ __launch_bounds__(256) void softmax_argmax_kernel(const float* __rest
 #pragma unroll
     for (int k = 1; k < K; ++k) { const float v = x[k] / s; if (v > bv) { bv = v; best = k; } }
     mask[i] = best;
+  }
+}
+
+// class probabilities of the exported inference model: softmax over the class dim (K > 1) or sigmoid (K == 1)
+template <int K>
+__global__ __launch_bounds__(256) void class_probs_kernel(const float* __restrict__ logits, int B, int64_t HW,
+                                                          float* __restrict__ probs) {
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / HW, p = i - b * HW;
+    if constexpr (K == 1) {
+      probs[i] = 1.0f / (1.0f + expf(-logits[i]));
+    } else {
+      float x[K], mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < K; ++k) { x[k] = logits[(b * K + k) * HW + p]; mx = fmaxf(mx, x[k]); }
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) { x[k] = expf(x[k] - mx); s += x[k]; }
+#pragma unroll
+      for (int k = 0; k < K; ++k) probs[(b * K + k) * HW + p] = x[k] / s;
+    }
   }
 }
 
@@ -693,6 +749,15 @@ extern "C" int gdl_dofa_pack_kernel(const float* g, int C, int PP, int D, float 
   return GDL_OK;
 }
 
+extern "C" int gdl_dofa_unpack_grad(const float* dw, int C, int PP, int D, float scaler, int Kpad, float* dg,
+                                    gdl_stream_t stream) {
+  GDL_CHECK_ARG(dw && dg && Kpad >= C * PP, "gdl_dofa_unpack_grad: bad args");
+  const int64_t total = (int64_t)C * PP * D;
+  hipLaunchKernelGGL(dofa_unpack_grad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dw, C * PP, D, scaler, Kpad, dg);
+  GDL_CHECK_LAUNCH("gdl_dofa_unpack_grad");
+  return GDL_OK;
+}
+
 extern "C" int gdl_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, gdl_stream_t stream) {
   GDL_CHECK_ARG(in && out, "gdl_cast: null pointer");
   if (n <= 0) return GDL_OK;
@@ -848,6 +913,14 @@ extern "C" int gdl_softmax_argmax(const float* logits, int B, int K, int64_t HW,
   return GDL_OK;
 }
 
+extern "C" int gdl_class_probs(const float* logits, int B, int K, int64_t HW, float* probs, gdl_stream_t stream) {
+  GDL_CHECK_ARG(logits && probs, "gdl_class_probs: null pointer");
+  const int64_t total = (int64_t)B * HW;
+  K_SWITCH(K, hipLaunchKernelGGL((class_probs_kernel<KK>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, logits, B, HW, probs));
+  GDL_CHECK_LAUNCH("gdl_class_probs");
+  return GDL_OK;
+}
+
 static int dice_blocks(int64_t total) {
   int64_t g = (total + 2047) / 2048;
   return (int)(g < 1 ? 1 : (g > 512 ? 512 : g));
@@ -903,5 +976,20 @@ extern "C" int gdl_adam_step(float* p, const float* g, float* m, float* v, int64
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                      eps, weight_decay, bc1, bc2, clip_coef);
   GDL_CHECK_LAUNCH("gdl_adam_step");
+  return GDL_OK;
+}
+
+extern "C" int gdl_iou_counts(const int64_t* pred, const int64_t* target, int B, int64_t P, int K, int64_t* counts,
+                              gdl_stream_t stream) {
+  GDL_CHECK_ARG(pred && target && counts && B > 0 && P > 0, "gdl_iou_counts: bad args");
+  GDL_CHECK_ARG(K > 0 && K <= 64, "gdl_iou_counts: 1..64 classes");
+  GDL_CHECK_ARG(P / 64 < (1ll << 32), "gdl_iou_counts: sample too large");
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(counts, 0, (size_t)B * 3 * K * sizeof(int64_t), s);
+  int64_t chunks = (P + 65535) / 65536;
+  if (chunks > 1024) chunks = 1024;
+  hipLaunchKernelGGL(iou_counts_kernel, dim3((unsigned)chunks, B), dim3(256), 0, s, pred, target, P, K,
+                     (unsigned long long*)counts);
+  GDL_CHECK_LAUNCH("gdl_iou_counts");
   return GDL_OK;
 }

@@ -99,6 +99,7 @@ SIGNATURES = {
     "gdl_patchify": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "gdl_dwconv3x3": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "gdl_dofa_pack_kernel": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p]),
+    "gdl_dofa_unpack_grad": (c_i, [c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_p]),
     "gdl_sincos_embed": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
     "gdl_bn_fold": (c_i, [c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),
     "gdl_pack_dgrad": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
@@ -116,6 +117,8 @@ SIGNATURES = {
     "gdl_upsample_logits_bwd_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "gdl_upsample_logits_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_l, c_p]),
     "gdl_softmax_argmax": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p]),
+    "gdl_class_probs": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p]),
+    "gdl_iou_counts": (c_i, [c_p, c_p, c_i, c_l, c_i, c_p, c_p]),
     "gdl_dice_loss_workspace": (c_l, [c_i, c_i, c_l]),
     "gdl_dice_loss_fwd": (c_i, [c_p, c_p, c_i, c_i, c_l, c_f, c_p, c_p, c_p, c_l, c_p]),
     "gdl_dice_loss_bwd": (c_i, [c_p, c_p, c_i, c_i, c_l, c_f, c_p, c_p, c_f, c_p, c_i, c_p]),

@@ -761,6 +761,16 @@ def dofa_pack_kernel(g: Tensor, Cc: int, PP: int, D: int, scaler: float, kpad: i
 _OMEGA: dict = {}
 
 
+def dofa_unpack_grad(dw: Tensor, Cc: int, PP: int, D: int, scaler: float) -> Tensor:
+    """f32 [D, Kpad] gradient of the packed patch-embed weight -> [C, PP*D] gradient of the generated kernel."""
+    if dw.dtype != torch.float32 or not dw.is_contiguous() or dw.shape[0] != D:
+        raise ValueError("dofa_unpack_grad: contiguous f32 [D, Kpad] expected")
+    dg = torch.empty((Cc, PP * D), device=dw.device, dtype=torch.float32)
+    check(_lib.load().gdl_dofa_unpack_grad(_p(dw), Cc, PP, D, scaler, dw.shape[1], _p(dg), _stream()),
+          "gdl_dofa_unpack_grad")
+    return dg
+
+
 def sincos_embed(pos: Tensor, D: int) -> Tensor:
     """position_embedding(D, pos) (dofa_v2.py:9-35); the frequency table is a host constant."""
     _need_cuda(pos)
@@ -927,6 +937,30 @@ def softmax_argmax(logits: Tensor) -> Tensor:
     check(_lib.load().gdl_softmax_argmax(_p(logits), B, K, H * W, _p(mask), _stream()),
           "gdl_softmax_argmax")
     return mask
+
+
+def class_probs(logits: Tensor) -> Tensor:
+    """NCHW f32 logits -> softmax(dim=1) (or sigmoid for one class) probabilities."""
+    _need_cuda(logits)
+    if logits.dtype != torch.float32 or not logits.is_contiguous() or logits.dim() != 4:
+        raise ValueError("class_probs: contiguous f32 NCHW logits expected")
+    B, K, H, W = logits.shape
+    out = torch.empty_like(logits)
+    check(_lib.load().gdl_class_probs(_p(logits), B, K, H * W, _p(out), _stream()), "gdl_class_probs")
+    return out
+
+
+def iou_counts(pred: Tensor, target: Tensor, num_classes: int) -> Tensor:
+    """int64 [B, 3, K]: per sample and class (intersection, |pred==k|, |target==k|); exact integer counts."""
+    _need_cuda(pred, target)
+    if pred.dtype != torch.int64 or target.dtype != torch.int64 or pred.shape != target.shape:
+        raise ValueError("iou_counts: int64 index tensors of one shape expected")
+    B = pred.shape[0]
+    p2, t2 = pred.reshape(B, -1).contiguous(), target.reshape(B, -1).contiguous()
+    counts = torch.empty((B, 3, num_classes), device=pred.device, dtype=torch.int64)
+    check(_lib.load().gdl_iou_counts(_p(p2), _p(t2), B, p2.shape[1], num_classes, _p(counts), _stream()),
+          "gdl_iou_counts")
+    return counts
 
 
 def dice_loss_fwd(logits: Tensor, target: Tensor, eps: float = 1e-7):

@@ -362,7 +362,8 @@ class _DofaTokens(Function):
         d = wq.shape[0]
         tok = torch.empty((b, n + 1, d), device=cols.device, dtype=torch.float32)
         ops.add_rows(cls_token.detach().view(1, d), None, tok[:, 0, :], b)
-        ops.conv_gemm(cols.view(b, 1, n, kp), wq.detach(), bias=bias.detach(),
+        wq_c = wq.detach() if wq.dtype == cols.dtype else ops.cast(wq.detach().contiguous(), cols.dtype)
+        ops.conv_gemm(cols.view(b, 1, n, kp), wq_c, bias=bias.detach(),
                       resid=pos_embed.detach()[0, 1:, :].view(1, 1, n, d), out=tok[:, 1:, :].unsqueeze(1))
         ctx.save_for_backward(cols)
         return tok
@@ -401,3 +402,101 @@ class _Tap(Function):
 
 def tap(tok: Tensor, hw: int, cd: torch.dtype) -> Tensor:
     return _Tap.apply(tok, hw, cd)
+
+
+# ------------------------------------------------------------------ DOFA dynamic weight generator
+class _DofaGenerator(Function):
+    """Wavelengths -> patch-embed GEMM operand, as ONE autograd node (dofa_v2.py:38-181: sincos embedding -> FCRes ->
+    [weight tokens ; wave tokens ; bias token] -> one post-norm nn.TransformerEncoderLayer (4 heads, gelu, ffn 2048)
+    -> fc_weight / fc_bias -> pack * 0.01).  Everything is tiny (132 tokens x 128) and runs in exact f32.
+
+    inputs: pos_embed E [C,128] (no grad), then the 22 parameters
+      0 fc.w1.w 1 fc.w1.b 2 fc.w2.w 3 fc.w2.b 4 weight_tokens 5 bias_token 6 in_proj_w 7 in_proj_b 8 out_proj.w
+      9 out_proj.b 10 linear1.w 11 linear1.b 12 linear2.w 13 linear2.b 14 norm1.w 15 norm1.b 16 norm2.w 17 norm2.b
+      18 fc_weight.w 19 fc_weight.b 20 fc_bias.w 21 fc_bias.b
+    outputs: wq f32 [D, Kpad] (k = c*P*P + p, times scaler), bias f32 [D] (times scaler)."""
+
+    @staticmethod
+    def forward(ctx, emb, heads, kk, embed_dim, scaler, kpad, eps1, eps2, *prm):
+        f32 = torch.float32
+        p = [t.detach() for t in prm]
+        c, d = emb.shape
+        wt = p[4].shape[0]
+        s = wt + c + 1
+
+        def w(i):
+            return gemm_weight(prm[i], f32)
+        y1 = ops.linear(emb, w(0), p[1], act=ops.ACT_RELU)
+        r2 = ops.linear(y1, w(2), p[3], act=ops.ACT_RELU)
+        waves = torch.empty_like(emb)
+        ops.add_rows(r2, emb, waves, c)
+        seq = torch.empty((s, d), device=emb.device, dtype=f32)
+        ops.add_rows(p[4], None, seq[:wt], wt)
+        ops.add_rows(waves, None, seq[wt:wt + c], c)
+        ops.add_rows(p[5], None, seq[s - 1:], 1)
+        qkv = ops.linear(seq, w(6), p[7])
+        att = ops.attention_unfused(*ops.split_qkv(qkv.unsqueeze(0)), heads)[0]
+        h = ops.linear(att, w(8), p[9], resid=seq)
+        x1 = ops.layernorm(h, p[14], p[15], eps1, f32)
+        u = torch.empty((s, prm[10].shape[0]), device=emb.device, dtype=f32)
+        f = ops.linear(x1, w(10), p[11], act=ACT_GELU, aux_out=u)
+        h2 = ops.linear(f, w(12), p[13], resid=x1)
+        out = ops.layernorm(h2, p[16], p[17], eps2, f32)
+        tok = torch.empty((c, d), device=emb.device, dtype=f32)
+        ops.add_rows(out[wt:wt + c], waves, tok, c)
+        weights = ops.linear(tok, w(18), p[19])
+        last = out[s - 1:]
+        bias = ops.linear(last, w(20), p[21]).reshape(-1)
+        wq = ops.dofa_pack_kernel(weights, c, kk, embed_dim, scaler, kpad, f32)
+        ctx.save_for_backward(emb, y1, r2, seq, qkv, att, h, x1, u, f, h2, out, tok, *prm)
+        ctx.cfg = (heads, kk, embed_dim, scaler, eps1, eps2, c, wt)
+        return wq, ops.scale_f32(bias, scaler)
+
+    @staticmethod
+    def backward(ctx, dwq, dbias):
+        emb, y1, r2, seq, qkv, att, h, x1, u, f, h2, out, tok, *prm = ctx.saved_tensors
+        heads, kk, embed_dim, scaler, eps1, eps2, c, wt = ctx.cfg
+        f32 = torch.float32
+        s, d = seq.shape
+        g = [None] * 22
+        dweights = ops.dofa_unpack_grad(dwq.float().contiguous(), c, kk, embed_dim, scaler)      # [C, kk*D]
+        dbias_raw = ops.scale_f32(dbias.float().contiguous(), scaler).view(1, -1)
+        g[18], g[19] = linear_dw(tok, dweights)
+        dtok = linear_dx(dweights, prm[18])                                                      # [C, d]
+        last = out[s - 1:]
+        g[20], g[21] = linear_dw(last, dbias_raw)
+        dlast = linear_dx(dbias_raw, prm[20])
+        dout = torch.zeros((s, d), device=seq.device, dtype=f32)
+        ops.add_rows(dtok, None, dout[wt:wt + c], c)
+        ops.add_rows(dlast, None, dout[s - 1:], 1)
+        # post-norm layer, second half: out = LN2(h2), h2 = f W2^T + b2 + x1, f = gelu(u), u = x1 W1^T + b1
+        dh2, g[16], g[17] = ops.layernorm_bwd(h2, dout, prm[16].detach(), eps2)
+        g[12], g[13] = linear_dw(f, dh2)
+        du = linear_dx(dh2, prm[12], resid=u, act=ACT_MUL_GELU_GRAD)
+        g[10], g[11] = linear_dw(x1, du)
+        dx1 = linear_dx(du, prm[10], resid=dh2)
+        # first half: x1 = LN1(h), h = att Wo^T + bo + seq
+        dh, g[14], g[15] = ops.layernorm_bwd(h, dx1, prm[14].detach(), eps1)
+        g[8], g[9] = linear_dw(att, dh)
+        datt = linear_dx(dh, prm[8])
+        dqkv = torch.empty_like(qkv)
+        q3, k3, v3 = ops.split_qkv(qkv.unsqueeze(0))
+        dq3, dk3, dv3 = ops.split_qkv(dqkv.unsqueeze(0))
+        ops.attention_bwd(q3, k3, v3, datt.unsqueeze(0), heads, dq3, dk3, dv3)
+        g[6], g[7] = linear_dw(seq, dqkv)
+        dseq = linear_dx(dqkv, prm[6], resid=dh)
+        g[4] = dseq[:wt].contiguous()
+        g[5] = dseq[s - 1:].contiguous()
+        dwaves = torch.empty((c, d), device=seq.device, dtype=f32)
+        ops.add_rows(dseq[wt:wt + c], dtok, dwaves, c)                 # tok = out[...] + waves  and  seq rows = waves
+        # FCRes: waves = relu(y1 W2^T + b2) + E, y1 = relu(E W1^T + b1)
+        dz2 = ops.relu_bwd(r2, dwaves)
+        g[2], g[3] = linear_dw(y1, dz2)
+        dz1 = ops.relu_bwd(y1, linear_dx(dz2, prm[2]))
+        g[0], g[1] = linear_dw(emb, dz1)
+        return (None,) * 8 + tuple(g)
+
+
+def dofa_generator(emb: Tensor, heads: int, kk: int, embed_dim: int, scaler: float, kpad: int, eps1: float,
+                   eps2: float, params: tuple) -> tuple[Tensor, Tensor]:
+    return _DofaGenerator.apply(emb, heads, kk, embed_dim, scaler, kpad, eps1, eps2, *params)

@@ -405,13 +405,30 @@ class DOFAv2(nn.Module):
         # depends only on the wavelengths + the generator weights: regenerated when those change
         return gnn.cached(params, f"dofa_dyn:{key}:{cd}", build)
 
+    def _trainable_operands(self, wavelengths: Tensor, cd: torch.dtype) -> tuple[Tensor, Tensor]:
+        """(f32 [D, Kpad] patch-embed weight, f32 [D] bias) with gradients into every generator parameter."""
+        host, _ = self._check_wavelengths(wavelengths)
+        pe = self.patch_embed
+        gen = pe.weight_generator
+        if len(gen.transformer_encoder.layers) != 1:
+            msg = "gdlhip DOFAv2: the generator backward is built for num_layers=1 (the reference's value)"
+            raise NotImplementedError(msg)
+        layer = gen.transformer_encoder.layers[0]
+        sa = layer.self_attn
+        dev = pe.fclayer.w1.weight.device
+        pos = (host * 1000).to(dev)
+        emb = position_embedding(pe.dynamic_embed_dim, pos)
+        prm = (pe.fclayer.w1.weight, pe.fclayer.w1.bias, pe.fclayer.w2.weight, pe.fclayer.w2.bias, gen.weight_tokens,
+               gen.bias_token, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+               layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm1.weight,
+               layer.norm1.bias, layer.norm2.weight, layer.norm2.bias, gen.fc_weight.weight, gen.fc_weight.bias,
+               gen.fc_bias.weight, gen.fc_bias.bias)
+        kpad = pe.k_padded(host.numel(), pe.kernel_size, cd)
+        return tnn.dofa_generator(emb, sa.num_heads, pe.kernel_size * pe.kernel_size, pe.embed_dim, pe.scaler, kpad,
+                                  layer.norm1.eps, layer.norm2.eps, prm)
+
     def _tokens(self, x: Tensor, wavelengths: Tensor, drop_masks):
         """Generator of (block index, f32 token stream [B, 1+n, D]) after every block."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.patch_embed.parameters()):
-            msg = ("gdlhip DOFAv2: the backward of the dynamic weight generator (patch_embed.*) is not built -- "
-                   "freeze it (freeze_layers=['encoder.patch_embed'] or the reference default ['encoder']); the "
-                   "ViT blocks and cls_token train with HIP kernels")
-            raise NotImplementedError(msg)
         cd = gnn.compute_dtype()
         b, c, h, w_ = x.shape
         k = self.patch_size
@@ -420,7 +437,10 @@ class DOFAv2(nn.Module):
         if n + 1 != self.pos_embed.shape[1]:
             msg = f"image {h}x{w_} gives {n} patches but pos_embed has {self.pos_embed.shape[1] - 1}"
             raise ValueError(msg)
-        wq, bias = self._dynamic_operands(wavelengths, x.device, cd)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.patch_embed.parameters()):
+            wq, bias = self._trainable_operands(wavelengths, cd)       # one autograd node (gdlhip.tnn._DofaGenerator)
+        else:
+            wq, bias = self._dynamic_operands(wavelengths, x.device, cd)
         cols = ops.patchify(x.float().contiguous(), k, 1, gh, gw, wq.shape[1], cd)
         # cls token rows (no pos-embed: dofa_v2.py:447-452), then patch GEMM + bias + pos_embed[1:]
         tok = tnn.dofa_tokens(cols.view(b, n, -1), wq, bias, self.cls_token, self.pos_embed)

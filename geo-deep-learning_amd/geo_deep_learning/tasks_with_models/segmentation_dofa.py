@@ -24,6 +24,7 @@ from torch import Tensor
 from geo_deep_learning.models.segmentation.dofa import DOFASegmentationModel
 from geo_deep_learning.utils.models import load_weights_from_checkpoint
 from gdlhip import nn as gnn
+from gdlhip.metrics import ClasswiseWrapper, MeanIoU
 
 try:  # pragma: no cover - lightning is absent in the build image
     from lightning.pytorch import LightningModule
@@ -98,6 +99,8 @@ class SegmentationDOFA(LightningModule):
         n = num_classes + 1 if num_classes == 1 else num_classes
         self.labels = [str(i) for i in range(n)] if class_labels is None else class_labels
         self._iou_classes = n
+        self.iou_metric = MeanIoU(num_classes=n, per_class=True, input_format="index", include_background=True)
+        self.iou_classwise_metric = ClasswiseWrapper(self.iou_metric, labels=self.labels)
         self.train_samples_count = 0
         self.val_samples_count = 0
         self.test_samples_count = 0
@@ -175,12 +178,8 @@ class SegmentationDOFA(LightningModule):
         outputs, y, loss, bs = self._loss(batch)
         self.test_samples_count += bs
         y_hat = self._predict(outputs)
-        n = self._iou_classes
-        conf = torch.bincount((y * n + y_hat).flatten(), minlength=n * n).view(n, n).double()
-        inter = conf.diag()
-        union = conf.sum(0) + conf.sum(1) - inter
-        iou = torch.where(union > 0, inter / union.clamp_min(1), torch.zeros_like(inter))
-        metrics = {f"multiclassjaccardindex_{self.labels[i]}": iou[i].float() for i in range(n)}
+        metrics = self.iou_classwise_metric(y_hat, y)      # per-class IoU from the integer count kernel
+        self.iou_classwise_metric.reset()
         metrics["test_loss"] = loss
         self.log_dict(metrics, batch_size=bs, prog_bar=False, logger=True, on_step=False, sync_dist=True,
                       rank_zero_only=True)

@@ -179,6 +179,12 @@ int gdl_dwconv3x3_gelu_bwd(const void* u, const void* dy, int dtype, int B, int 
 int gdl_col2im(const void* cols, int dtype, int B, int Ho, int Wo, int R, int S, int C, int stride, int pad, int H,
                int W, void* dx, int dx_dtype, int64_t dx_sB, int64_t dx_sH, int64_t dx_sW, gdl_stream_t stream);
 
+/* torchmetrics.segmentation.MeanIoU(input_format="index") update (segmentation_dofa.py:71-76,313): for each sample
+ * and class the exact counts counts[b][0][k] = |pred==k & target==k|, [b][1][k] = |pred==k|, [b][2][k] = |target==k|
+ * (int64, zeroed by the call); pred / target are [B][P] class indices, values outside 0..K-1 are ignored. */
+int gdl_iou_counts(const int64_t* pred, const int64_t* target, int B, int64_t P, int K, int64_t* counts,
+                   gdl_stream_t stream);
+
 /* ---- ResNet encoder / UNet++ decoder pieces (smp.UnetPlusPlus, segmentation_unetplus.py:126-131; torchvision
  * resnet.py BasicBlock / maxpool; smp decoders/unetplusplus/decoder.py DecoderBlock) ----------------------------
  * NHWC, strides in elements, channels a multiple of 8 (bf16) / 4 (f32); tensors may be slices of a concat buffer. */
@@ -247,6 +253,8 @@ int gdl_dwconv3x3(const void* in, int dtype, int B, int H, int W, int C, const f
  * dofa_v2.py:157-166) -> GEMM weight [D][Kpad], k = c*P*P + r*P + s, times `scaler` (0.01) */
 int gdl_dofa_pack_kernel(const float* g, int C, int PP, int D, float scaler, void* out,
                          int out_dtype, int Kpad, gdl_stream_t stream);
+/* backward of gdl_dofa_pack_kernel: dg[C][PP*D] = scaler * transpose(dw[D][Kpad]) (f32) */
+int gdl_dofa_unpack_grad(const float* dw, int C, int PP, int D, float scaler, int Kpad, float* dg, gdl_stream_t stream);
 
 /* position_embedding (dofa_v2.py:9-35): out[m] = [sin(pos[m]*omega[d]) | cos(pos[m]*omega[d])], f32;
  * omega [D/2] is the module's constant frequency table (1 / 10000^(d/(D/2))). */
@@ -298,6 +306,8 @@ int gdl_upsample_logits_bwd(const float* dout, int B, int Ho, int Wo, int K, flo
 /* softmax(dim=1).argmax(dim=1) on NCHW f32 logits -> int64 mask (segmentation_dofa.py:281) */
 int gdl_softmax_argmax(const float* logits, int B, int K, int64_t HW, int64_t* mask,
                        gdl_stream_t stream);
+/* f.softmax(output, dim=1) (K > 1) / f.sigmoid (K == 1) of the exported inference model (tools/script_model.py:55-59) */
+int gdl_class_probs(const float* logits, int B, int K, int64_t HW, float* probs, gdl_stream_t stream);
 /* smp DiceLoss(mode="multiclass", smooth=0, eps=1e-7) forward+backward on NCHW f32 logits
  * (configs/dofa_config_RGB.yaml:58-61).  sums [3*K] = (intersection, sum p, count y)
  * is produced by fwd and consumed by bwd.  dlogits = upstream[0]*grad_scale*dL/dlogits. */

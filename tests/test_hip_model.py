@@ -174,12 +174,13 @@ def test_tiny_train_step_f32(tiny):
             np.testing.assert_allclose(bufs[k[4:]].cpu().numpy(), g[k], atol=2e-5, rtol=1e-4, err_msg=k)
 
 
-def test_tiny_train_vit_blocks_unfrozen(tiny):
-    """Only the dynamic weight generator frozen: the ViT blocks + cls_token train through the HIP
-    block backward (attention / LayerNorm / LayerScale / GELU kernels).  Checked against the CPU oracle."""
+@pytest.mark.parametrize("freeze", [["encoder.patch_embed"], None], ids=["generator_frozen", "all_trainable"])
+def test_tiny_train_vit_blocks_unfrozen(tiny, freeze):
+    """Unfrozen encoder: the ViT blocks + cls_token train through the HIP block backward (attention / LayerNorm /
+    LayerScale / GELU kernels) and, with nothing frozen, the dynamic weight generator through its own autograd
+    node (FCRes, the post-norm transformer layer, fc_weight / fc_bias).  Checked against the CPU oracle."""
     g, meta, _, _, batch = tiny
     nc, img, b, seed = meta["num_classes"], meta["img"], meta["batch"], meta["seed"]
-    freeze = ["encoder.patch_embed"]
     ref = oracle.DOFASegmentationModel("dofa_tiny_test", (img,) * 2, num_classes=nc, _encoder_kwargs=meta["tiny"],
                                        freeze_layers=freeze).train()
     sd = procedural_state_dict(ref, seed)
@@ -211,7 +212,18 @@ def test_tiny_train_vit_blocks_unfrozen(tiny):
         # which the neck's train-mode BN removes -> analytically zero gradient (rounding noise in both)
         err, ref_n = (p.grad.cpu() - rg).norm().item(), rg.norm().item()
         assert err <= 3e-2 * ref_n + 2e-6, (n, err, ref_n)
-    assert n_enc > 40
+    assert n_enc > (60 if freeze is None else 40)
+    if freeze is None:   # bf16 autocast: the generator still runs in f32, its gradients stay finite and aligned
+        for p in model.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            r = model(batch["image"].to(DEV), batch["wavelengths"], masks, am)
+            lb = crit(r.out, y.to(DEV)) + 0.4 * crit(r.aux, y.to(DEV))
+        lb.backward()
+        gw = dict(model.named_parameters())["encoder.patch_embed.weight_generator.fc_weight.weight"].grad
+        rw = refp["encoder.patch_embed.weight_generator.fc_weight.weight"].grad
+        cos = (gw.cpu() * rw).sum() / (gw.norm().cpu() * rw.norm() + 1e-30)
+        assert torch.isfinite(gw).all() and cos > 0.9, cos
 
 
 def test_tiny_train_bf16_runs_and_descends(tiny):
@@ -236,13 +248,10 @@ def test_tiny_train_bf16_runs_and_descends(tiny):
 
 
 def test_frozen_contract(tiny):
-    """freeze_layers substring match (base.py:40-44) and loud failure for the unbuilt encoder backward."""
+    """freeze_layers substring match (base.py:40-44); mixed wavelengths in a batch are rejected (dofa_v2.py:437-442)."""
     g, meta, ref, model, batch = tiny
     assert all(not p.requires_grad for n, p in model.named_parameters() if "encoder" in n)
     assert all(p.requires_grad for n, p in model.named_parameters() if "encoder" not in n)
-    enc = DOFAv2(img_size=meta["img"], pretrained=False, **meta["tiny"]).to(DEV).train()
-    with pytest.raises(NotImplementedError):
-        enc(batch["image"].to(DEV), batch["wavelengths"])
     with pytest.raises(ValueError):
         wv = torch.tensor([[0.6, 0.5, 0.4], [0.6, 0.5, 0.41]])
         with torch.no_grad():
@@ -340,3 +349,23 @@ def test_size_independent_properties(base_model):
     assert (full[1:2] - single).abs().max().item() < 1e-4, "eval output depends on batch composition"
     m = gnn.predict_mask(full)
     assert m.dtype == torch.int64 and m.min().item() >= 0 and m.max().item() < 5
+
+
+def test_script_model_wrapper(tiny):
+    """tools/script_model.py contract: raw 0-255 tile -> normalise -> model -> softmax probabilities."""
+    from geo_deep_learning.tools.script_model import SegmentationScriptModel
+    from oracle.model import RGB_MEAN, RGB_STD
+    g, meta, ref, model, batch = tiny
+    sd = procedural_state_dict(ref, meta["seed"])       # earlier tests trained the shared model: fresh weights
+    ref.load_state_dict(sd)
+    model.load_state_dict(sd)
+    ref.eval()
+    wrap = SegmentationScriptModel(model, wavelengths=batch["wavelengths"], device=torch.device(DEV),
+                                   num_classes=meta["num_classes"], input_shape=(1, 3, meta["img"], meta["img"]),
+                                   mean=RGB_MEAN, std=RGB_STD)
+    probs = wrap(batch["image_u8"])
+    with torch.no_grad():
+        want = ref(batch["image"], batch["wavelengths"]).out.softmax(dim=1)
+    assert probs.shape == want.shape
+    assert (probs.cpu() - want).abs().max().item() < 2e-4
+    assert (probs.sum(1) - 1).abs().max().item() < 1e-5

@@ -415,3 +415,33 @@ def test_patchify_strided_stem():
     wq[:, : C * P * P] = w.reshape(N, -1)
     y = ops.linear(cols, wq.to(DEV)).view(B, g, g, N)
     close(y.permute(0, 3, 1, 2), ref, torch.float32, "7x7/s4 stem")
+
+
+def test_iou_counts_bit_exact_and_mean_iou():
+    """Integer work: the per-sample / per-class counts are bit-exact vs numpy; MeanIoU follows the restated
+    torchmetrics formula (per-sample I/U, 0 where the union is empty, batch mean, mean over updates)."""
+    import numpy as np
+    from gdlhip.metrics import ClasswiseWrapper, MeanIoU
+    g = torch.Generator().manual_seed(3)
+    B, K, H, W = 3, 5, 96, 70
+    pred = torch.randint(0, K, (B, H, W), generator=g)
+    tgt = torch.randint(0, K, (B, H, W), generator=g)
+    tgt[1][tgt[1] == 3] = 0                         # class 3 absent from sample 1's target
+    pred[2] = 4                                     # a constant prediction
+    counts = ops.iou_counts(pred.to(DEV), tgt.to(DEV), K).cpu().numpy()
+    pn, tn = pred.numpy(), tgt.numpy()
+    for b in range(B):
+        for k in range(K):
+            assert counts[b, 0, k] == np.sum((pn[b] == k) & (tn[b] == k))
+            assert counts[b, 1, k] == np.sum(pn[b] == k)
+            assert counts[b, 2, k] == np.sum(tn[b] == k)
+    inter = counts[:, 0].astype(np.float64)
+    union = (counts[:, 1] + counts[:, 2] - counts[:, 0]).astype(np.float64)
+    ref = np.where(union > 0, inter / np.maximum(union, 1), 0.0).mean(0)
+    m = ClasswiseWrapper(MeanIoU(num_classes=K, per_class=True, input_format="index"), labels=list("abcde")).to(DEV)
+    out = m(pred.to(DEV), tgt.to(DEV))
+    assert list(out) == [f"meaniou_{c}" for c in "abcde"]
+    got = np.array([v.item() for v in out.values()])
+    np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7)
+    m.update(pred.to(DEV), tgt.to(DEV))
+    np.testing.assert_allclose(np.array([v.item() for v in m.compute().values()]), ref, rtol=1e-6, atol=1e-7)
