@@ -108,6 +108,7 @@ SIGNATURES = {
     "gdl_add_rows": (c_i, [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_p]),
     "gdl_normalize_u8": (c_i, [c_p, c_p, c_i, c_i, c_l, c_p, c_p, c_p]),
     "gdl_normalize_raw": (c_i, [c_p, c_i, c_p, c_i, c_i, c_l, c_p, c_p, c_p]),
+    "gdl_augment": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "gdl_scale_outer": (c_i, [c_p, c_i, c_p, c_l, c_l, c_p]),
     "gdl_head_1x1": (c_i, [c_p, c_i, c_l, c_i, c_l, c_p, c_p, c_p, c_l, c_p, c_i, c_p]),
     "gdl_head_1x1_bwd_workspace": (c_l, [c_l, c_i, c_i]),

@@ -860,6 +860,30 @@ def normalize_raw(raw: Tensor, mean: Tensor, std: Tensor) -> Tensor:
     return out
 
 
+def augment(img: Tensor, mask: Tensor | None, params: Tensor, mean: Tensor | None = None,
+            std: Tensor | None = None) -> tuple[Tensor, Tensor | None]:
+    """Per-sample flip / rot90 / resized-crop of an NCHW tile (+ its int64 mask), optionally fused with the
+    /255 + standardise of a raw tile.  ``params``: f32 [B, 8] = {kind, k, y0, x0, h, w, -, -} on the device."""
+    _need_cuda(img, params)
+    if img.dtype not in _RAW_KIND or not img.is_contiguous() or img.dim() != 4:
+        raise ValueError("augment: contiguous NCHW uint8/uint16/int16/float32 tile expected")
+    B, Cc, H, W = img.shape
+    if params.shape != (B, 8) or params.dtype != torch.float32 or not params.is_contiguous():
+        raise ValueError("augment: params must be a contiguous f32 [B, 8] tensor")
+    out = torch.empty((B, Cc, H, W), device=img.device, dtype=torch.float32)
+    m2 = om = None
+    if mask is not None:
+        if mask.dtype != torch.int64 or mask.numel() != B * H * W:
+            raise ValueError("augment: int64 mask of B*H*W elements expected")
+        m2 = mask.contiguous()
+        om = torch.empty_like(m2)
+    check(_lib.load().gdl_augment(_p(img), _RAW_KIND[img.dtype], _p(out), _p(m2), _p(om), B, Cc, H, W,
+                                  _p(None if mean is None else _f32vec(mean, Cc, "mean")),
+                                  _p(None if std is None else _f32vec(std, Cc, "std")), _p(params), _stream()),
+          "gdl_augment")
+    return out, om
+
+
 def scale_outer(x: Tensor, s: Tensor) -> Tensor:
     """x[o, ...] *= s[o] in place."""
     if not x.is_contiguous():

@@ -10,6 +10,8 @@ between any iterable of host batch dicts and the training loop:
 * raw tiles (``image`` in uint8 / uint16 / int16 / f32 as stored) are normalised **on the GPU** by one
   HBM-bound kernel (``x/255 -> (x-mean)/std``, gdl_normalize_raw) on the compute stream, after it waited for the
   copy event: uint8 tiles cross PCIe at 1 byte / sample instead of the reference's 4;
+* with ``augment=gdlhip.augment.reference_pipeline(size)`` the reference's kornia augmentations (main-process CPU,
+  segmentation_dofa.py:201-211) run in that same kernel;
 * the yielded dict has the reference's keys and dtypes (``image`` f32 standardised, ``mask`` int64, ...), so
   ``training_step`` / ``validation_step`` are unchanged.
 """
@@ -29,7 +31,7 @@ class DeviceInputStage:
     """Iterate device-resident, normalised batches ``depth`` copies ahead of the consumer."""
 
     def __init__(self, batches: Iterable[dict[str, Any]], device: torch.device | str = "cuda", depth: int = 2,
-                 raw_key: str = "image") -> None:
+                 raw_key: str = "image", augment: Any | None = None) -> None:
         self.batches = batches
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -37,6 +39,7 @@ class DeviceInputStage:
             raise ValueError(msg)
         self.depth = max(1, int(depth))
         self.raw_key = raw_key
+        self.augment = augment      # gdlhip.augment.AugmentationSequential: fused with the normalise kernel
         self._copy_stream = torch.cuda.Stream(device=self.device)
         self._pinned: dict = {}      # (key, shape, dtype) -> ring of pinned host buffers
         self._slot = 0
@@ -78,7 +81,11 @@ class DeviceInputStage:
             if isinstance(v, torch.Tensor) and v.is_cuda:
                 v.record_stream(cur)  # allocated on the copy stream, consumed on the compute stream
         img = dev.get(self.raw_key)
-        if isinstance(img, torch.Tensor) and self._is_raw(img, dev):
+        raw = isinstance(img, torch.Tensor) and self._is_raw(img, dev)
+        if self.augment is not None and isinstance(img, torch.Tensor):
+            mean, std = self._sensor_stats(dev) if raw else (None, None)
+            dev = self.augment(dev, mean, std)          # ONE kernel: normalise each tap + flip / rot90 / crop-resize
+        elif raw:
             mean, std = self._sensor_stats(dev)
             dev[self.raw_key] = ops.normalize_raw(img.contiguous(), mean, std)
         return dev

@@ -165,6 +165,19 @@ class SegmentationDOFA(LightningModule):
             return (outputs.out.sigmoid().squeeze(1) > self.threshold).long()
         return gnn.predict_mask(outputs.out)  # softmax(dim=1).argmax(dim=1), segmentation_dofa.py:281
 
+    def _apply_aug(self):
+        """The reference's kornia pipeline (segmentation_dofa.py:91-121,201-211) as one GPU kernel (gdlhip.augment)."""
+        from gdlhip.augment import reference_pipeline
+        return reference_pipeline(tuple(self.image_size))
+
+    def on_after_batch_transfer(self, batch: dict[str, Any], dataloader_idx: int) -> dict[str, Any]:  # noqa: ARG002
+        """The reference augments on the CPU in ``on_before_batch_transfer``; here the batch is augmented on the GPU
+        right after the transfer (training only)."""
+        trainer = getattr(self, "trainer", None)
+        if trainer is not None and getattr(trainer, "training", False) and batch["image"].is_cuda:
+            batch = self._apply_aug()(batch)
+        return batch
+
     def validation_step(self, batch: dict[str, Any], batch_idx: int) -> Tensor:  # noqa: ARG002
         """segmentation_dofa.py:251-283."""
         outputs, _, loss, bs = self._loss(batch)

@@ -61,6 +61,19 @@ class SegmentationUnetPlus(LightningModule):
         self.log("train_loss", loss, batch_size=batch["image"].shape[0], on_step=False, on_epoch=True, sync_dist=True)
         return loss
 
+    def _apply_aug(self):
+        """The reference's kornia pipeline (segmentation_unetplus.py:84-122) as one GPU kernel (gdlhip.augment)."""
+        from gdlhip.augment import reference_pipeline
+        return reference_pipeline(tuple(self.image_size))
+
+    def on_after_batch_transfer(self, batch: dict[str, Any], dataloader_idx: int) -> dict[str, Any]:  # noqa: ARG002
+        """The reference augments on the CPU in ``on_before_batch_transfer``; here the batch is augmented on the GPU
+        right after the transfer (training only)."""
+        trainer = getattr(self, "trainer", None)
+        if trainer is not None and getattr(trainer, "training", False) and batch["image"].is_cuda:
+            batch = self._apply_aug()(batch)
+        return batch
+
     def validation_step(self, batch: dict[str, Any], batch_idx: int) -> Tensor:  # noqa: ARG002
         y_hat = self(batch["image"])
         loss = self.loss(y_hat, batch["mask"])

@@ -185,6 +185,14 @@ int gdl_col2im(const void* cols, int dtype, int B, int Ho, int Wo, int R, int S,
 int gdl_iou_counts(const int64_t* pred, const int64_t* target, int B, int64_t P, int K, int64_t* counts,
                    gdl_stream_t stream);
 
+/* ---- GPU-side augmentation (kornia pipeline of segmentation_dofa.py:91-121,201-211, fused with the normalise step)
+ * img: raw NCHW tile of `kind` (GDL_RAW_*); mean/std non-NULL -> each tap is normalised like gdl_normalize_raw first.
+ * params: f32 [B][8] per sample {kind, k, y0, x0, h, w, -, -}; kind 0 none, 1 horizontal flip, 2 vertical flip,
+ * 3 rot90 by k quarter turns (torch.rot90, square tiles), 4 crop [y0,y0+h) x [x0,x0+w) resized to H x W (bilinear
+ * align_corners=False for the image, nearest for the mask).  mask / out_mask optional int64 [B][H][W]. */
+int gdl_augment(const void* img, int kind, float* out, const int64_t* mask, int64_t* out_mask, int B, int C, int H,
+                int W, const float* mean, const float* stdv, const float* params, gdl_stream_t stream);
+
 /* ---- ResNet encoder / UNet++ decoder pieces (smp.UnetPlusPlus, segmentation_unetplus.py:126-131; torchvision
  * resnet.py BasicBlock / maxpool; smp decoders/unetplusplus/decoder.py DecoderBlock) ----------------------------
  * NHWC, strides in elements, channels a multiple of 8 (bf16) / 4 (f32); tensors may be slices of a concat buffer. */

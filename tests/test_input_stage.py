@@ -76,3 +76,60 @@ def test_device_input_stage_matches_reference(stats, kind):
     assert n == 7
     raw_bytes = batches[0]["image"].numel() * batches[0]["image"].element_size()
     assert stage.bytes_h2d < 7 * (raw_bytes + 2 * 24 * 24 * 8 + 4096)     # raw tiles, not f32, crossed PCIe
+
+
+@pytest.mark.gpu
+def test_augment_kernel_matches_torch():
+    """Every augmentation kind vs torch.flip / torch.rot90 / F.interpolate on the crop (image bilinear, mask nearest),
+    with and without the fused normalisation of a raw uint8 tile."""
+    import torch.nn.functional as F
+    from gdlhip import ops
+    g = torch.Generator().manual_seed(0)
+    B, C, H = 6, 3, 64
+    u8 = torch.randint(0, 256, (B, C, H, H), generator=g, dtype=torch.uint8)
+    mask = torch.randint(0, 5, (B, 1, H, H), generator=g, dtype=torch.int64)
+    mean, std = torch.tensor([0.4, 0.43, 0.4]), torch.tensor([0.17, 0.18, 0.16])
+    x = ((u8.float() / 255.0) - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+    prm = torch.zeros(B, 8)
+    prm[1, 0] = 1
+    prm[2, 0] = 2
+    prm[3, 0], prm[3, 1] = 3, 1
+    prm[4, 0], prm[4, 1] = 3, 3
+    prm[5, 0], prm[5, 2:6] = 4, torch.tensor([5.0, 9.0, 40.0, 31.0])
+    want_img = [x[0], x[1].flip(-1), x[2].flip(-2), torch.rot90(x[3], 1, (-2, -1)), torch.rot90(x[4], 3, (-2, -1)),
+                F.interpolate(x[5:6, :, 5:45, 9:40], size=(H, H), mode="bilinear", align_corners=False)[0]]
+    want_mask = [mask[0], mask[1].flip(-1), mask[2].flip(-2), torch.rot90(mask[3], 1, (-2, -1)),
+                 torch.rot90(mask[4], 3, (-2, -1)),
+                 F.interpolate(mask[5:6, :, 5:45, 9:40].float(), size=(H, H), mode="nearest")[0].long()]
+    for fused in (True, False):
+        src = u8.to("cuda") if fused else x.to("cuda")
+        img, om = ops.augment(src, mask.to("cuda").view(B, H, H), prm.to("cuda"),
+                              mean.to("cuda") if fused else None, std.to("cuda") if fused else None)
+        for i in range(B):
+            assert torch.equal(om[i].cpu(), want_mask[i][0]), f"mask {i}"
+            if i < 5:
+                assert torch.equal(img[i].cpu(), want_img[i]), f"image {i} fused={fused}"     # pure index maps: bit-exact
+            else:
+                assert (img[i].cpu() - want_img[i]).abs().max().item() < 2e-6
+
+
+@pytest.mark.gpu
+def test_reference_pipeline_through_the_stage(stats):
+    from gdlhip.augment import reference_pipeline
+    from geo_deep_learning.datamodules.device_input import DeviceInputStage
+    g, norm = stats
+    proc = SampleProcessor("sensorA", norm, "dofa")
+    s = _sample(g, "u8")
+    batches = [collate([proc(s)] * 4) for _ in range(12)]
+    torch.manual_seed(5)
+    stage = DeviceInputStage(batches, "cuda", depth=2, augment=reference_pipeline((24, 24)))
+    ref = torch.from_numpy(g["u8_dofa_image"])
+    changed = 0
+    for b in stage:
+        img, m = b["image"].cpu(), b["mask"].cpu()
+        assert img.shape == (4, 4, 24, 24) and img.dtype == torch.float32 and m.dtype == torch.int64
+        assert torch.isfinite(img).all() and int(m.min()) >= 0 and int(m.max()) <= 4
+        # value range can only shrink under flips / turns / bilinear crops
+        assert img.max() <= ref.max() + 1e-5 and img.min() >= ref.min() - 1e-5
+        changed += int(any(not torch.equal(img[i], ref) for i in range(4)))
+    assert changed >= 6      # p = 0.5 per sample, 4 samples, 12 batches
