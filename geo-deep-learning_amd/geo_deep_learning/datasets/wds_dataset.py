@@ -10,21 +10,28 @@ dict, with ``image`` raw and the sensor's ``mean`` / ``std`` beside it, and
 HBM-bound HIP kernel after an asynchronous pinned-memory H2D copy (4x fewer PCIe bytes for uint8).
 ``defer_normalization=False`` reproduces the reference's host arithmetic exactly (used by the parity tests).
 
-Reading the WebDataset tar shards themselves (third-party ``webdataset``; I/O, not arithmetic) is out of scope:
-any iterable of sample dicts with the reference's keys can be fed to :class:`SampleProcessor`.
+The shard side (``load_sensor_configs`` :46-49, ``create_shard_split_paths`` :52-79, ``create_sensor_datasets``
+:82-137, ``ShardedDataset.build_web_dataset`` :391-431) is mirrored too, on a small built-in reader of the WebDataset
+tar layout (``<key>.image_patch.npy`` / ``<key>.label_patch.npy`` / ``<key>.metadata.json`` members grouped by key) --
+the third-party ``webdataset`` package is not required.
 """
 
 from __future__ import annotations
 
+import io
 import json
 import logging
 import math
+import random
+import tarfile
+from collections.abc import Iterator
 from datetime import datetime
 from pathlib import Path
 from typing import Any
 
 import numpy as np
 import torch
+import yaml
 
 from geo_deep_learning.utils.tensors import normalization, standardization
 
@@ -136,3 +143,132 @@ def collate(samples: list[dict[str, Any]]) -> dict[str, Any]:
         vals = [s[k] for s in samples]
         out[k] = torch.stack(vals) if isinstance(vals[0], torch.Tensor) else vals
     return out
+
+
+# ------------------------------------------------------------------ shards
+def load_sensor_configs(config_path: str) -> dict[str, dict[str, str]]:
+    """wds_dataset.py:46-49."""
+    with Path(config_path).open() as f:
+        return yaml.safe_load(f)
+
+
+def create_shard_split_paths(manifest_path: str, split: str, parent_dir: str | None = None) -> tuple[list[str], int]:
+    """wds_dataset.py:52-79."""
+    parent = Path(manifest_path).parent / split if parent_dir is None else Path(parent_dir) / split
+    with Path(manifest_path).open() as f:
+        data = json.load(f)
+    return ([(parent / item["path"]).as_posix() for item in data["shards"][split]],
+            data["statistics"]["patch_counts"][split])
+
+
+def read_tar_samples(path: str) -> Iterator[dict[str, Any]]:
+    """One WebDataset shard: members are grouped by the basename up to its first dot; ``.npy`` members are decoded
+    to arrays, ``.json`` to objects (what ``wds.WebDataset(...).decode()`` yields for these extensions)."""
+    cur: dict[str, Any] = {}
+    with tarfile.open(path, "r") as tf:
+        for member in tf:
+            if not member.isfile():
+                continue
+            name = Path(member.name).name
+            key, _, ext = name.partition(".")
+            prefix = (Path(member.name).parent / key).as_posix().lstrip("./")
+            if cur and cur["__key__"] != prefix:
+                yield cur
+                cur = {}
+            cur.setdefault("__key__", prefix)
+            data = tf.extractfile(member).read()
+            if ext.endswith(".npy") or ext == "npy":
+                cur[ext] = np.load(io.BytesIO(data), allow_pickle=False)
+            elif ext.endswith(".json") or ext == "json":
+                cur[ext] = json.loads(data)
+            else:
+                cur[ext] = data
+    if cur:
+        yield cur
+
+
+class ShardedDataset:
+    """wds_dataset.py:140-431: one sensor / split.  ``build_web_dataset()`` returns an iterable of BATCHES (dicts),
+    like the reference's ``.decode().map(_process_sample).batched(batch_size, partial=split != "trn")``."""
+
+    def __init__(self, sensor_name: str, shard_paths: list[str], patch_count: int, normalization_stats_path: str,
+                 model_type: str = "clay", split: str = "trn", batch_size: int = 16, shuffle_buffer: int = 1000,
+                 shardshuffle: int | None = None, seed: int = 42, epoch_size: int | None = None,
+                 wavelength_keys: list[str] | None = None, *, defer_normalization: bool = True) -> None:
+        self.sensor_name, self.shard_paths, self.patch_count = sensor_name, shard_paths, patch_count
+        self.model_type, self.split, self.batch_size = model_type, split, batch_size
+        self.shuffle_buffer, self.shardshuffle, self.seed, self.epoch_size = shuffle_buffer, shardshuffle, seed, epoch_size
+        self.norm_stats = load_normalization_stats(normalization_stats_path, sensor_name)
+        self.processor = SampleProcessor(sensor_name, self.norm_stats, model_type, wavelength_keys,
+                                         defer_normalization=defer_normalization)
+
+    def _process_sample(self, sample: dict[str, Any]) -> dict[str, Any]:
+        return self.processor.process_sample(sample)
+
+    def _shards(self) -> list[str]:
+        shard_list = sorted(self.shard_paths)
+        if self.split == "trn" and torch.distributed.is_available() and torch.distributed.is_initialized():
+            shard_list = shard_list[torch.distributed.get_rank()::torch.distributed.get_world_size()]   # :398-401
+        return shard_list
+
+    def _samples(self, epoch: int) -> Iterator[dict[str, Any]]:
+        shards = self._shards()
+        rng = random.Random((self.seed or 0) + epoch)
+        if self.split == "trn" and self.shardshuffle:
+            rng.shuffle(shards)
+        buf: list = []
+        for path in shards:
+            for sample in read_tar_samples(path):
+                if self.split != "trn" or not self.shuffle_buffer:
+                    yield sample
+                    continue
+                buf.append(sample)                      # wds .shuffle(n): reservoir of n samples
+                if len(buf) >= self.shuffle_buffer:
+                    yield buf.pop(rng.randrange(len(buf)))
+        while buf:
+            yield buf.pop(rng.randrange(len(buf)))
+
+    def build_web_dataset(self) -> "_BatchPipeline":
+        return _BatchPipeline(self)
+
+
+class _BatchPipeline:
+    def __init__(self, ds: ShardedDataset) -> None:
+        self.ds, self.epoch = ds, 0
+
+    def __iter__(self) -> Iterator[dict[str, Any]]:
+        ds = self.ds
+        batch: list = []
+        for sample in ds._samples(self.epoch):
+            try:
+                batch.append(ds._process_sample(sample))
+            except Exception as e:  # noqa: BLE001  (wds.warn_and_continue)
+                logger.warning("skipping sample %s: %s", sample.get("__key__"), e)
+                continue
+            if len(batch) == ds.batch_size:
+                yield collate(batch)
+                batch = []
+        if batch and ds.split != "trn":
+            yield collate(batch)                        # partial batches only outside training (:430)
+        self.epoch += 1
+
+
+def create_sensor_datasets(sensor_configs_path: str, **common_kwargs: object) -> dict[str, Any]:
+    """wds_dataset.py:82-137."""
+    datasets: dict[str, Any] = {}
+    for sensor_name, config in load_sensor_configs(sensor_configs_path).items():
+        datasets[sensor_name] = {}
+        for split in ("trn", "val", "tst"):
+            try:
+                shard_paths, patch_count = create_shard_split_paths(config["manifest_path"], split, config["parent_dir"])
+            except Exception:
+                logger.exception("Failed to create dataset for %s %s split", sensor_name, split)
+                continue
+            if not shard_paths:
+                logger.warning("No shards found for %s %s split", sensor_name, split)
+                continue
+            datasets[sensor_name][split] = ShardedDataset(
+                sensor_name=sensor_name, shard_paths=shard_paths, patch_count=patch_count,
+                normalization_stats_path=config["stats_path"], split=split,
+                wavelength_keys=config.get("wavelength_keys"), **common_kwargs)
+    return datasets

@@ -1,0 +1,132 @@
+"""MultiSensorDataModule mirror on real WebDataset-layout tar shards written by the test: shard / manifest /
+sensor-config handling (wds_dataset.py:46-137), per-sensor batching with the training-only "no partial batch" rule
+(:430), the random sensor mix, and the bytes of every yielded tile against what was written."""
+
+import io
+import json
+import tarfile
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from geo_deep_learning.datamodules.wds_datamodule import MultiSensorDataModule
+from geo_deep_learning.datasets.wds_dataset import read_tar_samples
+
+
+def _add(tf, name, data: bytes):
+    ti = tarfile.TarInfo(name)
+    ti.size = len(data)
+    tf.addfile(ti, io.BytesIO(data))
+
+
+def _write_sensor(root, sensor, bands, counts, rng):
+    """counts = {"trn": [n per shard...], "val": [...]} -> manifest, stats, shards; returns (config entry, tiles)."""
+    tiles = {}
+    manifest = {"shards": {}, "statistics": {"patch_counts": {}}}
+    for split in ("trn", "val", "tst"):
+        manifest["shards"][split] = []
+        manifest["statistics"]["patch_counts"][split] = int(sum(counts.get(split, [])))
+        (root / sensor / split).mkdir(parents=True, exist_ok=True)
+        for si, n in enumerate(counts.get(split, [])):
+            name = f"shard-{si:03d}.tar"
+            with tarfile.open(root / sensor / split / name, "w") as tf:
+                for j in range(n):
+                    key = f"{sensor}_{split}_{si}_{j}"
+                    img = rng.integers(0, 256, (bands, 16, 16)).astype(np.uint8)
+                    lab = rng.integers(0, 5, (1, 16, 16)).astype(np.uint8)
+                    meta = {"metadata": {"red_wavelength": 0.665, "green_wavelength": 0.549, "blue_wavelength": 0.481,
+                                         "nir_wavelength": 0.842, "datetime": "2022-03-01T10:00:00Z"}}
+                    tiles[key] = (img, lab)
+                    for ext, arr in (("image_patch.npy", img), ("label_patch.npy", lab)):
+                        b = io.BytesIO()
+                        np.save(b, arr)
+                        _add(tf, f"{key}.{ext}", b.getvalue())
+                    _add(tf, f"{key}.metadata.json", json.dumps(meta).encode())
+            manifest["shards"][split].append({"path": name})
+    (root / sensor / "manifest.json").write_text(json.dumps(manifest))
+    stats = {"statistics": {sensor: {"mean": [100.0 + i for i in range(bands)], "std": [40.0 + i for i in range(bands)],
+                                     "band_count": bands, "patch_count": 1, "dtype": "uint8"}}}
+    (root / sensor / "stats.json").write_text(json.dumps(stats))
+    return {"manifest_path": str(root / sensor / "manifest.json"), "parent_dir": str(root / sensor),
+            "stats_path": str(root / sensor / "stats.json")}, tiles, stats["statistics"][sensor]
+
+
+@pytest.fixture()
+def shards(tmp_path):
+    rng = np.random.default_rng(0)
+    cfg, tiles, stats = {}, {}, {}
+    for sensor, bands, counts in (("sensorA", 4, {"trn": [5, 4], "val": [3]}), ("sensorB", 3, {"trn": [6], "val": [2]})):
+        cfg[sensor], t, stats[sensor] = _write_sensor(tmp_path, sensor, bands, counts, rng)
+        tiles.update(t)
+    path = tmp_path / "sensors.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    return str(path), tiles, stats
+
+
+def test_tar_reader_groups_members_by_key(shards):
+    path, tiles, _ = shards
+    cfg = yaml.safe_load(open(path))
+    shard = cfg["sensorA"]["parent_dir"] + "/trn/shard-000.tar"
+    samples = list(read_tar_samples(shard))
+    assert len(samples) == 5
+    for s in samples:
+        assert set(s) == {"__key__", "image_patch.npy", "label_patch.npy", "metadata.json"}
+        np.testing.assert_array_equal(s["image_patch.npy"], tiles[s["__key__"]][0])
+
+
+def test_datamodule_batches_mix_and_contents(shards):
+    path, tiles, stats = shards
+    dm = MultiSensorDataModule(path, model_type="dofa", patch_size=(16, 16), batch_size=2, seed=3)
+    dm.setup()
+    seen = []
+    for batch in dm.train_dataloader():
+        assert batch["image"].dtype == torch.uint8 and batch["image"].shape[0] == 2      # raw tiles, full batches only
+        assert batch["mask"].dtype == torch.int64 and batch["mask"].shape == (2, 1, 16, 16)
+        sensor = batch["platform"][0]
+        assert batch["platform"] == [sensor] * 2                                         # one sensor per batch
+        st = stats[sensor]
+        mean = torch.tensor(st["mean"]).div(255.0).view(-1, 1, 1)
+        std = torch.tensor(st["std"]).div(255.0).view(-1, 1, 1)
+        for i, key in enumerate(batch["image_name"]):
+            np.testing.assert_array_equal(batch["image"][i].numpy(), tiles[key][0])
+            np.testing.assert_array_equal(batch["mask"][i].numpy(), tiles[key][1].astype(np.int64))
+            assert torch.equal(batch["mean"][i], mean) and torch.equal(batch["std"][i], std)
+            seen.append(key)
+    # sensorA: 9 training tiles -> 4 full batches, sensorB: 6 -> 3; the partial batch is dropped in training only
+    assert len(seen) == 14 and len(set(seen)) == 14
+    assert {k.split("_")[0] for k in seen} == {"sensorA", "sensorB"}
+    val = list(dm.val_dataloader())
+    assert sorted(b["image"].shape[0] for b in val) == [1, 2, 2]                         # partial batches kept
+    assert dm.test_dataloader() is None
+    dm.teardown()
+
+
+def test_epoch_size_caps_the_training_epoch(shards):
+    path, _, _ = shards
+    dm = MultiSensorDataModule(path, model_type="dofa", batch_size=2, epoch_size=6, seed=1)
+    dm.setup()
+    assert len(list(dm.train_dataloader())) == 3
+
+
+@pytest.mark.gpu
+def test_datamodule_to_device_matches_reference_formula(shards):
+    """device= wraps the loaders in the GPU input stage: tiles arrive normalised exactly like the reference's workers."""
+    from geo_deep_learning.utils.tensors import normalization, standardization
+    path, tiles, stats = shards
+    dm = MultiSensorDataModule(path, model_type="dofa", batch_size=2, seed=3, device="cuda")
+    dm.setup()
+    n = 0
+    for batch in dm.val_dataloader():
+        sensor = batch["platform"][0]
+        st = stats[sensor]
+        mean = torch.tensor(st["mean"]).div(255.0).view(-1, 1)
+        std = torch.tensor(st["std"]).div(255.0).view(-1, 1)
+        assert batch["image"].is_cuda and batch["image"].dtype == torch.float32
+        for i, key in enumerate(batch["image_name"]):
+            raw = torch.from_numpy(tiles[key][0]).float().unsqueeze(0)
+            want = standardization(normalization(raw), mean, std)[0]
+            assert torch.equal(batch["image"][i].cpu(), want)
+            n += 1
+    assert n == 5

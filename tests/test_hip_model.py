@@ -369,3 +369,32 @@ def test_script_model_wrapper(tiny):
     assert probs.shape == want.shape
     assert (probs.cpu() - want).abs().max().item() < 2e-4
     assert (probs.sum(1) - 1).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("encoder,size,bands,tol", [("dofa_base", 512, 6, 1e-3), ("dofa_large", 1024, 10, 2e-3)],
+                         ids=["config3_base_6band_512", "config4_large_10band_1024"])
+def test_multiband_configs_match_oracle(encoder, size, bands, tol):
+    """BASELINE configs[3] / configs[4] shapes (6-band DOFA-base 512^2; 10-band DOFA-large 1024^2), one tile:
+    f32 logits vs the CPU oracle, masks exact where the oracle's margin exceeds the tolerance, bf16 agreement."""
+    seed = 21
+    ref = oracle.DOFASegmentationModel(encoder, (size, size), num_classes=5, freeze_layers=["encoder"]).eval()
+    sd = procedural_state_dict(ref, seed)
+    ref.load_state_dict(sd)
+    model = DOFASegmentationModel(encoder, (size, size), num_classes=5, pretrained=False, freeze_layers=["encoder"])
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    batch = synthetic_batch(1, bands, size, 5, seed)
+    x = batch["image"].to(DEV)
+    with torch.no_grad():
+        yo = ref(batch["image"], batch["wavelengths"]).out
+        y = model(x, batch["wavelengths"]).out
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            yb = model(x, batch["wavelengths"]).out
+    scale = max(1.0, yo.abs().max().item())
+    assert (y.cpu() - yo).abs().max().item() < tol * scale
+    top2 = yo.topk(2, dim=1).values
+    decided = ((top2[:, 0] - top2[:, 1]) > 2 * tol * scale).numpy()
+    want = yo.softmax(1).argmax(1).numpy()
+    assert (gnn.predict_mask(y).cpu().numpy() == want)[decided].all()
+    assert (yb.float().cpu() - yo).abs().max().item() < 0.08 * yo.abs().max().item()
+    assert (gnn.predict_mask(yb).cpu().numpy() == want).mean() > 0.95
