@@ -437,53 +437,59 @@ __global__ __launch_bounds__(512) void wgrad_tr256_kernel(const W256 kk) {
   const unsigned lds_base =
       __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
 
-  // ---- DMA geometry: wave w feeds pixel rows 8w..8w+7 of all eight panels; lane l row (l>>3), slot (l&7)
+  // ---- DMA geometry ("ping-pong": the two waves of a SIMD, w and w+4, alternate as the loader of a K-step, so
+  // one of them is always in its MFMA phase): loader wave (w&3) feeds pixel rows 8(w&3)+64u.. of all eight panels
+  // for u = 0,1 -- i.e. row groups (w&3) and (w&3)+4; lane l row (l>>3), slot (l&7)
   const int lrow = lane >> 3, lslot = lane & 7;
-  const int rr = wave * 8 + lrow;
-  const int chunk = lslot ^ tr_swz(rr);
-  int pb, py, px;   // (batch, oy, ox) of this lane's pixel in the NEXT tile to fetch
-  {
-    const int64_t p = p_begin + rr;
-    pb = (int)(p / HoWo);
-    const int rem = (int)(p - (int64_t)pb * HoWo);
-    py = rem / a.Wo;
-    px = rem - py * a.Wo;
-  }
-  unsigned n_off[4], c_off[4];   // byte offset of this lane's chunk inside a pixel row, or kOob past the N / C tail
+  const int half = wave >> 2, lwave = wave & 3;
+  int rr[2], chunk[2], pb[2], py[2], px[2];   // (batch, oy, ox) of this lane's pixels in the NEXT tile to fetch
 #pragma unroll
-  for (int pn = 0; pn < 4; ++pn) {
-    const int nn = n0 + pn * 64 + chunk * 8, cc = c0 + pn * 64 + chunk * 8;
-    n_off[pn] = nn < a.N ? (unsigned)nn * 2u : kOob;
-    c_off[pn] = cc < a.C ? (unsigned)cc * 2u : kOob;
+  for (int u = 0; u < 2; ++u) {
+    rr[u] = (lwave + 4 * u) * 8 + lrow;
+    chunk[u] = lslot ^ tr_swz(rr[u]);
+    const int64_t p = p_begin + rr[u];
+    pb[u] = (int)(p / HoWo);
+    const int rem = (int)(p - (int64_t)pb[u] * HoWo);
+    py[u] = rem / a.Wo;
+    px[u] = rem - py[u] * a.Wo;
   }
   int64_t pnext = p_begin;   // first pixel of the NEXT tile to fetch
 
-  auto issue = [&](int stage) {
-    const unsigned lds = lds_base + stage * STAGE_BYTES + wave * 1024;
-    const bool pv = pnext + rr < p_end;
-    unsigned dyo, xo;
-    bool xv = pv;
-    if (k.dy_dense) dyo = (unsigned)((pnext + rr) * a.dy_sW * 2);
-    else dyo = (unsigned)((pb * a.dy_sB + py * a.dy_sH + px * a.dy_sW) * 2);
-    if (k.x_dense) {
-      xo = (unsigned)((pnext + rr) * a.in_sW * 2);
-    } else {
-      const int iy = py * a.stride + tap_r - a.pad, ix = px * a.stride + tap_s - a.pad;
-      xv = xv && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      xo = (unsigned)((pb * a.in_sB + iy * a.in_sH + ix * a.in_sW) * 2);
-    }
+  auto issue = [&](int stage, bool load) {
+    if (load) {
 #pragma unroll
-    for (int pn = 0; pn < 4; ++pn) {
-      const unsigned vd = (pv && n_off[pn] != kOob) ? dyo + n_off[pn] : kOob;
-      dma16_buf(vd, srd_dy, 0u, lds + pn * PANEL);
-      const unsigned vx = (xv && c_off[pn] != kOob) ? xo + c_off[pn] : kOob;
-      dma16_buf(vx, srd_x, 0u, lds + (4 + pn) * PANEL);
+      for (int u = 0; u < 2; ++u) {
+        const unsigned lds = lds_base + stage * STAGE_BYTES + (lwave + 4 * u) * 1024;
+        const bool pv = pnext + rr[u] < p_end;
+        unsigned dyo, xo;
+        bool xv = pv;
+        if (k.dy_dense) dyo = (unsigned)((pnext + rr[u]) * a.dy_sW * 2);
+        else dyo = (unsigned)((pb[u] * a.dy_sB + py[u] * a.dy_sH + px[u] * a.dy_sW) * 2);
+        if (k.x_dense) {
+          xo = (unsigned)((pnext + rr[u]) * a.in_sW * 2);
+        } else {
+          const int iy = py[u] * a.stride + tap_r - a.pad, ix = px[u] * a.stride + tap_s - a.pad;
+          xv = xv && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+          xo = (unsigned)((pb[u] * a.in_sB + iy * a.in_sH + ix * a.in_sW) * 2);
+        }
+#pragma unroll
+        for (int pn = 0; pn < 4; ++pn) {
+          const int nn = n0 + pn * 64 + chunk[u] * 8, cc = c0 + pn * 64 + chunk[u] * 8;
+          const unsigned vd = (pv && nn < a.N) ? dyo + (unsigned)nn * 2u : kOob;
+          dma16_buf(vd, srd_dy, 0u, lds + pn * PANEL);
+          const unsigned vx = (xv && cc < a.C) ? xo + (unsigned)cc * 2u : kOob;
+          dma16_buf(vx, srd_x, 0u, lds + (4 + pn) * PANEL);
+        }
+      }
     }
-    pnext += BKP;
+    pnext += BKP;   // every wave tracks the position, loader or not
     if (!(k.dy_dense && k.x_dense)) {
-      px += BKP;
-      while (px >= a.Wo) { px -= a.Wo; ++py; }
-      while (py >= a.Ho) { py -= a.Ho; ++pb; }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        px[u] += BKP;
+        while (px[u] >= a.Wo) { px[u] -= a.Wo; ++py[u]; }
+        while (py[u] >= a.Ho) { py[u] -= a.Ho; ++pb[u]; }
+      }
     }
   };
 
@@ -537,10 +543,10 @@ __global__ __launch_bounds__(512) void wgrad_tr256_kernel(const W256 kk) {
 
   const int KT = (int)((p_end - p_begin + BKP - 1) / BKP);
   if (KT > 0) {
-    issue(0);
+    issue(0, half == 0);                                 // tile t is loaded by half (t & 1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (KT > 1) issue(1);
+    if (KT > 1) issue(1, half == 1);
     fetch(smem, 0, 0);
     for (int kt = 0; kt < KT; ++kt) {
       const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
@@ -554,7 +560,7 @@ __global__ __launch_bounds__(512) void wgrad_tr256_kernel(const W256 kk) {
       if (kt + 1 < KT) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 2 < KT) issue(kt & 1);
+        if (kt + 2 < KT) issue(kt & 1, half == (kt & 1));
         fetch(smem + ((kt + 1) & 1) * STAGE_BYTES, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
