@@ -8,6 +8,7 @@ through PyTorch math or the CPU oracle.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "libgdlhip.so"
@@ -152,6 +153,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("GDL_CONV_SF") is not None:      # tuning hook: 0 disables the 3x3 shared-staging kernel
+        lib.gdl_debug_set_conv_sf.argtypes = [C.c_int]
+        lib.gdl_debug_set_conv_sf(int(os.environ["GDL_CONV_SF"]))
     _lib = lib
     return lib
 

@@ -143,7 +143,8 @@ class KernelTimer:
 
     VARIANT = {0: "conv_gemm_kernel<{dt},2,2,1,1> (64x64 tiles)", 1: "conv_gemm_kernel<{dt},2,2,2,2> (128x128 tiles)",
                2: "conv_gemm_kernel<{dt},2,4,4,2> (256x256 tiles)",
-               3: "conv_gemm_kernel<{dt},2,4,4,2,pingpong> (256x256 tiles, alternating loader halves)"}
+               3: "conv_gemm_kernel<{dt},2,4,4,2,pingpong> (256x256 tiles, alternating loader halves)",
+               4: "conv3x3_sf_kernel<{dt}> (256x256 tiles, 3x3 taps share one staged activation tile)"}
 
     def __init__(self) -> None:
         self.records: list = []

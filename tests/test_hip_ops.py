@@ -445,3 +445,30 @@ def test_iou_counts_bit_exact_and_mean_iou():
     np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7)
     m.update(pred.to(DEV), tgt.to(DEV))
     np.testing.assert_allclose(np.array([v.item() for v in m.compute().values()]), ref, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,N", [(3, 19, 23, 128, 256), (2, 16, 16, 64, 512), (1, 40, 7, 192, 256)])
+def test_conv3x3_shared_staging_kernel(dtype, B, H, W, C, N):
+    """The 3x3 kernel that stages one activation tile for the three taps of a filter row (image-edge taps are
+    zeroed per lane): forced on small multi-image shapes with M tails, vs F.conv2d and vs the generic kernel."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
+    x, w = q(rnd(B, C, H, W), dtype), q(rnd(N, C, 3, 3, seed=1) * 0.1, dtype)
+    bias, resid = rnd(N, seed=2), q(rnd(B, N, H, W, seed=3), dtype)
+    ref = F.relu(F.conv2d(x, w, bias, padding=1)) + resid
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    wq = w.permute(0, 2, 3, 1).reshape(N, -1).contiguous().to(DEV, dtype)
+    rn = resid.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    outs = {}
+    try:
+        for v in (4, 1):
+            lib.gdl_debug_force_conv_variant(v)
+            outs[v] = ops.conv_gemm(xn, wq, R=3, S=3, pad=1, bias=bias.to(DEV), act=ops.ACT_RELU, resid=rn,
+                                    out_dtype=torch.float32)
+    finally:
+        lib.gdl_debug_force_conv_variant(-1)
+    close(outs[4].permute(0, 3, 1, 2), ref, dtype, "3x3 shared staging")
+    assert (outs[4] - outs[1]).abs().max().item() <= 1e-5 * ref.abs().max().item()

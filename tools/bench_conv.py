@@ -69,7 +69,10 @@ def main():
         med2, _ = timeit(lambda: ops.conv_gemm(x, w, R=r, S=r, pad=r // 2))
         lib.gdl_debug_set_conv_dbg(0)
         print(f"   {name}: compute-only (no DMA) {flops / med1 / 1e9:7.1f} TF/s-equivalent, load-only (no MFMA) {flops / med2 / 1e9:7.1f}")
-        for v in (1, 2, 3, -1):
+        for v in (1, 2, 3, 4, -1):
+            if v == 4 and (r != 3 or n % 256):
+                row.append("   -   ")
+                continue
             if v in (2, 3) and n % 256:
                 row.append("   -   ")
                 continue
@@ -79,8 +82,10 @@ def main():
             row.append(f"{flops / med / 1e9:7.1f}")
         lib.gdl_debug_force_conv_variant(-1)
         same = "" if 3 not in outs else f"  v3==v2: {torch.equal(outs[2], outs[3])}"
+        if 4 in outs:
+            same += f" v4 max|diff| {(outs[4].float() - outs[3].float()).abs().max().item():.2e}"
         print(f"conv_gemm {name:14s} GF {flops / 1e9:8.1f}  TF/s v1(128^2) {row[0]}  v2(256^2) {row[1]}  "
-              f"v3(256^2 ping-pong) {row[2]}  auto {row[3]}{same}  [tap-outer K order: {flops / med0 / 1e9:7.1f}]")
+              f"v3(256^2 ping-pong) {row[2]}  v4(3x3 shared staging) {row[3]}  auto {row[4]}{same}  [tap-outer K order: {flops / med0 / 1e9:7.1f}]")
     for name, shp, n, r in CONVS[:6]:
         x = torch.randn(shp, device=DEV).to(bf)
         dy = torch.randn((shp[0], shp[1], shp[2], n), device=DEV).to(bf)

@@ -19,7 +19,7 @@ x = torch.randn(B, 144, 144, 768, device="cuda").to(torch.bfloat16)
 w = (torch.randn(768, 9 * 768, device="cuda") * 0.05).to(torch.bfloat16)
 buf = torch.zeros(8192, device="cuda", dtype=torch.int64)
 KT = 9 * 768 // 64
-for variant in (2, 3):
+for variant in (3, 4):
     for dbg in (0, 1, 2):
         lib.gdl_debug_force_conv_variant(variant)
         lib.gdl_debug_set_conv_dbg(dbg)
