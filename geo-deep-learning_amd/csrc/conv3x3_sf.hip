@@ -140,7 +140,6 @@ __global__ __launch_bounds__(512) void conv3x3_sf_kernel(const KArgs k) {
     for (int j = 0; j < TN; ++j) fb[buf][j] = *(const uint4*)(sb + j * 32 * 128);
   };
   auto mfmas = [&](int buf, unsigned bit) {
-    if (k.dbg == 2) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       if (!(fmask[i] & bit)) fa[buf][i] = make_uint4(0, 0, 0, 0);    // tap outside the image for this lane's row
@@ -165,7 +164,10 @@ __global__ __launch_bounds__(512) void conv3x3_sf_kernel(const KArgs k) {
   if (half == 0) { issue_b(0); issue_a(0, 0); } else { issue_a(0, 1); issue_a(0, 2); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  slot(-1 + 0 * 2);   // t = -1: half 1 loads the weights of step 1 and the first third of macro step 1
+  slot(-1);           // t = -1: half 1 loads the weights of step 1 and the first third of macro step 1
+  // all scalar (kernel-argument) loads are complete here: tell the waitcnt inserter, so that inside the loop it can
+  // wait for the OLDER fragment reads only (lgkmcnt(6)) instead of draining every LDS read before the first MFMAs
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
   fetch(0, 0, 0, 0, 0);
 
   // ---- main loop over macro steps g = (chunk, filter row); the three taps s are unrolled (static fragment offsets)

@@ -196,6 +196,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (k.KT > 1) issue(1, !PP || half == 1);
+  // all scalar (kernel-argument) loads are complete here: tell the waitcnt inserter, so that inside the loop it can
+  // wait for the OLDER fragment reads only (lgkmcnt(6)) instead of draining every LDS read before the first MFMAs
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
   fetch(smem, 0, 0);
   for (int kt = 0; kt < k.KT; ++kt) {
     const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
     for (int kk = 0; kk < 3; ++kk) {
       fetch(st, kk + 1, (kk + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (k.dbg != 2) mfmas(kk & 1);
+      mfmas(kk & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (kt + 1 < k.KT) {
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
       fetch(smem + ((kt + 1) & 1) * STAGE_BYTES, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (k.dbg != 2) mfmas(1);
+    mfmas(1);
     __builtin_amdgcn_sched_barrier(0);
   }
 

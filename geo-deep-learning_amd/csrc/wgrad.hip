@@ -547,6 +547,7 @@ __global__ __launch_bounds__(512) void wgrad_tr256_kernel(const W256 kk) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (KT > 1) issue(1, half == 1);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): no scalar load is pending past this point (see conv_gemm.hip)
     fetch(smem, 0, 0);
     for (int kt = 0; kt < KT; ++kt) {
       const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
