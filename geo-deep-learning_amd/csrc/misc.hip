@@ -853,7 +853,7 @@ extern "C" int gdl_head_1x1(const void* feat, int dtype, int64_t P, int C, int64
 }
 
 extern "C" int64_t gdl_head_1x1_bwd_workspace(int64_t P, int C, int K) {
-  int64_t ns = P / 256; if (ns < 1) ns = 1; if (ns > 128) ns = 128;
+  int64_t ns = P / 256; if (ns < 1) ns = 1; if (ns > 512) ns = 512;
   return ns * (K + 1) * (int64_t)C * sizeof(float);
 }
 
@@ -864,7 +864,7 @@ extern "C" int gdl_head_1x1_bwd(const void* feat, int dtype, const float* dlog, 
   GDL_CHECK_ARG(feat && dlog && w && dw && ws && C % 4 == 0 && f_sP % 4 == 0, "gdl_head_1x1_bwd: bad args");
   GDL_CHECK_ARG(ws_bytes >= gdl_head_1x1_bwd_workspace(P, C, K), "gdl_head_1x1_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  int64_t ns = P / 256; if (ns < 1) ns = 1; if (ns > 128) ns = 128;
+  int64_t ns = P / 256; if (ns < 1) ns = 1; if (ns > 512) ns = 512;
   const int nsplit = (int)ns;
   dim3 gridw((C + 255) / 256, nsplit);
   const int64_t total = P * (C / 4);

@@ -84,7 +84,17 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const void* __restrict__
   const int64_t p0 = per * blockIdx.y, p1 = p0 + per < P ? p0 + per : P;
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (c < C) {
-    for (int64_t p = p0 + w; p < p1; p += 4) {
+    int64_t p = p0 + w;
+    for (; p + 12 < p1; p += 16) {              // four independent loads in flight per lane
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load4<T>(x, (p + 4 * u) * x_sP + c, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] += v[u][j]; q[j] += v[u][j] * v[u][j]; }
+    }
+    for (; p < p1; p += 4) {
       float v[4];
       load4<T>(x, p * x_sP + c, v);
 #pragma unroll
@@ -184,7 +194,21 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const void* __restrict__ x
     for (int j = 0; j < 4; ++j) {
       mu[j] = mean[c + j]; rs[j] = rsqrtf(var[c + j] + eps); ga[j] = gamma[c + j]; be[j] = beta[c + j];
     }
-    for (int64_t p = p0 + w; p < p1; p += 4) {
+    int64_t p = p0 + w;
+    for (; p + 4 < p1; p += 8) {                // two pixel rows (four loads) in flight per lane
+      float v[2][4], g[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { load4<T>(x, (p + 4 * u) * x_sP + c, v[u]); load4<T>(dy, (p + 4 * u) * dy_sP + c, g[u]); }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (v[u][j] - mu[j]) * rs[j];
+          const float gg = (relu && !(xh * ga[j] + be[j] > 0.f)) ? 0.f : g[u][j];
+          s[j] += gg; q[j] += gg * xh;
+        }
+    }
+    for (; p < p1; p += 4) {
       float v[4], g[4];
       load4<T>(x, p * x_sP + c, v);
       load4<T>(dy, p * dy_sP + c, g);
@@ -268,10 +292,12 @@ int bn_ew_splits(int64_t P, int C) {
   return (int)n;
 }
 
-int bn_nsplit(int64_t P) {
+int bn_nsplit(int64_t P, int C) {
+  // ~2048 blocks in total (8 per CU): these reductions are HBM-bound and need many waves in flight
+  const int cg = (C + 255) / 256;
   int64_t n = P / 64;
   if (n < 1) n = 1;
-  if (n > 256) n = 256;
+  if (n > 2048 / cg) n = 2048 / cg;
   return (int)n;
 }
 
@@ -298,7 +324,7 @@ extern "C" int gdl_layernorm_fwd(const float* x, int64_t x_stride, const float* 
 }
 
 extern "C" int64_t gdl_bn_stats_workspace(int64_t P, int C) {
-  return (int64_t)bn_nsplit(P) * 2 * C * sizeof(float);
+  return (int64_t)bn_nsplit(P, C) * 2 * C * sizeof(float);
 }
 
 extern "C" int gdl_bn_stats(const void* x, int dtype, int64_t P, int C, int64_t x_sP, float* mean,
@@ -308,7 +334,7 @@ extern "C" int gdl_bn_stats(const void* x, int dtype, int64_t P, int C, int64_t 
   GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && P > 0, "gdl_bn_stats: C and stride must be multiples of 4");
   GDL_CHECK_ARG(ws_bytes >= gdl_bn_stats_workspace(P, C), "gdl_bn_stats: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  const int nsplit = bn_nsplit(P);
+  const int nsplit = bn_nsplit(P, C);
   dim3 grid((C + 255) / 256, nsplit);
   if (dtype == GDL_BF16) hipLaunchKernelGGL(bn_stats_partial<uint16_t>, grid, dim3(256), 0, s, x, P, C, x_sP, ws);
   else hipLaunchKernelGGL(bn_stats_partial<float>, grid, dim3(256), 0, s, x, P, C, x_sP, ws);
@@ -342,7 +368,7 @@ extern "C" int gdl_bn_bwd_reduce(const void* x, const void* dy, int dtype, int64
   GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && dy_sP % 4 == 0, "gdl_bn_bwd_reduce: C/strides % 4");
   GDL_CHECK_ARG(ws_bytes >= gdl_bn_stats_workspace(P, C), "gdl_bn_bwd_reduce: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  const int nsplit = bn_nsplit(P);
+  const int nsplit = bn_nsplit(P, C);
   dim3 grid((C + 255) / 256, nsplit);
   if (dtype == GDL_BF16)
     hipLaunchKernelGGL(bn_bwd_partial<uint16_t>, grid, dim3(256), 0, s, x, dy, P, C, x_sP, dy_sP, mean, var, gamma, beta, eps, relu, ws);
