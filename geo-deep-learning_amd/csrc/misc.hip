@@ -319,19 +319,26 @@ __global__ __launch_bounds__(256) void head_1x1_bwd_w_partial(const void* __rest
 }
 
 template <int K>
-__global__ void head_1x1_bwd_w_final(const float* __restrict__ ws, int nsplit, int C, float* __restrict__ dw,
-                                     float* __restrict__ db) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < K * C) {
-    double s = 0;
-    for (int sp = 0; sp < nsplit; ++sp) s += ws[(int64_t)sp * (K + 1) * C + i];
-    dw[i] = (float)s;
+__global__ __launch_bounds__(256) void head_1x1_bwd_w_final(const float* __restrict__ ws, int nsplit, int C,
+                                                            float* __restrict__ dw, float* __restrict__ db) {
+  // outputs 0..K*C-1 = dw, K*C..K*C+K-1 = db; block = 8 outputs x 32 split groups
+  __shared__ double part[32][8];
+  const int cl = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + cl;
+  const int total = K * C + (db ? K : 0);
+  double s = 0;
+  if (i < total) {
+    const int64_t off = i < K * C ? i : (int64_t)K * C + (i - K * C);
+    for (int sp = grp; sp < nsplit; sp += 32) s += ws[(int64_t)sp * (K + 1) * C + off];
   }
-  if (i < K && db) {
-    double s = 0;
-    for (int sp = 0; sp < nsplit; ++sp) s += ws[(int64_t)sp * (K + 1) * C + (int64_t)K * C + i];
-    db[i] = (float)s;
-  }
+  part[grp][cl] = s;
+  __syncthreads();
+  if (grp != 0 || i >= total) return;
+  s = 0;
+#pragma unroll
+  for (int g = 0; g < 32; ++g) s += part[g][cl];
+  if (i < K * C) dw[i] = (float)s;
+  else db[i - K * C] = (float)s;
 }
 
 __device__ __forceinline__ void src_index2(float ratio, int dst, int in_size, int& i0, int& i1, float& l1) {
@@ -876,7 +883,7 @@ extern "C" int gdl_head_1x1_bwd(const void* feat, int dtype, const float* dlog, 
       if (dfeat) hipLaunchKernelGGL((head_1x1_bwd_feat_kernel<float, KK>), dim3(grid_for(total)), dim3(256), 0, s, dlog, P, C, w, chan_scale, pix_per_img, dfeat, d_sP);
       hipLaunchKernelGGL((head_1x1_bwd_w_partial<float, KK>), gridw, dim3(256), 0, s, feat, dlog, P, C, f_sP, chan_scale, pix_per_img, ws);
     }
-    hipLaunchKernelGGL((head_1x1_bwd_w_final<KK>), dim3((KK * C + 255) / 256), dim3(256), 0, s, ws, nsplit, C, dw, db));
+    hipLaunchKernelGGL((head_1x1_bwd_w_final<KK>), dim3((KK * C + KK + 7) / 8), dim3(256), 0, s, ws, nsplit, C, dw, db));
   GDL_CHECK_LAUNCH("gdl_head_1x1_bwd");
   return GDL_OK;
 }

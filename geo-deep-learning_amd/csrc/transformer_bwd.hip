@@ -8,24 +8,25 @@ namespace {
 // out[i] (+)= sum_blk ws[blk*total + i]; 32 columns x 8 block-groups per 256-thread block
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, int nblk, int64_t stride,
                                                               int total, float* __restrict__ out, int accumulate) {
-  __shared__ double part[8][32];
-  const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + cl;
+  // block = 8 columns x 32 partial groups
+  __shared__ double part[32][8];
+  const int cl = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + cl;
   double s = 0;
   if (i < total)
-    for (int b = grp; b < nblk; b += 8) s += ws[(int64_t)b * stride + i];
+    for (int b = grp; b < nblk; b += 32) s += ws[(int64_t)b * stride + i];
   part[grp][cl] = s;
   __syncthreads();
   if (grp != 0 || i >= total) return;
   s = 0;
 #pragma unroll
-  for (int g = 0; g < 8; ++g) s += part[g][cl];
+  for (int g = 0; g < 32; ++g) s += part[g][cl];
   out[i] = accumulate ? out[i] + (float)s : (float)s;
 }
 
 inline void launch_reduce(const float* ws, int nblk, int64_t stride, int total, float* out, int accumulate,
                           hipStream_t s) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 31) / 32), dim3(256), 0, s, ws, nblk, stride, total, out,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((total + 7) / 8), dim3(256), 0, s, ws, nblk, stride, total, out,
                      accumulate);
 }
 
