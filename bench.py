@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--with-input-stage", action="store_true",
                     help="also time the train step fed by host uint8 tiles through DeviceInputStage (PCIe-inclusive; "
                          "reported beside `value`, never as `value`)")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="take the multi-GPU code path (RCCL group, SyncBatchNorm, DDP) even with one rank (self-test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     return ap.parse_args()
@@ -120,6 +122,11 @@ def cpu_baseline():
 
 def main() -> None:
     args = parse()
+    # RCCL prints a version banner to the C-level stdout of every rank: keep a private handle on the real stdout for
+    # the ONE JSON line and send everything else written to fd 1 to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -129,8 +136,12 @@ def main() -> None:
             sys.exit(2)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    dist_on = world > 1 or args.force_ddp
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=device)
 
     from gdlhip import ops
@@ -155,7 +166,7 @@ def main() -> None:
             optimizer=lambda params: FusedAdam(params, lr=6e-5, max_grad_norm=1.0))
     task.configure_model()
     task.to(device)
-    if world > 1:
+    if dist_on:
         # Lightning's `sync_batchnorm: true` + DDPStrategy(gradient_as_bucket_view=true)
         task.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(task.model)
         task.model = torch.nn.parallel.DistributedDataParallel(
@@ -220,7 +231,7 @@ def main() -> None:
                 "note": "host uint8 tiles -> pinned ring -> copy stream (2 batches ahead) -> normalise kernel -> step"}
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -277,8 +288,9 @@ def main() -> None:
         out["pcie_inclusive"] = pcie
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(out))
-    if world > 1:
+    json_out.write(json.dumps(out) + "\n")
+    json_out.flush()
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -89,6 +89,8 @@ def _param_grad(dw: Tensor, weight: Tensor, cpad: int) -> Tensor:
     d = dw.view(-1, r * s, cpad)[:n, :, :c]
     if _is_flat(weight):
         return d.reshape(weight.shape)
+    if r == 1 and s == 1:
+        return d.reshape(n, c, 1, 1)
     return d.reshape(n, r, s, c).permute(0, 3, 1, 2)
 
 

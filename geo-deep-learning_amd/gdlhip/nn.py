@@ -180,7 +180,9 @@ class _ConvBNActTrain(Function):
         dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, p_local * world, out=y)
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(x, dy, R=r, S=s, pad=pad).view(n, r, s, c).permute(0, 3, 1, 2)
+            dw = ops.conv_wgrad(x, dy, R=r, S=s, pad=pad)
+            # same strides as the channels-last parameter (for 1x1 kernels torch keeps (C,1,1,1))
+            dw = dw.view(n, c, 1, 1) if r == 1 and s == 1 else dw.view(n, r, s, c).permute(0, 3, 1, 2)
         dbias = None
         if has_bias and ctx.needs_input_grad[2]:
             # a bias feeding train-mode BN has an analytically zero gradient

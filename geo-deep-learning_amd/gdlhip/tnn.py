@@ -78,6 +78,8 @@ def _as_param_grad(dw: Tensor, weight: Tensor) -> Tensor:
     if weight.dim() == 2:
         return dw
     n, c, r, s = weight.shape
+    if r == 1 and s == 1:
+        return dw.view(n, c, 1, 1)          # the strides torch keeps for a channels-last 1x1 parameter
     return dw.view(n, r, s, c).permute(0, 3, 1, 2)
 
 

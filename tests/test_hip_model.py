@@ -398,3 +398,57 @@ def test_multiband_configs_match_oracle(encoder, size, bands, tol):
     assert (gnn.predict_mask(y).cpu().numpy() == want)[decided].all()
     assert (yb.float().cpu() - yo).abs().max().item() < 0.08 * yo.abs().max().item()
     assert (gnn.predict_mask(yb).cpu().numpy() == want).mean() > 0.95
+
+
+def test_ddp_syncbn_wrapper_single_rank(tiny):
+    """The N>1 launch path of bench.py (SyncBatchNorm conversion + DistributedDataParallel with
+    gradient_as_bucket_view + the fused optimizer) on a 1-rank RCCL group: same loss and gradients as the bare model,
+    and the optimizer step works on the bucket-view gradients."""
+    import os
+    import torch.distributed as dist
+    g, meta, ref, _, batch = tiny
+    nc, img, b, seed = meta["num_classes"], meta["img"], meta["batch"], meta["seed"]
+    sd = procedural_state_dict(ref, seed)
+
+    def build():
+        enc = DOFAv2(img_size=img, pretrained=False, **meta["tiny"])
+        m = DOFASegmentationModel(enc, (img,) * 2, num_classes=nc, pretrained=False, freeze_layers=["encoder"])
+        m.load_state_dict(sd)
+        return m.to(DEV).train()
+    masks = _drop_masks(meta["tiny"]["depth"], 0.1, b, seed)
+    am = _aux_mask(b, 256, seed)
+    y = batch["mask"].squeeze(1).long().to(DEV)
+    crit = gnn.DiceLoss(mode="multiclass")
+
+    def step(model):
+        r = model(batch["image"].to(DEV), batch["wavelengths"], masks, am)
+        loss = crit(r.out, y) + 0.4 * crit(r.aux, y)
+        loss.backward()
+        return loss.item()
+    bare = build()
+    l0 = step(bare)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 2000))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(build())
+        ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], gradient_as_bucket_view=True,
+                                                        find_unused_parameters=False)
+        l1 = step(ddp)
+        assert abs(l1 - l0) < 1e-6
+        for (n, p), (_, q) in zip(bare.named_parameters(), m.named_parameters()):
+            if p.grad is None:
+                assert q.grad is None, n
+                continue
+            assert torch.allclose(p.grad, q.grad, atol=1e-6, rtol=1e-5), n
+        before = {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+        opt = gnn.FusedAdam([p for p in m.parameters() if p.requires_grad], lr=1e-3, max_grad_norm=1.0)
+        opt.step()
+        moved = [n for n, p in m.named_parameters() if p.requires_grad and not torch.equal(before[n], p.detach())]
+        expect = [n for n, p in m.named_parameters() if p.requires_grad and p.grad.abs().max() > 0]
+        assert moved == expect and len(moved) > 60      # zero-gradient biases in front of a BN do not move
+        opt.zero_grad(set_to_none=True)
+        l2 = step(ddp)                      # a second step through the same buckets
+        assert abs(l2 - l1) > 0 and l2 == l2
+    finally:
+        dist.destroy_process_group()
