@@ -73,28 +73,42 @@ __device__ __forceinline__ void store4(void* p, int64_t off, const float (&o)[4]
   }
 }
 
+// Lane -> (4-channel group, pixel sub-index).  Wide layers: the 64 lanes of a wave cover 256 channels of ONE pixel.
+// Narrow layers (C <= 128: MiT stages 1-2, ResNet / UNet++ 64- and 128-channel maps): 16 or 32 lanes cover a pixel
+// and the wave handles 4 or 2 pixels per step, so no lane idles.  A wave then strides 4 * nsub pixels.
+struct LaneMap { int c, sub, nsub, lpp; };
+__device__ __forceinline__ LaneMap lane_map(int lane, int C, int block_x) {
+  const int lpp = C > 128 ? 64 : (C > 64 ? 32 : 16);
+  LaneMap m;
+  m.lpp = lpp; m.nsub = 64 / lpp; m.sub = lane / lpp; m.c = block_x * 256 + (lane % lpp) * 4;
+  return m;
+}
+// index into a per-wave [64 lanes][4] scratch row of the value lane-group `sub` holds for channel t of the block
+__device__ __forceinline__ int lane_slot(const LaneMap& m, int sub, int t) { return (sub * m.lpp + (t >> 2)) * 4 + (t & 3); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_partial(const void* __restrict__ x, int64_t P, int C,
                                                         int64_t x_sP, float* __restrict__ ws) {
   __shared__ float red[2][4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 256 + lane * 4;
+  const LaneMap lm = lane_map(lane, C, blockIdx.x);
+  const int c = lm.c, st = 4 * lm.nsub;
   const int nsplit = gridDim.y;
   const int64_t per = (P + nsplit - 1) / nsplit;
   const int64_t p0 = per * blockIdx.y, p1 = p0 + per < P ? p0 + per : P;
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   if (c < C) {
-    int64_t p = p0 + w;
-    for (; p + 12 < p1; p += 16) {              // four independent loads in flight per lane
+    int64_t p = p0 + w * lm.nsub + lm.sub;
+    for (; p + 3 * st < p1; p += 4 * st) {      // four independent loads in flight per lane
       float v[4][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) load4<T>(x, (p + 4 * u) * x_sP + c, v[u]);
+      for (int u = 0; u < 4; ++u) load4<T>(x, (p + st * u) * x_sP + c, v[u]);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s[j] += v[u][j]; q[j] += v[u][j] * v[u][j]; }
     }
-    for (; p < p1; p += 4) {
+    for (; p < p1; p += st) {
       float v[4];
       load4<T>(x, p * x_sP + c, v);
 #pragma unroll
@@ -107,8 +121,12 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const void* __restrict__
   const int t = threadIdx.x;
   const int cc = blockIdx.x * 256 + t;
   if (cc < C) {
-    const float ss = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
-    const float qq = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+    float ss = 0.f, qq = 0.f;
+    for (int sub = 0; sub < lm.nsub; ++sub) {
+      const int i = lane_slot(lm, sub, t);
+      ss += (red[0][0][i] + red[0][1][i]) + (red[0][2][i] + red[0][3][i]);
+      qq += (red[1][0][i] + red[1][1][i]) + (red[1][2][i] + red[1][3][i]);
+    }
     ws[((int64_t)blockIdx.y * 2 + 0) * C + cc] = ss;
     ws[((int64_t)blockIdx.y * 2 + 1) * C + cc] = qq;
   }
@@ -152,14 +170,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ 
                                                        int relu) {
   // lane owns 4 fixed channels (params live in registers); grid = (C/256, pixel splits)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 256 + lane * 4;
+  const LaneMap lm = lane_map(lane, C, blockIdx.x);
+  const int c = lm.c;
   if (c >= C) return;
   float mu[4], sc[4], be[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; sc[j] = rsqrtf(var[c + j] + eps) * gamma[c + j]; be[j] = beta[c + j]; }
   const int64_t per = (P + gridDim.y - 1) / gridDim.y;
   const int64_t p0 = per * blockIdx.y, p1 = p0 + per < P ? p0 + per : P;
-  for (int64_t p = p0 + w; p < p1; p += 4) {
+  for (int64_t p = p0 + w * lm.nsub + lm.sub; p < p1; p += 4 * lm.nsub) {
     float v[4];
     load4<T>(x, p * x_sP + c, v);
 #pragma unroll
@@ -183,7 +202,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const void* __restrict__ x
                                                       float* __restrict__ ws) {
   __shared__ float red[2][4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 256 + lane * 4;
+  const LaneMap lm = lane_map(lane, C, blockIdx.x);
+  const int c = lm.c, st = 4 * lm.nsub;
   const int nsplit = gridDim.y;
   const int64_t per = (P + nsplit - 1) / nsplit;
   const int64_t p0 = per * blockIdx.y, p1 = p0 + per < P ? p0 + per : P;
@@ -194,11 +214,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const void* __restrict__ x
     for (int j = 0; j < 4; ++j) {
       mu[j] = mean[c + j]; rs[j] = rsqrtf(var[c + j] + eps); ga[j] = gamma[c + j]; be[j] = beta[c + j];
     }
-    int64_t p = p0 + w;
-    for (; p + 4 < p1; p += 8) {                // two pixel rows (four loads) in flight per lane
+    int64_t p = p0 + w * lm.nsub + lm.sub;
+    for (; p + st < p1; p += 2 * st) {          // two pixel rows (four loads) in flight per lane
       float v[2][4], g[2][4];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) { load4<T>(x, (p + 4 * u) * x_sP + c, v[u]); load4<T>(dy, (p + 4 * u) * dy_sP + c, g[u]); }
+      for (int u = 0; u < 2; ++u) { load4<T>(x, (p + st * u) * x_sP + c, v[u]); load4<T>(dy, (p + st * u) * dy_sP + c, g[u]); }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const void* __restrict__ x
           s[j] += gg; q[j] += gg * xh;
         }
     }
-    for (; p < p1; p += 4) {
+    for (; p < p1; p += st) {
       float v[4], g[4];
       load4<T>(x, p * x_sP + c, v);
       load4<T>(dy, p * dy_sP + c, g);
@@ -225,8 +245,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const void* __restrict__ x
   __syncthreads();
   const int t = threadIdx.x, cc = blockIdx.x * 256 + t;
   if (cc < C) {
-    ws[((int64_t)blockIdx.y * 2 + 0) * C + cc] = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
-    ws[((int64_t)blockIdx.y * 2 + 1) * C + cc] = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+    float ss = 0.f, qq = 0.f;
+    for (int sub = 0; sub < lm.nsub; ++sub) {
+      const int i = lane_slot(lm, sub, t);
+      ss += (red[0][0][i] + red[0][1][i]) + (red[0][2][i] + red[0][3][i]);
+      qq += (red[1][0][i] + red[1][1][i]) + (red[1][2][i] + red[1][3][i]);
+    }
+    ws[((int64_t)blockIdx.y * 2 + 0) * C + cc] = ss;
+    ws[((int64_t)blockIdx.y * 2 + 1) * C + cc] = qq;
   }
 }
 
@@ -259,7 +285,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx(const void* __restrict__ x, con
                                                  const float* __restrict__ dbeta) {
   const float invP = 1.0f / (float)P_total;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 256 + lane * 4;
+  const LaneMap lm = lane_map(lane, C, blockIdx.x);
+  const int c = lm.c;
   if (c >= C) return;
   float mu[4], rs[4], ga[4], be[4], k1[4], k2[4];
 #pragma unroll
@@ -269,7 +296,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx(const void* __restrict__ x, con
   }
   const int64_t per = (P + gridDim.y - 1) / gridDim.y;
   const int64_t p0 = per * blockIdx.y, p1 = p0 + per < P ? p0 + per : P;
-  for (int64_t p = p0 + w; p < p1; p += 4) {
+  for (int64_t p = p0 + w * lm.nsub + lm.sub; p < p1; p += 4 * lm.nsub) {
     float v[4], g[4];
     load4<T>(x, p * x_sP + c, v);
     load4<T>(dy, p * dy_sP + c, g);

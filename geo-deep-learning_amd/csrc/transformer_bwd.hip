@@ -1,7 +1,7 @@
 // Backward kernels of the transformer blocks (timm ViT Block / SegFormer MiT Block): all HBM-bound,
 // f32 arithmetic, wave-shuffle row reductions; column reductions go through per-block partials in a
 // workspace + a deterministic (double) final pass -- no float atomics anywhere.
-#include "gdl_common.h"
+#include "dwconv_walk.h"
 
 namespace {
 
@@ -221,89 +221,70 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const void* __res
 }
 
 // ---------------------------------------------------------------- depthwise 3x3 (+GELU) backward
-// forward: pre = dw3x3(u) + b ; y = gelu(pre).  (a) dpre = dy * gelu'(pre)   [pre recomputed from u]
+// forward: pre = dw3x3(u) + b ; y = gelu(pre).  One pass over u and dy with the 3x3 window of u in registers
+// (dwconv_walk.h):  dpre = dy * gelu'(pre) [pre recomputed], written once, and in the same step
+//   dw9[t][c] += dpre[p,c] * u[p + tap t, c] ; db[c] += dpre[p,c]      -> partials ws[split][10][C]
+// Narrow tensors (C <= 128) put 4 or 2 row segments side by side in a wave.
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv_gelu_bwd_pre_kernel(const void* __restrict__ u, const void* __restrict__ dy,
-                                                                  int B, int H, int W, int C, const float* __restrict__ w9,
-                                                                  const float* __restrict__ bias, void* dpre) {
-  const int cv = C / 4;
-  const int64_t total = (int64_t)B * H * W * cv;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % cv) * 4;
-    int64_t t = i / cv;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H);
-    const int b = (int)(t / H);
-    const float4 bb = *(const float4*)(bias + c);
-    float acc[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int yy = y + r - 1;
-      if ((unsigned)yy >= (unsigned)H) continue;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int xx = x + s - 1;
-        if ((unsigned)xx >= (unsigned)W) continue;
-        const int64_t off = (((int64_t)b * H + yy) * W + xx) * C + c;
-        float v[4];
-        v[0] = ElemIO<T>::load(u, off); v[1] = ElemIO<T>::load(u, off + 1); v[2] = ElemIO<T>::load(u, off + 2); v[3] = ElemIO<T>::load(u, off + 3);
-        const float4 ww = *(const float4*)(w9 + (r * 3 + s) * C + c);
-        acc[0] += v[0] * ww.x; acc[1] += v[1] * ww.y; acc[2] += v[2] * ww.z; acc[3] += v[3] * ww.w;
-      }
-    }
-    const int64_t o = (((int64_t)b * H + y) * W + x) * C + c;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float xv = acc[j];
-      const float cdf = 0.5f * (1.0f + erff(xv * 0.70710678118654752440f));
-      const float pdf = 0.3989422804014327f * expf(-0.5f * xv * xv);
-      ElemIO<T>::store(dpre, o + j, ElemIO<T>::load(dy, o + j) * (cdf + xv * pdf));
-    }
-  }
-}
-
-// (c) dw9[t][c] = sum_pixels dpre[p,c] * u[p+tap t, c] ; db[c] = sum dpre  -> partials ws[split][10][C]
-template <typename T>
-__global__ __launch_bounds__(256) void dwconv_wgrad_partial_kernel(const void* __restrict__ u, const void* __restrict__ dpre,
-                                                                   int B, int H, int W, int C, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void dwconv_gelu_bwd_kernel(const void* __restrict__ u, const void* __restrict__ dy,
+                                                              int H, int W, int C, const float* __restrict__ w9,
+                                                              const float* __restrict__ bias, void* __restrict__ dpre,
+                                                              float* __restrict__ ws, int seglen, int nseg,
+                                                              int64_t items) {
   __shared__ float red[4][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c = blockIdx.x * 256 + lane * 4;
-  const int64_t P = (int64_t)B * H * W;
-  const int64_t per = (P + gridDim.y - 1) / gridDim.y;
-  const int64_t p0 = per * blockIdx.y, p1 = p0 + per < P ? p0 + per : P;
+  const int lpp = C > 128 ? 64 : (C > 64 ? 32 : 16), nsub = 64 / lpp, sub = lane / lpp;
+  const int c = blockIdx.x * 256 + (lane % lpp) * 4;
+  const int64_t per = (items + gridDim.y - 1) / gridDim.y;
+  const int64_t i0 = per * blockIdx.y, i1 = i0 + per < items ? i0 + per : items;
   float acc[10][4];
 #pragma unroll
   for (int t = 0; t < 10; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
-  if (c < C)
-    for (int64_t p = p0 + wv; p < p1; p += 4) {
-      const int x = (int)(p % W);
-      const int64_t q = p / W;
-      const int y = (int)(q % H);
-      float d[4];
+  if (c < C) {
+    gdldw::Taps tp;
+    tp.load(w9, bias, C, c);
+    for (int64_t item = i0 + wv * nsub + sub; item < i1; item += 4 * nsub) {
+      const gdldw::Seg sg = gdldw::seg_of(item, H, W, seglen, nseg);
+      gdldw::walk<T>(u, sg, H, W, C, c, [&](int x, const float (&L)[3][4], const float (&M)[3][4], const float (&R)[3][4]) {
+        const int64_t off = (sg.pix + x) * C + c;
+        const typename gdldw::Px<T>::raw graw = gdldw::Px<T>::ld(dy, off);
+        float pre[4], g[4], d[4];
+        tp.apply(L, M, R, pre);
+        gdldw::Px<T>::cvt(graw, g);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { d[j] = ElemIO<T>::load(dpre, p * C + c + j); acc[9][j] += d[j]; }
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const int yy = y + r - 1;
-        if ((unsigned)yy >= (unsigned)H) continue;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const int xx = x + s - 1;
-          if ((unsigned)xx >= (unsigned)W) continue;
-          const int64_t off = (p + (int64_t)(r - 1) * W + (s - 1)) * C + c;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[r * 3 + s][j] += d[j] * ElemIO<T>::load(u, off + j);
+        for (int j = 0; j < 4; ++j) d[j] = g[j] * gelu_erf_grad(pre[j]);
+        gdldw::Px<T>::st(dpre, off, d);
+        if (sizeof(typename gdldw::Px<T>::raw) == 8) {       // the weight gradient sees dpre as stored (bf16)
+          d[0] = __uint_as_float(pack_bf16x2(0.f, d[0]) & 0xffff0000u); d[1] = __uint_as_float(pack_bf16x2(0.f, d[1]) & 0xffff0000u);
+          d[2] = __uint_as_float(pack_bf16x2(0.f, d[2]) & 0xffff0000u); d[3] = __uint_as_float(pack_bf16x2(0.f, d[3]) & 0xffff0000u);
         }
-      }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[r * 3 + 0][j] += d[j] * L[r][j];
+            acc[r * 3 + 1][j] += d[j] * M[r][j];
+            acc[r * 3 + 2][j] += d[j] * R[r][j];
+          }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[9][j] += d[j];
+      });
     }
+  }
   float* wsb = ws + (int64_t)blockIdx.y * 10 * C;
   for (int t = 0; t < 10; ++t) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[wv][lane * 4 + j] = acc[t][j];
     __syncthreads();
     const int tt = threadIdx.x, cc = blockIdx.x * 256 + tt;
-    if (cc < C) wsb[(int64_t)t * C + cc] = (red[0][tt] + red[1][tt]) + (red[2][tt] + red[3][tt]);
+    if (cc < C) {
+      float sum = 0.f;
+      for (int sb = 0; sb < nsub; ++sb) {
+        const int i = (sb * lpp + (tt >> 2)) * 4 + (tt & 3);
+        sum += (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+      }
+      wsb[(int64_t)t * C + cc] = sum;
+    }
     __syncthreads();
   }
 }
@@ -445,17 +426,16 @@ extern "C" int gdl_dwconv3x3_gelu_bwd(const void* u, const void* dy, int dtype, 
   GDL_CHECK_ARG(ws_bytes >= gdl_colreduce_workspace(P, C, 10), "gdl_dwconv3x3_gelu_bwd: workspace too small");
   if (P <= 0) return GDL_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int64_t total = P * (C / 4);
-  const unsigned nb = (unsigned)((total + 255) / 256 < 65535 * 4 ? (total + 255) / 256 : 65535 * 4);
-  const int nblk = row_blocks(P);
+  const int seglen = gdldw::seg_len(W), nseg = (W + seglen - 1) / seglen;
+  const int64_t items = (int64_t)B * nseg * H;
+  const int nsub = C > 128 ? 1 : (C > 64 ? 2 : 4);
+  int nblk = row_blocks(P);                                   // the workspace holds row_blocks(P) partials
+  if (nblk > (items + 4 * nsub - 1) / (4 * nsub)) nblk = (int)((items + 4 * nsub - 1) / (4 * nsub));
   const dim3 grid((C + 255) / 256, nblk);
-  if (dtype == GDL_BF16) {
-    hipLaunchKernelGGL(dwconv_gelu_bwd_pre_kernel<bf16_tag>, dim3(nb), dim3(256), 0, s, u, dy, B, H, W, C, w9, bias, dpre);
-    hipLaunchKernelGGL(dwconv_wgrad_partial_kernel<bf16_tag>, grid, dim3(256), 0, s, u, dpre, B, H, W, C, ws);
-  } else {
-    hipLaunchKernelGGL(dwconv_gelu_bwd_pre_kernel<float>, dim3(nb), dim3(256), 0, s, u, dy, B, H, W, C, w9, bias, dpre);
-    hipLaunchKernelGGL(dwconv_wgrad_partial_kernel<float>, grid, dim3(256), 0, s, u, dpre, B, H, W, C, ws);
-  }
+  if (dtype == GDL_BF16)
+    hipLaunchKernelGGL(dwconv_gelu_bwd_kernel<bf16_tag>, grid, dim3(256), 0, s, u, dy, H, W, C, w9, bias, dpre, ws, seglen, nseg, items);
+  else
+    hipLaunchKernelGGL(dwconv_gelu_bwd_kernel<float>, grid, dim3(256), 0, s, u, dy, H, W, C, w9, bias, dpre, ws, seglen, nseg, items);
   launch_reduce(ws, nblk, 10 * (int64_t)C, 9 * C, dw9, accumulate, s);
   launch_reduce(ws + 9 * (int64_t)C, nblk, 10 * (int64_t)C, C, dbias, accumulate, s);
   GDL_CHECK_LAUNCH("gdl_dwconv3x3_gelu_bwd");

@@ -160,7 +160,7 @@ def test_layernorm(out_dtype, D):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,W,C", [(2, 9, 7, 64), (2, 1, 1, 256), (3, 24, 24, 128)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 7, 64), (2, 1, 1, 256), (3, 24, 24, 128), (2, 31, 9, 32), (1, 17, 23, 320)])
 def test_batchnorm_train(dtype, B, H, W, C):
     x = q(rnd(B, H, W, C) * 2 + 0.5, dtype)
     g, b = rnd(C, seed=1), rnd(C, seed=2)
@@ -262,6 +262,36 @@ def test_wgrad_strided_dy(dtype, C, N):
     w = torch.zeros(N, C, 3, 3, requires_grad=True)
     F.conv2d(xr, w, padding=1).backward(big[..., N:2 * N].permute(0, 3, 1, 2))
     close(dw.view(N, 3, 3, C).permute(0, 3, 1, 2), w.grad, dtype, "wgrad strided dy")
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 5, 64, 64, 64), (1, 3, 128, 128, 32), (2, 1, 64, 72, 64), (1, 24, 64, 192, 128),
+                                       (3, 64, 64, 64, 16)])
+def test_wgrad_row_segment_kernel(B, H, W, C, N):
+    """3x3 convs on maps whose width is a multiple of 64 take the row-segment kernel (all nine taps per block): checked
+    against autograd and against the per-tap kernel it replaces (same products, different summation order)."""
+    from gdlhip import _lib
+    dtype = torch.bfloat16
+    x = q(rnd(B, C, H, W), dtype)
+    dy = q(rnd(B, N, H, W, seed=2), dtype)
+    w = torch.zeros(N, C, 3, 3, requires_grad=True)
+    F.conv2d(x, w, padding=1).backward(dy)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    dw = ops.conv_wgrad(xn, dyn, R=3, S=3, pad=1)
+    close(dw.view(N, 3, 3, C).permute(0, 3, 1, 2), w.grad, dtype, "row-segment wgrad")
+    lib = _lib.load()
+    lib.gdl_debug_force_wgrad_small(3)
+    try:
+        old = ops.conv_wgrad(xn, dyn, R=3, S=3, pad=1)
+    finally:
+        lib.gdl_debug_force_wgrad_small(0)
+    assert (dw - old).abs().max().item() <= 1e-4 * old.abs().max().item()
+    # accumulate into an existing gradient, dy as a channel slice of a wider buffer
+    big = torch.zeros(B, H, W, N + 16, device=DEV, dtype=dtype)
+    big[..., 8:8 + N] = dyn
+    acc = torch.ones_like(dw)
+    ops.conv_wgrad(xn, big[..., 8:8 + N], R=3, S=3, pad=1, dw=acc, accumulate=True)
+    assert (acc - 1 - dw).abs().max().item() <= 1e-3 * dw.abs().max().item() + 1e-5
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -367,7 +397,7 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 256), (1, 9, 7, 64)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 256), (1, 9, 7, 64), (2, 5, 70, 128), (1, 1, 1, 64), (2, 3, 33, 320)])
 def test_dwconv3x3_gelu(dtype, B, H, W, C):
     x = q(rnd(B, C, H, W), dtype)
     w, b = rnd(C, 1, 3, 3, seed=1) * 0.3, rnd(C, seed=2)

@@ -68,7 +68,7 @@ def test_colsum_and_layerscale_bwd(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 256), (1, 9, 7, 64)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 256), (1, 9, 7, 64), (2, 5, 70, 128), (1, 1, 1, 64), (2, 3, 33, 320)])
 def test_dwconv_gelu_bwd(dtype, B, H, W, C):
     u = q(rnd(B, H, W, C), dtype).requires_grad_()
     w = (0.3 * rnd(C, 1, 3, 3, seed=1)).requires_grad_()
