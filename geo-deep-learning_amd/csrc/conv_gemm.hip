@@ -34,7 +34,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // PP ("ping-pong", 8-wave tile only): the two waves that share a SIMD (w and w+4) take turns being the LOADER of a
 // K-step: the loader half issues the whole next tile's DMA while its partners go straight to their MFMAs, so the
 // matrix pipe never idles behind a workgroup-wide DMA-issue phase; the halves swap roles every K-step.
-template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false>
+// CT ("channel tail", small tiles only): C is not a multiple of the K chunk (MiT-B0: 32 / 160 channels in bf16, 32-wide
+// attention heads); the 16-byte pieces past C in the last chunk of every tap are fetched as zeros.
+template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false, bool CT = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const KArgs k) {
   constexpr int ES = TileTraits<T>::ES;
   constexpr int BKE = TileTraits<T>::BKE;
@@ -76,11 +78,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   const int half = PP ? (wave >> 2) : 0;      // waves w and w+4 share a SIMD
   int a_voff[CA];        // byte offset of (b, iy0, ix0, chunk) for the row at tap (0,0), cc = 0 (may be negative)
   unsigned a_mask[CA];   // bit t set <=> filter tap t of this row reads inside the image
+  unsigned a_tail = 0, b_tail = 0;   // CT: bit i set <=> instruction i's 16-byte piece lies inside the last chunk's C tail
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int i = 0; i < CA; ++i) {
     const int r = (i * NW + lwave) * 8 + lrow;
     const int chunk = lslot ^ ((r >> 1) & 7);
+    if (CT && chunk * (16 / ES) < k.c_tail) a_tail |= 1u << i;
     const int m = m0 + r;
     const bool ok = m < k.M;
     const int mm = ok ? m : 0;
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
     const int chunk = lslot ^ ((r >> 1) & 7);
     const int n = n0 + r;
     b_voff[i] = n < a.N ? (unsigned)((n * a.w_sN + chunk * (16 / ES)) * ES) : kOob;
+    if (CT && chunk * (16 / ES) < k.c_tail) b_tail |= 1u << i;
   }
 
   int tap_r = 0, tap_s = 0, cc = 0;  // position of the NEXT tile to fetch
@@ -121,20 +126,29 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
     if (load) {
       const unsigned lds_a = lds_base + stage * STAGE_BYTES + lwave * 1024;
       const unsigned lds_b = lds_a + BM * 128;
+      // CT: in the last channel chunk only the pieces below C are real
+      const unsigned ta = (CT && cc == k.kc - 1) ? a_tail : 0xffffffffu;
+      const unsigned tb = (CT && cc == k.kc - 1) ? b_tail : 0xffffffffu;
       if (k.in_dense) {
 #pragma unroll
-        for (int i = 0; i < CA; ++i) dma16_buf((unsigned)a_voff[i], srd_a, wk, lds_a + i * NW * 1024);
+        for (int i = 0; i < CA; ++i) {
+          const unsigned v = (!CT || ((ta >> i) & 1u)) ? (unsigned)a_voff[i] : kOob;
+          dma16_buf(v, srd_a, wk, lds_a + i * NW * 1024);
+        }
       } else {
         const int tap_off = (int)((tap_r * a.in_sH + tap_s * a.in_sW + cc * BKE) * ES);
         const unsigned bit = a.pad == 0 ? 1u : 1u << (tap_r * a.S + tap_s);
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
-          const unsigned v = (a_mask[i] & bit) ? (unsigned)(a_voff[i] + tap_off) : kOob;
+          const unsigned v = ((a_mask[i] & bit) && (!CT || ((ta >> i) & 1u))) ? (unsigned)(a_voff[i] + tap_off) : kOob;
           dma16_buf(v, srd_a, 0u, lds_a + i * NW * 1024);
         }
       }
 #pragma unroll
-      for (int i = 0; i < CB; ++i) dma16_buf(b_voff[i], srd_b, wk, lds_b + i * NW * 1024);
+      for (int i = 0; i < CB; ++i) {
+        const unsigned v = (!CT || ((tb >> i) & 1u)) ? b_voff[i] : kOob;
+        dma16_buf(v, srd_b, wk, lds_b + i * NW * 1024);
+      }
     }
     // every wave tracks the tile position, loader or not.  K order = channel chunk OUTER, filter tap INNER: the
     // R*S taps of one chunk re-read (shifted) the same activation bytes back to back, while they are hot in L2
@@ -228,14 +242,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   if (k.probe && tid == 0 && blockIdx.x < 2048) k.probe[4096 + blockIdx.x] = __builtin_readcyclecounter() - t0c;
 }
 
-template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false>
+template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false, bool CT = false>
 int launch_x(const KArgs& k, hipStream_t stream) {
   constexpr int BM = WARPS_M * TM * 32, BN = WARPS_N * TN * 32;
   KArgs kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.a.N + BN - 1) / BN;
   const size_t lds = 2 * (BM + BN) * 128;
-  auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA, PP>;
+  auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA, PP, CT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -249,7 +263,12 @@ int launch_x(const KArgs& k, hipStream_t stream) {
 
 template <typename T, int WARPS_M, int WARPS_N, int TM, int TN>
 int launch(const KArgs& k, hipStream_t stream) {
-  if (k.a.aux_out || k.a.act == GDL_ACT_MUL_GELU_GRAD) return launch_x<T, WARPS_M, WARPS_N, TM, TN, true>(k, stream);
+  const bool extra = k.a.aux_out || k.a.act == GDL_ACT_MUL_GELU_GRAD;
+  if (k.c_tail) {
+    if (extra) return launch_x<T, WARPS_M, WARPS_N, TM, TN, true, false, true>(k, stream);
+    return launch_x<T, WARPS_M, WARPS_N, TM, TN, false, false, true>(k, stream);
+  }
+  if (extra) return launch_x<T, WARPS_M, WARPS_N, TM, TN, true>(k, stream);
   return launch_x<T, WARPS_M, WARPS_N, TM, TN, false>(k, stream);
 }
 
@@ -272,7 +291,7 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   GDL_CHECK_ARG(a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0 && a.N > 0 && a.Ho > 0 && a.Wo > 0,
                 "gdl_conv_gemm: non-positive dims");
   GDL_CHECK_ARG(a.R > 0 && a.S > 0 && a.stride > 0 && a.pad >= 0, "gdl_conv_gemm: bad filter");
-  GDL_CHECK_ARG(a.C % bke == 0, "gdl_conv_gemm: C=%d must be a multiple of %d", a.C, bke);
+  GDL_CHECK_ARG(a.C % al == 0, "gdl_conv_gemm: C=%d must be a multiple of %d", a.C, al);
   GDL_CHECK_ARG(a.in_sB % al == 0 && a.in_sH % al == 0 && a.in_sW % al == 0 && a.w_sN % al == 0 &&
                     a.in_sZ0 % al == 0 && a.in_sZ1 % al == 0 && a.w_sZ0 % al == 0 && a.w_sZ1 % al == 0,
                 "gdl_conv_gemm: strides must keep 16-byte alignment");
@@ -308,7 +327,8 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   KArgs k;
   k.a = a;
   k.M = a.B * a.Ho * a.Wo;
-  k.kc = a.C / bke;
+  k.kc = (a.C + bke - 1) / bke;
+  k.c_tail = a.C % bke;
   k.KT = a.R * a.S * k.kc;
   // "dense" = the (b,oy,ox) -> offset map is linear in m, so no divisions are needed
   k.tap_inner = g_tap_inner;
@@ -350,6 +370,7 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
   if (flops) *flops = 2 * M * a.N * ((int64_t)a.R * a.S * a.C) * a.nz;
   if (g_forced_variant >= 0 && !(g_forced_variant >= 2 && (a.aux_out || a.act == GDL_ACT_MUL_GELU_GRAD)) &&
+      !(g_forced_variant >= 2 && a.C % (a.dtype == GDL_BF16 ? 64 : 32) != 0) &&
       !(g_forced_variant == 4 && !conv3x3_sf_applicable(a)))
     return g_forced_variant;
   const int64_t t256 = ((M + 255) / 256) * ((a.N + 255) / 256) * a.nz;
@@ -359,7 +380,8 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   // for shallow K (ViT linears, 12 K-steps) the 128^2 tile's shorter prologue/epilogue wins
   // the training-only epilogue (aux_out / GELU-grad) does not fit the 256^2 tile's register budget
   const bool extra = a.aux_out != nullptr || a.act == GDL_ACT_MUL_GELU_GRAD;
-  if (!extra && a.N % 256 == 0 && (t256 >= 512 || (t256 >= 256 && ksteps >= 32)))
+  const bool ctail = a.C % (a.dtype == GDL_BF16 ? 64 : 32) != 0;   // only the small tiles zero-fill a channel tail
+  if (!extra && !ctail && a.N % 256 == 0 && (t256 >= 512 || (t256 >= 256 && ksteps >= 32)))
     return (g_sf_enabled && conv3x3_sf_applicable(a)) ? 4 : 3;   // ping-pong 256^2 (4: 3x3 with shared staging)
   if (t128 >= 256 && a.N >= 128) return 1;
   return 0;

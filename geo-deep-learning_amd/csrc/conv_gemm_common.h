@@ -10,7 +10,8 @@ namespace gdlconv {
 struct KArgs {
   gdl_conv_args a;
   int M;        // B*Ho*Wo
-  int kc;       // C / BKE
+  int kc;       // ceil(C / BKE)
+  int c_tail;   // channels in the last K chunk when C is not a multiple of BKE (else 0): the CT kernels zero-fill
   int KT;       // R*S*kc
   int tiles_m, tiles_n;
   int in_dense, out_dense, res_dense;

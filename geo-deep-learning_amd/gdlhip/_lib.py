@@ -71,6 +71,13 @@ SIGNATURES = {
     "gdl_dwconv3x3_gelu_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l,
                                      c_p]),
     "gdl_col2im": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_l, c_l, c_l, c_p]),
+    "gdl_chan_weights_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p]),
+    "gdl_chan_weights_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                   c_p]),
+    "gdl_chan_pool_fwd": (c_i, [c_p, c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_f, c_p, c_p, c_p]),
+    "gdl_chan_pool_workspace": (c_l, [c_i, c_i, c_l, c_i, c_i]),
+    "gdl_chan_pool_bwd": (c_i, [c_p, c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_l,
+                                c_p]),
     "gdl_maxpool3x3s2_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p]),
     "gdl_maxpool3x3s2_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l,
                                    c_p]),

@@ -398,9 +398,9 @@ def attention_unfused(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor
     a packed qkv or kv tensor).  Returns [B,Nq,D]."""
     B, Nq, Nkv, D, hd = _attn_check(q, k, v, num_heads)
     es = 4 if q.dtype == torch.float32 else 2
-    bke = 128 // es
-    if hd % bke != 0:
-        raise ValueError(f"attention: head_dim {hd} must be a multiple of {bke} for {q.dtype}")
+    al = 16 // es
+    if hd % al != 0:
+        raise ValueError(f"attention: head_dim {hd} must be a multiple of {al} for {q.dtype}")
     npad = (Nkv + 63) // 64 * 64
     lib = _lib.load()
     vt = _v_transposed(v, num_heads, hd, npad)
@@ -566,6 +566,78 @@ def dwconv3x3_gelu_bwd(u: Tensor, dy: Tensor, w9: Tensor, bias: Tensor):
     return du, dw9, db
 
 
+# ------------------------------------------------------------------ dynamic (channel-adaptive) SegFormer stem
+def _f32c(t: Tensor, shape: tuple, name: str) -> Tensor:
+    if t.dtype != torch.float32 or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous f32 tensor of shape {tuple(shape)}, got {tuple(t.shape)} {t.dtype}")
+    return t
+
+
+def chan_weights(pos: Tensor, W0: Tensor, b0: Tensor, W2: Tensor, b2: Tensor, W1: Tensor, b1: Tensor):
+    """weight_gen + the position half of channel_attention[0] (mix_transformer.py:781-801).
+    pos [C, PD]; W1 = channel_attention.0.weight as [H1, E + PD].  -> (hid [C,HD], cw [C,E], hb [C,H1])"""
+    _need_cuda(pos, W0, W2, W1)
+    Cn, PD = pos.shape
+    HD, E, H1 = W0.shape[0], W2.shape[0], W1.shape[0]
+    _f32c(pos, (Cn, PD), "pos"), _f32c(W0, (HD, PD), "weight_gen.0.weight"), _f32c(W2, (E, HD), "weight_gen.2.weight")
+    _f32c(W1, (H1, E + PD), "channel_attention.0.weight")
+    hid = torch.empty((Cn, HD), device=pos.device, dtype=torch.float32)
+    cw = torch.empty((Cn, E), device=pos.device, dtype=torch.float32)
+    hb = torch.empty((Cn, H1), device=pos.device, dtype=torch.float32)
+    w1b = W1[:, E:]
+    check(_lib.load().gdl_chan_weights_fwd(_p(pos), Cn, PD, HD, E, H1, _p(W0), _p(_f32vec(b0, HD, "weight_gen.0.bias")),
+                                           _p(W2), _p(_f32vec(b2, E, "weight_gen.2.bias")), _p(w1b), W1.stride(0),
+                                           _p(_f32vec(b1, H1, "channel_attention.0.bias")), _p(hid), _p(cw), _p(hb),
+                                           _stream()), "gdl_chan_weights_fwd")
+    return hid, cw, hb
+
+
+def chan_weights_bwd(pos: Tensor, W2: Tensor, hid: Tensor, cw: Tensor, dcw: Tensor, dhb: Tensor):
+    """-> (dW0 [HD,PD], db0, dW2 [E,HD], db2, dW1b [H1,PD], db1)"""
+    _need_cuda(pos, dcw, dhb)
+    Cn, PD = pos.shape
+    HD, E, H1 = hid.shape[1], cw.shape[1], dhb.shape[1]
+    _f32c(dcw, (Cn, E), "dcw"), _f32c(dhb, (Cn, H1), "dhb"), _f32c(W2, (E, HD), "weight_gen.2.weight")
+    dev = pos.device
+    outs = [torch.empty(sh, device=dev, dtype=torch.float32) for sh in ((HD, PD), (HD,), (E, HD), (E,), (H1, PD), (H1,))]
+    check(_lib.load().gdl_chan_weights_bwd(_p(pos), Cn, PD, HD, E, H1, _p(W2), _p(hid), _p(cw), _p(dcw), _p(dhb),
+                                           *[_p(o) for o in outs], _stream()), "gdl_chan_weights_bwd")
+    return tuple(outs)
+
+
+def chan_pool(conv: Tensor, cw: Tensor, W1: Tensor, hb: Tensor, w2: Tensor, b2s: float):
+    """conv [B, C, P, E] f32 -> (agg [B, P, E] f32, attn [B, P, C]) (mix_transformer.py:823-853)."""
+    _need_cuda(conv, cw, W1, hb, w2)
+    B, Cn, P, E = conv.shape
+    H1 = hb.shape[1]
+    _f32c(conv, (B, Cn, P, E), "conv"), _f32c(cw, (Cn, E), "cw"), _f32c(hb, (Cn, H1), "hb")
+    if W1.dtype != torch.float32 or W1.shape[0] != H1 or W1.shape[1] < E or W1.stride(1) != 1:
+        raise ValueError("chan_pool: W1 must be f32 [H1, >= E] with unit column stride")
+    agg = torch.empty((B, P, E), device=conv.device, dtype=torch.float32)
+    attn = torch.empty((B, P, Cn), device=conv.device, dtype=torch.float32)
+    check(_lib.load().gdl_chan_pool_fwd(_p(conv), B, Cn, P, E, H1, _p(cw), _p(W1), W1.stride(0), _p(hb),
+                                        _p(_f32vec(w2, H1, "channel_attention.2.weight")), float(b2s), _p(agg), _p(attn),
+                                        _stream()), "gdl_chan_pool_fwd")
+    return agg, attn
+
+
+def chan_pool_bwd(conv: Tensor, cw: Tensor, W1: Tensor, hb: Tensor, w2: Tensor, b2s: float, dagg: Tensor):
+    """-> (dconv like conv, dW1a [H1,E], dhb [C,H1], dw2 [H1], dcw [C,E])"""
+    _need_cuda(conv, dagg)
+    B, Cn, P, E = conv.shape
+    H1 = hb.shape[1]
+    _f32c(dagg, (B, P, E), "dagg")
+    lib = _lib.load()
+    nbytes = lib.gdl_chan_pool_workspace(B, Cn, P, E, H1)
+    ws = torch.empty(max(nbytes, 4) // 4, device=conv.device, dtype=torch.float32)
+    dconv = torch.empty_like(conv)
+    grads = torch.empty(H1 * E + Cn * H1 + H1 + Cn * E, device=conv.device, dtype=torch.float32)
+    check(lib.gdl_chan_pool_bwd(_p(conv), B, Cn, P, E, H1, _p(cw), _p(W1), W1.stride(0), _p(hb), _p(w2), float(b2s),
+                                _p(dagg), _p(dconv), _p(grads), _p(ws), nbytes, _stream()), "gdl_chan_pool_bwd")
+    o1, o2, o3 = H1 * E, H1 * E + Cn * H1, H1 * E + Cn * H1 + H1
+    return dconv, grads[:o1].view(H1, E), grads[o1:o2].view(Cn, H1), grads[o2:o3], grads[o3:].view(Cn, E)
+
+
 def col2im(cols: Tensor, B: int, Ho: int, Wo: int, R: int, S: int, Cc: int, stride: int, pad: int, H: int, W: int,
            out_dtype: torch.dtype) -> Tensor:
     """cols [B*Ho*Wo, R*S*C] -> dx NHWC [B,H,W,C] (data gradient of a strided conv)."""
@@ -628,9 +700,9 @@ def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, num_heads: int, d
     dQ = dS K (batched GEMM against K^T); dK = dS^T Q, dV = P^T dO (batched weight-gradient kernels)."""
     B, Nq, Nkv, D, hd = _attn_check(q, k, v, num_heads)
     cdt = q.dtype
-    bke = 32 if cdt == torch.float32 else 64
-    if hd % bke != 0:
-        raise ValueError(f"attention_bwd: head_dim {hd} must be a multiple of {bke} for {cdt}")
+    al = 4 if cdt == torch.float32 else 8
+    if hd % al != 0:
+        raise ValueError(f"attention_bwd: head_dim {hd} must be a multiple of {al} for {cdt}")
     for t, n in ((do, Nq), (dq, Nq), (dk, Nkv), (dv, Nkv)):
         if t.shape != (B, n, D) or t.dtype != cdt or t.stride(2) != 1:
             raise ValueError("attention_bwd: gradient tensor shape / dtype / stride mismatch")

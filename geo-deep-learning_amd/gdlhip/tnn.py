@@ -176,6 +176,41 @@ def stem_linear(cols: Tensor, weight: Tensor, bias: Tensor, wq: Tensor, out_dtyp
     return _StemLinear.apply(cols, weight, bias, wq, out_dtype)
 
 
+# ------------------------------------------------------------------ dynamic SegFormer stem: band weighting + pooling
+class _ChanPool(Function):
+    """agg = sum_c softmax_c(s)[c] * conv[c] * cw[c] (DynamicChannelEmbed.forward, mix_transformer.py:823-853) with the
+    band weights cw and the attention biases generated from the position codes (:781-801) inside the node."""
+
+    @staticmethod
+    def forward(ctx, conv, pos, wg0w, wg0b, wg2w, wg2b, ca0w, ca0b, ca2w, ca2b):
+        W1 = ca0w.detach().reshape(ca0w.shape[0], -1)            # Conv1d(k=1) weight [H1, E + PD, 1]
+        w2 = ca2w.detach().reshape(-1)
+        hid, cw, hb = ops.chan_weights(pos, wg0w.detach(), wg0b.detach(), wg2w.detach(), wg2b.detach(), W1, ca0b.detach())
+        b2s = 0.0   # channel_attention[2].bias shifts every band's logit alike: the softmax (and so agg) ignores it
+        agg, _ = ops.chan_pool(conv, cw, W1, hb, w2, b2s)
+        ctx.save_for_backward(conv, pos, wg2w, hid, cw, hb, W1, w2)
+        ctx.b2s = b2s
+        ctx.shapes = (ca0w.shape, ca2w.shape, ca2b.shape)
+        return agg
+
+    @staticmethod
+    def backward(ctx, g):
+        conv, pos, wg2w, hid, cw, hb, W1, w2 = ctx.saved_tensors
+        dconv, dW1a, dhb, dw2, dcw = ops.chan_pool_bwd(conv, cw, W1, hb, w2, ctx.b2s, _dense(g).float())
+        dW0, db0, dW2, db2, dW1b, db1 = ops.chan_weights_bwd(pos, wg2w.detach(), hid, cw, dcw.contiguous(), dhb.contiguous())
+        s0, s2, sb = ctx.shapes
+        dca0 = torch.cat([dW1a, dW1b], dim=1).reshape(s0)
+        return (dconv, None, dW0, db0, dW2, db2, dca0, db1, dw2.reshape(s2),
+                torch.zeros(sb, device=g.device, dtype=torch.float32))
+
+
+def chan_pool(conv: Tensor, pos: Tensor, weight_gen, channel_attention) -> Tensor:
+    """conv [B, C, P, E] f32 (shared spatial conv of every band) -> pooled tokens [B, P, E] f32."""
+    return _ChanPool.apply(conv, pos, weight_gen[0].weight, weight_gen[0].bias, weight_gen[2].weight, weight_gen[2].bias,
+                           channel_attention[0].weight, channel_attention[0].bias, channel_attention[2].weight,
+                           channel_attention[2].bias)
+
+
 # ------------------------------------------------------------------ LayerNorm node
 class _LayerNorm(Function):
     @staticmethod

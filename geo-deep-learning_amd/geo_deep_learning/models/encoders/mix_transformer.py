@@ -206,13 +206,16 @@ class MixVisionTransformer(nn.Module):
             setattr(self, f"norm{i + 1}", norm_layer(embed_dims[i]))
             cur += depths[i]
 
+    def _embed(self, i: int) -> nn.Module:
+        return getattr(self, f"patch_embed{i + 1}")
+
     def forward_features_nhwc(self, x: Tensor, drop_masks=None) -> list[Tensor]:
         """-> 4 NHWC features in the compute dtype ([B,128,128,64] ... [B,16,16,512] for B2 @512^2)."""
         cd = gnn.compute_dtype()
         b = x.shape[0]
         outs, bi = [], 0
         for i in range(4):
-            tok, h, w = getattr(self, f"patch_embed{i + 1}")(x)
+            tok, h, w = self._embed(i)(x)
             for blk in getattr(self, f"block{i + 1}"):
                 tok = blk(tok, h, w, None if drop_masks is None else drop_masks[bi])
                 bi += 1
@@ -288,3 +291,99 @@ def get_encoder(name: str, in_channels: int = 3, depth: int = 5, weights: str | 
     params = dict(entry["params"])
     params.update(in_channels=in_channels, depth=depth)
     return entry["encoder"](**params)
+
+
+class DynamicChannelEmbed(nn.Module):
+    """Channel-adaptive stem (mix_transformer.py:762-859): every band passes ONE shared 7x7/stride-4 convolution, is
+    scaled by a weight vector generated from its sinusoidal position code, and the bands are pooled per pixel by a
+    softmax attention over bands; then Linear + LayerNorm.  Any band count up to 16.
+
+    The shared conv is the patchify + GEMM path of the image stem with B*C single-band images; the band weighting /
+    attention / pooling is one fused HIP kernel pair (csrc/dynembed.hip)."""
+
+    def __init__(self, patch_size: int = 7, stride: int = 4, embed_dim: int = 64, hidden_dim: int = 128) -> None:
+        super().__init__()
+        self.patch_size = patch_size
+        self.stride = stride
+        self.embed_dim = embed_dim
+        self.pos_dim = hidden_dim
+        self.weight_gen = nn.Sequential(nn.Linear(self.pos_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, embed_dim),
+                                        nn.Tanh())
+        self.spatial_conv = nn.Conv2d(1, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
+        self.channel_attention = nn.Sequential(nn.Conv1d(embed_dim + self.pos_dim, embed_dim // 2, 1), nn.ReLU(),
+                                               nn.Conv1d(embed_dim // 2, 1, 1))
+        self.proj = nn.Linear(embed_dim, embed_dim)
+        self.norm = nn.LayerNorm(embed_dim)
+        self._pos: dict = {}
+
+    def get_position_encoding(self, n_channels: int, device: torch.device) -> Tensor:
+        """Sinusoidal band codes [C, pos_dim] (:810-821); a constant per band count, built once on the host."""
+        key = (n_channels, str(device))
+        if key not in self._pos:
+            positions = torch.arange(n_channels).float()
+            dim_t = torch.arange(0, self.pos_dim, 2).float()
+            inv_freq = 1.0 / (10000 ** (dim_t / self.pos_dim))
+            pe = torch.zeros(n_channels, self.pos_dim)
+            pe[:, 0::2] = torch.sin(positions.unsqueeze(1) * inv_freq)
+            pe[:, 1::2] = torch.cos(positions.unsqueeze(1) * inv_freq)
+            self._pos[key] = pe.to(device)
+        return self._pos[key]
+
+    def _stem_weight(self, cd: torch.dtype, kpad: int) -> Tensor:
+        w = self.spatial_conv.weight
+
+        def build():
+            flat = w.detach().reshape(w.shape[0], -1)
+            out = torch.zeros((w.shape[0], kpad), device=w.device, dtype=torch.float32)
+            out[:, : flat.shape[1]] = flat
+            return out if cd == torch.float32 else ops.cast(out, cd)
+        return gnn.cached((w,), f"dynstem:{cd}:{kpad}", build)
+
+    def forward(self, x: Tensor) -> tuple[Tensor, int, int]:
+        """NCHW f32 image with any number of bands -> (f32 tokens [B, h*w, E], h, w)."""
+        cd = gnn.compute_dtype()
+        b, c, hi, wi = x.shape
+        k, s, p = self.patch_size, self.stride, self.patch_size // 2
+        h, w = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
+        bke = 32 if cd == torch.float32 else 64
+        kpad = (k * k + bke - 1) // bke * bke
+        cols = ops.patchify(x.float().contiguous().view(b * c, 1, hi, wi), k, p, h, w, kpad, cd, stride=s)
+        conv = tnn.stem_linear(cols, self.spatial_conv.weight, self.spatial_conv.bias, self._stem_weight(cd, kpad),
+                               torch.float32)
+        agg = tnn.chan_pool(conv.view(b, c, h * w, self.embed_dim), self.get_position_encoding(c, x.device),
+                            self.weight_gen, self.channel_attention)
+        tok = gnn.to_compute(agg.view(b, h, w, self.embed_dim), cd)
+        y = tnn.linear(tok, self.proj.weight, self.proj.bias, out_dtype=torch.float32)
+        return tnn.layernorm(y.view(b, h * w, self.embed_dim), self.norm, torch.float32), h, w
+
+
+class DynamicMixTransformer(nn.Module):
+    """MiT whose first patch embedding is the channel-adaptive stem (mix_transformer.py:862-934); stages 2-4, the blocks
+    and the norms are those of the named variant."""
+
+    def __init__(self, encoder: str = "mit_b0", in_channels: int = 3, weights: str | None = None) -> None:
+        super().__init__()
+        base = get_encoder(name=encoder, in_channels=in_channels, weights=weights)
+        self.dynamic_patch_embed1 = DynamicChannelEmbed(patch_size=7, stride=4,
+                                                        embed_dim=base.patch_embed1.proj.weight.shape[0], hidden_dim=128)
+        for i in (2, 3, 4):
+            setattr(self, f"patch_embed{i}", getattr(base, f"patch_embed{i}"))
+        for i in (1, 2, 3, 4):
+            setattr(self, f"block{i}", getattr(base, f"block{i}"))
+        for i in (1, 2, 3, 4):
+            setattr(self, f"norm{i}", getattr(base, f"norm{i}"))
+        self.depths = base.depths
+
+    def _embed(self, i: int) -> nn.Module:
+        return self.dynamic_patch_embed1 if i == 0 else getattr(self, f"patch_embed{i + 1}")
+
+    forward_features_nhwc = MixVisionTransformer.forward_features_nhwc
+
+    def forward_nhwc(self, x: Tensor, drop_masks=None) -> list[Tensor]:
+        return self.forward_features_nhwc(x, drop_masks)
+
+    def forward_features(self, x: Tensor) -> list[Tensor]:
+        return [ops.as_nchw(f) for f in self.forward_features_nhwc(x)]
+
+    def forward(self, x: Tensor) -> list[Tensor]:
+        return self.forward_features(x)

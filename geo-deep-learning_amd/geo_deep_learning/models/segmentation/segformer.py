@@ -5,7 +5,7 @@ from __future__ import annotations
 import torch
 
 from geo_deep_learning.models.decoders.segformer_mlp import Decoder
-from geo_deep_learning.models.encoders.mix_transformer import get_encoder
+from geo_deep_learning.models.encoders.mix_transformer import DynamicMixTransformer, get_encoder
 
 from .base import BaseSegmentationModel
 
@@ -18,9 +18,9 @@ class SegFormerSegmentationModel(BaseSegmentationModel):
                  use_dynamic_encoder: bool = False) -> None:
         super().__init__()
         if use_dynamic_encoder:
-            msg = "gdlhip SegFormer: DynamicMixTransformer (off by default, segmentation_segformer.py:47) is not built"
-            raise NotImplementedError(msg)
-        self.encoder = get_encoder(name=encoder, in_channels=in_channels, depth=5, weights=weights)
+            self.encoder = DynamicMixTransformer(encoder=encoder, weights=weights)
+        else:
+            self.encoder = get_encoder(name=encoder, in_channels=in_channels, depth=5, weights=weights)
         if freeze_layers:
             self._freeze_layers(layers=freeze_layers)
         self.decoder = Decoder(encoder=encoder, num_classes=num_classes)

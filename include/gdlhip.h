@@ -179,6 +179,30 @@ int gdl_dwconv3x3_gelu_bwd(const void* u, const void* dy, int dtype, int B, int 
 int gdl_col2im(const void* cols, int dtype, int B, int Ho, int Wo, int R, int S, int C, int stride, int pad, int H,
                int W, void* dx, int dx_dtype, int64_t dx_sB, int64_t dx_sH, int64_t dx_sW, gdl_stream_t stream);
 
+/* ---- channel-adaptive stem of the "dynamic" SegFormer encoder (DynamicChannelEmbed, mix_transformer.py:762-859) ----
+ * Input-independent part (weight_gen :781-786 and the position half of channel_attention[0] :797-801), all f32:
+ *   hid[C][HD] = relu(pos W0^T + b0); cw[C][E] = tanh(hid W2^T + b2); hb[C][H1] = pos W1b^T + b1
+ * pos[C][PD] is the sinusoidal band code (:810-821); W1b = channel_attention.0.weight[:, E:], row stride w1b_ld. */
+int gdl_chan_weights_fwd(const float* pos, int C, int PD, int HD, int E, int H1, const float* W0, const float* b0,
+                         const float* W2, const float* b2, const float* W1b, int64_t w1b_ld, const float* b1,
+                         float* hid, float* cw, float* hb, gdl_stream_t stream);
+/* its backward: (dcw, dhb) -> dW0 [HD][PD], db0, dW2 [E][HD], db2, dW1b [H1][PD], db1 (overwritten) */
+int gdl_chan_weights_bwd(const float* pos, int C, int PD, int HD, int E, int H1, const float* W2, const float* hid,
+                         const float* cw, const float* dcw, const float* dhb, float* dW0, float* db0, float* dW2,
+                         float* db2, float* dW1b, float* db1, gdl_stream_t stream);
+/* Per output pixel (:823-853): conv [B][C][P][E] f32 is the shared 7x7 conv of every band (gdl_patchify + gdl_conv_gemm);
+ *   xw[c] = conv[c]*cw[c]; s[c] = w2 . relu(W1a xw[c] + hb[c]) + b2s; a = softmax_c(s); agg[b][p][:] = sum_c a[c] xw[c]
+ * W1a = channel_attention.0.weight[:, :E] (row stride w1a_ld); attn [B][P][C] is returned for inspection. */
+int gdl_chan_pool_fwd(const float* conv, int B, int C, int64_t P, int E, int H1, const float* cw, const float* w1a,
+                      int64_t w1a_ld, const float* hb, const float* w2, float b2s, float* agg, float* attn,
+                      gdl_stream_t stream);
+/* its backward: dagg -> dconv [B][C][P][E] and grads = [dW1a H1*E | dhb C*H1 | dw2 H1 | dcw C*E] (overwritten;
+ * d b2s is identically zero: softmax is shift invariant) */
+int64_t gdl_chan_pool_workspace(int B, int C, int64_t P, int E, int H1);
+int gdl_chan_pool_bwd(const float* conv, int B, int C, int64_t P, int E, int H1, const float* cw, const float* w1a,
+                      int64_t w1a_ld, const float* hb, const float* w2, float b2s, const float* dagg, float* dconv,
+                      float* grads, float* ws, int64_t ws_bytes, gdl_stream_t stream);
+
 /* torchmetrics.segmentation.MeanIoU(input_format="index") update (segmentation_dofa.py:71-76,313): for each sample
  * and class the exact counts counts[b][0][k] = |pred==k & target==k|, [b][1][k] = |pred==k|, [b][2][k] = |target==k|
  * (int64, zeroed by the call); pred / target are [B][P] class indices, values outside 0..K-1 are ignored. */

@@ -1,7 +1,7 @@
 """Oracle restatement of SegFormer: MixVisionTransformer encoder + all-MLP decoder.
 
 TEST INFRASTRUCTURE ONLY.  Follows, with identical state-dict keys:
-  /root/reference/geo_deep_learning/models/encoders/mix_transformer.py   (S1-S4)
+  /root/reference/geo_deep_learning/models/encoders/mix_transformer.py   (S1-S4, S7)
   /root/reference/geo_deep_learning/models/decoders/segformer_mlp.py     (S5)
   /root/reference/geo_deep_learning/models/segmentation/segformer.py     (S6)
 Pinned against outputs of the real reference in tests/golden/segformer_*.npz.
@@ -135,11 +135,14 @@ class MixVisionTransformerEncoder(nn.Module):
             setattr(self, f"norm{i + 1}", nn.LayerNorm(dims[i], eps=eps))
             cur += depths[i]
 
+    def _embed(self, i: int) -> nn.Module:
+        return getattr(self, f"patch_embed{i + 1}")
+
     def forward(self, x: Tensor, drop_masks=None) -> list[Tensor]:
         b = x.shape[0]
         outs, bi = [], 0
         for i in range(4):
-            x, h, w = getattr(self, f"patch_embed{i + 1}")(x)
+            x, h, w = self._embed(i)(x)
             for blk in getattr(self, f"block{i + 1}"):
                 x = blk(x, h, w, None if drop_masks is None else drop_masks[bi])
                 bi += 1
@@ -147,6 +150,60 @@ class MixVisionTransformerEncoder(nn.Module):
             x = x.reshape(b, h, w, -1).permute(0, 3, 1, 2).contiguous()
             outs.append(x)
         return outs
+
+
+class DynamicChannelEmbed(nn.Module):
+    """mix_transformer.py:762-859 restated band by band.  With x_c the c-th band, k_c its sinusoidal code (:810-821):
+        u_c   = spatial_conv(x_c)                        one shared 1->E 7x7/4 convolution         (:825-826)
+        w_c   = tanh(L2 relu(L0 k_c))                    weight_gen                                 (:823, :781-786)
+        v_c   = u_c * w_c                                                                           (:829-830)
+        s_c   = A2 relu(A0 [v_c ; k_c])                  1x1 Conv1d pair on every (pixel, band)     (:832-846)
+        out   = LayerNorm(proj(sum_c softmax_c(s)_c v_c))                                           (:847-853)
+    """
+
+    def __init__(self, patch_size: int = 7, stride: int = 4, embed_dim: int = 64, hidden_dim: int = 128) -> None:
+        super().__init__()
+        self.pos_dim = hidden_dim
+        self.weight_gen = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, embed_dim),
+                                        nn.Tanh())
+        self.spatial_conv = nn.Conv2d(1, embed_dim, patch_size, stride=stride, padding=patch_size // 2)
+        self.channel_attention = nn.Sequential(nn.Conv1d(embed_dim + hidden_dim, embed_dim // 2, 1), nn.ReLU(),
+                                               nn.Conv1d(embed_dim // 2, 1, 1))
+        self.proj = nn.Linear(embed_dim, embed_dim)
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def band_codes(self, n: int) -> Tensor:
+        half = torch.arange(0, self.pos_dim, 2).float()
+        ang = torch.arange(n).float()[:, None] / (10000 ** (half / self.pos_dim))[None, :]
+        return torch.stack([ang.sin(), ang.cos()], dim=-1).flatten(1)      # sin on even, cos on odd columns
+
+    def forward(self, x: Tensor):
+        b, c, _, _ = x.shape
+        k = self.band_codes(c).to(x)                                        # [C, D]
+        u = torch.stack([self.spatial_conv(x[:, i:i + 1]) for i in range(c)], dim=1)   # [B, C, E, h, w]
+        h, w = u.shape[-2:]
+        v = u * self.weight_gen(k)[None, :, :, None, None]
+        a0, a2 = self.channel_attention[0], self.channel_attention[2]
+        feat = torch.cat([v, k[None, :, :, None, None].expand(b, c, -1, h, w)], dim=2)  # [B, C, E+D, h, w]
+        hid = torch.einsum("bcfhw,jf->bcjhw", feat, a0.weight[:, :, 0]) + a0.bias[None, None, :, None, None]
+        s = torch.einsum("bcjhw,j->bchw", hid.relu(), a2.weight[0, :, 0]) + a2.bias
+        pooled = (v * s.softmax(dim=1)[:, :, None]).sum(dim=1)              # [B, E, h, w]
+        tok = pooled.flatten(2).transpose(1, 2)
+        return self.norm(self.proj(tok)), h, w
+
+
+class DynamicMixTransformer(MixVisionTransformerEncoder):
+    """mix_transformer.py:862-934: the named MiT with patch_embed1 replaced by DynamicChannelEmbed (state-dict key
+    dynamic_patch_embed1.*, no patch_embed1.*)."""
+
+    def __init__(self, name: str = "mit_b0", drop_path_rate: float = 0.1) -> None:
+        super().__init__(name, 3, drop_path_rate)
+        e = self.patch_embed1.proj.out_channels
+        del self.patch_embed1
+        self.dynamic_patch_embed1 = DynamicChannelEmbed(7, 4, e, 128)
+
+    def _embed(self, i: int) -> nn.Module:
+        return self.dynamic_patch_embed1 if i == 0 else getattr(self, f"patch_embed{i + 1}")
 
 
 class MLP(nn.Module):
@@ -194,11 +251,12 @@ class Decoder(nn.Module):
 
 
 class SegFormerSegmentationModel(nn.Module):
-    """models/segmentation/segformer.py:15-57 (use_dynamic_encoder=False, weights=None)."""
+    """models/segmentation/segformer.py:15-57 (weights=None)."""
 
-    def __init__(self, encoder: str = "mit_b0", in_channels: int = 3, num_classes: int = 1) -> None:
+    def __init__(self, encoder: str = "mit_b0", in_channels: int = 3, num_classes: int = 1, *,
+                 use_dynamic_encoder: bool = False) -> None:
         super().__init__()
-        self.encoder = MixVisionTransformerEncoder(encoder, in_channels)
+        self.encoder = DynamicMixTransformer(encoder) if use_dynamic_encoder else MixVisionTransformerEncoder(encoder, in_channels)
         self.decoder = Decoder(encoder, num_classes)
 
     def forward(self, img: Tensor, drop_masks=None, dec_drop_mask=None) -> Tensor:

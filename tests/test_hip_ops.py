@@ -42,7 +42,8 @@ def q(t, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,K,N", [(300, 128, 192), (64, 64, 64), (1297, 768, 256), (3, 128, 1024)])
+@pytest.mark.parametrize("M,K,N", [(300, 128, 192), (64, 64, 64), (1297, 768, 256), (3, 128, 1024), (500, 32, 128),
+                                   (2000, 160, 640), (77, 24, 8)])
 def test_linear_plain(dtype, M, K, N):
     x, w = q(rnd(M, K), dtype), q(rnd(N, K, seed=1), dtype)
     y = ops.linear(x.to(DEV, dtype), w.to(DEV, dtype), out_dtype=torch.float32)
@@ -73,7 +74,10 @@ def test_linear_epilogues(dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,C,N,R", [(2, 10, 12, 64, 96, 3), (1, 18, 18, 128, 256, 3), (2, 7, 5, 64, 64, 1),
-                                         (3, 36, 36, 64, 128, 3)])
+                                         (3, 36, 36, 64, 128, 3),
+                                         # channel tails (C not a multiple of the K chunk: MiT-B0's 32 / 160 channels)
+                                         (2, 9, 11, 32, 64, 3), (1, 40, 40, 160, 256, 1), (2, 6, 6, 96, 32, 3),
+                                         (1, 48, 48, 40, 128, 1), (3, 20, 20, 8, 16, 3)])
 def test_conv_nhwc(dtype, B, H, W, C, N, R):
     x, w = q(rnd(B, C, H, W), dtype), q(rnd(N, C, R, R, seed=1) * 0.1, dtype)
     bias = rnd(N, seed=2)
@@ -103,10 +107,10 @@ def test_conv_strided_views():
 
 
 def test_conv_arg_validation():
-    x = torch.zeros(1, 4, 4, 48, device=DEV)
-    w = torch.zeros(64, 48, device=DEV)
+    x = torch.zeros(1, 4, 4, 50, device=DEV)
+    w = torch.zeros(64, 50, device=DEV)
     with pytest.raises(ValueError):
-        ops.conv_gemm(x, w)  # C not a multiple of 32
+        ops.conv_gemm(x, w)  # C not a multiple of 4 (16-byte pieces)
     with pytest.raises(ValueError):
         ops.conv_gemm(torch.zeros(1, 4, 4, 64), torch.zeros(64, 64))  # CPU tensors
 
@@ -114,8 +118,6 @@ def test_conv_arg_validation():
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,N,H,hd", [(2, 70, 2, 64), (1, 197, 3, 64), (1, 132, 4, 32)])
 def test_attention_unfused(dtype, B, N, H, hd):
-    if dtype == torch.bfloat16 and hd % 64:
-        pytest.skip("bf16 needs head_dim % 64 == 0")
     D = H * hd
     qkv = q(rnd(B, N, 3 * D), dtype)
     o = ops.attention_unfused(*ops.split_qkv(qkv.to(DEV, dtype)), H)

@@ -84,7 +84,7 @@ def test_dwconv_gelu_bwd(dtype, B, H, W, C):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,Nq,Nkv,H,hd", [(2, 70, 70, 2, 64), (1, 256, 64, 1, 64), (2, 197, 50, 5, 64)])
+@pytest.mark.parametrize("B,Nq,Nkv,H,hd", [(2, 70, 70, 2, 64), (1, 256, 64, 1, 64), (2, 197, 50, 5, 64), (2, 100, 36, 5, 32)])
 def test_attention_bwd(dtype, B, Nq, Nkv, H, hd):
     D = H * hd
     qf = q(rnd(B, Nq, D), dtype).requires_grad_()
@@ -107,7 +107,10 @@ def test_attention_bwd(dtype, B, Nq, Nkv, H, hd):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("k,s,p,C,N,hw", [(3, 2, 1, 64, 128, 16), (8, 8, 0, 64, 64, 32), (2, 2, 0, 320, 320, 8),
-                                          (3, 1, 1, 64, 64, 9), (1, 1, 0, 128, 64, 5)])
+                                          (3, 1, 1, 64, 64, 9), (1, 1, 0, 128, 64, 5),
+                                          # MiT-B0 widths: channel tails in bf16
+                                          (8, 8, 0, 32, 32, 32), (3, 2, 1, 32, 64, 16), (3, 2, 1, 160, 256, 8),
+                                          (1, 1, 0, 160, 32, 7)])
 def test_conv_node(dtype, k, s, p, C, N, hw):
     B = 2
     x = q(rnd(B, hw, hw, C), dtype).requires_grad_()

@@ -64,3 +64,30 @@ def test_segformer_oracle_train_step_matches_reference(golden_dir):
     for n, buf in m.named_buffers():
         if n.endswith(("running_mean", "running_var")):
             np.testing.assert_allclose(buf.numpy(), g["buf/" + n], atol=1e-5, rtol=1e-5)
+
+
+def test_dynamic_segformer_oracle_matches_reference(golden_dir):
+    """S7 (use_dynamic_encoder=True): channel-adaptive stem on 6 and 3 bands, eval logits, and the full train step
+    (every gradient) vs the real reference."""
+    g = np.load(golden_dir / "segformer_dynamic.npz")
+    meta = json.loads(str(g["meta"]))
+    seed, b, nc, bands = meta["seed"], meta["batch"], meta["num_classes"], meta["bands"]
+    m = SegFormerSegmentationModel(meta["encoder"], 3, nc, use_dynamic_encoder=True).eval()
+    m.load_state_dict(procedural_state_dict(m, seed))
+    batch = synthetic_batch(b, bands, meta["size"], nc, seed)
+    with torch.no_grad():
+        tok, _, _ = m.encoder.dynamic_patch_embed1(batch["image"])
+        tok3, _, _ = m.encoder.dynamic_patch_embed1(batch["image"][:, :3])
+        y = m(batch["image"])
+    np.testing.assert_allclose(tok.numpy(), g["stem_tokens"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(tok3.numpy(), g["stem_tokens_3band"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(y.numpy(), g["eval_out"], atol=2e-4, rtol=0)
+    m.train()
+    y = m(batch["image"], mit_drop_masks(meta["depths"], 0.1, b, seed), chan_mask(b, m.decoder.linear_pred.in_channels, seed))
+    np.testing.assert_allclose(y.detach().numpy(), g["train_out"], atol=2e-4, rtol=0)
+    loss = dice_loss_multiclass(y, batch["mask"].squeeze(1).long())
+    assert abs(loss.item() - float(g["train_loss"])) < 1e-5
+    loss.backward()
+    named = [(n, p.grad) for n, p in m.named_parameters()]
+    assert sorted(n for n, _ in named) == sorted(meta["grad_names"])
+    check_grads(named, g, tol=6e-3)      # 64^2 tiles leave stage 4 with 2x2 tokens: f32 summation-order noise
