@@ -611,9 +611,9 @@ __global__ __launch_bounds__(512) void wgrad_tr256_kernel(const W256 kk) {
 // (UNet++ decoder, ResNet / MiT high-resolution levels).  The per-tap kernels above re-stage the SAME input pixels for
 // each of the nine taps and, on 64-channel layers, fill half of every 128-wide tile with zeros; here one block owns
 // (64 n) x (64 c) x ALL NINE taps and walks 64-pixel row segments (b, y, x0..x0+63):
-//   LDS stage = dy [64 px][64 n]  +  x rows y-1, y, y+1 as [66 px: x0-1 .. x0+64][64 c]      (35 KiB, three stages)
-//   wave r (3 waves) owns kernel row r: taps (r, 0..2) are the x row r read at pixel shifts 0, 1, 2, so every staged
-//   byte feeds 9 (dy) / 3 (x) MFMA operands: 144 MFMAs per 33.5 KiB staged instead of 16 per 32 KiB.
+//   LDS stage = dy [64 px][64 n]  +  x rows y-1, y, y+1 as [66 px: x0-1 .. x0+64][64 c]      (35 KiB, two stages)
+//   the nine taps are the three staged rows read at pixel shifts 0, 1, 2, so every staged byte feeds 9 (dy) / 3 (x)
+//   MFMA operands: 144 MFMAs per 33.5 KiB staged instead of 16 per 32 KiB.
 // Image borders are zero-filled by the buffer descriptor (voffset = OOB); the x descriptor starts one pixel BEFORE
 // the tensor so that panel pixel 0 (x0 - 1) has a non-negative offset (it is masked whenever x0 == 0).
 struct WRows {
@@ -624,19 +624,24 @@ struct WRows {
   int nsegs, segs_per_split;
 };
 
-__global__ __launch_bounds__(192) void wgrad_rows_kernel(const WRows kk) {
-  constexpr int DYB = 64 * 128;                  // dy panel
-  constexpr int XROW = 72 * 128;                 // one staged input row (9 DMA pieces of 8 pixels, 66 pixels used)
+// Work split: 4 waves, wave (i, j) owns the 32 (n) x 32 (c) quadrant of the 64 x 64 tile for ALL nine taps
+// (9 accumulators = 144 registers), so all four SIMDs carry MFMA work and the kernel stays under 256 registers: two
+// blocks share a CU (2 x 70 KiB of LDS) and one block's DMA issue / barrier waits are covered by the other's MFMAs.
+// (A 3-wave variant -- one wave per kernel row, 192 accumulator registers, one block per CU -- measured 5-45 % slower.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_rows_kernel(const WRows kk) {
+  constexpr int DYB = 64 * 128;
+  constexpr int XROW = 72 * 128;
   constexpr int STAGE_BYTES = DYB + 3 * XROW;
   constexpr unsigned kOob = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const WArgs& k = kk.w;
   const gdl_wgrad_args& a = k.a;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = kernel row r
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wi = wave & 1, wj = wave >> 1;            // n half, c half
   const int n0 = (blockIdx.x % kk.ntiles) * 64, c0 = (blockIdx.x / kk.ntiles) * 64;
   const int split = blockIdx.y;
-  const unsigned xpix = (unsigned)(a.in_sW * 2), dypix = (unsigned)(a.dy_sW * 2);   // bytes per pixel step
+  const unsigned xpix = (unsigned)(a.in_sW * 2), dypix = (unsigned)(a.dy_sW * 2);
   const srd_t srd_x = make_srd((const unsigned char*)a.in - xpix, kk.in_span + xpix);
   const srd_t srd_dy = make_srd((const unsigned char*)a.dy, kk.dy_span);
   const int seg_begin = split * kk.segs_per_split;
@@ -644,15 +649,15 @@ __global__ __launch_bounds__(192) void wgrad_rows_kernel(const WRows kk) {
   const unsigned lds_base =
       __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
 
-  // ---- DMA geometry: a piece = 8 pixels x 128 B, lane l -> pixel (l >> 3), 16-byte slot (l & 7).  The source chunk
-  // of a slot depends on the panel row through tr_swz, i.e. only on the piece's parity.
+  // ---- DMA: 9 pieces per wave and stage.  Waves 0..2 stage input rows y-1, y, y+1; wave 3 the dy panel (8 pieces,
+  // the last one twice so that every wave has the same number of loads in flight).
   const int lrow = lane >> 3, lslot = lane & 7;
   const int chunk_e = lslot ^ tr_swz(lrow), chunk_o = lslot ^ tr_swz(8 + lrow);
-  const unsigned vdy_e = n0 + chunk_e * 8 < a.N ? lrow * dypix + (unsigned)(n0 + chunk_e * 8) * 2u : kOob;
-  const unsigned vdy_o = n0 + chunk_o * 8 < a.N ? lrow * dypix + (unsigned)(n0 + chunk_o * 8) * 2u : kOob;
-  const unsigned vx_e = c0 + chunk_e * 8 < a.C ? lrow * xpix + (unsigned)(c0 + chunk_e * 8) * 2u : kOob;
-  const unsigned vx_o = c0 + chunk_o * 8 < a.C ? lrow * xpix + (unsigned)(c0 + chunk_o * 8) * 2u : kOob;
-  // next segment to fetch (wave-uniform)
+  const bool is_dy = wave == 3;
+  const int ch0 = is_dy ? n0 : c0, chn = is_dy ? a.N : a.C;
+  const unsigned pix = is_dy ? dypix : xpix;
+  const unsigned v_e = ch0 + chunk_e * 8 < chn ? lrow * pix + (unsigned)(ch0 + chunk_e * 8) * 2u : kOob;
+  const unsigned v_o = ch0 + chunk_o * 8 < chn ? lrow * pix + (unsigned)(ch0 + chunk_o * 8) * 2u : kOob;
   int sx = seg_begin % kk.segs_per_row;
   int sy = (seg_begin / kk.segs_per_row) % a.H;
   int sb = seg_begin / kk.segs_per_row / a.H;
@@ -660,43 +665,46 @@ __global__ __launch_bounds__(192) void wgrad_rows_kernel(const WRows kk) {
   auto issue = [&](int stage) {
     const unsigned lds = lds_base + stage * STAGE_BYTES;
     const int x0 = sx * 64;
-    const unsigned soff_dy = (unsigned)((sb * a.dy_sB + sy * a.dy_sH + (int64_t)x0 * a.dy_sW) * 2);
+    if (is_dy) {
+      const unsigned soff = (unsigned)((sb * a.dy_sB + sy * a.dy_sH + (int64_t)x0 * a.dy_sW) * 2);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      // dy pieces 0..7 dealt round-robin to the 3 waves; wave 2 repeats piece 7 so that every wave has exactly
-      // kDmaPerStage loads in flight per stage (the vmcnt bookkeeping below relies on it)
-      const int piece = wave + 3 * q < 8 ? wave + 3 * q : 7;
-      dma16_buf((piece & 1) ? vdy_o : vdy_e, srd_dy, soff_dy + piece * 8 * dypix, lds + piece * 1024);
-    }
-    const int iy = sy + wave - 1;
-    const bool rowok = (unsigned)iy < (unsigned)a.H;
-    const unsigned soff_x = (unsigned)((sb * a.in_sB + iy * a.in_sH + (int64_t)x0 * a.in_sW) * 2);
-    const unsigned ldx = lds + DYB + wave * XROW;
+      for (int q = 0; q < 9; ++q) {
+        const int piece = q < 8 ? q : 7;
+        dma16_buf((piece & 1) ? v_o : v_e, srd_dy, soff + piece * 8 * dypix, lds + piece * 1024);
+      }
+    } else {
+      const int iy = sy + wave - 1;
+      const bool rowok = (unsigned)iy < (unsigned)a.H;
+      const unsigned soff = (unsigned)((sb * a.in_sB + iy * a.in_sH + (int64_t)x0 * a.in_sW) * 2);
+      const unsigned ldx = lds + DYB + wave * XROW;
 #pragma unroll
-    for (int piece = 0; piece < 9; ++piece) {
-      unsigned v = (piece & 1) ? vx_o : vx_e;
-      if (!rowok) v = kOob;
-      if (piece == 0 && x0 == 0 && lrow == 0) v = kOob;                          // x0 - 1 < 0
-      if (piece == 8 && (lrow > 1 || (lrow == 1 && x0 + 64 >= a.W))) v = kOob;   // x0 + 64 >= W; pixels 66.. unused
-      dma16_buf(v, srd_x, soff_x + piece * 8 * xpix, ldx + piece * 1024);
+      for (int piece = 0; piece < 9; ++piece) {
+        unsigned v = (piece & 1) ? v_o : v_e;
+        if (!rowok) v = kOob;
+        if (piece == 0 && x0 == 0 && lrow == 0) v = kOob;
+        if (piece == 8 && (lrow > 1 || (lrow == 1 && x0 + 64 >= a.W))) v = kOob;
+        dma16_buf(v, srd_x, soff + piece * 8 * xpix, ldx + piece * 1024);
+      }
     }
     if (++sx == kk.segs_per_row) { sx = 0; if (++sy == a.H) { sy = 0; ++sb; } }
   };
 
-  // ---- fragment addressing (ds_read_b64_tr_b16, see wgrad_tr_kernel): panel row = pixel (+ tap shift for x)
+  // ---- fragment addressing: this wave's 32-channel tile of the dy panel (wi) and of the x rows (wj)
   const int g = lane >> 4, s = lane & 15;
   const int R0 = 8 * (g >> 1) + (s >> 2);
-  int foff[3][2][2];   // [pixel shift][32-channel tile][read t]
+  int foff_dy[2], foff_x[3][2];
 #pragma unroll
-  for (int sh = 0; sh < 3; ++sh)
+  for (int t = 0; t < 2; ++t) {
+    const int row = 4 * t + R0;
+    const int ch = wi * 32 + 16 * (g & 1) + 4 * (s & 3);
+    foff_dy[t] = row * 128 + (((ch >> 3) ^ tr_swz(row)) << 4) + (ch & 7) * 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int row = 4 * t + R0 + sh;
-        const int channel = i * 32 + 16 * (g & 1) + 4 * (s & 3);
-        foff[sh][i][t] = row * 128 + (((channel >> 3) ^ tr_swz(row)) << 4) + (channel & 7) * 2;
-      }
+    for (int sh = 0; sh < 3; ++sh) {
+      const int rx = row + sh;
+      const int cx = wj * 32 + 16 * (g & 1) + 4 * (s & 3);
+      foff_x[sh][t] = DYB + rx * 128 + (((cx >> 3) ^ tr_swz(rx)) << 4) + (cx & 7) * 2;
+    }
+  }
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
   auto frag = [&](const unsigned char* q, int o0, int o1) {
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(q + o0));
@@ -704,70 +712,41 @@ __global__ __launch_bounds__(192) void wgrad_rows_kernel(const WRows kk) {
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
-  bf16x8_t fa[2][2], fb[2][3][2];
-  auto fetch = [&](const unsigned char* st, int kq, int buf) {
-    const unsigned char* pa = st + kq * 2048;
-    const unsigned char* px_ = st + DYB + wave * XROW + kq * 2048;
+  f32x16_t acc[3][3];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fa[buf][i] = frag(pa, foff[0][i][0], foff[0][i][1]);
+  for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int sh = 0; sh < 3; ++sh)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[buf][sh][j] = frag(px_, foff[sh][j][0], foff[sh][j][1]);
-  };
-  f32x16_t acc[3][2][2];
-#pragma unroll
-  for (int sh = 0; sh < 3; ++sh)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[sh][i][j][r] = 0.f;
-  auto mfmas = [&](int buf) {
-#pragma unroll
-    for (int sh = 0; sh < 3; ++sh)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[sh][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i], fb[buf][sh][j], acc[sh][i][j], 0, 0, 0);
-  };
+      for (int q = 0; q < 16; ++q) acc[r][sh][q] = 0.f;
 
-  // Three LDS stages: while segment kt is multiplied, kt+1 and kt+2 are in flight (12 loads per wave and stage).
   const int KT = seg_end - seg_begin;
-  if (KT > 0) {
-    issue(0);
-    if (KT > 1) issue(1);
-    if (KT > 2) issue(2);
-    if (KT > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (KT > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): no scalar load is pending past this point (see conv_gemm.hip)
-    fetch(smem, 0, 0);
-    int cur = 0;                          // stage of segment kt
-    for (int kt = 0; kt < KT; ++kt) {
-      const unsigned char* st = smem + cur * STAGE_BYTES;
-      const int nxt = cur == 2 ? 0 : cur + 1;
+  if (KT > 0) issue(0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // segment kt landed everywhere; stage (kt+1)&1 fully read
+    if (kt + 1 < KT) issue((kt + 1) & 1);
+    const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
+    // 12 groups (kq, r) of three MFMAs; the fragments of group g+1 are fetched while group g multiplies
+    bf16x8_t fa[2], fb[2][3];
+    auto fetch = [&](int grp) {
+      const int kq = grp / 3, r = grp - kq * 3;
+      const unsigned char* q = st + kq * 2048;
+      if (r == 0) fa[kq & 1] = frag(q, foff_dy[0], foff_dy[1]);
 #pragma unroll
-      for (int kq = 0; kq < 3; ++kq) {
-        fetch(st, kq + 1, (kq + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(kq & 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (kt + 1 < KT) {
-        if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                  // segment kt+1 landed everywhere, stage `cur` fully read
-        if (kt + 3 < KT) issue(cur);
-        fetch(smem + nxt * STAGE_BYTES, 0, 0);
-      }
+      for (int sh = 0; sh < 3; ++sh) fb[grp & 1][sh] = frag(q + r * XROW, foff_x[sh][0], foff_x[sh][1]);
+    };
+    fetch(0);
+#pragma unroll
+    for (int grp = 0; grp < 12; ++grp) {
+      if (grp + 1 < 12) fetch(grp + 1);
       __builtin_amdgcn_sched_barrier(0);
-      mfmas(1);
+      const int kq = grp / 3, r = grp - kq * 3;
+#pragma unroll
+      for (int sh = 0; sh < 3; ++sh)
+        acc[r][sh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kq & 1], fb[grp & 1][sh], acc[r][sh], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      cur = nxt;
     }
   }
 
@@ -782,25 +761,21 @@ __global__ __launch_bounds__(192) void wgrad_rows_kernel(const WRows kk) {
     ld = a.dw_sN;
     dst = a.dw;
   }
+  const int c = c0 + wj * 32 + frow;
 #pragma unroll
-  for (int sh = 0; sh < 3; ++sh) {
-    const int tap = wave * 3 + sh;
+  for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int sh = 0; sh < 3; ++sh) {
+      const int tap = r * 3 + sh;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-        if (n >= a.N) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int c = c0 + j * 32 + frow;
-          if (c >= a.C) continue;
-          float* q = dst + (int64_t)n * ld + (int64_t)tap * a.C + c;
-          const float v = acc[sh][i][j][r];
-          *q = (k.splits == 1 && a.accumulate) ? *q + v : v;
-        }
+      for (int q = 0; q < 16; ++q) {
+        const int n = n0 + wi * 32 + (q & 3) + 8 * (q >> 2) + 4 * fhalf;
+        if (n >= a.N || c >= a.C) continue;
+        float* o = dst + (int64_t)n * ld + (int64_t)tap * a.C + c;
+        const float v = acc[r][sh][q];
+        *o = (k.splits == 1 && a.accumulate) ? *o + v : v;
       }
-  }
+    }
 }
 
 // split-K reduction for many partials: 32 outputs x 8 partial groups per block, fixed summation order
@@ -843,7 +818,7 @@ int64_t span_bytes(int B, int H, int W, int C, int64_t sB, int64_t sH, int64_t s
   return (((int64_t)B - 1) * sB + ((int64_t)H - 1) * sH + ((int64_t)W - 1) * sW + C) * es;
 }
 
-int g_wgrad_force_small = 0;   // A/B hook: bit 0 = never use the 256^2 kernel, bit 1 = never use the row-segment kernel
+int g_wgrad_force_small = 0;   // A/B hook: bit 0 = never use the 256^2 kernel, bit 1 = never use the row-segment kernel, bit 3 = N, C >= 256 layers on the 256^2 kernel
 
 // 256^2 tiles for wide bf16 layers whose operands fit 32-bit buffer offsets
 int wgrad_tile(const gdl_wgrad_args& a) {
@@ -854,9 +829,10 @@ int wgrad_tile(const gdl_wgrad_args& a) {
   return 256;
 }
 
-// row-segment kernel: 3x3 / stride 1 / pad 1, width a multiple of 64, anything the 256^2 kernel does not take
+// row-segment kernel: every 3x3 / stride 1 / pad 1 layer on a map whose width is a multiple of 64
 bool wgrad_rows_ok(const gdl_wgrad_args& a) {
-  if (a.dtype != GDL_BF16 || (g_wgrad_force_small & 2) || wgrad_tile(a) == 256) return false;
+  if (a.dtype != GDL_BF16 || (g_wgrad_force_small & 2)) return false;
+  if ((g_wgrad_force_small & 8) && wgrad_tile(a) == 256) return false;   // A/B hook: wide layers on the 256^2 per-tap kernel
   if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.H != a.Ho || a.W != a.Wo || a.W % 64 != 0 || a.nz != 1)
     return false;
   return span_bytes(a.B, a.H, a.W, a.C, a.in_sB, a.in_sH, a.in_sW, 2) + a.in_sW * 2 <= 0x7ffffff0ll &&
@@ -865,12 +841,12 @@ bool wgrad_rows_ok(const gdl_wgrad_args& a) {
 
 int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
   if (wgrad_rows_ok(a)) {
-    // one 3-wave block per CU (108 KiB of LDS): ~256 blocks, >= 8 segments per split
+    // two blocks per CU: ~512 blocks, >= 8 segments per split
     const int64_t tiles = (int64_t)((a.N + 63) / 64) * ((a.C + 63) / 64);
-    int64_t want = 256 / tiles;
+    int64_t want = 512 / tiles;
     const int64_t max_by_k = P / 64 / 8;
     if (want > max_by_k) want = max_by_k;
-    if (want > 256) want = 256;
+    if (want > 512) want = 512;
     if (want < 1) want = 1;
     return (int)want;
   }
@@ -945,10 +921,10 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
     kr.segs_per_split = (kr.nsegs + k.splits - 1) / k.splits;
     static bool rows_attr_set = false;
     if (!rows_attr_set) {
-      (void)hipFuncSetAttribute((const void*)wgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 35840);
+      (void)hipFuncSetAttribute((const void*)wgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 35840);
       rows_attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad_rows_kernel, dim3(kr.ntiles * kr.cchunks, k.splits), dim3(192), 3 * 35840, s, kr);
+    hipLaunchKernelGGL(wgrad_rows_kernel, dim3(kr.ntiles * kr.cchunks, k.splits), dim3(256), 2 * 35840, s, kr);
   } else if (wgrad_tile(a) == 256 && !g_wgrad_force_v1) {
     W256 kb;
     kb.w = k;
