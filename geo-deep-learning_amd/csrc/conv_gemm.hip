@@ -346,17 +346,19 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
     if (variant == 4) return conv3x3_sf_launch(k, s);
     if (variant == 3) return launch_x<bf16_tag, 2, 4, 4, 2, false, true>(k, s);
     if (variant == 2) return launch_x<bf16_tag, 2, 4, 4, 2, false>(k, s);
+    if (variant == 5) return launch_x<bf16_tag, 4, 1, 2, 2, false>(k, s);
     if (variant == 1) return launch<bf16_tag, 2, 2, 2, 2>(k, s);
     return launch<bf16_tag, 2, 2, 1, 1>(k, s);
   }
   if (variant == 4) return conv3x3_sf_launch(k, s);
   if (variant == 3) return launch_x<float, 2, 4, 4, 2, false, true>(k, s);
   if (variant == 2) return launch_x<float, 2, 4, 4, 2, false>(k, s);
+  if (variant == 5) return launch_x<float, 4, 1, 2, 2, false>(k, s);
   if (variant == 1) return launch<float, 2, 2, 2, 2>(k, s);
   return launch<float, 2, 2, 1, 1>(k, s);
 }
 
-// Tile selection by available parallelism (256 CUs): 256x256 tiles / 8 waves (variant 2) when
+// Tile selection by available parallelism (256 CUs) and output width: 256x256 tiles / 8 waves (variants 2-4) when
 // they still give >= 512 blocks, 128x128 / 4 waves (variant 1) when that gives >= 256 blocks,
 // else 64x64 (variant 0).  Also reports the ALGORITHMIC flops of the call (2*M*N*K, no padding).
 static int g_forced_variant = -1;
@@ -370,7 +372,7 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
   if (flops) *flops = 2 * M * a.N * ((int64_t)a.R * a.S * a.C) * a.nz;
   if (g_forced_variant >= 0 && !(g_forced_variant >= 2 && (a.aux_out || a.act == GDL_ACT_MUL_GELU_GRAD)) &&
-      !(g_forced_variant >= 2 && a.C % (a.dtype == GDL_BF16 ? 64 : 32) != 0) &&
+      !(g_forced_variant >= 2 && a.C % (a.dtype == GDL_BF16 ? 64 : 32) != 0) && !(g_forced_variant == 5 && a.N > 64) &&
       !(g_forced_variant == 4 && !conv3x3_sf_applicable(a)))
     return g_forced_variant;
   const int64_t t256 = ((M + 255) / 256) * ((a.N + 255) / 256) * a.nz;
@@ -384,5 +386,8 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   if (!extra && !ctail && a.N % 256 == 0 && (t256 >= 512 || (t256 >= 256 && ksteps >= 32)))
     return (g_sf_enabled && conv3x3_sf_applicable(a)) ? 4 : 3;   // ping-pong 256^2 (4: 3x3 with shared staging)
   if (t128 >= 256 && a.N >= 128) return 1;
+  // narrow outputs (N <= 64: UNet++ decoder, ResNet layer1, MiT stage 1): a 256 (m) x 64 (n) tile, four waves of
+  // 64 x 64 -- one LDS fragment read per MFMA instead of the two of the 64^2 tile's 32 x 32 waves
+  if (!extra && !ctail && a.N <= 64 && ((M + 255) / 256) * a.nz >= 256) return 5;
   return 0;
 }

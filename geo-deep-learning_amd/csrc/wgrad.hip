@@ -607,10 +607,10 @@ __global__ __launch_bounds__(512) void wgrad_tr256_kernel(const W256 kk) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// bf16 row-segment kernel for 3x3 / stride 1 / pad 1 convolutions on feature maps whose width is a multiple of 64
+// bf16 row-segment kernel for 3x3 / stride 1 / pad 1 convolutions on feature maps at least 32 pixels wide
 // (UNet++ decoder, ResNet / MiT high-resolution levels).  The per-tap kernels above re-stage the SAME input pixels for
 // each of the nine taps and, on 64-channel layers, fill half of every 128-wide tile with zeros; here one block owns
-// (64 n) x (64 c) x ALL NINE taps and walks 64-pixel row segments (b, y, x0..x0+63):
+// (64 n) x (64 c) x ALL NINE taps and walks row segments (b, y, x0..x0+len-1) of up to 64 pixels:
 //   LDS stage = dy [64 px][64 n]  +  x rows y-1, y, y+1 as [66 px: x0-1 .. x0+64][64 c]      (35 KiB, two stages)
 //   the nine taps are the three staged rows read at pixel shifts 0, 1, 2, so every staged byte feeds 9 (dy) / 3 (x)
 //   MFMA operands: 144 MFMAs per 33.5 KiB staged instead of 16 per 32 KiB.
@@ -620,7 +620,7 @@ struct WRows {
   WArgs w;
   unsigned in_span, dy_span;   // bytes, < 2 GiB
   int ntiles, cchunks;         // ceil(N / 64), ceil(C / 64)
-  int segs_per_row;            // W / 64
+  int seglen, segs_per_row;    // pixels per row segment (multiple of 16, <= 64), ceil(W / seglen)
   int nsegs, segs_per_split;
 };
 
@@ -662,32 +662,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int sy = (seg_begin / kk.segs_per_row) % a.H;
   int sb = seg_begin / kk.segs_per_row / a.H;
 
+  // A segment covers pixels x0 .. x0+len-1 of one image row, len <= seglen (a multiple of 16; the last segment of a
+  // row may be shorter).  It is multiplied in nkq = ceil(len / 16) groups of 16 pixels, so the panels are filled up
+  // to 16 * nkq (+2 halo) pixels and everything outside the image / past len arrives as zeros.
+  auto seg_nkq = [&](int sxi) {
+    const int rem = a.W - sxi * kk.seglen;
+    return ((rem < kk.seglen ? rem : kk.seglen) + 15) >> 4;
+  };
   auto issue = [&](int stage) {
     const unsigned lds = lds_base + stage * STAGE_BYTES;
-    const int x0 = sx * 64;
+    const int x0 = sx * kk.seglen;
+    const int nkq = seg_nkq(sx);
     if (is_dy) {
       const unsigned soff = (unsigned)((sb * a.dy_sB + sy * a.dy_sH + (int64_t)x0 * a.dy_sW) * 2);
+      const int rem = a.W - x0 - lrow;                    // piece * 8 < rem <=> the lane's pixel is inside the row
+      const int len = (a.W - x0 < kk.seglen ? a.W - x0 : kk.seglen) - lrow;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const int piece = q < 8 ? q : 7;
-        dma16_buf((piece & 1) ? v_o : v_e, srd_dy, soff + piece * 8 * dypix, lds + piece * 1024);
+      for (int piece = 0; piece < 8; ++piece) {
+        if (piece < 2 * nkq) {
+          unsigned v = (piece & 1) ? v_o : v_e;
+          if (piece * 8 >= rem || piece * 8 >= len) v = kOob;
+          dma16_buf(v, srd_dy, soff + piece * 8 * dypix, lds + piece * 1024);
+        }
       }
     } else {
       const int iy = sy + wave - 1;
       const bool rowok = (unsigned)iy < (unsigned)a.H;
       const unsigned soff = (unsigned)((sb * a.in_sB + iy * a.in_sH + (int64_t)x0 * a.in_sW) * 2);
       const unsigned ldx = lds + DYB + wave * XROW;
+      const int ixl = x0 - 1 + lrow;                      // image x of the lane's pixel in piece 0
 #pragma unroll
       for (int piece = 0; piece < 9; ++piece) {
-        unsigned v = (piece & 1) ? v_o : v_e;
-        if (!rowok) v = kOob;
-        if (piece == 0 && x0 == 0 && lrow == 0) v = kOob;
-        if (piece == 8 && (lrow > 1 || (lrow == 1 && x0 + 64 >= a.W))) v = kOob;
-        dma16_buf(v, srd_x, soff + piece * 8 * xpix, ldx + piece * 1024);
+        if (piece < 2 * nkq + 1) {
+          unsigned v = (piece & 1) ? v_o : v_e;
+          if (!rowok || (unsigned)(ixl + piece * 8) >= (unsigned)a.W) v = kOob;
+          dma16_buf(v, srd_x, soff + piece * 8 * xpix, ldx + piece * 1024);
+        }
       }
     }
     if (++sx == kk.segs_per_row) { sx = 0; if (++sy == a.H) { sy = 0; ++sb; } }
   };
+  int csx = sx;                                           // segment-in-row index of the segment being multiplied
 
   // ---- fragment addressing: this wave's 32-channel tile of the dy panel (wi) and of the x rows (wj)
   const int g = lane >> 4, s = lane & 15;
@@ -737,16 +752,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int sh = 0; sh < 3; ++sh) fb[grp & 1][sh] = frag(q + r * XROW, foff_x[sh][0], foff_x[sh][1]);
     };
+    const int ngrp = 3 * seg_nkq(csx);
+    if (++csx == kk.segs_per_row) csx = 0;
     fetch(0);
 #pragma unroll
     for (int grp = 0; grp < 12; ++grp) {
-      if (grp + 1 < 12) fetch(grp + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      const int kq = grp / 3, r = grp - kq * 3;
+      if (grp < ngrp) {
+        if (grp + 1 < 12 && grp + 1 < ngrp) fetch(grp + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int kq = grp / 3, r = grp - kq * 3;
 #pragma unroll
-      for (int sh = 0; sh < 3; ++sh)
-        acc[r][sh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kq & 1], fb[grp & 1][sh], acc[r][sh], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int sh = 0; sh < 3; ++sh)
+          acc[r][sh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kq & 1], fb[grp & 1][sh], acc[r][sh], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
@@ -829,14 +848,20 @@ int wgrad_tile(const gdl_wgrad_args& a) {
   return 256;
 }
 
-// row-segment kernel: every 3x3 / stride 1 / pad 1 layer on a map whose width is a multiple of 64
+// row-segment kernel: every 3x3 / stride 1 / pad 1 layer on a map at least 32 pixels wide
 bool wgrad_rows_ok(const gdl_wgrad_args& a) {
   if (a.dtype != GDL_BF16 || (g_wgrad_force_small & 2)) return false;
   if ((g_wgrad_force_small & 8) && wgrad_tile(a) == 256) return false;   // A/B hook: wide layers on the 256^2 per-tap kernel
-  if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.H != a.Ho || a.W != a.Wo || a.W % 64 != 0 || a.nz != 1)
+  if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.H != a.Ho || a.W != a.Wo || a.W < 32 || a.nz != 1)
     return false;
   return span_bytes(a.B, a.H, a.W, a.C, a.in_sB, a.in_sH, a.in_sW, 2) + a.in_sW * 2 <= 0x7ffffff0ll &&
          span_bytes(a.B, a.Ho, a.Wo, a.N, a.dy_sB, a.dy_sH, a.dy_sW, 2) <= 0x7ffffff0ll;
+}
+
+// rows are cut into ceil(W / 64) segments of equal length in 16-pixel units: 144 -> 3 x 48, 72 -> 48 + 24, 128 -> 2 x 64
+int rows_seglen(int W) {
+  const int u = (W + 15) / 16, n = (W + 63) / 64;
+  return 16 * ((u + n - 1) / n);
 }
 
 int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
@@ -844,7 +869,8 @@ int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
     // two blocks per CU: ~512 blocks, >= 8 segments per split
     const int64_t tiles = (int64_t)((a.N + 63) / 64) * ((a.C + 63) / 64);
     int64_t want = 512 / tiles;
-    const int64_t max_by_k = P / 64 / 8;
+    const int seglen = rows_seglen(a.W);
+    const int64_t max_by_k = (int64_t)a.B * a.H * ((a.W + seglen - 1) / seglen) / 8;
     if (want > max_by_k) want = max_by_k;
     if (want > 512) want = 512;
     if (want < 1) want = 1;
@@ -916,8 +942,9 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
     kr.dy_span = (unsigned)span_bytes(a.B, a.Ho, a.Wo, a.N, a.dy_sB, a.dy_sH, a.dy_sW, 2);
     kr.ntiles = (a.N + 63) / 64;
     kr.cchunks = (a.C + 63) / 64;
-    kr.segs_per_row = a.W / 64;
-    kr.nsegs = (int)(k.P / 64);
+    kr.seglen = rows_seglen(a.W);
+    kr.segs_per_row = (a.W + kr.seglen - 1) / kr.seglen;
+    kr.nsegs = a.B * a.H * kr.segs_per_row;
     kr.segs_per_split = (kr.nsegs + k.splits - 1) / k.splits;
     static bool rows_attr_set = false;
     if (!rows_attr_set) {

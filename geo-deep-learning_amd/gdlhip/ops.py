@@ -144,7 +144,8 @@ class KernelTimer:
     VARIANT = {0: "conv_gemm_kernel<{dt},2,2,1,1> (64x64 tiles)", 1: "conv_gemm_kernel<{dt},2,2,2,2> (128x128 tiles)",
                2: "conv_gemm_kernel<{dt},2,4,4,2> (256x256 tiles)",
                3: "conv_gemm_kernel<{dt},2,4,4,2,pingpong> (256x256 tiles, alternating loader halves)",
-               4: "conv3x3_sf_kernel<{dt}> (256x256 tiles, 3x3 taps share one staged activation tile)"}
+               4: "conv3x3_sf_kernel<{dt}> (256x256 tiles, 3x3 taps share one staged activation tile)",
+               5: "conv_gemm_kernel<{dt},4,1,2,2> (256x64 tiles, narrow outputs)"}
 
     def __init__(self) -> None:
         self.records: list = []

@@ -267,9 +267,12 @@ def test_wgrad_strided_dy(dtype, C, N):
 
 
 @pytest.mark.parametrize("B,H,W,C,N", [(2, 5, 64, 64, 64), (1, 3, 128, 128, 32), (2, 1, 64, 72, 64), (1, 24, 64, 192, 128),
-                                       (3, 64, 64, 64, 16)])
+                                       (3, 64, 64, 64, 16),
+                                       # widths that are not multiples of 64 / 16: 144 -> 3 x 48, 72 -> 48 + 24, 100 -> 64 + 36
+                                       (2, 7, 144, 256, 256), (2, 9, 72, 64, 128), (1, 11, 36, 320, 64), (2, 6, 100, 64, 64),
+                                       (1, 5, 33, 64, 40)])
 def test_wgrad_row_segment_kernel(B, H, W, C, N):
-    """3x3 convs on maps whose width is a multiple of 64 take the row-segment kernel (all nine taps per block): checked
+    """3x3 convs on maps at least 32 pixels wide take the row-segment kernel (all nine taps per block): checked
     against autograd and against the per-tap kernel it replaces (same products, different summation order)."""
     from gdlhip import _lib
     dtype = torch.bfloat16
@@ -504,3 +507,30 @@ def test_conv3x3_shared_staging_kernel(dtype, B, H, W, C, N):
         lib.gdl_debug_force_conv_variant(-1)
     close(outs[4].permute(0, 3, 1, 2), ref, dtype, "3x3 shared staging")
     assert (outs[4] - outs[1]).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,N,R", [(2, 37, 23, 64, 64, 3), (1, 50, 50, 128, 32, 1), (3, 16, 16, 192, 64, 3)])
+def test_conv_narrow_output_tile(dtype, B, H, W, C, N, R):
+    """256 x 64 tile for N <= 64 layers (forced here; chosen automatically on large maps): M tails, N tails,
+    bias + ReLU + residual epilogue, vs F.conv2d and vs the 64^2 tile."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
+    x, w = q(rnd(B, C, H, W), dtype), q(rnd(N, C, R, R, seed=1) * 0.1, dtype)
+    bias, resid = rnd(N, seed=2), q(rnd(B, N, H, W, seed=3), dtype)
+    ref = F.relu(F.conv2d(x, w, bias, padding=R // 2)) + resid
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    wq = w.permute(0, 2, 3, 1).reshape(N, -1).contiguous().to(DEV, dtype)
+    rn = resid.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    outs = {}
+    try:
+        for v in (5, 0):
+            lib.gdl_debug_force_conv_variant(v)
+            outs[v] = ops.conv_gemm(xn, wq, R=R, S=R, pad=R // 2, bias=bias.to(DEV), act=ops.ACT_RELU, resid=rn,
+                                    out_dtype=torch.float32)
+    finally:
+        lib.gdl_debug_force_conv_variant(-1)
+    close(outs[5].permute(0, 3, 1, 2), ref, dtype, "256x64 tile")
+    assert (outs[5] - outs[0]).abs().max().item() <= 1e-5 * ref.abs().max().item()

@@ -28,6 +28,11 @@ LAYERS = [  # name, H, W, C, N
     ("upernet psp 2816->256 @16", 16, 16, 2816, 256),
     ("neck 768->768 @128", 128, 128, 768, 768),
     ("neck 768->768 @64", 64, 64, 768, 768),
+    ("dofa@512 neck 768->768 @144", 144, 144, 768, 768),
+    ("dofa@512 neck 768->768 @72", 72, 72, 768, 768),
+    ("dofa@512 fuse 1024->256 @144", 144, 144, 1024, 256),
+    ("dofa@512 fpn 256->256 @144", 144, 144, 256, 256),
+    ("dofa@512 fpn 256->256 @36", 36, 36, 256, 256),
     ("unet++ 64->64 @256", 256, 256, 64, 64),
     ("unet++ 128->64 @256", 256, 256, 128, 64),
     ("unet++ 192->64 @128", 128, 128, 192, 64),
