@@ -13,31 +13,38 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             int y_dtype, int64_t rows, int D,
                                                             float eps) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // narrow rows (D <= 128): 16 or 32 lanes hold a row, a wave normalises 4 or 2 rows (rows_per_block = 4 * nsub)
+  const int lpp = (VPL == 1 && D <= 128) ? (D <= 64 ? 16 : 32) : 64;
+  const int nsub = 64 / lpp, cl = lane % lpp;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * nsub + lane / lpp;
   if (row >= rows) return;
+  auto group_sum = [&](float t) {
+    for (int o = lpp >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    return t;
+  };
   const float* xr = x + row * x_stride;
   float4 v[VPL];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
-    const int c = (i * 64 + lane) * 4;
+    const int c = (i * 64 + cl) * 4;
     v[i] = c < D ? *(const float4*)(xr + c) : make_float4(0, 0, 0, 0);
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
-  const float mean = wave_sum(s) / (float)D;
+  const float mean = group_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
-    const int c = (i * 64 + lane) * 4;
+    const int c = (i * 64 + cl) * 4;
     if (c < D) {
       const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
       q += (a * a + b * b) + (cc * cc + d * d);
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const float rstd = rsqrtf(group_sum(q) / (float)D + eps);
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
-    const int c = (i * 64 + lane) * 4;
+    const int c = (i * 64 + cl) * 4;
     if (c >= D) continue;
     const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
     const float o0 = (v[i].x - mean) * rstd * g.x + b.x, o1 = (v[i].y - mean) * rstd * g.y + b.y;
@@ -338,7 +345,8 @@ extern "C" int gdl_layernorm_fwd(const float* x, int64_t x_stride, const float* 
   GDL_CHECK_ARG(x_stride % 4 == 0, "gdl_layernorm_fwd: x_stride must be a multiple of 4");
   if (rows <= 0) return GDL_OK;
   hipStream_t s = (hipStream_t)stream;
-  const unsigned grid = (unsigned)((rows + 3) / 4);
+  const int rpb = 4 * (D <= 64 ? 4 : (D <= 128 ? 2 : 1));   // rows per block: narrow rows share a wave
+  const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
   const int vpl = (D + 255) / 256;
 #define LN_LAUNCH(V) hipLaunchKernelGGL(layernorm_fwd_kernel<V>, dim3(grid), dim3(256), 0, s, x, x_stride, gamma, beta, y, y_dtype, rows, D, eps)
   if (vpl <= 1) LN_LAUNCH(1);

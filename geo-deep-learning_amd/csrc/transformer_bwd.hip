@@ -49,22 +49,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float eps, float* __restrict__ ws) {
   __shared__ float red[2][4][64 * 4 * VPL];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // narrow rows (D <= 128, MiT stages 1-2): 16 or 32 lanes hold a row and a wave normalises 4 or 2 rows at once
+  const int lpp = (VPL == 1 && D <= 128) ? (D <= 64 ? 16 : 32) : 64;
+  const int nsub = 64 / lpp, sub = lane / lpp, cl = lane % lpp;
+  auto group_sum = [&](float v) {
+    for (int o = lpp >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
   float4 pg[VPL], pb[VPL], gm[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     pg[i] = make_float4(0, 0, 0, 0); pb[i] = make_float4(0, 0, 0, 0);
-    const int c = (i * 64 + lane) * 4;
+    const int c = (i * 64 + cl) * 4;
     gm[i] = c < D ? *(const float4*)(gamma + c) : make_float4(0, 0, 0, 0);
   }
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = per * blockIdx.x, r1 = r0 + per < rows ? r0 + per : rows;
-  for (int64_t row = r0 + w; row < r1; row += 4) {
+  for (int64_t row = r0 + w * nsub + sub; row < r1; row += 4 * nsub) {
     const float* xr = x + row * x_stride;
     float4 v[VPL], d[VPL];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-      const int c = (i * 64 + lane) * 4;
+      const int c = (i * 64 + cl) * 4;
       if (c < D) {
         v[i] = *(const float4*)(xr + c);
         if constexpr (sizeof(TDY) == 4) {
@@ -79,17 +86,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       }
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
-    const float mean = wave_sum(s) / (float)D;
+    const float mean = group_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-      const int c = (i * 64 + lane) * 4;
+      const int c = (i * 64 + cl) * 4;
       if (c < D) {
         v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
         q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
       }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    const float rstd = rsqrtf(group_sum(q) / (float)D + eps);
     float sg = 0.f, sgx = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -100,10 +107,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       sg += (d[i].x + d[i].y) + (d[i].z + d[i].w);
       sgx += (d[i].x * v[i].x + d[i].y * v[i].y) + (d[i].z * v[i].z + d[i].w * v[i].w);
     }
-    const float mg = wave_sum(sg) / (float)D, mgx = wave_sum(sgx) / (float)D;
+    const float mg = group_sum(sg) / (float)D, mgx = group_sum(sgx) / (float)D;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-      const int c = (i * 64 + lane) * 4;
+      const int c = (i * 64 + cl) * 4;
       if (c >= D) continue;
       float4 o;
       o.x = rstd * (d[i].x - mg - v[i].x * mgx); o.y = rstd * (d[i].y - mg - v[i].y * mgx);
@@ -122,9 +129,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
   __syncthreads();
   for (int c = threadIdx.x; c < D; c += 256) {
-    ws[((int64_t)blockIdx.x * 2 + 0) * D + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-    ws[((int64_t)blockIdx.x * 2 + 1) * D + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    float sg = 0.f, sb = 0.f;
+    for (int q = 0; q < nsub; ++q) {
+      const int i = nsub == 1 ? c : (q * lpp + (c >> 2)) * 4 + (c & 3);
+      sg += (red[0][0][i] + red[0][1][i]) + (red[0][2][i] + red[0][3][i]);
+      sb += (red[1][0][i] + red[1][1][i]) + (red[1][2][i] + red[1][3][i]);
+    }
+    ws[((int64_t)blockIdx.x * 2 + 0) * D + c] = sg;
+    ws[((int64_t)blockIdx.x * 2 + 1) * D + c] = sb;
   }
+}
+
+// Lane -> (4-channel group, row sub-index) for the column reductions below: 256 channels of one row per wave, or, on
+// narrow tensors (C <= 128), 4 or 2 rows side by side so that no lane idles.
+struct ColMap { int c, sub, nsub, lpp; };
+__device__ __forceinline__ ColMap col_map(int lane, int C, int block_x) {
+  const int lpp = C > 128 ? 64 : (C > 64 ? 32 : 16);
+  ColMap m;
+  m.lpp = lpp; m.nsub = 64 / lpp; m.sub = lane / lpp; m.c = block_x * 256 + (lane % lpp) * 4;
+  return m;
+}
+// sum over the 4 waves and the nsub row sub-indices of channel t's partials in red[4][256] (lane-major, 4 per lane)
+__device__ __forceinline__ float col_total(const float (&red)[4][256], const ColMap& m, int t) {
+  float s = 0.f;
+  for (int q = 0; q < m.nsub; ++q) {
+    const int i = (q * m.lpp + (t >> 2)) * 4 + (t & 3);
+    s += (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
+  return s;
 }
 
 // ---------------------------------------------------------------- column sums (bias gradients)
@@ -133,12 +165,13 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restr
                                                              int64_t x_stride, float* __restrict__ ws) {
   __shared__ float red[4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 256 + lane * 4;
+  const ColMap cm = col_map(lane, C, blockIdx.x);
+  const int c = cm.c;
   const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
   const int64_t r0 = per * blockIdx.y, r1 = r0 + per < rows ? r0 + per : rows;
   float s[4] = {0, 0, 0, 0};
   if (c < C)
-    for (int64_t r = r0 + w; r < r1; r += 4) {
+    for (int64_t r = r0 + w * cm.nsub + cm.sub; r < r1; r += 4 * cm.nsub) {
       if constexpr (sizeof(T) == 4) {
         const float4 v = *(const float4*)((const float*)x + r * x_stride + c);
         s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
@@ -152,7 +185,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restr
   for (int j = 0; j < 4; ++j) red[w][lane * 4 + j] = s[j];
   __syncthreads();
   const int t = threadIdx.x, cc = blockIdx.x * 256 + t;
-  if (cc < C) ws[(int64_t)blockIdx.y * C + cc] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+  if (cc < C) ws[(int64_t)blockIdx.y * C + cc] = col_total(red, cm, t);
 }
 
 // ---------------------------------------------------------------- LayerScale / DropPath backward
@@ -165,23 +198,26 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
                                                              float* __restrict__ ws) {
   __shared__ float red[4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 256 + lane * 4;
+  const ColMap cm = col_map(lane, C, blockIdx.x);
+  const int c = cm.c;
   const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
   const int64_t r0 = per * blockIdx.y, r1 = r0 + per < rows ? r0 + per : rows;
   float acc[4] = {0, 0, 0, 0};
   if (c < C) {
     float gm[4] = {1.f, 1.f, 1.f, 1.f};
     if (gamma) { const float4 t = *(const float4*)(gamma + c); gm[0] = t.x; gm[1] = t.y; gm[2] = t.z; gm[3] = t.w; }
-    for (int64_t r = r0 + w; r < r1; r += 4) {
+    for (int64_t r = r0 + w * cm.nsub + cm.sub; r < r1; r += 4 * cm.nsub) {
       const float sb = s ? s[r / rows_per_batch] : 1.f;
       const float4 gv = *(const float4*)(g + r * C + c);
       const float gg[4] = {gv.x * sb, gv.y * sb, gv.z * sb, gv.w * sb};
       if (gamma && z) {
+        float zv[4];
+        gdldw::Px<TZ>::cvt(gdldw::Px<TZ>::ld(z, r * C + c), zv);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += gg[j] * ElemIO<TZ>::load(z, r * C + c + j);
+        for (int j = 0; j < 4; ++j) acc[j] += gg[j] * zv[j];
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ElemIO<TD>::store(dz, r * C + c + j, gg[j] * gm[j]);
+      const float o[4] = {gg[0] * gm[0], gg[1] * gm[1], gg[2] * gm[2], gg[3] * gm[3]};
+      gdldw::Px<TD>::st(dz, r * C + c, o);
     }
   }
   if (ws) {
@@ -189,7 +225,7 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
     for (int j = 0; j < 4; ++j) red[w][lane * 4 + j] = acc[j];
     __syncthreads();
     const int t = threadIdx.x, cc = blockIdx.x * 256 + t;
-    if (cc < C) ws[(int64_t)blockIdx.y * C + cc] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (cc < C) ws[(int64_t)blockIdx.y * C + cc] = col_total(red, cm, t);
   }
 }
 

@@ -881,7 +881,10 @@ int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
   int64_t want = ((t == 256 ? 512 : 1024) + tiles - 1) / tiles;   // aim for ~1024 (512 big-tile) blocks
   const int64_t max_by_k = P / (8 * bkp);              // keep >= 8 K-steps per split
   if (want > max_by_k) want = max_by_k;
-  if (want > 64) want = 64;
+  // few-tile layers (narrow linears over many pixels: MiT stage 1-2) need many splits to fill 256 CUs; the wide
+  // reduction kernel makes them cheap.  Batched calls (attention dK / dV) already have nz-fold parallelism.
+  const int64_t cap = a.nz > 1 ? 64 : 512;
+  if (want > cap) want = cap;
   if (want < 1) want = 1;
   return (int)want;
 }

@@ -151,7 +151,7 @@ def test_attention_flash_spike():
 
 
 @pytest.mark.parametrize("out_dtype", DTYPES)
-@pytest.mark.parametrize("D", [128, 768, 1024])
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 160, 768, 1024])
 def test_layernorm(out_dtype, D):
     x, g, b = rnd(5, 33, D) * 3 + 1, rnd(D, seed=1), rnd(D, seed=2)
     y = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, out_dtype)

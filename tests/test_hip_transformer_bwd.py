@@ -38,7 +38,7 @@ def q(t, dtype):
 
 
 @pytest.mark.parametrize("dy_dtype", DTYPES)
-@pytest.mark.parametrize("rows,D", [(37, 64), (300, 320), (1297, 768), (50, 1024)])
+@pytest.mark.parametrize("rows,D", [(37, 64), (300, 320), (1297, 768), (50, 1024), (1003, 32), (515, 128), (77, 96), (6, 64)])
 def test_layernorm_bwd(dy_dtype, rows, D):
     x = rnd(rows, D).requires_grad_()
     gamma, beta = (1 + 0.2 * rnd(D, seed=1)).requires_grad_(), rnd(D, seed=2).requires_grad_()
