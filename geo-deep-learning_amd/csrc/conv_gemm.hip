@@ -34,7 +34,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // PP ("ping-pong", 8-wave tile only): the two waves that share a SIMD (w and w+4) take turns being the LOADER of a
 // K-step: the loader half issues the whole next tile's DMA while its partners go straight to their MFMAs, so the
 // matrix pipe never idles behind a workgroup-wide DMA-issue phase; the halves swap roles every K-step.
-// CT ("channel tail", small tiles only): C is not a multiple of the K chunk (MiT-B0: 32 / 160 channels in bf16, 32-wide
+// CT ("channel tail", 64^2 / 128^2 / 256x64 tiles only): C is not a multiple of the K chunk (MiT-B0: 32 / 160 channels in bf16, 32-wide
 // attention heads); the 16-byte pieces past C in the last chunk of every tap are fetched as zeros.
 template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false, bool CT = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const KArgs k) {
@@ -346,14 +346,14 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
     if (variant == 4) return conv3x3_sf_launch(k, s);
     if (variant == 3) return launch_x<bf16_tag, 2, 4, 4, 2, false, true>(k, s);
     if (variant == 2) return launch_x<bf16_tag, 2, 4, 4, 2, false>(k, s);
-    if (variant == 5) return launch_x<bf16_tag, 4, 1, 2, 2, false>(k, s);
+    if (variant == 5) return k.c_tail ? launch_x<bf16_tag, 4, 1, 2, 2, false, false, true>(k, s) : launch_x<bf16_tag, 4, 1, 2, 2, false>(k, s);
     if (variant == 1) return launch<bf16_tag, 2, 2, 2, 2>(k, s);
     return launch<bf16_tag, 2, 2, 1, 1>(k, s);
   }
   if (variant == 4) return conv3x3_sf_launch(k, s);
   if (variant == 3) return launch_x<float, 2, 4, 4, 2, false, true>(k, s);
   if (variant == 2) return launch_x<float, 2, 4, 4, 2, false>(k, s);
-  if (variant == 5) return launch_x<float, 4, 1, 2, 2, false>(k, s);
+  if (variant == 5) return k.c_tail ? launch_x<float, 4, 1, 2, 2, false, false, true>(k, s) : launch_x<float, 4, 1, 2, 2, false>(k, s);
   if (variant == 1) return launch<float, 2, 2, 2, 2>(k, s);
   return launch<float, 2, 2, 1, 1>(k, s);
 }
@@ -372,7 +372,8 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
   if (flops) *flops = 2 * M * a.N * ((int64_t)a.R * a.S * a.C) * a.nz;
   if (g_forced_variant >= 0 && !(g_forced_variant >= 2 && (a.aux_out || a.act == GDL_ACT_MUL_GELU_GRAD)) &&
-      !(g_forced_variant >= 2 && a.C % (a.dtype == GDL_BF16 ? 64 : 32) != 0) && !(g_forced_variant == 5 && a.N > 64) &&
+      !(g_forced_variant >= 2 && g_forced_variant != 5 && a.C % (a.dtype == GDL_BF16 ? 64 : 32) != 0) &&
+      !(g_forced_variant == 5 && a.N > 64) &&
       !(g_forced_variant == 4 && !conv3x3_sf_applicable(a)))
     return g_forced_variant;
   const int64_t t256 = ((M + 255) / 256) * ((a.N + 255) / 256) * a.nz;
@@ -388,6 +389,6 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   if (t128 >= 256 && a.N >= 128) return 1;
   // narrow outputs (N <= 64: UNet++ decoder, ResNet layer1, MiT stage 1): a 256 (m) x 64 (n) tile, four waves of
   // 64 x 64 -- one LDS fragment read per MFMA instead of the two of the 64^2 tile's 32 x 32 waves
-  if (!extra && !ctail && a.N <= 64 && ((M + 255) / 256) * a.nz >= 256) return 5;
+  if (!extra && a.N <= 64 && ((M + 255) / 256) * a.nz >= 256) return 5;
   return 0;
 }

@@ -165,6 +165,7 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& k, f32x16_t (&acc)[TM
       // row and the high half-wave channels [16p+8, 16p+16)
 #pragma unroll
       for (int p2 = 0; p2 < 2; ++p2) {
+        if (nt + 16 * p2 >= a.N) continue;            // N % 32 == 16: the tile's upper 16 channels do not exist
         const int na = nt + 16 * p2 + 4 * fhalf, nb = na + 8;
         float ba[4], sa[4], ha[4], bb[4], sb[4], hb[4];
         load4(a.bias, na, 0.f, ba); load4(a.scale, na, 1.f, sa); load4(a.shift, na, 0.f, ha);

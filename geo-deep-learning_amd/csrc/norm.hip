@@ -81,11 +81,11 @@ __device__ __forceinline__ void store4(void* p, int64_t off, const float (&o)[4]
 }
 
 // Lane -> (4-channel group, pixel sub-index).  Wide layers: the 64 lanes of a wave cover 256 channels of ONE pixel.
-// Narrow layers (C <= 128: MiT stages 1-2, ResNet / UNet++ 64- and 128-channel maps): 16 or 32 lanes cover a pixel
-// and the wave handles 4 or 2 pixels per step, so no lane idles.  A wave then strides 4 * nsub pixels.
+// Narrow layers (C <= 128: ResNet / UNet++ 16- to 128-channel maps): 4 .. 32 lanes cover a pixel and the wave
+// handles 16 .. 2 pixels per step, so no lane idles.  A wave then strides 4 * nsub pixels.
 struct LaneMap { int c, sub, nsub, lpp; };
 __device__ __forceinline__ LaneMap lane_map(int lane, int C, int block_x) {
-  const int lpp = C > 128 ? 64 : (C > 64 ? 32 : 16);
+  const int lpp = C > 128 ? 64 : (C > 64 ? 32 : (C > 32 ? 16 : (C > 16 ? 8 : 4)));
   LaneMap m;
   m.lpp = lpp; m.nsub = 64 / lpp; m.sub = lane / lpp; m.c = block_x * 256 + (lane % lpp) * 4;
   return m;

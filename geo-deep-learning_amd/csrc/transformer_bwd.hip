@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // narrow tensors (C <= 128), 4 or 2 rows side by side so that no lane idles.
 struct ColMap { int c, sub, nsub, lpp; };
 __device__ __forceinline__ ColMap col_map(int lane, int C, int block_x) {
-  const int lpp = C > 128 ? 64 : (C > 64 ? 32 : 16);
+  const int lpp = C > 128 ? 64 : (C > 64 ? 32 : (C > 32 ? 16 : (C > 16 ? 8 : 4)));
   ColMap m;
   m.lpp = lpp; m.nsub = 64 / lpp; m.sub = lane / lpp; m.c = block_x * 256 + (lane % lpp) * 4;
   return m;

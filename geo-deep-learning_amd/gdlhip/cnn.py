@@ -1,11 +1,11 @@
 """Convolutional building blocks of the ResNet-encoder / UNet++ path (smp.UnetPlusPlus; reference call site
 tasks_with_models/segmentation_unetplus.py:126-131) as autograd nodes over libgdlhip.so kernels.
 
-Channel padding: the implicit-GEMM kernel consumes K in 128-byte chunks (64 bf16 / 32 f32 channels per filter
-tap), while UNet++'s last decoder stages have 32 and 16 channels.  Those tensors are simply carried with their
-channel dim zero-padded to the chunk size: a conv whose input has more channels than its weight treats the extra
-channels as zero-weight, a conv whose output count is not a chunk multiple pads it (zero weight rows, BN gamma =
-beta = 0 => exactly 0 after BN/ReLU), and every gradient is sliced back to the parameter's real shape.
+Channel granularity: activations carry multiples of 8 (bf16) / 4 (f32) channels, i.e. whole 16-byte pieces; the
+implicit-GEMM kernels zero-fill the rest of a 128-byte K chunk themselves, so UNet++'s 32- and 16-channel decoder
+stages are stored and normalised at their true width.  A conv whose input has more channels than its weight treats
+the extra channels as zero-weight, an output count that is not a multiple of the granularity is padded (zero weight
+rows, BN gamma = beta = 0 => exactly 0 after BN/ReLU), and every gradient is sliced back to the parameter's shape.
 """
 
 from __future__ import annotations
@@ -22,7 +22,13 @@ from .tnn import _dense
 
 
 def chunk(cd: torch.dtype) -> int:
+    """channels per 128-byte K chunk of the implicit-GEMM kernel"""
     return 32 if cd == torch.float32 else 64
+
+
+def grain(cd: torch.dtype) -> int:
+    """channel granularity of activations: 16-byte pieces (the kernels zero-fill the tail of a K chunk)"""
+    return 4 if cd == torch.float32 else 8
 
 
 def pad_to(n: int, m: int) -> int:
@@ -113,9 +119,9 @@ class _ConvBNTrain(Function):
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, momentum, eps, stride, pad, relu, sync_group):
         cd = x.dtype
         n, c, r, s = _wshape(weight)
-        cpad, npad = x.shape[-1], pad_to(n, chunk(cd))
-        if cpad < c or cpad % chunk(cd):
-            raise ValueError(f"conv input has {cpad} channels, weight expects {c} (padded to a multiple of {chunk(cd)})")
+        cpad, npad = x.shape[-1], pad_to(n, grain(cd))
+        if cpad < c or cpad % grain(cd):
+            raise ValueError(f"conv input has {cpad} channels, weight expects {c} (padded to a multiple of {grain(cd)})")
         wq, _ = padded_operands(weight, cd, cpad, npad)
         y = ops.conv_gemm(x, wq, R=r, S=s, stride=stride, pad=pad)
         world = _world(sync_group) if sync_group is not False else 1
@@ -170,7 +176,7 @@ def conv_bn(x: Tensor, weight: Tensor, norm: nn.Module, *, stride: int = 1, pad:
         msg = ("gdlhip: autograd through eval-mode BatchNorm is not implemented; call under torch.no_grad() for "
                "inference or model.train() for training")
         raise NotImplementedError(msg)
-    cpad, npad = x.shape[-1], pad_to(n, chunk(cd))
+    cpad, npad = x.shape[-1], pad_to(n, grain(cd))
 
     def fold():
         scale, shift = ops.bn_fold(norm.weight.detach(), norm.bias.detach(), norm.running_mean, norm.running_var,
@@ -207,7 +213,7 @@ class _ConvBias(Function):
         db = ops.colsum(dy)[:n] if ctx.needs_input_grad[2] else None
         dx = None
         if ctx.needs_input_grad[0]:
-            npk = pad_to(n, chunk(cd))                      # K of the data-gradient GEMM
+            npk = pad_to(n, grain(cd))                      # K of the data-gradient GEMM
             dyk = dy if npk == npad else ops.pad_channels(g, npk, cd)
             dx = ops.conv_gemm(dyk, padded_operands(weight, cd, cpad, npk)[1], R=r, S=s, pad=r - 1 - pad)
         return dx, dw, db, None, None

@@ -7,7 +7,7 @@ Everything runs NHWC in the compute dtype on the implicit-GEMM MFMA kernel:
 * BasicBlock = conv3x3-BN-ReLU, conv3x3-BN, (+ 1x1/s downsample-BN), residual add + ReLU (one kernel in
   training; folded into the second conv's epilogue in eval);
 * DecoderBlock = nearest x2 of the input written straight into the dense-skip concat buffer, then two
-  conv3x3-BN-ReLU; the 32- and 16-channel stages are carried zero-padded to the kernel's K-chunk (gdlhip.cnn);
+  conv3x3-BN-ReLU; the 32- and 16-channel stages run at their true width (channel-tail kernels, gdlhip.cnn);
 * head = 3x3 conv to ``classes`` -> NCHW f32 logits.
 """
 

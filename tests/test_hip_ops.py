@@ -86,6 +86,13 @@ def test_conv_nhwc(dtype, B, H, W, C, N, R):
     wq = w.permute(0, 2, 3, 1).reshape(N, -1).contiguous().to(DEV, dtype)
     y = ops.conv_gemm(xn, wq, R=R, S=R, pad=R // 2, bias=bias.to(DEV), out_dtype=torch.float32)
     close(y.permute(0, 3, 1, 2), ref, dtype, "conv")
+    # output in the compute dtype inside a wider buffer: the 16-byte store path must respect N (also N % 32 == 16)
+    buf = torch.full((B, H, W, N + 16), 7.0, device=DEV, dtype=dtype)
+    ops.conv_gemm(xn, wq, R=R, S=R, pad=R // 2, bias=bias.to(DEV), out=buf[..., 8:8 + N])
+    close(buf[..., 8:8 + N].float().permute(0, 3, 1, 2), ref, dtype, "conv into a slice")
+    assert (buf[..., :8] == 7).all() and (buf[..., 8 + N:] == 7).all()
+    dense = ops.conv_gemm(xn, wq, R=R, S=R, pad=R // 2, bias=bias.to(DEV), out_dtype=dtype)
+    close(dense.float().permute(0, 3, 1, 2), ref, dtype, "conv dense compute-dtype output")
 
 
 def test_conv_strided_views():

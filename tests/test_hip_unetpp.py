@@ -68,9 +68,11 @@ def test_upcat_and_add_relu(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cin,cout,stride,k", [(64, 32, 1, 3), (64, 128, 2, 3), (64, 128, 2, 1), (128, 16, 1, 3)])
+@pytest.mark.parametrize("cin,cout,stride,k", [(64, 32, 1, 3), (64, 128, 2, 3), (64, 128, 2, 1), (128, 16, 1, 3),
+                                               (32, 16, 1, 3), (16, 16, 1, 3), (64, 20, 1, 3), (24, 40, 2, 3)])
 def test_conv_bn_node_padded(dtype, cin, cout, stride, k):
-    """conv-BN-ReLU training node with channel padding / stride vs torch autograd."""
+    """conv-BN-ReLU training node with narrow channels (K-chunk tails), output padding to the 16-byte granularity
+    and stride vs torch autograd."""
     B, H = 2, 12
     conv = torch.nn.Conv2d(cin, cout, k, stride, k // 2, bias=False)
     bn = torch.nn.BatchNorm2d(cout)
@@ -90,7 +92,7 @@ def test_conv_bn_node_padded(dtype, cin, cout, stride, k):
     bg.running_mean.zero_(); bg.running_var.fill_(1.0); bg.num_batches_tracked.zero_()
     xd = x.to(DEV, dtype).requires_grad_()
     yd = cnn.conv_bn(xd, cg.weight, bg, stride=stride, pad=k // 2)
-    npad = cnn.pad_to(cout, cnn.chunk(dtype))
+    npad = cnn.pad_to(cout, cnn.grain(dtype))
     assert yd.shape[-1] == npad
     tol = 2e-4 if dtype == torch.float32 else 4e-2
     sc = y.abs().max().item()
