@@ -36,7 +36,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // matrix pipe never idles behind a workgroup-wide DMA-issue phase; the halves swap roles every K-step.
 // CT ("channel tail", 64^2 / 128^2 / 256x64 tiles only): C is not a multiple of the K chunk (MiT-B0: 32 / 160 channels in bf16, 32-wide
 // attention heads); the 16-byte pieces past C in the last chunk of every tap are fetched as zeros.
-template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false, bool CT = false>
+// TP ("tap packed", 4-wave tiles, C < one K chunk and a divisor of it): a K chunk holds 64 / C whole filter taps
+// instead of one zero-padded tap, so a 3x3 conv on 16 channels takes 3 K-steps instead of 9.  The weight rows
+// [N][(tap, c)] are already contiguous in that order; on the activation side a lane's 16-byte piece belongs to tap
+// (chunk's first tap + piece / pieces-per-tap), which only shifts its pixel offset and its halo bit.
+template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false, bool CT = false,
+          bool TP = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const KArgs k) {
   constexpr int ES = TileTraits<T>::ES;
   constexpr int BKE = TileTraits<T>::BKE;
@@ -46,6 +51,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   constexpr int CA = BM / (8 * NW), CB = BN / (8 * NW);  // DMA instructions per loading wave per tile
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/waves mismatch");
   static_assert(!PP || NWALL == 8, "ping-pong needs two waves per SIMD");
+  static_assert(!TP || (NW == 4 && !PP && !CT), "tap packing relies on the 4-wave DMA geometry");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE_BYTES = (BM + BN) * 128;  // [A: BM rows | B: BN rows] x 128 B
@@ -79,11 +85,15 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   int a_voff[CA];        // byte offset of (b, iy0, ix0, chunk) for the row at tap (0,0), cc = 0 (may be negative)
   unsigned a_mask[CA];   // bit t set <=> filter tap t of this row reads inside the image
   unsigned a_tail = 0, b_tail = 0;   // CT: bit i set <=> instruction i's 16-byte piece lies inside the last chunk's C tail
+  // TP: with four loading waves a lane's source chunk is the same for every instruction i
+  const int tp_chunk = lslot ^ ((((lwave & 1) << 2) + (lrow >> 1)) & 7);
+  const int tp_ppt = TP ? a.C / (16 / ES) : 1;                 // 16-byte pieces per filter tap
+  const int tp_tap = tp_chunk / tp_ppt, tp_tpk = 8 / tp_ppt;   // the lane's tap inside a chunk, taps per chunk
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int i = 0; i < CA; ++i) {
     const int r = (i * NW + lwave) * 8 + lrow;
-    const int chunk = lslot ^ ((r >> 1) & 7);
+    const int chunk = TP ? tp_chunk % tp_ppt : lslot ^ ((r >> 1) & 7);
     if (CT && chunk * (16 / ES) < k.c_tail) a_tail |= 1u << i;
     const int m = m0 + r;
     const bool ok = m < k.M;
@@ -129,6 +139,20 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
       // CT: in the last channel chunk only the pieces below C are real
       const unsigned ta = (CT && cc == k.kc - 1) ? a_tail : 0xffffffffu;
       const unsigned tb = (CT && cc == k.kc - 1) ? b_tail : 0xffffffffu;
+      if constexpr (TP) {
+        const int t = cc * tp_tpk + tp_tap;               // this lane's filter tap in K chunk cc
+        const int tr = t / a.S, ts = t - tr * a.S;
+        const int toff = (int)((tr * a.in_sH + ts * a.in_sW) * ES);
+        const unsigned bit = (t < a.R * a.S) ? (a.pad == 0 ? 1u : 1u << (t & 31)) : 0u;
+#pragma unroll
+        for (int i = 0; i < CA; ++i) {
+          const unsigned v = (a_mask[i] & bit) ? (unsigned)(a_voff[i] + toff) : kOob;
+          dma16_buf(v, srd_a, 0u, lds_a + i * NW * 1024);
+        }
+        const bool bv = cc * 128 + tp_chunk * 16 < a.R * a.S * a.C * ES;   // past the end of the weight row
+#pragma unroll
+        for (int i = 0; i < CB; ++i) dma16_buf(bv ? b_voff[i] : kOob, srd_b, wk, lds_b + i * NW * 1024);
+      } else
       if (k.in_dense) {
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
@@ -144,20 +168,27 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
           dma16_buf(v, srd_a, 0u, lds_a + i * NW * 1024);
         }
       }
+      if constexpr (!TP) {
 #pragma unroll
-      for (int i = 0; i < CB; ++i) {
-        const unsigned v = (!CT || ((tb >> i) & 1u)) ? b_voff[i] : kOob;
-        dma16_buf(v, srd_b, wk, lds_b + i * NW * 1024);
+        for (int i = 0; i < CB; ++i) {
+          const unsigned v = (!CT || ((tb >> i) & 1u)) ? b_voff[i] : kOob;
+          dma16_buf(v, srd_b, wk, lds_b + i * NW * 1024);
+        }
       }
     }
     // every wave tracks the tile position, loader or not.  K order = channel chunk OUTER, filter tap INNER: the
     // R*S taps of one chunk re-read (shifted) the same activation bytes back to back, while they are hot in L2
-    if (k.tap_inner) {
-      if (++tap_s == a.S) { tap_s = 0; if (++tap_r == a.R) { tap_r = 0; ++cc; } }
+    if constexpr (TP) {
+      ++cc;
+      wk = (unsigned)(cc * 128);
     } else {
-      if (++cc == k.kc) { cc = 0; if (++tap_s == a.S) { tap_s = 0; ++tap_r; } }
+      if (k.tap_inner) {
+        if (++tap_s == a.S) { tap_s = 0; if (++tap_r == a.R) { tap_r = 0; ++cc; } }
+      } else {
+        if (++cc == k.kc) { cc = 0; if (++tap_s == a.S) { tap_s = 0; ++tap_r; } }
+      }
+      wk = (unsigned)(((tap_r * a.S + tap_s) * a.C + cc * BKE) * ES);
     }
-    wk = (unsigned)(((tap_r * a.S + tap_s) * a.C + cc * BKE) * ES);
   };
 
   f32x16_t acc[TM][TN];
@@ -242,14 +273,15 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   if (k.probe && tid == 0 && blockIdx.x < 2048) k.probe[4096 + blockIdx.x] = __builtin_readcyclecounter() - t0c;
 }
 
-template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false, bool CT = false>
+template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false, bool CT = false,
+          bool TP = false>
 int launch_x(const KArgs& k, hipStream_t stream) {
   constexpr int BM = WARPS_M * TM * 32, BN = WARPS_N * TN * 32;
   KArgs kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.a.N + BN - 1) / BN;
   const size_t lds = 2 * (BM + BN) * 128;
-  auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA, PP, CT>;
+  auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA, PP, CT, TP>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -274,7 +306,8 @@ int launch(const KArgs& k, hipStream_t stream) {
 
 }  // namespace
 
-static int g_tap_inner = 1, g_dbg = 0;
+static int g_tap_inner = 1, g_dbg = 0, g_tap_packing = 1;
+extern "C" void gdl_debug_set_conv_tap_packing(int on) { g_tap_packing = on; }  // A/B hook
 extern "C" void gdl_debug_set_conv_dbg(int mode) { g_dbg = mode; }
 static unsigned long long* g_probe = nullptr;
 extern "C" void gdl_debug_set_conv_probe(void* dev_buf_2048x2_u64) { g_probe = (unsigned long long*)dev_buf_2048x2_u64; }
@@ -342,10 +375,19 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   k.res_dense = !a.resid || (a.res_sH == (int64_t)a.Wo * a.res_sW && a.res_sB == (int64_t)a.Ho * a.res_sH);
   hipStream_t s = (hipStream_t)stream;
   const int variant = gdl_conv_gemm_plan(ap, nullptr);
+  // tap packing: several whole filter taps per K chunk when C divides the chunk (UNet++'s 16 / 32-channel stages)
+  const bool tap_packed = g_tap_packing && variant == 5 && a.R * a.S > 1 && a.R * a.S <= 32 && !k.in_dense &&
+                          a.C < bke && bke % a.C == 0 && a.C >= al;
+  if (tap_packed) {
+    k.kc = (a.R * a.S * a.C + bke - 1) / bke;
+    k.KT = k.kc;
+    k.c_tail = 0;
+  }
   if (a.dtype == GDL_BF16) {
     if (variant == 4) return conv3x3_sf_launch(k, s);
     if (variant == 3) return launch_x<bf16_tag, 2, 4, 4, 2, false, true>(k, s);
     if (variant == 2) return launch_x<bf16_tag, 2, 4, 4, 2, false>(k, s);
+    if (variant == 5 && tap_packed) return launch_x<bf16_tag, 4, 1, 2, 2, false, false, false, true>(k, s);
     if (variant == 5) return k.c_tail ? launch_x<bf16_tag, 4, 1, 2, 2, false, false, true>(k, s) : launch_x<bf16_tag, 4, 1, 2, 2, false>(k, s);
     if (variant == 1) return launch<bf16_tag, 2, 2, 2, 2>(k, s);
     return launch<bf16_tag, 2, 2, 1, 1>(k, s);
@@ -353,6 +395,7 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   if (variant == 4) return conv3x3_sf_launch(k, s);
   if (variant == 3) return launch_x<float, 2, 4, 4, 2, false, true>(k, s);
   if (variant == 2) return launch_x<float, 2, 4, 4, 2, false>(k, s);
+  if (variant == 5 && tap_packed) return launch_x<float, 4, 1, 2, 2, false, false, false, true>(k, s);
   if (variant == 5) return k.c_tail ? launch_x<float, 4, 1, 2, 2, false, false, true>(k, s) : launch_x<float, 4, 1, 2, 2, false>(k, s);
   if (variant == 1) return launch<float, 2, 2, 2, 2>(k, s);
   return launch<float, 2, 2, 1, 1>(k, s);

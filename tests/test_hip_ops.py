@@ -517,10 +517,13 @@ def test_conv3x3_shared_staging_kernel(dtype, B, H, W, C, N):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,W,C,N,R", [(2, 37, 23, 64, 64, 3), (1, 50, 50, 128, 32, 1), (3, 16, 16, 192, 64, 3)])
+@pytest.mark.parametrize("B,H,W,C,N,R", [(2, 37, 23, 64, 64, 3), (1, 50, 50, 128, 32, 1), (3, 16, 16, 192, 64, 3),
+                                         # C divides the K chunk: several filter taps are packed into one chunk
+                                         (2, 37, 23, 32, 16, 3), (1, 20, 20, 16, 16, 3), (2, 9, 9, 8, 24, 3),
+                                         (1, 30, 11, 16, 64, 5)])
 def test_conv_narrow_output_tile(dtype, B, H, W, C, N, R):
     """256 x 64 tile for N <= 64 layers (forced here; chosen automatically on large maps): M tails, N tails,
-    bias + ReLU + residual epilogue, vs F.conv2d and vs the 64^2 tile."""
+    bias + ReLU + residual epilogue, tap packing for C in {8, 16, 32}, vs F.conv2d and vs the 64^2 tile."""
     import ctypes
     from gdlhip import _lib
     lib = _lib.load()
