@@ -213,17 +213,35 @@ def test_tiny_train_vit_blocks_unfrozen(tiny, freeze):
         err, ref_n = (p.grad.cpu() - rg).norm().item(), rg.norm().item()
         assert err <= 3e-2 * ref_n + 2e-6, (n, err, ref_n)
     assert n_enc > (60 if freeze is None else 40)
-    if freeze is None:   # bf16 autocast: the generator still runs in f32, its gradients stay finite and aligned
-        for p in model.parameters():
+    if freeze is None:
+        # bf16 autocast: the generator still runs in f32 and its gradients stay finite and aligned with the f32
+        # reference.  Checked at batch 8: with the fixture's B = 2 the PSP branch's 1x1 bins put TWO samples through a
+        # batch-statistics BatchNorm, which is a sign function of their difference -- any rounding change flips
+        # channels and the encoder gradients turn by tens of degrees (an input perturbation of 1e-6 already gives
+        # cos 0.96, tools/debug/blk_probe.py), so bf16-vs-f32 alignment is not a meaningful quantity there.
+        b8 = 8
+        batch8 = synthetic_batch(b8, 3, img, nc, seed + 1)
+        masks8 = _drop_masks(meta["tiny"]["depth"], 0.1, b8, seed)
+        am8 = _aux_mask(b8, 256, seed)
+        y8 = batch8["mask"].squeeze(1).long()
+        for p in list(model.parameters()) + list(ref.parameters()):
             p.grad = None
+        ro = ref(batch8["image"], batch8["wavelengths"], masks8, am8)
+        (dice_loss_multiclass(ro.out, y8) + 0.4 * dice_loss_multiclass(ro.aux, y8)).backward()
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            r = model(batch["image"].to(DEV), batch["wavelengths"], masks, am)
-            lb = crit(r.out, y.to(DEV)) + 0.4 * crit(r.aux, y.to(DEV))
+            r = model(batch8["image"].to(DEV), batch8["wavelengths"], masks8, am8)
+            lb = crit(r.out, y8.to(DEV)) + 0.4 * crit(r.aux, y8.to(DEV))
         lb.backward()
-        gw = dict(model.named_parameters())["encoder.patch_embed.weight_generator.fc_weight.weight"].grad
-        rw = refp["encoder.patch_embed.weight_generator.fc_weight.weight"].grad
-        cos = (gw.cpu() * rw).sum() / (gw.norm().cpu() * rw.norm() + 1e-30)
-        assert torch.isfinite(gw).all() and cos > 0.9, cos
+        coss = {}
+        for n, p in model.named_parameters():
+            rg = refp[n].grad
+            if n.startswith("encoder.") and rg is not None and rg.numel() >= 64 and rg.norm() > 1e-7:
+                assert torch.isfinite(p.grad).all(), n
+                gq = p.grad.float().cpu()
+                coss[n] = float((gq * rg).sum() / (gq.norm() * rg.norm() + 1e-30))
+        worst = sorted(coss.items(), key=lambda kv: kv[1])[:5]
+        assert coss["encoder.patch_embed.weight_generator.fc_weight.weight"] > 0.9, worst
+        assert np.median(list(coss.values())) > 0.95, worst
 
 
 def test_tiny_train_bf16_runs_and_descends(tiny):
