@@ -52,7 +52,8 @@ const char* gdl_last_error(void);
  * residual add -- timm Block (dofa_v2.py:248-263), ConvModule (models/utils.py:10-52,
  * multilevel_neck.py:28-67), upernet.py:62-101, fcn_head.py:36-84; with transposed /
  * flipped weights it is also the data-gradient of those convs.
- * Requirements: C % (128/elem_size) == 0, all base pointers and row strides 16-byte
+ * Requirements: C % (16/elem_size) == 0 (whole 16-byte pieces; a channel count that does not fill
+ * the 128-byte K chunk is zero-filled by the kernel), all base pointers and row strides 16-byte
  * aligned, dtype of `in` and `w` equal (GDL_F32 -> exact-f32 MFMA, GDL_BF16 -> bf16 MFMA
  * with f32 accumulate).
  */
@@ -85,8 +86,9 @@ typedef struct {
 } gdl_conv_args;
 
 int gdl_conv_gemm(const gdl_conv_args* a, gdl_stream_t stream);
-/* Which kernel variant the call above will launch (1 = 128x128 tiles, 0 = 64x64 tiles) and its
- * algorithmic flops 2*M*N*K (for roofline accounting in bench.py). */
+/* Which kernel variant the call above will launch (0 = 64x64 tiles, 1 = 128x128, 3 = 256x256 with alternating loader
+ * halves, 4 = 256x256 3x3 with shared activation staging, 5 = 256x64 for narrow outputs) and its algorithmic flops
+ * 2*M*N*K (for roofline accounting in bench.py). */
 int gdl_conv_gemm_plan(const gdl_conv_args* a, int64_t* flops);
 
 /* Weight gradient of the same convolution:

@@ -152,3 +152,64 @@ def test_packed_weight_cache_rejects_recycled_ids():
     with torch.no_grad():
         p2.add_(1)
     assert gnn.cached((p2,), "t_cache", lambda: "third") == "third"          # in-place update bumps the version
+
+
+# ------------------------------------------------------------------ host-side kernel selection (pure host code)
+def _conv_args(B, H, W, C, N, R, dtype=1, stride=1, aux=False):
+    from gdlhip._lib import ConvArgs
+    a = ConvArgs()
+    a.inp, a.w, a.out = 0x1000, 0x2000, 0x3000
+    a.dtype = a.out_dtype = dtype
+    a.B, a.H, a.W, a.C = B, H, W, C
+    a.in_sW, a.in_sH, a.in_sB = C, W * C, H * W * C
+    pad = R // 2
+    a.Ho, a.Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    a.R, a.S, a.stride, a.pad, a.N = R, R, stride, pad, N
+    a.w_sN = R * R * C
+    a.out_sW, a.out_sH, a.out_sB = N, a.Wo * N, a.Ho * a.Wo * N
+    a.alpha, a.nz, a.nz_inner = 1.0, 1, 1
+    if aux:
+        a.aux_out = 0x4000
+    return a
+
+
+def test_conv_tile_selection(lib):
+    """gdl_conv_gemm_plan: which tile a layer gets (0 = 64^2, 1 = 128^2, 3 = 256^2 ping-pong, 4 = 3x3 shared staging,
+    5 = 256x64) and the algorithmic flops it reports."""
+    import ctypes as C
+
+    def plan(*a, **k):
+        fl = C.c_int64()
+        v = lib.gdl_conv_gemm_plan(C.byref(_conv_args(*a, **k)), C.byref(fl))
+        return v, fl.value
+    v, fl = plan(32, 144, 144, 768, 768, 3)                  # DOFA neck conv
+    assert v == 4 and fl == 2 * 32 * 144 * 144 * 768 * 9 * 768
+    assert plan(32, 144, 144, 768, 256, 1)[0] == 3           # lateral 1x1: 256^2 ping-pong
+    assert plan(1, 1, 32 * 1297, 768, 2304, 1)[0] == 3       # ViT qkv
+    assert plan(32, 256, 256, 64, 64, 3)[0] == 5             # UNet++ decoder: narrow output on a large map
+    assert plan(32, 512, 512, 32, 16, 3)[0] == 5             # 32 -> 16 channels at 512^2 (tap-packed K chunks)
+    assert plan(2, 16, 16, 64, 64, 3)[0] == 0                # too few pixels for 256-row tiles
+    assert plan(32, 128, 128, 160, 256, 1)[0] in (0, 1)      # channel tail (MiT-B0 width): small tiles only
+    assert plan(32, 128, 128, 768, 3072, 1, aux=True)[0] in (0, 1)   # training epilogue: never the 256^2 tiles
+
+
+def test_wgrad_split_selection(lib):
+    """gdl_conv_wgrad_workspace = splits * N * R*S*C * 4: the row-segment kernel aims at two blocks per CU."""
+    import ctypes as C
+    from gdlhip._lib import WgradArgs
+
+    def splits(B, H, W, Cc, N, R=3, nz=1):
+        a = WgradArgs()
+        a.inp, a.dy, a.dw, a.dtype = 0x1000, 0x2000, 0x3000, 1
+        a.B, a.H, a.W, a.C = B, H, W, Cc
+        a.in_sW, a.in_sH, a.in_sB = Cc, W * Cc, H * W * Cc
+        a.Ho, a.Wo, a.R, a.S, a.stride, a.pad, a.N = H, W, R, R, 1, R // 2, N
+        a.dy_sW, a.dy_sH, a.dy_sB = N, W * N, H * W * N
+        a.dw_sN, a.nz, a.nz_inner = R * R * Cc, nz, 1
+        return lib.gdl_conv_wgrad_workspace(C.byref(a)) // (max(nz, 1) * N * R * R * Cc * 4)
+    assert splits(32, 144, 144, 768, 768) == 3               # 144 tiles of 64x64 -> 3 x 144 = 432 blocks
+    assert splits(32, 144, 144, 256, 256) == 32
+    assert splits(32, 256, 256, 64, 64) == 512               # one tile: all the parallelism comes from split-K
+    assert splits(2, 16, 16, 256, 256) <= 1                  # narrow map: per-tap kernel, too few pixels to split
+    assert splits(1, 1, 524288, 64, 256, R=1) > 64           # narrow linear over many pixels
+    assert splits(4, 1, 1297, 64, 1297, R=1, nz=48) <= 64    # batched (attention dK / dV): nz-fold parallelism
