@@ -213,3 +213,20 @@ def test_wgrad_split_selection(lib):
     assert splits(2, 16, 16, 256, 256) <= 1                  # narrow map: per-tap kernel, too few pixels to split
     assert splits(1, 1, 524288, 64, 256, R=1) > 64           # narrow linear over many pixels
     assert splits(4, 1, 1297, 64, 1297, R=1, nz=48) <= 64    # batched (attention dK / dV): nz-fold parallelism
+
+
+def test_dynamic_segformer_mirror_has_the_reference_state_dict():
+    """use_dynamic_encoder=True (segmentation_segformer.py:47): the mirror's parameter names and shapes are those of the
+    oracle restatement, which is pinned to the real reference (tests/golden/segformer_dynamic.npz); no patch_embed1."""
+    from geo_deep_learning.models.segmentation.segformer import SegFormerSegmentationModel
+    from oracle.segformer import SegFormerSegmentationModel as OracleSegFormer
+    for enc in ("mit_b0", "mit_b2"):
+        m = SegFormerSegmentationModel(enc, 3, None, None, 5, use_dynamic_encoder=True)
+        o = OracleSegFormer(enc, 3, 5, use_dynamic_encoder=True)
+        ms, os_ = m.state_dict(), o.state_dict()
+        assert sorted(ms) == sorted(os_)
+        assert all(tuple(ms[k].shape) == tuple(os_[k].shape) for k in ms)
+        assert not any(k.startswith("encoder.patch_embed1.") for k in ms)
+        assert any(k.startswith("encoder.dynamic_patch_embed1.channel_attention.") for k in ms)
+    with pytest.raises(ValueError):                       # no CPU fallback: the stem needs the device library
+        SegFormerSegmentationModel("mit_b0", 3, None, None, 5, use_dynamic_encoder=True)(torch.zeros(1, 4, 32, 32))
