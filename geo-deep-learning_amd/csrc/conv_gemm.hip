@@ -270,7 +270,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
     k.probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
   }
   conv_epilogue<TM, TN, EXTRA>(k, acc, m0, n0, wm, wn, lane, out_zoff);
-  if (k.probe && tid == 0 && blockIdx.x < 2048) k.probe[4096 + blockIdx.x] = __builtin_readcyclecounter() - t0c;
+  if (k.probe && tid == 0 && blockIdx.x < 2048) {
+    k.probe[4096 + blockIdx.x] = __builtin_readcyclecounter() - t0c;
+    k.probe[8192 + 2 * blockIdx.x] = t0r;                                   // block timeline (100 MHz ticks)
+    k.probe[8192 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false, bool CT = false,

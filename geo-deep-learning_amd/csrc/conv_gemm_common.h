@@ -18,7 +18,7 @@ struct KArgs {
   unsigned in_span, w_span;   // bytes addressed from the (z-offset) operand base: buffer num_records
   int tap_inner;              // K order: 1 = channel chunk outer / filter tap inner (default), 0 = tap outer
   int dbg;                    // tuning experiments only: 1 = no DMA after the first tile, 2 = no MFMA
-  unsigned long long* probe;  // tuning only: per block {shader cycles, 100 MHz ticks} of the K loop
+  unsigned long long* probe;  // tuning only (12288 u64): per block {shader cycles, 100 MHz ticks} of the K loop, K loop + epilogue cycles, {start, end} ticks
 };
 
 template <typename T> struct TileTraits;
