@@ -200,7 +200,8 @@ __global__ __launch_bounds__(512) void conv3x3_sf_kernel(const KArgs k) {
     k.probe[2 * blockIdx.x] = __builtin_readcyclecounter() - t0c;
     k.probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
   }
-  conv_epilogue<TM, TN, false>(k, acc, m0, n0, wm, wn, lane, 0);
+  __syncthreads();   // every wave is past its last fragment read: the stages become the epilogue's transpose buffers
+  conv_epilogue<TM, TN, false>(k, acc, m0, n0, wm, wn, lane, 0, smem + wave * 8192, smem + 8 * 8192 + wave * 1024);
   if (k.probe && tid == 0 && blockIdx.x < 2048) {
     k.probe[4096 + blockIdx.x] = __builtin_readcyclecounter() - t0c;
     k.probe[8192 + 2 * blockIdx.x] = t0r;                                   // block timeline (100 MHz ticks)

@@ -35,6 +35,35 @@ __device__ __noinline__ float4 mul_gelu_grad4(float4 v, float4 u) {
                      v.w * gelu_erf_grad(u.w));
 }
 
+// bf16 compute path: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 rounding of the result);
+// one v_rcp + one v_exp instead of the ~50-instruction branchy erff.  The exact-f32 (parity) path keeps erff.
+struct GeluTerms { float half_pe, e; };   // 0.5 * poly(t) * exp(-x^2/2) and exp(-x^2/2)
+__device__ __forceinline__ GeluTerms gelu_terms_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * z * z);
+  return {0.5f * p * t * e, e};
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float h = gelu_terms_fast(x).half_pe;          // 0.5 * erfc(|x|/sqrt2)
+  return x * (x >= 0.f ? 1.0f - h : h);
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  const GeluTerms g = gelu_terms_fast(x);
+  return (x >= 0.f ? 1.0f - g.half_pe : g.half_pe) + x * 0.3989422804014327f * g.e;
+}
+__device__ __forceinline__ float4 gelu4_fast(float4 v) {
+  return make_float4(gelu_fast(v.x), gelu_fast(v.y), gelu_fast(v.z), gelu_fast(v.w));
+}
+__device__ __forceinline__ float4 mul_gelu_grad4_fast(float4 v, float4 u) {
+  return make_float4(v.x * gelu_grad_fast(u.x), v.y * gelu_grad_fast(u.y), v.z * gelu_grad_fast(u.z),
+                     v.w * gelu_grad_fast(u.w));
+}
+
 __device__ __forceinline__ int xcd_remap(int id, int n) {
   // bijective "XCD-major" remap (cdna guide T1): hardware places block id on XCD id % 8.
   const int q = n >> 3, r = n & 7, xcd = id & 7, idx = id >> 3;
@@ -46,13 +75,212 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 bool conv3x3_sf_applicable(const gdl_conv_args& a);
 int conv3x3_sf_launch(const KArgs& k, hipStream_t stream);
 
+
+// Coalesced epilogue through a wave-private LDS transpose (see conv_epilogue).  Returns false (nothing done) when the
+// call does not qualify; the decision depends on kernel arguments only, i.e. it is uniform over the workgroup.
+// `lds` = 8 KiB transpose buffer, `ldc` = 768 B for the wave's per-channel constants (bias | scale | shift of its 64
+// channels): they are fetched from global memory ONCE per tile, every pass re-reads them from the LDS.
+template <int TM, bool EXTRA>
+__device__ __forceinline__ bool conv_epilogue_rows(const KArgs& k, f32x16_t (&acc)[TM][2], int m0, int n0, int wm,
+                                                   int wn, int lane, int64_t out_zoff, unsigned char* lds,
+                                                   unsigned char* ldc) {
+  const gdl_conv_args& a = k.a;
+  const bool out_bf16 = a.out_dtype == GDL_BF16;
+  const bool mulgrad = EXTRA && a.act == GDL_ACT_MUL_GELU_GRAD;
+  const bool plain = !a.resid && !a.batch_scale;
+  const bool fast = a.dtype == GDL_BF16;                 // bf16 compute path: fast erf
+  const int HoWo = a.Ho * a.Wo;
+  const bool vec_ok = ((uintptr_t)a.out % 16 == 0) && ((uintptr_t)a.aux_out % 16 == 0) && (a.out_sW % 8 == 0) &&
+                      (out_zoff % 8 == 0) && (a.N % 16 == 0);
+  const bool res_ok = !a.resid || (((uintptr_t)a.resid % 16 == 0) && (a.res_sW % 4 == 0));
+  const bool vecs_ok = ((uintptr_t)a.bias % 16 == 0) && ((uintptr_t)a.scale % 16 == 0) && ((uintptr_t)a.shift % 16 == 0);
+  if (!(k.out_dense && k.res_dense && vec_ok && res_ok && vecs_ok && (!a.batch_scale || HoWo >= 32))) return false;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int n_w = n0 + wn * 64;                          // first channel of the wave's 64-channel strip
+  const bool packed = plain && out_bf16;                 // LDS holds bf16 rows of 128 B; otherwise f32 rows of 256 B
+  // ---- per-channel constants of the strip -> LDS (lanes 0..15: one float4 of each array)
+  if (lane < 16) {
+    const int n = n_w + 4 * lane;
+    const bool in = n < a.N;                             // N % 16 == 0: a group of 4 is all in or all out
+    // (explicit branches: a `cond ? *p : constant` select makes hipcc pick between POINTERS, one of them to a scratch copy)
+    float4 vb = make_float4(0.f, 0.f, 0.f, 0.f), vs = make_float4(1.f, 1.f, 1.f, 1.f), vh = vb;
+    if (a.bias && in) vb = *(const float4*)(a.bias + n);
+    if (a.scale && in) vs = *(const float4*)(a.scale + n);
+    if (a.scale && a.shift && in) vh = *(const float4*)(a.shift + n);
+    *(float4*)(ldc + lane * 16) = vb;
+    if (a.scale) {
+      *(float4*)(ldc + 256 + lane * 16) = vs;
+      *(float4*)(ldc + 512 + lane * 16) = vh;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  // per-channel part of one 4-channel group at strip offset c: v = act(scale * (alpha * acc + bias) + shift),
+  // pre = alpha * acc + bias
+  auto channel_terms = [&](const f32x16_t& cacc, int g, int c, float (&v)[4], float (&pre)[4]) {
+    const float4 b4 = *(const float4*)(ldc + c * 4);
+    const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+    float s[4] = {1.f, 1.f, 1.f, 1.f}, h[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.scale) {
+      const float4 s4 = *(const float4*)(ldc + 256 + c * 4), h4 = *(const float4*)(ldc + 512 + c * 4);
+      s[0] = s4.x; s[1] = s4.y; s[2] = s4.z; s[3] = s4.w;
+      h[0] = h4.x; h[1] = h4.y; h[2] = h4.z; h[3] = h4.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = cacc[4 * g + e] * a.alpha + b[e];
+      pre[e] = x;
+      if (a.scale) x = x * s[e] + h[e];
+      if (a.act == GDL_ACT_RELU) x = fmaxf(x, 0.f);
+      v[e] = x;
+    }
+    if (a.act == GDL_ACT_GELU) {
+      const float4 t = fast ? gelu4_fast(make_float4(v[0], v[1], v[2], v[3])) : gelu4(make_float4(v[0], v[1], v[2], v[3]));
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int mp = m0 + (wm * TM + i) * 32;              // first row of this pass (wave-uniform)
+    if (mp >= k.M) break;
+    // ---- (0) per-row operands of this pass, requested before anything is stored: the residual as coalesced row
+    // segments (lane = (row (lane >> 4) + 4t, 16-byte slot lane & 15)) and the (at most two) DropPath scales
+    float rv[8][4];
+    float rs0 = 1.f, rs1 = 1.f;
+    int rem0 = 0;
+    if (!packed && !plain) {
+      if (a.batch_scale) {
+        const int b0 = mp / HoWo;                        // HoWo >= 32: a pass spans at most two samples
+        rem0 = mp - b0 * HoWo;
+        rs0 = a.batch_scale[b0];
+        rs1 = b0 + 1 < a.B ? a.batch_scale[b0 + 1] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int m = mp + (lane >> 4) + 4 * t, n = n_w + 4 * (lane & 15);
+        rv[t][0] = rv[t][1] = rv[t][2] = rv[t][3] = 0.f;
+        if (a.resid && m < k.M && n < a.N) {
+          const int64_t ro = (int64_t)m * a.res_sW + n;
+          if (a.resid_dtype == GDL_BF16) {
+            const uint2 u = *(const uint2*)((const uint16_t*)a.resid + ro);
+            rv[t][0] = __uint_as_float(u.x << 16); rv[t][1] = __uint_as_float(u.x & 0xffff0000u);
+            rv[t][2] = __uint_as_float(u.y << 16); rv[t][3] = __uint_as_float(u.y & 0xffff0000u);
+          } else {
+            const float4 u = *(const float4*)((const float*)a.resid + ro);
+            rv[t][0] = u.x; rv[t][1] = u.y; rv[t][2] = u.z; rv[t][3] = u.w;
+          }
+        }
+      }
+    }
+    // ---- (1) MFMA layout -> LDS.  `which` = 0: the output values, 1: the pre-activation copy (aux_out)
+    auto to_lds = [&](int which) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (packed) {
+#pragma unroll
+          for (int p2 = 0; p2 < 2; ++p2) {
+            float va[4], vb[4], pa[4], pb[4];
+            channel_terms(acc[i][j], 2 * p2, 32 * j + 16 * p2 + 4 * fhalf, va, pa);
+            channel_terms(acc[i][j], 2 * p2 + 1, 32 * j + 16 * p2 + 8 + 4 * fhalf, vb, pb);
+            const float (&xa)[4] = which ? pa : va;
+            const float (&xb)[4] = which ? pb : vb;
+            unsigned a0 = pack_bf16x2(xa[0], xa[1]), a1 = pack_bf16x2(xa[2], xa[3]);
+            unsigned b0 = pack_bf16x2(xb[0], xb[1]), b1 = pack_bf16x2(xb[2], xb[3]);
+            // lane pair (l, l+32) trades one 8-byte piece: low lanes end with channels [16p2, 16p2+8), high lanes
+            // with [16p2+8, 16p2+16) of their row
+            const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            const int slot = 4 * j + 2 * p2 + fhalf;     // 16-byte slot of the 128-byte row
+            *(uint4*)(lds + frow * 128 + ((slot ^ (frow & 7)) << 4)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float v[4], pre[4];
+            channel_terms(acc[i][j], g, 32 * j + 8 * g + 4 * fhalf, v, pre);
+            const float (&x)[4] = which ? pre : v;
+            const int slot = 8 * j + 2 * g + fhalf;      // 16-byte slot of the 256-byte row
+            *(float4*)(lds + frow * 256 + ((slot ^ (frow & 7)) << 4)) = make_float4(x[0], x[1], x[2], x[3]);
+          }
+        }
+      }
+    };
+    // ---- (2) LDS -> full row segments in global memory
+    auto from_lds = [&](void* base, bool row_terms) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS writes are done (wave-private region)
+      __builtin_amdgcn_wave_barrier();
+      if (packed) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int rr = (lane >> 3) + 8 * t, slot = lane & 7;
+          const uint4 v = *(const uint4*)(lds + rr * 128 + ((slot ^ (rr & 7)) << 4));
+          const int m = mp + rr, n = n_w + 8 * slot;
+          if (m < k.M && n < a.N) *(uint4*)((uint16_t*)base + (int64_t)m * a.out_sW + out_zoff + n) = v;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int rr = (lane >> 4) + 4 * t, slot = lane & 15;
+          const float4 q = *(const float4*)(lds + rr * 256 + ((slot ^ (rr & 7)) << 4));
+          float v[4] = {q.x, q.y, q.z, q.w};
+          const int m = mp + rr, n = n_w + 4 * slot;
+          if (m >= k.M || n >= a.N) continue;
+          if (row_terms && !plain) {
+            if (a.batch_scale) {
+              const float rs = rem0 + rr >= HoWo ? rs1 : rs0;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= rs;
+            }
+            if (EXTRA && mulgrad) {
+              const float4 u = make_float4(rv[t][0], rv[t][1], rv[t][2], rv[t][3]);
+              const float4 x = fast ? mul_gelu_grad4_fast(make_float4(v[0], v[1], v[2], v[3]), u)
+                                    : mul_gelu_grad4(make_float4(v[0], v[1], v[2], v[3]), u);
+              v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float x = v[e] + rv[t][e];
+                if (a.act == GDL_ACT_RESID_RELU) x = fmaxf(x, 0.f);
+                v[e] = x;
+              }
+            }
+          }
+          const int64_t off = (int64_t)m * a.out_sW + out_zoff + n;
+          if (out_bf16) *(uint2*)((uint16_t*)base + off) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          else *(float4*)((float*)base + off) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    if (EXTRA && a.aux_out) {
+      to_lds(1);
+      from_lds(a.aux_out, false);
+    }
+    to_lds(0);
+    from_lds(a.out, true);
+  }
+  return true;
+}
+
 // ---- epilogue.  Call with the accumulators of MFMAs that ran with SWAPPED operands (D = W_tile x X_tile^T).
+// `lds_wave` / `lds_consts`: 8 KiB + 768 B of LDS private to this wave and free to overwrite (the caller has passed a
+// workgroup barrier after the last fragment read of the K loop), or nullptr.  With it, and for pixel-dense outputs, the tile leaves
+// through a wave-private LDS transpose: 32 rows x 64 channels per pass are written in the MFMA layout (16-byte pieces,
+// slot ^ (row & 7): conflict-free), read back with 8 (bf16) / 16 (f32) consecutive lanes per row and stored as FULL
+// 128 / 256-byte row segments -- instead of 64 scattered 16-byte pieces per store instruction, which cost 120-250
+// cycles per instruction in the memory pipeline and doubled the bytes written to HBM (partial lines; PMC, round 2).
+// Per-channel terms (bias, scale/shift, activation) are applied before the transpose, per-row terms (DropPath scale,
+// residual, GELU-gradient multiply) after it, where the residual is read as coalesced row segments too.
 template <int TM, int TN, bool EXTRA>
 __device__ __forceinline__ void conv_epilogue(const KArgs& k, f32x16_t (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                                              int lane, int64_t out_zoff) {
+                                              int lane, int64_t out_zoff, unsigned char* lds_wave = nullptr,
+                                              unsigned char* lds_consts = nullptr) {
   const gdl_conv_args& a = k.a;
   const int frow = lane & 31, fhalf = lane >> 5;
   const int HoWo = a.Ho * a.Wo;
+  if constexpr (TN == 2) {
+    if (lds_wave && conv_epilogue_rows<TM, EXTRA>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds_wave, lds_consts)) return;
+  }
   // ---- epilogue.  The MFMAs ran with swapped operands (D = W_tile x X_tile^T), so a lane owns ONE output row
   // m = lane&31 of each 32x32 tile and its 16 accumulators are 4 groups of 4 CONSECUTIVE channels
   // n = 8g + 4*(lane>>5) + e: per-channel terms are float4 loads, per-row terms (DropPath scale, residual) are

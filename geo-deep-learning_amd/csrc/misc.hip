@@ -584,6 +584,49 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------ Dice loss (smp binary)
+// smp DiceLoss(mode="binary") (configs/unetplus_config_RGB.yaml: num_classes 1): p = exp(logsigmoid(x)), one class,
+// sums over dims (batch, pixels); the target is used as a 0/1 weight.  Partials have the multiclass layout with K = 1
+// ([I | S | N]) so dice_final_kernel<1> finishes them (loss * [sum y > 0], mean over the single class).
+__global__ __launch_bounds__(256) void dice_binary_partial_kernel(const float* __restrict__ logits,
+                                                                  const int64_t* __restrict__ target, int64_t total,
+                                                                  float* __restrict__ ws) {
+  __shared__ float red[4][3];
+  float I = 0.f, S = 0.f, Nc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float x = logits[i];
+    // exp(logsigmoid(x)) with logsigmoid(x) = min(x, 0) - log1p(exp(-|x|)), as torch computes it
+    const float p = expf(fminf(x, 0.f) - log1pf(expf(-fabsf(x))));
+    const float y = (float)target[i];
+    I += p * y; S += p; Nc += y;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float a = wave_sum(I), b = wave_sum(S), c = wave_sum(Nc);
+  if (lane == 0) { red[wv][0] = a; red[wv][1] = b; red[wv][2] = c; }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    ws[(int64_t)blockIdx.x * 3 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void dice_binary_bwd_kernel(const float* __restrict__ logits,
+                                                              const int64_t* __restrict__ target, int64_t total,
+                                                              const float* __restrict__ sums, float eps,
+                                                              const float* __restrict__ upstream, float grad_scale,
+                                                              float* __restrict__ dlogits, int accumulate) {
+  const float up = (upstream ? upstream[0] : 1.f) * grad_scale;
+  const float I = sums[0], card = sums[1] + sums[2];
+  const bool on = sums[2] > 0.f && card > eps;
+  const float ca = on ? -2.f / card * up : 0.f;              // dL/dp = ca * y + cb
+  const float cb = on ? 2.f * I / (card * card) * up : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float x = logits[i];
+    const float p = expf(fminf(x, 0.f) - log1pf(expf(-fabsf(x))));
+    const float v = (cb + ca * (float)target[i]) * p * (1.f - p);
+    dlogits[i] = accumulate ? dlogits[i] + v : v;
+  }
+}
+
 // ------------------------------------------------------------------ optimizer
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
   __shared__ float red[4];
@@ -956,6 +999,28 @@ extern "C" int gdl_dice_loss_bwd(const float* logits, const int64_t* target, int
   const int64_t total = (int64_t)B * HW;
   K_SWITCH(K, hipLaunchKernelGGL((dice_bwd_kernel<KK>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, logits, target, B, HW, sums, eps, upstream, grad_scale, dlogits, accumulate));
   GDL_CHECK_LAUNCH("gdl_dice_loss_bwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_dice_binary_loss_fwd(const float* logits, const int64_t* target, int64_t total, float eps,
+                                        float* sums, float* loss, float* ws, int64_t ws_bytes, gdl_stream_t stream) {
+  GDL_CHECK_ARG(logits && target && sums && loss && ws, "gdl_dice_binary_loss_fwd: null pointer");
+  const int nblk = dice_blocks(total);
+  GDL_CHECK_ARG(ws_bytes >= (int64_t)nblk * 3 * (int64_t)sizeof(float), "gdl_dice_binary_loss_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(dice_binary_partial_kernel, dim3(nblk), dim3(256), 0, s, logits, target, total, ws);
+  hipLaunchKernelGGL((dice_final_kernel<1>), dim3(1), dim3(256), 0, s, ws, nblk, eps, sums, loss);
+  GDL_CHECK_LAUNCH("gdl_dice_binary_loss_fwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_dice_binary_loss_bwd(const float* logits, const int64_t* target, int64_t total, float eps,
+                                        const float* sums, const float* upstream, float grad_scale, float* dlogits,
+                                        int accumulate, gdl_stream_t stream) {
+  GDL_CHECK_ARG(logits && target && sums && dlogits, "gdl_dice_binary_loss_bwd: null pointer");
+  hipLaunchKernelGGL(dice_binary_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, logits, target,
+                     total, sums, eps, upstream, grad_scale, dlogits, accumulate);
+  GDL_CHECK_LAUNCH("gdl_dice_binary_loss_bwd");
   return GDL_OK;
 }
 

@@ -351,19 +351,50 @@ class _DiceLoss(Function):
         return ops.dice_loss_bwd(logits, target, sums, g.contiguous().float(), 1.0, ctx.eps), None, None
 
 
-class DiceLoss(nn.Module):
-    """Drop-in for ``segmentation_models_pytorch.losses.DiceLoss(mode="multiclass")``."""
+class _DiceBinaryLoss(Function):
+    """smp DiceLoss(mode='binary') (configs/unetplus_config_RGB.yaml:40-47, num_classes 1)."""
 
-    def __init__(self, mode: str = "multiclass", smooth: float = 0.0, eps: float = 1e-7, **kw) -> None:
+    @staticmethod
+    def forward(ctx, logits, target, eps):
+        loss, sums = ops.dice_binary_loss_fwd(logits, target, eps)
+        ctx.save_for_backward(logits, target, sums)
+        ctx.eps = eps
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, sums = ctx.saved_tensors
+        return ops.dice_binary_loss_bwd(logits, target, sums, g.contiguous().float(), 1.0, ctx.eps), None, None
+
+
+class DiceLoss(nn.Module):
+    """Drop-in for ``segmentation_models_pytorch.losses.DiceLoss`` in the two modes the reference's configs use:
+    ``mode="multiclass"`` (configs/dofa_config_RGB.yaml:58-61, segformer) and ``mode="binary"``
+    (configs/unetplus_config_RGB.yaml, ``num_classes: 1``); ``smooth=0``, ``ignore_index=None``, ``from_logits=True``,
+    ``log_loss=False``, ``classes=None`` (smp's defaults, which are also what the configs pass)."""
+
+    def __init__(self, mode: str = "multiclass", classes=None, log_loss: bool = False, from_logits: bool = True,
+                 smooth: float = 0.0, ignore_index=None, eps: float = 1e-7) -> None:
         super().__init__()
-        if mode != "multiclass" or smooth != 0.0 or kw:
-            msg = "gdlhip DiceLoss implements mode='multiclass', smooth=0 (the reference's config)"
+        if mode not in ("multiclass", "binary"):
+            msg = f"gdlhip DiceLoss implements mode='multiclass' and mode='binary' (got {mode!r})"
             raise NotImplementedError(msg)
-        self.eps = eps
+        if classes is not None or log_loss or not from_logits or smooth != 0.0 or ignore_index is not None:
+            msg = ("gdlhip DiceLoss implements smp's defaults (classes=None, log_loss=False, from_logits=True, "
+                   "smooth=0, ignore_index=None), which are what the reference's configs use")
+            raise NotImplementedError(msg)
+        self.mode, self.eps = mode, eps
 
     def forward(self, y_pred: Tensor, y_true: Tensor) -> Tensor:
         if y_pred.dtype != torch.float32 or not y_pred.is_contiguous():
             y_pred = y_pred.float().contiguous()
+        if self.mode == "binary":
+            if y_pred.shape[0] != y_true.shape[0] or y_pred.numel() != y_true.numel():
+                msg = f"DiceLoss(binary): y_pred {tuple(y_pred.shape)} and y_true {tuple(y_true.shape)} do not match"
+                raise ValueError(msg)
+            return _DiceBinaryLoss.apply(y_pred, y_true.long().contiguous(), self.eps)
+        if y_true.dim() == y_pred.dim() and y_true.shape[1] == 1:
+            y_true = y_true[:, 0]          # smp views the target as [B, -1]: an un-squeezed [B,1,H,W] mask is the same
         return _DiceLoss.apply(y_pred, y_true.long().contiguous(), self.eps)
 
 

@@ -51,6 +51,16 @@ def _f32vec(t: Tensor | None, n: int, name: str) -> Tensor | None:
     return t
 
 
+def image_f32(img: Tensor, who: str) -> Tensor:
+    """Model-entry check: tiles must arrive normalised (floating point).  A raw integer tile would silently train on
+    0..255 pixels -- the reference never sees one (its workers normalise, wds_dataset.py:230-236); here raw tiles are
+    only legal upstream of DeviceInputStage / normalize_raw."""
+    if not img.is_floating_point():
+        raise TypeError(f"{who}: image dtype {img.dtype} is a raw tile; normalise it first (DeviceInputStage, "
+                        f"gdlhip.ops.normalize_raw or the host path of SampleProcessor)")
+    return img.float().contiguous()
+
+
 def as_nhwc(x: Tensor) -> Tensor:
     """Logical NCHW tensor -> NHWC view (copying only if its channels are not contiguous)."""
     v = x.permute(0, 2, 3, 1)
@@ -1087,6 +1097,32 @@ def dice_loss_bwd(logits: Tensor, target: Tensor, sums: Tensor, upstream: Tensor
     check(_lib.load().gdl_dice_loss_bwd(_p(logits), _p(target), B, K, H * W, eps, _p(sums),
                                         _p(upstream), grad_scale, _p(out), int(accumulate),
                                         _stream()), "gdl_dice_loss_bwd")
+    return out
+
+
+def dice_binary_loss_fwd(logits: Tensor, target: Tensor, eps: float = 1e-7):
+    """smp DiceLoss(mode="binary"): logits [B,1,H,W] (or any shape) f32, target of the same numel, int64 0/1."""
+    _need_cuda(logits, target)
+    if logits.dtype != torch.float32 or not logits.is_contiguous():
+        raise ValueError("dice_binary_loss: contiguous f32 logits expected")
+    if target.dtype != torch.int64 or not target.is_contiguous() or target.numel() != logits.numel():
+        raise ValueError("dice_binary_loss: contiguous int64 target with one entry per logit expected")
+    total = logits.numel()
+    sums = torch.empty(3, device=logits.device, dtype=torch.float32)
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    lib = _lib.load()
+    nbytes = lib.gdl_dice_loss_workspace(1, 1, total)
+    ws = torch.empty(nbytes // 4, device=logits.device, dtype=torch.float32)
+    check(lib.gdl_dice_binary_loss_fwd(_p(logits), _p(target), total, eps, _p(sums), _p(loss), _p(ws), nbytes,
+                                       _stream()), "gdl_dice_binary_loss_fwd")
+    return loss, sums
+
+
+def dice_binary_loss_bwd(logits: Tensor, target: Tensor, sums: Tensor, upstream: Tensor | None,
+                         grad_scale: float = 1.0, eps: float = 1e-7) -> Tensor:
+    out = torch.empty_like(logits)
+    check(_lib.load().gdl_dice_binary_loss_bwd(_p(logits), _p(target), logits.numel(), eps, _p(sums), _p(upstream),
+                                               grad_scale, _p(out), 0, _stream()), "gdl_dice_binary_loss_bwd")
     return out
 
 

@@ -37,7 +37,8 @@ class RandomMix:
         self.datasets, self.seed, self.epoch = datasets, seed, 0
 
     def __iter__(self) -> Iterator[dict[str, Any]]:
-        rng = random.Random(None if self.seed is None else self.seed + self.epoch)
+        epoch, self.epoch = self.epoch, self.epoch + 1     # advances at the START of an iteration (early stops count)
+        rng = random.Random(None if self.seed is None else self.seed + epoch)
         sources = [iter(d) for d in self.datasets]
         while sources:
             i = rng.randrange(len(sources))
@@ -45,12 +46,13 @@ class RandomMix:
                 yield next(sources[i])
             except StopIteration:
                 del sources[i]
-        self.epoch += 1
 
 
 class PrefetchLoader:
-    """Decode batches on a background thread, ``prefetch`` ahead of the consumer (tile decode overlaps compute);
-    ``epoch_size`` (samples) caps an epoch like ``WebLoader.with_epoch``."""
+    """Decode batches on a background thread, ``prefetch`` ahead of the consumer (tile decode overlaps compute).
+    ``epoch_batches`` reproduces ``WebLoader(batch_size=None).with_epoch(n)`` (wds_datamodule.py:104-113): an epoch is
+    exactly n items of the loader -- BATCHES, because the dataset is already ``.batched()`` -- and a source that runs out
+    earlier is started again (each restart is a new shard / shuffle epoch of the pipeline)."""
 
     def __init__(self, dataset: Any, prefetch: int = 2, epoch_batches: int | None = None) -> None:
         self.dataset, self.prefetch, self.epoch_batches = dataset, max(1, prefetch), epoch_batches
@@ -62,10 +64,17 @@ class PrefetchLoader:
 
         def work() -> None:
             try:
-                for n, b in enumerate(self.dataset):
-                    if stop.is_set() or (self.epoch_batches is not None and n >= self.epoch_batches):
+                n = 0
+                while not stop.is_set():
+                    got = 0
+                    for b in self.dataset:
+                        if stop.is_set() or (self.epoch_batches is not None and n >= self.epoch_batches):
+                            break
+                        q.put(b)
+                        n += 1
+                        got += 1
+                    if self.epoch_batches is None or n >= self.epoch_batches or got == 0:
                         break
-                    q.put(b)
             except Exception as e:  # noqa: BLE001
                 q.put(e)
             q.put(done)
@@ -109,10 +118,12 @@ class MultiSensorDataModule(LightningDataModule):
         """Nothing to download."""
 
     def setup(self, stage: str | None = None) -> None:  # noqa: ARG002
+        # raw (uint8) tiles + GPU normalisation only when a DeviceInputStage will finish them; with the reference's
+        # data config (no ``device``) the batches are normalised on the host exactly like wds_dataset.py:217-244
         self.datasets = create_sensor_datasets(
             sensor_configs_path=self.sensor_configs_path, model_type=self.model_type, batch_size=self.batch_size,
             epoch_size=self.epoch_size, shuffle_buffer=self.shuffle_buffer, shardshuffle=self.shardshuffle,
-            seed=self.seed if self.seed is not None else 42)
+            seed=self.seed if self.seed is not None else 42, defer_normalization=self.device is not None)
         self.train_loader = self._loader("trn")
         self.val_loader = self._loader("val")
         self.test_loader = self._loader("tst")
@@ -124,9 +135,7 @@ class MultiSensorDataModule(LightningDataModule):
             return None
         pipes = [d.build_web_dataset() for d in per_sensor.values()]
         source = pipes[0] if len(pipes) == 1 else RandomMix(pipes, self.seed)
-        epoch_batches = None
-        if split == "trn" and self.epoch_size:
-            epoch_batches = max(1, self.epoch_size // self.batch_size)
+        epoch_batches = self.epoch_size if split == "trn" and self.epoch_size else None   # with_epoch counts batches
         loader: Any = PrefetchLoader(source, self.prefetch_factor or 2, epoch_batches)
         if self.device is not None:
             from geo_deep_learning.datamodules.device_input import DeviceInputStage

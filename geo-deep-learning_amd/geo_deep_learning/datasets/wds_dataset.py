@@ -8,7 +8,9 @@ reference's stats files describe): ``process_sample(..., defer_normalization=Tru
 dict, with ``image`` raw and the sensor's ``mean`` / ``std`` beside it, and
 ``geo_deep_learning.datamodules.device_input.DeviceInputStage`` finishes ``x/255 -> (x-mean)/std`` in one
 HBM-bound HIP kernel after an asynchronous pinned-memory H2D copy (4x fewer PCIe bytes for uint8).
-``defer_normalization=False`` reproduces the reference's host arithmetic exactly (used by the parity tests).
+``defer_normalization=False`` reproduces the reference's host arithmetic exactly; it is what
+``MultiSensorDataModule`` selects when no ``device=`` is given, so the reference's data config yields the reference's
+normalised f32 batches.
 
 The shard side (``load_sensor_configs`` :46-49, ``create_shard_split_paths`` :52-79, ``create_sensor_datasets``
 :82-137, ``ShardedDataset.build_web_dataset`` :391-431) is mirrored too, on a small built-in reader of the WebDataset
@@ -82,10 +84,12 @@ def encode_spatial(lat: float, lon: float) -> torch.Tensor:
 class SampleProcessor:
     """The arithmetic half of the reference's ``ShardedDataset`` (one instance per sensor / split)."""
 
-    RAW_DTYPES = (torch.uint8, torch.uint16, torch.int16, torch.float32)
+    # integer tiles may stay raw for DeviceInputStage (which recognises exactly these dtypes); f32 tiles are always
+    # normalised here, as the reference does (wds_dataset.py:230-236)
+    RAW_DTYPES = (torch.uint8, torch.uint16, torch.int16)
 
     def __init__(self, sensor_name: str, norm_stats: dict[str, Any], model_type: str = "dofa",
-                 wavelength_keys: list[str] | None = None, *, defer_normalization: bool = True) -> None:
+                 wavelength_keys: list[str] | None = None, *, defer_normalization: bool = False) -> None:
         self.sensor_name = sensor_name
         self.norm_stats = norm_stats
         self.model_type = model_type
@@ -194,7 +198,7 @@ class ShardedDataset:
     def __init__(self, sensor_name: str, shard_paths: list[str], patch_count: int, normalization_stats_path: str,
                  model_type: str = "clay", split: str = "trn", batch_size: int = 16, shuffle_buffer: int = 1000,
                  shardshuffle: int | None = None, seed: int = 42, epoch_size: int | None = None,
-                 wavelength_keys: list[str] | None = None, *, defer_normalization: bool = True) -> None:
+                 wavelength_keys: list[str] | None = None, *, defer_normalization: bool = False) -> None:
         self.sensor_name, self.shard_paths, self.patch_count = sensor_name, shard_paths, patch_count
         self.model_type, self.split, self.batch_size = model_type, split, batch_size
         self.shuffle_buffer, self.shardshuffle, self.seed, self.epoch_size = shuffle_buffer, shardshuffle, seed, epoch_size
@@ -239,7 +243,10 @@ class _BatchPipeline:
     def __iter__(self) -> Iterator[dict[str, Any]]:
         ds = self.ds
         batch: list = []
-        for sample in ds._samples(self.epoch):
+        # the epoch counter advances when an iteration STARTS (like wds' shard lists do): a consumer that stops early
+        # (``epoch_size``) still gets a different shard / shuffle order next time
+        epoch, self.epoch = self.epoch, self.epoch + 1
+        for sample in ds._samples(epoch):
             try:
                 batch.append(ds._process_sample(sample))
             except Exception as e:  # noqa: BLE001  (wds.warn_and_continue)
@@ -250,7 +257,6 @@ class _BatchPipeline:
                 batch = []
         if batch and ds.split != "trn":
             yield collate(batch)                        # partial batches only outside training (:430)
-        self.epoch += 1
 
 
 def create_sensor_datasets(sensor_configs_path: str, **common_kwargs: object) -> dict[str, Any]:

@@ -181,7 +181,7 @@ class DOFAv2Embedding(nn.Module):
         k = self.kernel_size
         gh, gw = (h + 2 - k) // k + 1, (w_ + 2 - k) // k + 1
         wq, bias = self.dynamic_gemm_operands(wavelengths, cd)
-        cols = ops.patchify(x.float().contiguous(), k, 1, gh, gw, wq.shape[1], cd)
+        cols = ops.patchify(ops.image_f32(x, "DOFAv2"), k, 1, gh, gw, wq.shape[1], cd)
         return ops.linear(cols, wq, bias, out_dtype=torch.float32).view(b, gh * gw, self.embed_dim)
 
 
@@ -441,7 +441,7 @@ class DOFAv2(nn.Module):
             wq, bias = self._trainable_operands(wavelengths, cd)       # one autograd node (gdlhip.tnn._DofaGenerator)
         else:
             wq, bias = self._dynamic_operands(wavelengths, x.device, cd)
-        cols = ops.patchify(x.float().contiguous(), k, 1, gh, gw, wq.shape[1], cd)
+        cols = ops.patchify(ops.image_f32(x, "DOFAv2"), k, 1, gh, gw, wq.shape[1], cd)
         # cls token rows (no pos-embed: dofa_v2.py:447-452), then patch GEMM + bias + pos_embed[1:]
         tok = tnn.dofa_tokens(cols.view(b, n, -1), wq, bias, self.cls_token, self.pos_embed)
         for i, blk in enumerate(self.blocks):

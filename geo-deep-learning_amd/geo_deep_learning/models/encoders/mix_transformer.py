@@ -164,7 +164,7 @@ class OverlapPatchEmbed(nn.Module):
             h, w = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
             bke = 32 if cd == torch.float32 else 64
             kpad = (c * k * k + bke - 1) // bke * bke
-            cols = ops.patchify(x.float().contiguous(), k, p, h, w, kpad, cd, stride=s)
+            cols = ops.patchify(ops.image_f32(x, "OverlapPatchEmbed"), k, p, h, w, kpad, cd, stride=s)
             y = tnn.stem_linear(cols, self.proj.weight, self.proj.bias, self._stem_weight(cd, kpad), torch.float32)
         else:
             b, hi, wi, c = x.shape  # NHWC feature of the previous stage
@@ -347,7 +347,7 @@ class DynamicChannelEmbed(nn.Module):
         h, w = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
         bke = 32 if cd == torch.float32 else 64
         kpad = (k * k + bke - 1) // bke * bke
-        cols = ops.patchify(x.float().contiguous().view(b * c, 1, hi, wi), k, p, h, w, kpad, cd, stride=s)
+        cols = ops.patchify(ops.image_f32(x, "DynamicChannelEmbed").view(b * c, 1, hi, wi), k, p, h, w, kpad, cd, stride=s)
         conv = tnn.stem_linear(cols, self.spatial_conv.weight, self.spatial_conv.bias, self._stem_weight(cd, kpad),
                                torch.float32)
         agg = tnn.chan_pool(conv.view(b, c, h * w, self.embed_dim), self.get_position_encoding(c, x.device),

@@ -73,7 +73,7 @@ class ResNetEncoder(nn.Module):
         b, c, h, w = img.shape
         gh, gw = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
         kpad = cnn.pad_to(c * 49, cnn.chunk(cd))
-        cols = ops.patchify(img.float().contiguous(), 7, 3, gh, gw, kpad, cd, stride=2).view(b, gh, gw, kpad)
+        cols = ops.patchify(ops.image_f32(img, "UnetPlusPlus"), 7, 3, gh, gw, kpad, cd, stride=2).view(b, gh, gw, kpad)
         cnn.mark_flat(self.conv1.weight)    # the stem parameter is the [64, (c,r,s)] matrix of the patch GEMM
         x = cnn.conv_bn(cols, self.conv1.weight, self.bn1)
         feats = [x]

@@ -353,6 +353,16 @@ int gdl_dice_loss_bwd(const float* logits, const int64_t* target, int B, int K, 
                       const float* sums, const float* upstream, float grad_scale, float* dlogits,
                       int accumulate, gdl_stream_t stream);
 
+/* smp DiceLoss(mode="binary", smooth=0, eps=1e-7) on `total` = B*H*W logits of the single class (the reference's
+ * UNet++ config: configs/unetplus_config_RGB.yaml:40-47 with num_classes 1; smp 0.5.0 losses/dice.py): p =
+ * exp(logsigmoid(x)), sums over batch and pixels, loss = (1 - 2I/(sum p + sum y)) * [sum y > 0].  Workspace: the
+ * multiclass one for K = 1 (gdl_dice_loss_workspace(B, 1, HW)); sums [3] = (I, sum p, sum y). */
+int gdl_dice_binary_loss_fwd(const float* logits, const int64_t* target, int64_t total, float eps, float* sums,
+                             float* loss, float* workspace, int64_t workspace_bytes, gdl_stream_t stream);
+int gdl_dice_binary_loss_bwd(const float* logits, const int64_t* target, int64_t total, float eps,
+                             const float* sums, const float* upstream, float grad_scale, float* dlogits,
+                             int accumulate, gdl_stream_t stream);
+
 /* ---- optimizer -------------------------------------------------------------------------
  * torch.optim.Adam step (configs/dofa_config_RGB.yaml:62-65) on one flat f32 tensor, with the
  * global-norm clip coefficient read from device memory (gradient_clip_val 1.0, :11). */

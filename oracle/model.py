@@ -84,6 +84,22 @@ def dice_loss_multiclass(logits: Tensor, target: Tensor, smooth: float = 0.0,
     return loss.mean()
 
 
+def dice_loss_binary(logits: Tensor, target: Tensor, smooth: float = 0.0, eps: float = 1e-7) -> Tensor:
+    """smp 0.5.0 ``DiceLoss(mode="binary")`` (third-party, absent from /root/reference; restated from its published
+    algorithm, "parity unpinned"): ``p = logsigmoid(x).exp()``, both tensors viewed ``[B, 1, -1]``, soft Dice over dims
+    (0, 2), ``loss = (1 - dice) * [sum y > 0]``, mean over the single class.  Used by the reference's UNet++ config
+    (configs/unetplus_config_RGB.yaml:36-47: ``num_classes: 1``, ``mode: "binary"``); the task passes the
+    ``[B,1,H,W]`` mask unsqueezed (segmentation_unetplus.py:232)."""
+    b = target.shape[0]
+    p = F.logsigmoid(logits).exp().view(b, 1, -1)
+    y = target.view(b, 1, -1).type_as(p)
+    inter = torch.sum(p * y, dim=(0, 2))
+    card = torch.sum(p + y, dim=(0, 2))
+    dice = (2.0 * inter + smooth) / (card + smooth).clamp_min(eps)
+    loss = (1.0 - dice) * (y.sum(dim=(0, 2)) > 0).to(p.dtype)
+    return loss.mean()
+
+
 def training_loss(outputs: SegmentationOutput, mask: Tensor) -> Tensor:
     """loss_main + 0.4*loss_aux.  Reference: segmentation_dofa.py:224-228."""
     y = mask.squeeze(1).long()

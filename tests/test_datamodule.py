@@ -77,12 +77,15 @@ def test_tar_reader_groups_members_by_key(shards):
 
 
 def test_datamodule_batches_mix_and_contents(shards):
+    """Default construction (the reference's data config has no ``device``): batches are normalised on the host with the
+    reference's arithmetic (wds_dataset.py:230-236), bit for bit."""
+    from geo_deep_learning.utils.tensors import normalization, standardization
     path, tiles, stats = shards
     dm = MultiSensorDataModule(path, model_type="dofa", patch_size=(16, 16), batch_size=2, seed=3)
     dm.setup()
     seen = []
     for batch in dm.train_dataloader():
-        assert batch["image"].dtype == torch.uint8 and batch["image"].shape[0] == 2      # raw tiles, full batches only
+        assert batch["image"].dtype == torch.float32 and batch["image"].shape[0] == 2    # full batches only
         assert batch["mask"].dtype == torch.int64 and batch["mask"].shape == (2, 1, 16, 16)
         sensor = batch["platform"][0]
         assert batch["platform"] == [sensor] * 2                                         # one sensor per batch
@@ -90,7 +93,8 @@ def test_datamodule_batches_mix_and_contents(shards):
         mean = torch.tensor(st["mean"]).div(255.0).view(-1, 1, 1)
         std = torch.tensor(st["std"]).div(255.0).view(-1, 1, 1)
         for i, key in enumerate(batch["image_name"]):
-            np.testing.assert_array_equal(batch["image"][i].numpy(), tiles[key][0])
+            want = standardization(normalization(torch.from_numpy(tiles[key][0]).float()), mean, std)
+            assert torch.equal(batch["image"][i], want)
             np.testing.assert_array_equal(batch["mask"][i].numpy(), tiles[key][1].astype(np.int64))
             assert torch.equal(batch["mean"][i], mean) and torch.equal(batch["std"][i], std)
             seen.append(key)
@@ -103,11 +107,34 @@ def test_datamodule_batches_mix_and_contents(shards):
     dm.teardown()
 
 
-def test_epoch_size_caps_the_training_epoch(shards):
+def test_deferred_normalization_keeps_raw_tiles(shards):
+    """With a device input stage downstream (``defer_normalization=True``) integer tiles stay raw, byte for byte;
+    f32 tiles are never deferred."""
+    from geo_deep_learning.datasets.wds_dataset import SampleProcessor, create_sensor_datasets
+    path, tiles, _ = shards
+    ds = create_sensor_datasets(sensor_configs_path=path, model_type="dofa", batch_size=2, seed=3,
+                                defer_normalization=True)
+    for batch in ds["sensorB"]["trn"].build_web_dataset():
+        assert batch["image"].dtype == torch.uint8
+        for i, key in enumerate(batch["image_name"]):
+            np.testing.assert_array_equal(batch["image"][i].numpy(), tiles[key][0])
+    assert torch.float32 not in SampleProcessor.RAW_DTYPES
+
+
+def test_epoch_size_counts_batches_and_epochs_differ(shards):
+    """``WebLoader(batch_size=None).with_epoch(n)`` (wds_datamodule.py:104-113): an epoch is n BATCHES; a capped epoch
+    still advances the shuffle epoch, and a source shorter than the cap is restarted."""
     path, _, _ = shards
-    dm = MultiSensorDataModule(path, model_type="dofa", batch_size=2, epoch_size=6, seed=1)
+    dm = MultiSensorDataModule(path, model_type="dofa", batch_size=2, epoch_size=3, seed=1, shuffle_buffer=4,
+                               shardshuffle=True)
     dm.setup()
-    assert len(list(dm.train_dataloader())) == 3
+    e1 = [tuple(b["image_name"]) for b in dm.train_dataloader()]
+    e2 = [tuple(b["image_name"]) for b in dm.train_dataloader()]
+    assert len(e1) == 3 and len(e2) == 3
+    assert e1 != e2                                     # not a replay of the first 3 batches
+    dm = MultiSensorDataModule(path, model_type="dofa", batch_size=2, epoch_size=10, seed=1)
+    dm.setup()
+    assert len(list(dm.train_dataloader())) == 10       # 7 batches per pass: the pipeline is started again
 
 
 @pytest.mark.gpu

@@ -72,6 +72,53 @@ def test_linear_epilogues(dtype):
     close(y, 0.5 * base, dtype if dtype == torch.float32 else torch.bfloat16, "alpha / out dtype")
 
 
+@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_epilogue_row_segments(dtype, variant):
+    """The coalesced (LDS-transposed) epilogue of the 128^2 and 256^2 tiles: residual in f32 / bf16, DropPath scale with
+    a sample boundary inside a 32-row pass (T = 1297), bf16 / f32 outputs, pre-activation copy, GELU-gradient multiply,
+    M and N tails, channel-slice output (row stride > N)."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
+    B, T, K, N = 3, 1297, 128, 208          # M = 3891 (tail of 51 rows), N % 64 = 16, N % 256 != 0
+    if variant == 3:
+        N = 512                              # the 256^2 tile needs N % 256 == 0
+    x, w = q(rnd(B, T, K), dtype), q(rnd(N, K, seed=1), dtype) * 0.1
+    bias, scale, shift = rnd(N, seed=2), rnd(N, seed=3), rnd(N, seed=4)
+    resid, bs = rnd(B, T, N, seed=5), torch.tensor([0.0, 1.25, 0.5])
+    xd, wd = x.to(DEV, dtype).view(B, 1, T, K), w.to(DEV, dtype)
+    base = (x @ w.t())
+    lib.gdl_debug_force_conv_variant(variant)
+    try:
+        for odt in DTYPES:
+            for rdt in DTYPES:
+                out = torch.empty(B, 1, T, N, device=DEV, dtype=odt)
+                rq = q(resid, rdt)
+                ops.conv_gemm(xd, wd, bias=bias.to(DEV), scale=scale.to(DEV), shift=shift.to(DEV), batch_scale=bs.to(DEV),
+                              resid=rq.to(DEV, rdt).view(B, 1, T, N), out=out)
+                ref = rq + ((base + bias) * scale + shift) * bs.view(B, 1, 1)
+                close(out.view(B, T, N), ref, dtype if odt == torch.float32 else torch.bfloat16, f"resid {odt} {rdt}")
+        # plain bf16 output (packed rows) into a channel slice of a wider buffer
+        wide = torch.zeros(B, 1, T, N + 64, device=DEV, dtype=torch.bfloat16)
+        ops.conv_gemm(xd, wd, bias=bias.to(DEV), act=ops.ACT_RELU, out=wide[..., 32:32 + N])
+        close(wide[..., 32:32 + N].reshape(B, T, N), F.relu(base + bias), torch.bfloat16, "slice out")
+        assert float(wide[..., :32].abs().max()) == 0.0 and float(wide[..., 32 + N:].abs().max()) == 0.0
+        if variant == 1:                     # training-only epilogue features live in the small-tile instantiations
+            pre = torch.empty(B, 1, T, N, device=DEV, dtype=dtype)
+            y = ops.conv_gemm(xd, wd, bias=bias.to(DEV), act=ops.ACT_GELU, aux_out=pre, out_dtype=dtype)
+            close(pre.view(B, T, N), base + bias, dtype, "aux_out")
+            close(y.view(B, T, N), F.gelu(base + bias), dtype, "gelu with aux_out")
+            u = rnd(B, T, N, seed=9)
+            g = ops.conv_gemm(xd, wd, act=ops.ACT_MUL_GELU_GRAD, resid=u.to(DEV).view(B, 1, T, N), out_dtype=torch.float32)
+            ug = u.clone().requires_grad_(True)
+            F.gelu(ug).sum().backward()
+            close(g.view(B, T, N), base * ug.grad, dtype, "gelu-grad multiply")
+    finally:
+        lib.gdl_debug_force_conv_variant(-1)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,C,N,R", [(2, 10, 12, 64, 96, 3), (1, 18, 18, 128, 256, 3), (2, 7, 5, 64, 64, 1),
                                          (3, 36, 36, 64, 128, 3),
@@ -349,6 +396,29 @@ def test_dice_loss():
     (loss * 0.4).backward()
     assert abs(loss.item() - ref.item()) < 1e-6
     close(ld.grad, logits.grad, torch.float32, "dice grad")
+
+
+@pytest.mark.parametrize("empty", [False, True])
+def test_dice_loss_binary(empty):
+    """DiceLoss(mode="binary") of the reference's UNet++ config (num_classes 1), un-squeezed [B,1,H,W] mask."""
+    import oracle
+    B, H = 3, 40
+    logits = (rnd(B, 1, H, H) * 3).requires_grad_(True)
+    y = torch.zeros(B, 1, H, H, dtype=torch.int64) if empty else \
+        torch.randint(0, 2, (B, 1, H, H), generator=torch.Generator().manual_seed(2))
+    ref = oracle.model.dice_loss_binary(logits, y)
+    (ref * 0.7).backward()
+    ld = logits.detach().to(DEV).requires_grad_(True)
+    loss = gnn.DiceLoss(mode="binary")(ld, y.to(DEV))
+    (loss * 0.7).backward()
+    assert abs(loss.item() - ref.item()) < 1e-6
+    close(ld.grad, logits.grad, torch.float32, "binary dice grad")
+
+
+def test_dice_loss_multiclass_accepts_unsqueezed_mask():
+    logits = (rnd(2, 5, 24, 24) * 2).to(DEV)
+    y = torch.randint(0, 5, (2, 1, 24, 24), generator=torch.Generator().manual_seed(3)).to(DEV)
+    assert gnn.DiceLoss()(logits, y).item() == gnn.DiceLoss()(logits, y[:, 0]).item()
 
 
 def test_adam_and_clip():

@@ -44,7 +44,7 @@ def test_process_sample_matches_reference(stats, kind, layout):
 
 def test_deferred_sample_keeps_raw_dtype(stats):
     g, norm = stats
-    proc = SampleProcessor("sensorA", norm, "dofa")
+    proc = SampleProcessor("sensorA", norm, "dofa", defer_normalization=True)
     r = proc(_sample(g, "u8"))
     assert r["image"].dtype == torch.uint8 and r["image"].shape == (4, 24, 24)
     b = collate([r, proc(_sample(g, "u8"))])
@@ -56,7 +56,7 @@ def test_deferred_sample_keeps_raw_dtype(stats):
 def test_device_input_stage_matches_reference(stats, kind):
     from geo_deep_learning.datamodules.device_input import DeviceInputStage
     g, norm = stats
-    proc = SampleProcessor("sensorA", norm, "dofa")
+    proc = SampleProcessor("sensorA", norm, "dofa", defer_normalization=True)
     batches = []
     for i in range(7):    # more batches than ring slots: buffers are reused while copies are in flight
         s = _sample(g, kind)
@@ -118,7 +118,7 @@ def test_reference_pipeline_through_the_stage(stats):
     from gdlhip.augment import reference_pipeline
     from geo_deep_learning.datamodules.device_input import DeviceInputStage
     g, norm = stats
-    proc = SampleProcessor("sensorA", norm, "dofa")
+    proc = SampleProcessor("sensorA", norm, "dofa", defer_normalization=True)
     s = _sample(g, "u8")
     batches = [collate([proc(s)] * 4) for _ in range(12)]
     torch.manual_seed(5)
