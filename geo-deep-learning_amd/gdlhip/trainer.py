@@ -1,0 +1,353 @@
+"""MiniTrainer: the part of ``lightning.pytorch.Trainer`` that the reference's ``train.py fit`` exercises
+(/root/reference/geo_deep_learning/train.py:27-80, configs/dofa_config_RGB.yaml:1-33,62-77), for images where Lightning is
+not installed.  It drives the task classes through exactly the hooks Lightning would call:
+
+    configure_model -> configure_optimizers -> per batch: on_before_batch_transfer -> (H2D) -> on_after_batch_transfer ->
+    training_step -> backward -> clip -> optimizer step; per epoch: validation_step, scheduler (ReduceLROnPlateau on the
+    monitored metric), best-``val_loss`` checkpoint with the state dict under ``model.*`` keys; after fit: ``test`` of the
+    best checkpoint on rank 0 (``GeoDeepLearningCLI.after_fit``).
+
+One process per GPU: under ``torchrun`` the inner ``model.model`` is wrapped in ``DistributedDataParallel`` (RCCL =
+backend "nccl"; "gloo" for the CPU tests), ``sync_batchnorm`` converts the BatchNorm containers, metrics are averaged
+over ranks.  ``torch.optim.Adam`` from ``configure_optimizers`` is executed by the fused multi-tensor Adam + clip kernels
+(``gdlhip.nn.FusedAdam``) on the SAME param groups, so schedulers keep working; any other optimizer runs as is.
+Host logic only -- no tensor arithmetic of the hot path lives here.
+"""
+
+from __future__ import annotations
+
+import logging
+import math
+import os
+import random
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+logger = logging.getLogger(__name__)
+
+try:  # pragma: no cover - lightning is absent in the build image
+    from lightning.pytorch import LightningModule
+except ImportError:
+    class LightningModule(nn.Module):  # type: ignore[no-redef]
+        """Minimal stand-in with the surface the task hooks use (``log``, ``log_dict``, ``hparams``, ``trainer``,
+        ``device``, ``save_hyperparameters``)."""
+
+        def __init__(self) -> None:
+            super().__init__()
+            self.hparams: dict[str, Any] = {}
+            self.trainer = None
+            self.logged: dict[str, Any] = {}
+
+        def save_hyperparameters(self, **kw: Any) -> None:
+            self.hparams.update(kw)
+
+        def log(self, name: str, value: Any, batch_size: int | None = None, **_kw: Any) -> None:
+            self.logged[name] = value
+            sink = getattr(self.trainer, "_collect", None)
+            if sink is not None:
+                sink(name, value, batch_size)
+
+        def log_dict(self, d: dict[str, Any], batch_size: int | None = None, **_kw: Any) -> None:
+            for k, v in d.items():
+                self.log(k, v, batch_size=batch_size)
+
+        @property
+        def device(self) -> torch.device:
+            try:
+                return next(self.parameters()).device
+            except StopIteration:
+                return torch.device("cpu")
+
+
+def seed_everything(seed: int = 42, workers: bool = True) -> int:  # noqa: ARG001, FBT001, FBT002
+    """lightning.pytorch.seed_everything (train.py:67)."""
+    os.environ["PL_GLOBAL_SEED"] = str(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    return seed
+
+
+class _Checkpoint:
+    def __init__(self) -> None:
+        self.best_model_path = ""
+        self.best_model_score: float | None = None
+
+
+def _to_device(obj: Any, device: torch.device) -> Any:
+    if isinstance(obj, Tensor):
+        return obj if obj.device == device else obj.to(device, non_blocking=True)
+    if isinstance(obj, dict):
+        return {k: _to_device(v, device) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)) and obj and isinstance(obj[0], Tensor):
+        return type(obj)(_to_device(v, device) for v in obj)
+    return obj
+
+
+class MiniTrainer:
+    """See the module docstring.  Constructor keywords follow ``lightning.pytorch.Trainer`` for the options the
+    reference's configs set; unknown ones are accepted and ignored (logger / strategy objects, ...)."""
+
+    def __init__(self, max_epochs: int = 10, precision: str | int = "32", gradient_clip_val: float | None = None,
+                 sync_batchnorm: bool = False, accelerator: str = "auto", devices: Any = "auto",  # noqa: ARG002
+                 default_root_dir: str | None = None, accumulate_grad_batches: int = 1,
+                 limit_train_batches: int | None = None, limit_val_batches: int | None = None,
+                 limit_test_batches: int | None = None, monitor: str = "val_loss", mode: str = "min",
+                 checkpoint_filename: str = "model-{epoch:02d}-{val_loss:.3f}", early_stopping_patience: int | None = None,
+                 use_fused_adam: bool = True, fast_dev_run: bool = False, **ignored: Any) -> None:
+        self.max_epochs, self.precision = max_epochs, str(precision)
+        self.gradient_clip_val, self.sync_batchnorm = gradient_clip_val, sync_batchnorm
+        self.accumulate_grad_batches = max(1, int(accumulate_grad_batches))
+        self.default_root_dir = Path(default_root_dir or os.getcwd())
+        self.limit = {"train": limit_train_batches, "val": limit_val_batches, "test": limit_test_batches}
+        if fast_dev_run:
+            self.max_epochs, self.limit = 1, {"train": 1, "val": 1, "test": 1}
+        self.monitor, self.mode = monitor, mode
+        self.checkpoint_filename, self.early_stopping_patience = checkpoint_filename, early_stopping_patience
+        self.use_fused_adam = use_fused_adam
+        if ignored:
+            logger.info("MiniTrainer: ignoring trainer options %s", sorted(ignored))
+        self.checkpoint_callback = _Checkpoint()
+        self.training = False
+        self.datamodule = None
+        self.current_epoch = 0
+        self.global_step = 0
+        self.estimated_stepping_batches = -1
+        self.callback_metrics: dict[str, float] = {}
+        self.should_stop = False
+        self._sums: dict[str, list[float]] = {}
+        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.global_rank = dist.get_rank() if self.world_size > 1 else 0
+
+    # ------------------------------------------------------------------ small helpers
+    @property
+    def is_global_zero(self) -> bool:
+        return self.global_rank == 0
+
+    def _collect(self, name: str, value: Any, batch_size: int | None) -> None:
+        """Sink of ``LightningModule.log``: batch-size weighted epoch means (on_epoch=True semantics)."""
+        w = float(batch_size or 1)
+        v = float(value.detach().float().item() if isinstance(value, Tensor) else value)
+        s = self._sums.setdefault(name, [0.0, 0.0])
+        s[0] += v * w
+        s[1] += w
+
+    def _epoch_means(self, device: torch.device) -> dict[str, float]:
+        names = sorted(self._sums)
+        vals = torch.tensor([[self._sums[n][0], self._sums[n][1]] for n in names], dtype=torch.float64, device=device)
+        if self.world_size > 1 and len(names):
+            dist.all_reduce(vals)                        # sync_dist=True
+        out = {n: (vals[i, 0] / vals[i, 1].clamp_min(1e-12)).item() for i, n in enumerate(names)}
+        self._sums = {}
+        return out
+
+    def _autocast(self, device: torch.device):
+        if self.precision in ("bf16-mixed", "bf16", "16-mixed", "16") and device.type == "cuda":
+            # fp16-mixed of the reference's config maps to bf16 here (BASELINE.json: bf16; no loss scaler needed)
+            return torch.autocast("cuda", dtype=torch.bfloat16)
+        return torch.autocast(device.type, enabled=False)
+
+    @staticmethod
+    def _inner(model: nn.Module) -> nn.Module:
+        m = getattr(model, "model", None)
+        return m.module if isinstance(m, nn.parallel.DistributedDataParallel) else m
+
+    def _device(self) -> torch.device:
+        if torch.cuda.is_available():
+            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        return torch.device("cpu")
+
+    def _loaders(self, datamodule, train=None, val=None):
+        if datamodule is not None:
+            if hasattr(datamodule, "prepare_data"):
+                datamodule.prepare_data()
+            datamodule.setup("fit")
+            return datamodule.train_dataloader(), datamodule.val_dataloader()
+        return train, val
+
+    # ------------------------------------------------------------------ checkpoints
+    def state_dict_of(self, model: nn.Module) -> dict[str, Tensor]:
+        """Lightning layout: the LightningModule's state dict, i.e. the inner model's keys under ``model.`` (what
+        utils/models.py:33 strips again).  The DDP wrapper's ``module.`` level is removed."""
+        inner = self._inner(model)
+        sd = {f"model.{k}": v.detach().cpu() for k, v in inner.state_dict().items()}
+        for k, v in model.state_dict().items():
+            if not k.startswith("model."):
+                sd[k] = v.detach().cpu()
+        return sd
+
+    def save_checkpoint(self, model: nn.Module, path: str | Path, **extra: Any) -> None:
+        path = Path(path)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        hp = {k: v for k, v in getattr(model, "hparams", {}).items() if isinstance(v, (int, float, str, bool, list, tuple, type(None), dict))}
+        torch.save({"state_dict": self.state_dict_of(model), "epoch": self.current_epoch,
+                    "global_step": self.global_step, "hyper_parameters": hp, **extra}, path)
+
+    def load_checkpoint(self, model: nn.Module, path: str | Path) -> None:
+        ckpt = torch.load(path, map_location="cpu")
+        sd = {k.removeprefix("model."): v for k, v in ckpt["state_dict"].items() if k.startswith("model.")}
+        self._inner(model).load_state_dict(sd, strict=True)
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, model: nn.Module, datamodule=None, train_dataloaders=None, val_dataloaders=None) -> None:
+        device = self._device()
+        model.trainer = self
+        self.datamodule = datamodule
+        model.configure_model()
+        model.to(device)
+        train_loader, val_loader = self._loaders(datamodule, train_dataloaders, val_dataloaders)
+        if self.world_size > 1:
+            if self.sync_batchnorm:
+                model.model = nn.SyncBatchNorm.convert_sync_batchnorm(model.model)
+            ddp_kw = {"device_ids": [device.index]} if device.type == "cuda" else {}
+            model.model = nn.parallel.DistributedDataParallel(model.model, gradient_as_bucket_view=True,
+                                                              find_unused_parameters=False, **ddp_kw)
+        try:
+            per_epoch = len(train_loader)
+            self.estimated_stepping_batches = math.ceil(per_epoch / self.accumulate_grad_batches) * self.max_epochs
+        except TypeError:
+            self.estimated_stepping_batches = -1         # iterable loaders (the WebDataset datamodule)
+        optimizers, sched_cfgs = model.configure_optimizers()
+        opt = optimizers[0]
+        step_opt = self._maybe_fuse(opt, device)
+        best, bad_epochs = None, 0
+        for epoch in range(self.max_epochs):
+            self.current_epoch = epoch
+            self._run_train_epoch(model, train_loader, step_opt, opt, sched_cfgs, device)
+            metrics = self._epoch_means(device)
+            if hasattr(model, "on_train_epoch_end"):
+                model.on_train_epoch_end()
+            if val_loader is not None:
+                metrics.update(self._run_eval(model, val_loader, "val", device))
+                if hasattr(model, "on_validation_epoch_end"):
+                    model.on_validation_epoch_end()
+            self.callback_metrics.update(metrics)
+            for cfg in sched_cfgs:
+                if cfg.get("interval", "epoch") == "epoch" and (epoch + 1) % int(cfg.get("frequency", 1)) == 0:
+                    self._step_scheduler(cfg, metrics)
+            score = metrics.get(self.monitor)
+            if score is not None:
+                better = best is None or (score < best if self.mode == "min" else score > best)
+                if better:
+                    best, bad_epochs = score, 0
+                    if self.is_global_zero:
+                        name = self.checkpoint_filename.format(epoch=epoch, **{self.monitor: score}) + ".ckpt"
+                        path = self.default_root_dir / "checkpoints" / name
+                        old = self.checkpoint_callback.best_model_path
+                        self.save_checkpoint(model, path)
+                        if old and Path(old).exists() and Path(old) != path:
+                            Path(old).unlink()           # save_top_k: 1
+                        self.checkpoint_callback.best_model_path = str(path)
+                    self.checkpoint_callback.best_model_score = score
+                else:
+                    bad_epochs += 1
+            if self.is_global_zero:
+                logger.info("epoch %d: %s", epoch, {k: round(v, 5) for k, v in metrics.items()})
+            if self.early_stopping_patience is not None and bad_epochs > self.early_stopping_patience:
+                break
+        if self.world_size > 1:
+            paths = [self.checkpoint_callback.best_model_path]
+            dist.broadcast_object_list(paths, src=0)
+            self.checkpoint_callback.best_model_path = paths[0]
+            dist.barrier()
+
+    def _maybe_fuse(self, opt: torch.optim.Optimizer, device: torch.device):
+        """torch.optim.Adam -> the fused multi-tensor Adam + clip kernels on the same param groups."""
+        if not (self.use_fused_adam and device.type == "cuda" and type(opt) is torch.optim.Adam):
+            return opt
+        g0 = opt.param_groups[0]
+        if any(g.get("amsgrad") or g.get("maximize") or g.get("capturable") for g in opt.param_groups):
+            return opt
+        from gdlhip.nn import FusedAdam
+        fused = FusedAdam(opt.param_groups, lr=g0["lr"], betas=g0["betas"], eps=g0["eps"],
+                          weight_decay=g0["weight_decay"], max_grad_norm=self.gradient_clip_val)
+        fused.param_groups = opt.param_groups            # the scheduler keeps writing `lr` into these dicts
+        return fused
+
+    def _step_scheduler(self, cfg: dict[str, Any], metrics: dict[str, float]) -> None:
+        sched = cfg["scheduler"]
+        if isinstance(sched, torch.optim.lr_scheduler.ReduceLROnPlateau):
+            key = cfg.get("monitor", self.monitor)
+            if key not in metrics:
+                msg = f"ReduceLROnPlateau monitors {key!r}, which was not logged (have {sorted(metrics)})"
+                raise KeyError(msg)
+            sched.step(metrics[key])
+        else:
+            sched.step()
+
+    def _batches(self, loader, split: str):
+        limit = self.limit[split]
+        for i, batch in enumerate(loader):
+            if limit is not None and i >= limit:
+                break
+            yield i, batch
+
+    def _run_train_epoch(self, model, loader, step_opt, opt, sched_cfgs, device) -> None:
+        model.train()
+        self.training = True
+        fused_clip = step_opt is not opt
+        step_opt.zero_grad(set_to_none=True)
+        for i, batch in self._batches(loader, "train"):
+            batch = model.on_before_batch_transfer(batch, 0) if hasattr(model, "on_before_batch_transfer") else batch
+            batch = _to_device(batch, device)
+            batch = model.on_after_batch_transfer(batch, 0) if hasattr(model, "on_after_batch_transfer") else batch
+            with self._autocast(device):
+                loss = model.training_step(batch, i)
+            (loss / self.accumulate_grad_batches).backward()
+            if (i + 1) % self.accumulate_grad_batches:
+                continue
+            if self.gradient_clip_val and not fused_clip:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), self.gradient_clip_val)
+            step_opt.step()
+            step_opt.zero_grad(set_to_none=True)
+            self.global_step += 1
+            for cfg in sched_cfgs:
+                if cfg.get("interval") == "step" and self.global_step % int(cfg.get("frequency", 1)) == 0:
+                    self._step_scheduler(cfg, {})
+        self.training = False
+
+    @torch.no_grad()
+    def _run_eval(self, model, loader, split: str, device) -> dict[str, float]:
+        model.eval()
+        self.training = False
+        step = model.validation_step if split == "val" else model.test_step
+        for i, batch in self._batches(loader, split):
+            batch = model.on_before_batch_transfer(batch, 0) if hasattr(model, "on_before_batch_transfer") else batch
+            batch = _to_device(batch, device)
+            batch = model.on_after_batch_transfer(batch, 0) if hasattr(model, "on_after_batch_transfer") else batch
+            with self._autocast(device):
+                step(batch, i)
+        return self._epoch_means(device)
+
+    # ------------------------------------------------------------------ validate / test
+    def validate(self, model, dataloaders=None, datamodule=None) -> list[dict[str, float]]:
+        return [self._eval_entry(model, dataloaders, datamodule, "val")]
+
+    def test(self, model, dataloaders=None, datamodule=None, ckpt_path: str | None = None) -> list[dict[str, float]]:
+        if ckpt_path:
+            model.trainer = self
+            model.configure_model()
+            self.load_checkpoint(model, ckpt_path)
+        return [self._eval_entry(model, dataloaders, datamodule, "test")]
+
+    def _eval_entry(self, model, loader, datamodule, split: str) -> dict[str, float]:
+        device = self._device()
+        model.trainer = self
+        model.configure_model()
+        model.to(device)
+        if loader is None and datamodule is not None:
+            datamodule.setup("test" if split == "test" else "validate")
+            loader = datamodule.test_dataloader() if split == "test" else datamodule.val_dataloader()
+        metrics = self._run_eval(model, loader, split, device)
+        hook = getattr(model, "on_test_epoch_end" if split == "test" else "on_validation_epoch_end", None)
+        if hook is not None:
+            hook()
+        self.callback_metrics.update(metrics)
+        return metrics
