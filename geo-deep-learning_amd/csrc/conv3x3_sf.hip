@@ -158,7 +158,6 @@ __global__ __launch_bounds__(512) void conv3x3_sf_kernel(const KArgs k) {
     }
   };
 
-  conv_stagger(k, 256);
   const unsigned long long t0c = k.probe ? __builtin_readcyclecounter() : 0;
   const unsigned long long t0r = k.probe ? __builtin_amdgcn_s_memrealtime() : 0;
   // ---- prologue: weights of step 0 and the whole first activation tile, then the "slot -1" work

@@ -234,7 +234,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
         }
       }
   };
-  conv_stagger(k, 256 * (NWALL == 8 ? 1 : 2));
   const unsigned long long t0c = k.probe ? __builtin_readcyclecounter() : 0;
   const unsigned long long t0r = k.probe ? __builtin_amdgcn_s_memrealtime() : 0;
   // tile t is loaded by half (t & 1) in the ping-pong variant, by everyone otherwise
@@ -312,8 +311,7 @@ int launch(const KArgs& k, hipStream_t stream) {
 
 }  // namespace
 
-static int g_tap_inner = 1, g_dbg = 0, g_tap_packing = 1, g_stagger = 1;
-extern "C" void gdl_debug_set_conv_stagger(int on) { g_stagger = on; }   // A/B hook: start-up stagger of the first round
+static int g_tap_inner = 1, g_dbg = 0, g_tap_packing = 1;
 extern "C" void gdl_debug_set_conv_tap_packing(int on) { g_tap_packing = on; }  // A/B hook
 extern "C" void gdl_debug_set_conv_dbg(int mode) { g_dbg = mode; }
 static unsigned long long* g_probe = nullptr;
@@ -373,7 +371,6 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   // "dense" = the (b,oy,ox) -> offset map is linear in m, so no divisions are needed
   k.tap_inner = g_tap_inner;
   k.dbg = g_dbg;
-  k.stagger = 0;
   k.probe = g_probe;
   k.in_span = (unsigned)in_span;
   k.w_span = (unsigned)w_span;
@@ -390,18 +387,6 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
     k.kc = (a.R * a.S * a.C + bke - 1) / bke;
     k.KT = k.kc;
     k.c_tail = 0;
-  }
-  if (g_stagger && a.nz == 1 && (variant == 1 || variant == 3 || variant == 4 || variant == 2)) {
-    // tile period estimate in shader cycles (K steps at ~2900 (256^2) / ~1900 (128^2, two blocks per CU) + epilogue)
-    const bool big = variant != 1;
-    const int64_t tm = big ? 256 : 128;
-    const int64_t tiles = ((k.M + tm - 1) / tm) * ((a.N + tm - 1) / tm);
-    const int64_t resident = big ? 256 : 512;
-    if (tiles >= 3 * resident) {
-      const int64_t period = (int64_t)k.KT * (big ? 2900 : 1900) + (big ? 20000 : 10000);
-      k.stagger = (int)(period / 4 < (1 << 24) ? period / 4 : (1 << 24));
-      if (g_stagger > 1) k.stagger = g_stagger;   // tuning: explicit quarter period
-    }
   }
   if (a.dtype == GDL_BF16) {
     if (variant == 4) return conv3x3_sf_launch(k, s);

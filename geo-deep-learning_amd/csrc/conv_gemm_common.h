@@ -17,7 +17,6 @@ struct KArgs {
   int in_dense, out_dense, res_dense;
   unsigned in_span, w_span;   // bytes addressed from the (z-offset) operand base: buffer num_records
   int tap_inner;              // K order: 1 = channel chunk outer / filter tap inner (default), 0 = tap outer
-  int stagger;                // > 0: first-round blocks start (block >> 3) % 4 * stagger cycles late (see conv_stagger)
   int dbg;                    // tuning experiments only: 1 = no DMA after the first tile, 2 = no MFMA
   unsigned long long* probe;  // tuning only (12288 u64): per block {shader cycles, 100 MHz ticks} of the K loop, K loop + epilogue cycles, {start, end} ticks
 };
@@ -71,19 +70,6 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-
-// Start-up stagger.  All tiles of a GEMM take the same time, so the CUs stay in lock step from the first round on:
-// every CU runs its K loop (no HBM writes at all) and then its epilogue (nothing but HBM traffic) at the same moment,
-// and the epilogue phases are bound by HBM bandwidth (measured: 128 KiB per tile at ~7 B/clk/CU = 3.2 TB/s chip-wide
-// while the K loops leave HBM idle).  Delaying the first-round blocks by 0, 1, 2, 3 quarters of a tile period puts a
-// quarter of the chip in its epilogue at any time: the writes of one group overlap the K loops of the others, and the
-// phase offsets persist because tile times are equal.  Costs 3/8 of a tile period once per launch; the host enables it
-// for launches of >= 3 rounds.
-__device__ __forceinline__ void conv_stagger(const KArgs& k, int first_round_blocks) {
-  if (k.stagger <= 0 || (int)blockIdx.x >= first_round_blocks || blockIdx.y != 0) return;
-  const int q = (blockIdx.x >> 3) & 3;                   // blocks b, b+8, b+16, ... share an XCD
-  for (int n = q * (k.stagger >> 13); n > 0; --n) __builtin_amdgcn_s_sleep(127);   // 127 * 64 cycles each
-}
 
 // 3x3 shared-staging kernel (conv3x3_sf.hip)
 bool conv3x3_sf_applicable(const gdl_conv_args& a);

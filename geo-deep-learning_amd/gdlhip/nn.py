@@ -36,14 +36,18 @@ _CACHE: dict = {}
 
 
 def mark_updated(p: Tensor) -> None:
-    """Called by the fused optimizer for every parameter it rewrites through a raw pointer."""
+    """Called for every tensor a kernel rewrites through a raw pointer (fused optimizer: parameters; single-GPU
+    BatchNorm statistics kernel: running_mean / running_var) -- ``tensor._version`` does not see those writes."""
+    if id(p) not in _RAW_WRITES:
+        weakref.finalize(p, _RAW_WRITES.pop, id(p), None)
     _RAW_WRITES[id(p)] = _RAW_WRITES.get(id(p), 0) + 1
 
 
 def cached(params: tuple, kind: str, builder):
     """Memoise ``builder()`` on the identity + version of ``params`` (tensors).  Frozen
     parameters never change version, so e.g. the DOFA dynamic patch-embed kernel of a frozen
-    encoder is generated once per sensor, not once per step."""
+    encoder is generated once per sensor, not once per step.  An entry dies with the tensors it was
+    built from (weakref finalizers), so the cache never pins the device tensors of a dead model."""
     key = (kind, *[id(p) for p in params])
     ver = tuple((p._version, _RAW_WRITES.get(id(p), 0), p.data_ptr()) for p in params)
     hit = _CACHE.get(key)
@@ -52,6 +56,9 @@ def cached(params: tuple, kind: str, builder):
     if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
         return hit[1]
     val = builder()
+    if hit is None:
+        for p in params:
+            weakref.finalize(p, _CACHE.pop, key, None)
     _CACHE[key] = (ver, val, tuple(weakref.ref(p) for p in params))
     return val
 
@@ -159,6 +166,9 @@ class _ConvBNActTrain(Function):
                 update_running_stats(running_mean, running_var, mean, var, momentum, y.numel() // n * world)
         else:
             mean, var = ops.bn_stats(y, running_mean, running_var, momentum)
+            if running_mean is not None:     # written through raw pointers: invalidate the eval-mode fold cache
+                mark_updated(running_mean)
+                mark_updated(running_var)
         out = ops.bn_apply(y, mean, var, gamma.detach(), beta.detach(), eps, relu)
         ctx.save_for_backward(x, weight, y, mean, var, gamma, beta)
         ctx.cfg = (pad, relu, eps, conv_bias is not None, sync_group, world)

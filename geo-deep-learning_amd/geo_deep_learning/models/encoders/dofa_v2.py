@@ -308,11 +308,25 @@ class DOFAv2(nn.Module):
         self.pos_embed.data.copy_(pos.unsqueeze(0))
         nn.init.normal_(self.cls_token, std=0.02)
 
+    CHECKPOINT_FILES = {"dofa_base": "dofav2_vit_base_e150.pth", "dofa_large": "dofav2_vit_large_e150.pth"}
+
     def load_pretrained_weights(self):
-        """HF checkpoint download (dofa_v2.py:286-347) needs network access; load a local
-        checkpoint with ``load_pretrained_state_dict`` instead."""
-        msg = ("pretrained=True downloads from huggingface.co, which this build cannot reach; pass "
-               "pretrained=False and call load_pretrained_state_dict(torch.load(path))")
+        """dofa_v2.py:286-347.  The reference fetches ``hf.co/earthflow/DOFA/.../dofav2_vit_{base,large}_e150.pth`` with
+        ``torch.hub.load_state_dict_from_url``, which caches the file under ``<torch hub dir>/checkpoints``.  This build
+        never opens a network connection: it reads that same cache location (or ``$GDL_DOFA_CHECKPOINT``) and fails
+        loudly, naming the file it wants, when the checkpoint is not there."""
+        import os
+        from pathlib import Path
+        if self.encoder_name not in self.CHECKPOINT_FILES:
+            msg = f"Unknown model name: {self.encoder_name}"
+            raise ValueError(msg)
+        name = self.CHECKPOINT_FILES[self.encoder_name]
+        candidates = [os.environ.get("GDL_DOFA_CHECKPOINT"), str(Path(torch.hub.get_dir()) / "checkpoints" / name)]
+        for path in candidates:
+            if path and Path(path).is_file():
+                return self.load_pretrained_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+        msg = (f"pretrained=True needs the published checkpoint {name} (https://hf.co/earthflow/DOFA); this build does not "
+               f"download: put it at {candidates[1]} or point GDL_DOFA_CHECKPOINT at it, or pass pretrained=False")
         raise RuntimeError(msg)
 
     def load_pretrained_state_dict(self, state_dict: dict) -> tuple[list[str], list[str]]:

@@ -9,13 +9,12 @@ import torch
 from torch import Tensor
 
 from geo_deep_learning.models.segmentation.segformer import SegFormerSegmentationModel
-from geo_deep_learning.tasks_with_models.segmentation_dofa import LightningModule
+from geo_deep_learning.tasks_with_models._common import LightningModule, SegmentationTaskHooks
 from geo_deep_learning.utils.models import load_weights_from_checkpoint
-from gdlhip import nn as gnn
 
 
-class SegmentationSegformer(LightningModule):
-    """Same constructor keywords / hooks as the reference (segmentation_segformer.py:35-54,202-316)."""
+class SegmentationSegformer(SegmentationTaskHooks, LightningModule):
+    """Same constructor keywords / hooks as the reference (segmentation_segformer.py:35-54,128-316)."""
 
     def __init__(self, encoder: str, in_channels: int, num_classes: int, max_samples: int, loss: Callable,
                  image_size: tuple[int, int] = (512, 512), weights: str | None = None,
@@ -26,7 +25,10 @@ class SegmentationSegformer(LightningModule):
                  weights_from_checkpoint_path: str | None = None, *, use_dynamic_encoder: bool = False,
                  **kwargs: object) -> None:
         super().__init__()
-        self.save_hyperparameters(encoder=encoder, in_channels=in_channels, num_classes=num_classes, **kwargs)
+        try:
+            self.save_hyperparameters(encoder=encoder, in_channels=in_channels, num_classes=num_classes, **kwargs)
+        except TypeError:  # real Lightning inspects the frame instead of taking kwargs
+            self.save_hyperparameters()
         self.encoder, self.in_channels, self.weights = encoder, in_channels, weights
         self.image_size = tuple(image_size)
         self.use_dynamic_encoder = use_dynamic_encoder
@@ -35,12 +37,11 @@ class SegmentationSegformer(LightningModule):
         self.optimizer, self.scheduler = optimizer, scheduler
         self.scheduler_config = scheduler_config or {"interval": "epoch"}
         self.class_colors, self.max_samples, self.num_classes = class_colors, max_samples, num_classes
-        self.threshold = 0.5
         self.loss = loss
-        n = num_classes + 1 if num_classes == 1 else num_classes
-        self.labels = [str(i) for i in range(n)] if class_labels is None else class_labels
+        self._init_metrics(num_classes, class_labels)
 
     def configure_model(self) -> None:
+        """segmentation_segformer.py:128-148."""
         if getattr(self, "model", None) is not None:
             return
         self.model = SegFormerSegmentationModel(encoder=self.encoder, in_channels=self.in_channels,
@@ -51,36 +52,31 @@ class SegmentationSegformer(LightningModule):
             load_weights_from_checkpoint(self.model, self.weights_from_checkpoint_path,
                                          load_parts=self.hparams.get("load_parts"), map_location=self.device)
 
-    def configure_optimizers(self):
-        optimizer = self.optimizer(self.parameters())
-        return [optimizer], [{"scheduler": self.scheduler(optimizer), **self.scheduler_config}]
-
     def forward(self, image: Tensor) -> Tensor:
         return self.model(image)
 
+    def _loss(self, batch: dict[str, Any]):
+        x = batch["image"]
+        y = batch["mask"].squeeze(1).long()
+        y_hat = self(x)
+        return y_hat, y, self.loss(y_hat, y), x.shape[0]
+
     def training_step(self, batch: dict[str, Any], batch_idx: int) -> Tensor:  # noqa: ARG002
-        y_hat = self(batch["image"])
-        loss = self.loss(y_hat, batch["mask"].squeeze(1).long())
-        self.log("train_loss", loss, batch_size=batch["image"].shape[0], on_step=False, on_epoch=True, sync_dist=True)
+        """segmentation_segformer.py:216-241."""
+        _, _, loss, bs = self._loss(batch)
+        self.train_samples_count += bs
+        self._log_loss("train_loss", loss, bs)
         return loss
 
-    def _apply_aug(self):
-        """The reference's kornia pipeline (segmentation_segformer.py _apply_aug) as one GPU kernel (gdlhip.augment)."""
-        from gdlhip.augment import reference_pipeline
-        return reference_pipeline(tuple(self.image_size))
-
-    def on_after_batch_transfer(self, batch: dict[str, Any], dataloader_idx: int) -> dict[str, Any]:  # noqa: ARG002
-        """The reference augments on the CPU in ``on_before_batch_transfer``; here the batch is augmented on the GPU
-        right after the transfer (training only)."""
-        trainer = getattr(self, "trainer", None)
-        if trainer is not None and getattr(trainer, "training", False) and batch["image"].is_cuda:
-            batch = self._apply_aug()(batch)
-        return batch
-
     def validation_step(self, batch: dict[str, Any], batch_idx: int) -> Tensor:  # noqa: ARG002
-        y_hat = self(batch["image"])
-        loss = self.loss(y_hat, batch["mask"].squeeze(1).long())
-        self.log("val_loss", loss, batch_size=batch["image"].shape[0], on_step=False, on_epoch=True, sync_dist=True)
-        if self.num_classes == 1:
-            return (y_hat.sigmoid().squeeze(1) > self.threshold).long()
-        return gnn.predict_mask(y_hat)
+        """segmentation_segformer.py:243-274."""
+        y_hat, _, loss, bs = self._loss(batch)
+        self.val_samples_count += bs
+        self._log_loss("val_loss", loss, bs)
+        return self._predict(y_hat)
+
+    def test_step(self, batch: dict[str, Any], batch_idx: int) -> None:  # noqa: ARG002
+        """segmentation_segformer.py:276-316."""
+        y_hat, y, loss, bs = self._loss(batch)
+        self.test_samples_count += bs
+        self._log_test_metrics(self._predict(y_hat), y, loss, bs)

@@ -11,13 +11,12 @@ import torch
 from torch import Tensor
 
 from geo_deep_learning.models.segmentation.unetplusplus import UnetPlusPlus
-from geo_deep_learning.tasks_with_models.segmentation_dofa import LightningModule
+from geo_deep_learning.tasks_with_models._common import LightningModule, SegmentationTaskHooks
 from geo_deep_learning.utils.models import load_weights_from_checkpoint
-from gdlhip import nn as gnn
 
 
-class SegmentationUnetPlus(LightningModule):
-    """segmentation_unetplus.py:33-83 (constructor), :124-142 (configure_model), :223-283 (steps)."""
+class SegmentationUnetPlus(SegmentationTaskHooks, LightningModule):
+    """segmentation_unetplus.py:33-83 (constructor), :124-142 (configure_model), :223-320 (steps)."""
 
     def __init__(self, encoder: str, image_size: tuple[int, int], in_channels: int, num_classes: int,
                  max_samples: int, loss: Callable, optimizer: Callable = torch.optim.Adam,
@@ -26,7 +25,10 @@ class SegmentationUnetPlus(LightningModule):
                  class_labels: list[str] | None = None, class_colors: list[str] | None = None,
                  weights_from_checkpoint_path: str | None = None, **kwargs: object) -> None:
         super().__init__()
-        self.save_hyperparameters(encoder=encoder, in_channels=in_channels, num_classes=num_classes, **kwargs)
+        try:
+            self.save_hyperparameters(encoder=encoder, in_channels=in_channels, num_classes=num_classes, **kwargs)
+        except TypeError:  # real Lightning inspects the frame instead of taking kwargs
+            self.save_hyperparameters()
         self.encoder, self.in_channels, self.num_classes = encoder, in_channels, num_classes
         self.image_size, self.max_samples = tuple(image_size), max_samples
         self.loss = loss
@@ -35,9 +37,7 @@ class SegmentationUnetPlus(LightningModule):
         self.weights = weights
         self.weights_from_checkpoint_path = weights_from_checkpoint_path
         self.class_colors = class_colors
-        self.threshold = 0.5
-        n = num_classes + 1 if num_classes == 1 else num_classes
-        self.labels = [str(i) for i in range(n)] if class_labels is None else class_labels
+        self._init_metrics(num_classes, class_labels)
 
     def configure_model(self) -> None:
         if getattr(self, "model", None) is not None:
@@ -48,36 +48,30 @@ class SegmentationUnetPlus(LightningModule):
             load_weights_from_checkpoint(self.model, self.weights_from_checkpoint_path,
                                          load_parts=self.hparams.get("load_parts"), map_location=self.device)
 
-    def configure_optimizers(self):
-        optimizer = self.optimizer(self.parameters())
-        return [optimizer], [{"scheduler": self.scheduler(optimizer), **self.scheduler_config}]
-
     def forward(self, image: Tensor) -> Tensor:
         return self.model(image)
 
     def training_step(self, batch: dict[str, Any], batch_idx: int) -> Tensor:  # noqa: ARG002
-        y_hat = self(batch["image"])
-        loss = self.loss(y_hat, batch["mask"])      # the reference passes the [B,1,H,W] mask as is (:232)
-        self.log("train_loss", loss, batch_size=batch["image"].shape[0], on_step=False, on_epoch=True, sync_dist=True)
+        """segmentation_unetplus.py:223-247: the ``[B,1,H,W]`` mask goes to the loss AS IS (the squeeze at :232 is
+        commented out in the reference); smp's DiceLoss views it ``[B,-1]`` / ``[B,1,-1]`` itself."""
+        x, y = batch["image"], batch["mask"]
+        loss = self.loss(self(x), y)
+        self.train_samples_count += x.shape[0]
+        self._log_loss("train_loss", loss, x.shape[0])
         return loss
 
-    def _apply_aug(self):
-        """The reference's kornia pipeline (segmentation_unetplus.py:84-122) as one GPU kernel (gdlhip.augment)."""
-        from gdlhip.augment import reference_pipeline
-        return reference_pipeline(tuple(self.image_size))
-
-    def on_after_batch_transfer(self, batch: dict[str, Any], dataloader_idx: int) -> dict[str, Any]:  # noqa: ARG002
-        """The reference augments on the CPU in ``on_before_batch_transfer``; here the batch is augmented on the GPU
-        right after the transfer (training only)."""
-        trainer = getattr(self, "trainer", None)
-        if trainer is not None and getattr(trainer, "training", False) and batch["image"].is_cuda:
-            batch = self._apply_aug()(batch)
-        return batch
-
     def validation_step(self, batch: dict[str, Any], batch_idx: int) -> Tensor:  # noqa: ARG002
-        y_hat = self(batch["image"])
-        loss = self.loss(y_hat, batch["mask"])
-        self.log("val_loss", loss, batch_size=batch["image"].shape[0], on_step=False, on_epoch=True, sync_dist=True)
-        if self.num_classes == 1:
-            return (y_hat.sigmoid().squeeze(1) > self.threshold).long()
-        return gnn.predict_mask(y_hat)
+        """segmentation_unetplus.py:249-276."""
+        x, y = batch["image"], batch["mask"]
+        y_hat = self(x)
+        self.val_samples_count += x.shape[0]
+        self._log_loss("val_loss", self.loss(y_hat, y), x.shape[0])
+        return self._predict(y_hat)
+
+    def test_step(self, batch: dict[str, Any], batch_idx: int) -> None:  # noqa: ARG002
+        """segmentation_unetplus.py:278-320: loss on the un-squeezed mask, metrics on ``mask.squeeze(1).long()``."""
+        x, y = batch["image"], batch["mask"]
+        y_hat = self(x)
+        loss = self.loss(y_hat, y)
+        self.test_samples_count += x.shape[0]
+        self._log_test_metrics(self._predict(y_hat), y.squeeze(1).long(), loss, x.shape[0])

@@ -1,0 +1,511 @@
+"""GPU parity tests, TASK level: the three LightningModule mirrors are driven
+through ``training_step`` / ``validation_step`` / ``test_step`` on a batch dict, exactly as a trainer would, and compared
+with the CPU oracle: loss, argmax mask, per-class IoU, gradients.  The stochastic draws of a training step (DropPath,
+Dropout2d) come from the device RNG inside the model; the tests replay the same draws after re-seeding and hand them to
+the oracle as explicit masks.  Also: the full-size training legs of BASELINE configs[3] / configs[4], and a fit through
+MiniTrainer with a checkpoint round trip."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+gdlhip = pytest.importorskip("gdlhip")
+import oracle  # noqa: E402
+from gdlhip import nn as gnn  # noqa: E402
+from gdlhip.trainer import MiniTrainer  # noqa: E402
+from geo_deep_learning.models.encoders.dofa_v2 import DOFAv2  # noqa: E402
+from geo_deep_learning.models.segmentation.dofa import DOFASegmentationModel  # noqa: E402
+from geo_deep_learning.tasks_with_models.segmentation_dofa import SegmentationDOFA  # noqa: E402
+from geo_deep_learning.tasks_with_models.segmentation_segformer import SegmentationSegformer  # noqa: E402
+from geo_deep_learning.tasks_with_models.segmentation_unetplus import SegmentationUnetPlus  # noqa: E402
+from geo_deep_learning.utils.models import load_weights_from_checkpoint  # noqa: E402
+from oracle import procedural_state_dict, synthetic_batch  # noqa: E402
+from oracle.model import dice_loss_binary, dice_loss_multiclass  # noqa: E402
+from oracle.segformer import SegFormerSegmentationModel as OracleSegFormer  # noqa: E402
+from oracle.unetpp import UnetPlusPlus as OracleUnetPlusPlus  # noqa: E402
+
+DEV = "cuda"
+TINY = dict(patch_size=14, embed_dim=128, depth=4, num_heads=2, out_indices=[0, 1, 2, 3])
+
+
+class _Trainer:
+    """What the hooks read from a trainer."""
+    def __init__(self, training):
+        self.training, self.datamodule, self.estimated_stepping_batches = training, None, 100
+        self.accumulate_grad_batches, self.max_epochs = 1, 3
+
+
+def _to_dev(batch):
+    return {k: (v.to(DEV) if isinstance(v, torch.Tensor) and k != "wavelengths" else v) for k, v in batch.items()}
+
+
+def _iou_per_class(pred, target, k):
+    """torchmetrics MeanIoU(per_class=True, input_format="index") as restated in gdlhip/metrics.py."""
+    p, t = pred.numpy(), target.numpy()
+    out = np.zeros(k)
+    for c in range(k):
+        inter = ((p == c) & (t == c)).reshape(p.shape[0], -1).sum(1).astype(np.float64)
+        union = ((p == c) | (t == c)).reshape(p.shape[0], -1).sum(1).astype(np.float64)
+        out[c] = np.where(union > 0, inter / np.maximum(union, 1), 0.0).mean()
+    return out
+
+
+def _mask_agrees(got, ref_logits, tol=1e-3):
+    top2 = ref_logits.topk(2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > tol
+    want = ref_logits.softmax(1).argmax(1)
+    got = got.cpu()
+    assert got.dtype == torch.int64 and got.shape == want.shape
+    n_bad = int((got != want).sum())
+    print(f"mask: {n_bad} of {want.numel()} pixels differ from the oracle ({int((~decided).sum())} undecided at {tol})")
+    assert bool((got == want)[decided].all()) and n_bad <= 1e-4 * want.numel() + 1
+    return want
+
+
+def _grads_close(model, ref, tol=3e-2, floor=2e-6):
+    refp = dict(ref.named_parameters())
+    n = 0
+    for name, p in model.named_parameters():
+        rg = refp[name].grad
+        assert (p.grad is None) == (rg is None), name
+        if rg is None or (name.endswith("conv.bias") and name.startswith("neck.")):
+            continue
+        err, rn = (p.grad.float().cpu() - rg).norm().item(), rg.norm().item()
+        assert err <= tol * rn + floor, (name, err, rn)
+        n += 1
+    return n
+
+
+# ------------------------------------------------------------------------------------------------ DOFA
+def _dofa_task(freeze=("encoder",), num_classes=5, img=112, seed=7, **task_kw):
+    ref = oracle.DOFASegmentationModel("dofa_tiny_test", (img, img), num_classes=num_classes, _encoder_kwargs=TINY,
+                                       freeze_layers=list(freeze) if freeze else None)
+    sd = procedural_state_dict(ref, seed)
+    ref.load_state_dict(sd)
+    task = SegmentationDOFA("dofa_base", pretrained=False, image_size=(img, img), num_classes=num_classes,
+                            max_samples=2, loss=gnn.DiceLoss(mode="multiclass"),
+                            freeze_layers=list(freeze) if freeze else None, wavelengths=[0.665, 0.549, 0.481],
+                            **task_kw)
+    enc = DOFAv2(img_size=img, pretrained=False, **TINY)
+    task.model = DOFASegmentationModel(enc, (img, img), num_classes=num_classes, pretrained=False,
+                                       freeze_layers=list(freeze) if freeze else None)
+    task.configure_model()                                   # keeps the injected tiny model
+    task.model.load_state_dict(sd)
+    return ref, task.to(DEV)
+
+
+def _replay_dofa_draws(model, b, seed):
+    """The device-RNG draws of one training forward, in the order the model makes them (two DropPath masks per block
+    with a non-zero rate, then the aux head's Dropout2d channel mask)."""
+    torch.manual_seed(seed)
+    masks = []
+    for blk in model.encoder.blocks:
+        pair = []
+        for _ in range(2):
+            if blk.drop_prob > 0:
+                pair.append(torch.empty(b, device=DEV, dtype=torch.float32).bernoulli_(1.0 - blk.drop_prob).cpu())
+            else:
+                pair.append(torch.ones(b))
+        masks.append(tuple(pair))
+    aux = torch.empty((b, model.aux_head.channels), device=DEV, dtype=torch.float32).bernoulli_(0.9).cpu()
+    return masks, aux
+
+
+def test_dofa_task_steps_match_oracle():
+    """SegmentationDOFA.training_step / validation_step / test_step (segmentation_dofa.py:213-338)."""
+    ref, task = _dofa_task()
+    b, nc = 4, 5
+    batch = synthetic_batch(b, 3, 112, nc, 7)
+    batch["wavelengths"] = batch["wavelengths"].unsqueeze(0).expand(b, -1).contiguous()     # [B, C] like the loader
+    dev = _to_dev(batch)
+    y = batch["mask"].squeeze(1).long()
+    # ---- validation / test: eval mode, no stochastic op
+    task.trainer = _Trainer(False)
+    task.eval(); ref.eval()
+    with torch.no_grad():
+        o = ref(batch["image"], batch["wavelengths"][0])
+        want_loss = (dice_loss_multiclass(o.out, y) + 0.4 * dice_loss_multiclass(o.aux, y)).item()
+        y_hat = task.validation_step(dev, 0)
+        assert abs(task.logged["val_loss"].item() - want_loss) < 1e-5
+        want_mask = _mask_agrees(y_hat, o.out)
+        assert task.test_step(dev, 0) is None
+    assert abs(task.logged["test_loss"].item() - want_loss) < 1e-5
+    iou = _iou_per_class(want_mask, y, nc)
+    got = np.array([task.logged[f"meaniou_{c}"].item() for c in range(nc)])
+    np.testing.assert_allclose(got, iou, atol=2e-4)                       # a handful of undecided pixels at most
+    assert task.val_samples_count == b and task.test_samples_count == b
+    task.on_validation_epoch_end(); task.on_test_epoch_end()
+    assert task.val_samples_count == 0 and task.test_samples_count == 0
+    # ---- training step: train mode, device-RNG DropPath / Dropout2d, replayed for the oracle
+    task.trainer = _Trainer(True)
+    task.train(); ref.train()
+    torch.manual_seed(123)
+    loss = task.training_step(dev, 0)
+    loss.backward()
+    masks, aux = _replay_dofa_draws(task.model, b, 123)
+    assert any((m[0] == 0).any() or (m[1] == 0).any() for m in masks) or (aux == 0).any()
+    o = ref(batch["image"], batch["wavelengths"][0], masks, aux)
+    lo = dice_loss_multiclass(o.out, y) + 0.4 * dice_loss_multiclass(o.aux, y)
+    lo.backward()
+    assert loss.dim() == 0 and abs(loss.item() - lo.item()) < 1e-5
+    assert abs(task.logged["train_loss"].item() - lo.item()) < 1e-5 and task.train_samples_count == b
+    assert _grads_close(task.model, ref) > 30
+    # ---- configure_optimizers: ([optimizer], [{"scheduler", **scheduler_config}]) incl. the OneCycleLR branch
+    opts, scheds = task.configure_optimizers()
+    assert isinstance(opts[0], torch.optim.Adam) and scheds[0]["interval"] == "epoch"
+    task.hparams["scheduler"] = {"class_path": "torch.optim.lr_scheduler.OneCycleLR", "init_args": {"max_lr": 1e-3}}
+    _, scheds = task.configure_optimizers()
+    assert isinstance(scheds[0]["scheduler"], torch.optim.lr_scheduler.OneCycleLR)
+    assert scheds[0]["scheduler"].total_steps == 100                     # trainer.estimated_stepping_batches
+    task.trainer.estimated_stepping_batches = -1
+
+    class _DM:
+        epoch_size, batch_size = 40, 4
+    task.trainer.datamodule = _DM()
+    _, scheds = task.configure_optimizers()
+    assert scheds[0]["scheduler"].total_steps == (10 + 10) * 3            # (steps_per_epoch + buffer) * max_epochs
+
+
+def test_dofa_task_binary_head_and_raw_tile_rejected():
+    """num_classes == 1: sigmoid threshold masks (segmentation_dofa.py:278-279); raw integer tiles raise."""
+    ref, task = _dofa_task(num_classes=1)
+    task.loss = gnn.DiceLoss(mode="binary")
+    batch = synthetic_batch(2, 3, 112, 2, 3)
+    dev = _to_dev(batch)
+    task.trainer = _Trainer(False)
+    task.eval(); ref.eval()
+    with torch.no_grad():
+        o = ref(batch["image"], batch["wavelengths"])
+        y_hat = task._predict(task(dev["image"], dev["wavelengths"]).out)
+    want = (o.out.sigmoid().squeeze(1) > 0.5).long()
+    decided = (o.out.squeeze(1).abs() > 1e-3)
+    assert bool((y_hat.cpu() == want)[decided].all())
+    assert task.labels == ["0", "1"]
+    with pytest.raises(TypeError, match="raw tile"):
+        task(batch["image_u8"].to(DEV), dev["wavelengths"])
+
+
+# ------------------------------------------------------------------------------------------------ SegFormer
+def _replay_mit_draws(model, b, seed):
+    torch.manual_seed(seed)
+    masks = []
+    for stage in (model.encoder.block1, model.encoder.block2, model.encoder.block3, model.encoder.block4):
+        for blk in stage:
+            pair = []
+            for _ in range(2):
+                if blk.drop_prob > 0:
+                    pair.append(torch.empty(b, device=DEV, dtype=torch.float32).bernoulli_(1.0 - blk.drop_prob).cpu())
+                else:
+                    pair.append(torch.ones(b))
+            masks.append(tuple(pair))
+    dec = model.decoder
+    dmask = torch.empty((b, dec.linear_pred.in_channels), device=DEV, dtype=torch.float32).bernoulli_(1.0 - dec.dropout_ratio).cpu()
+    return masks, dmask
+
+
+def test_segformer_task_steps_match_oracle():
+    """SegmentationSegformer steps (segmentation_segformer.py:216-316)."""
+    seed, b, nc = 5, 2, 5
+    ora = OracleSegFormer("mit_b1", 3, nc)
+    sd = procedural_state_dict(ora, seed)
+    ora.load_state_dict(sd)
+    task = SegmentationSegformer("mit_b1", 3, nc, max_samples=2, loss=gnn.DiceLoss(mode="multiclass"), image_size=(64, 64))
+    task.configure_model()
+    task.model.load_state_dict(sd)
+    task = task.to(DEV)
+    batch = synthetic_batch(b, 3, 64, nc, seed)
+    dev = _to_dev(batch)
+    y = batch["mask"].squeeze(1).long()
+    task.trainer = _Trainer(False)
+    task.eval(); ora.eval()
+    with torch.no_grad():
+        yo = ora(batch["image"])
+        want_loss = dice_loss_multiclass(yo, y).item()
+        y_hat = task.validation_step(dev, 0)
+        task.test_step(dev, 0)
+    assert abs(task.logged["val_loss"].item() - want_loss) < 1e-5 and abs(task.logged["test_loss"].item() - want_loss) < 1e-5
+    want_mask = _mask_agrees(y_hat, yo)
+    got = np.array([task.logged[f"meaniou_{c}"].item() for c in range(nc)])
+    np.testing.assert_allclose(got, _iou_per_class(want_mask, y, nc), atol=5e-4)
+    task.trainer = _Trainer(True)
+    task.train(); ora.train()
+    torch.manual_seed(77)
+    loss = task.training_step(dev, 0)
+    loss.backward()
+    masks, dmask = _replay_mit_draws(task.model, b, 77)
+    lo = dice_loss_multiclass(ora(batch["image"], masks, dmask), y)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-4
+    assert _grads_close(task.model, ora, tol=5e-2, floor=1e-5) > 150
+
+
+# ------------------------------------------------------------------------------------------------ UNet++
+@pytest.mark.parametrize("num_classes", [5, 1], ids=["multiclass", "binary_reference_config"])
+def test_unetplus_task_steps_match_oracle(num_classes):
+    """SegmentationUnetPlus steps (segmentation_unetplus.py:223-320): train / val pass the UN-squeezed [B,1,H,W] mask to
+    the loss (:232), test squeezes only for the metrics.  ``num_classes: 1`` + ``DiceLoss(mode="binary")`` is the
+    configuration of configs/unetplus_config_RGB.yaml."""
+    seed, b = 9, 2
+    binary = num_classes == 1
+    ora = OracleUnetPlusPlus("resnet18", 3, num_classes)
+    sd = procedural_state_dict(ora, seed)
+    ora.load_state_dict(sd)
+    task = SegmentationUnetPlus("resnet18", (128, 128), 3, num_classes, max_samples=2,
+                                loss=gnn.DiceLoss(mode="binary" if binary else "multiclass"))
+    task.configure_model()
+    task.model.load_state_dict(sd)
+    task = task.to(DEV)
+    batch = synthetic_batch(b, 3, 128, 2 if binary else num_classes, seed)
+    dev = _to_dev(batch)
+    ref_loss = (lambda lg: dice_loss_binary(lg, batch["mask"])) if binary else \
+        (lambda lg: dice_loss_multiclass(lg, batch["mask"].squeeze(1).long()))
+    task.trainer = _Trainer(False)
+    task.eval(); ora.eval()
+    with torch.no_grad():
+        yo = ora(batch["image"])
+        y_hat = task.validation_step(dev, 0)
+        task.test_step(dev, 0)
+    want_loss = ref_loss(yo).item()
+    assert abs(task.logged["val_loss"].item() - want_loss) < 1e-5 and abs(task.logged["test_loss"].item() - want_loss) < 1e-5
+    if binary:
+        want_mask = (yo.sigmoid().squeeze(1) > 0.5).long()
+        decided = yo.squeeze(1).abs() > 2e-3
+        assert bool((y_hat.cpu() == want_mask)[decided].all())
+        k = 2
+    else:
+        want_mask = _mask_agrees(y_hat, yo, tol=2e-3)
+        k = num_classes
+    got = np.array([task.logged[f"meaniou_{c}"].item() for c in range(k)])
+    np.testing.assert_allclose(got, _iou_per_class(want_mask, batch["mask"].squeeze(1), k), atol=1e-3)
+    task.trainer = _Trainer(True)
+    task.train(); ora.train()
+    loss = task.training_step(dev, 0)
+    loss.backward()
+    lo = ref_loss(ora(batch["image"]))
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-5
+    assert _grads_close(task.model, ora) > 100
+
+
+# ------------------------------------------------------------------------------------------------ configs[3] / [4]
+@pytest.mark.parametrize("encoder,size,bands,batch", [("dofa_base", 512, 6, 2), ("dofa_large", 1024, 10, 2)],
+                         ids=["config3_base_6band_512", "config4_large_10band_1024"])
+def test_multiband_configs_train_step(encoder, size, bands, batch):
+    """Training legs of BASELINE configs[3] (DOFA-base, 6 bands, 512^2) and configs[4] (DOFA-large, 10 bands, 1024^2,
+    mixed precision): one step with the config's frozen encoder, f32 vs the CPU oracle (logits, loss, every gradient,
+    BN running stats) and the bf16 autocast step against it (loss and logits envelope, finite and aligned gradients)."""
+    seed = 31
+    ref = oracle.DOFASegmentationModel(encoder, (size, size), num_classes=5, freeze_layers=["encoder"]).train()
+    sd = procedural_state_dict(ref, seed)
+    ref.load_state_dict(sd)
+    model = DOFASegmentationModel(encoder, (size, size), num_classes=5, pretrained=False, freeze_layers=["encoder"])
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    b = synthetic_batch(batch, bands, size, 5, seed)
+    depth = len(model.encoder.blocks)
+    g = np.random.default_rng([seed, depth])
+    masks = [(torch.from_numpy((g.uniform(size=batch) < 0.95).astype(np.float32)),
+              torch.from_numpy((g.uniform(size=batch) < 0.95).astype(np.float32))) for _ in range(depth)]
+    aux = torch.from_numpy((g.uniform(size=(batch, 256)) < 0.9).astype(np.float32))
+    y = b["mask"].squeeze(1).long()
+    o = ref(b["image"], b["wavelengths"], masks, aux)
+    lo = dice_loss_multiclass(o.out, y) + 0.4 * dice_loss_multiclass(o.aux, y)
+    lo.backward()
+    crit = gnn.DiceLoss(mode="multiclass")
+    x, yd = b["image"].to(DEV), y.to(DEV)
+    r = model(x, b["wavelengths"], masks, aux)
+    loss = crit(r.out, yd) + 0.4 * crit(r.aux, yd)
+    loss.backward()
+    scale = max(1.0, o.out.abs().max().item())
+    tol = 1e-3 if encoder == "dofa_base" else 2e-3
+    assert (r.out.detach().cpu() - o.out.detach()).abs().max().item() < tol * scale
+    assert abs(loss.item() - lo.item()) < 1e-4
+    refp = dict(ref.named_parameters())
+    for n, p in model.named_parameters():
+        rg = refp[n].grad
+        assert (p.grad is None) == (rg is None), n
+        if rg is None or (n.endswith("conv.bias") and n.startswith("neck.")):
+            continue
+        rel = 2e-3 if n.startswith(("head.", "aux_head.", "decoder.fpn_bottleneck.")) else 3e-2
+        err, rn = (p.grad.cpu() - rg).norm().item(), rg.norm().item()
+        assert err <= rel * rn + 2e-6, (n, err, rn)
+    rb = dict(ref.named_buffers())
+    for n, buf in model.named_buffers():
+        if n.endswith(("running_mean", "running_var")):
+            assert torch.allclose(buf.cpu(), rb[n], atol=1e-4, rtol=1e-3), n
+    f32_grads = {n: p.grad.float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+    for p in model.parameters():
+        p.grad = None
+    model.load_state_dict(sd)                                    # fresh running stats for the mixed-precision step
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        rb16 = model(x, b["wavelengths"], masks, aux)
+        lb = crit(rb16.out, yd) + 0.4 * crit(rb16.aux, yd)
+    lb.backward()
+    assert abs(lb.item() - lo.item()) < 2e-2
+    assert (rb16.out.detach().float().cpu() - o.out.detach()).abs().max().item() < 0.08 * o.out.abs().max().item()
+    coss = []
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        assert torch.isfinite(p.grad).all(), n
+        g32 = f32_grads[n]
+        if g32.numel() >= 64 and g32.norm() > 1e-7:
+            gq = p.grad.float().cpu()
+            coss.append(float((gq * g32).sum() / (gq.norm() * g32.norm() + 1e-30)))
+    assert np.median(coss) > 0.98 and np.quantile(coss, 0.1) > 0.9, (np.median(coss), np.quantile(coss, 0.1))
+
+
+# ------------------------------------------------------------------------------------------------ MiniTrainer on the GPU
+def test_minitrainer_fit_on_gpu_and_checkpoint_round_trip(tmp_path):
+    """The reference's ``train.py fit`` flow (train.py:27-80, configs/dofa_config_RGB.yaml:3-33,62-77) through MiniTrainer
+    with the real task on the GPU: seed 42, bf16 autocast, clip 1.0, Adam run by the fused kernels, ReduceLROnPlateau on
+    val_loss, best checkpoint under ``model.*`` keys, post-fit test, then utils/models.load_weights_from_checkpoint."""
+    from functools import partial
+    from gdlhip.trainer import seed_everything
+    seed_everything(42)
+    _, task = _dofa_task(optimizer=partial(torch.optim.Adam, lr=2e-3),
+                         scheduler=partial(torch.optim.lr_scheduler.ReduceLROnPlateau, mode="min", factor=0.1, patience=10),
+                         scheduler_config={"interval": "epoch", "frequency": 1, "monitor": "val_loss"})
+    batches = [synthetic_batch(4, 3, 112, 5, s) for s in (1, 2, 3)]
+    for bt in batches:                                          # a learnable target: class from the first band
+        bt["mask"] = (bt["image"][:, :1] * 1.2 + 2).clamp(0, 4).long()
+    val = [batches[0]]
+    tr = MiniTrainer(max_epochs=3, precision="bf16-mixed", gradient_clip_val=1.0, default_root_dir=str(tmp_path))
+    tr.fit(task, train_dataloaders=batches, val_dataloaders=val)
+    assert tr.global_step == 9
+    best = tr.checkpoint_callback.best_model_path
+    ckpt = torch.load(best)
+    assert len(ckpt["state_dict"]) == len(task.model.state_dict()) and all(k.startswith("model.") for k in ckpt["state_dict"])
+    first_val = None
+    # val_loss went down over the three epochs (the best checkpoint is not the first epoch's)
+    assert ckpt["epoch"] >= 1, ckpt["epoch"]
+    res = tr.test(task, dataloaders=val)[0]
+    assert set(res) >= {"test_loss", "meaniou_0", "meaniou_4"} and abs(res["test_loss"] - tr.checkpoint_callback.best_model_score) < 0.1
+    del first_val
+    # round trip: decoder-only load into a fresh model, then everything
+    _, fresh = _dofa_task(seed=99)
+    out = load_weights_from_checkpoint(fresh.model, best, load_parts=["decoder", "head"], map_location="cpu")
+    assert all(not k.startswith(("decoder.", "head.")) for k in out.missing_keys) and not out.unexpected_keys
+    assert torch.equal(fresh.model.decoder.fpn_bottleneck.conv.weight.cpu(), ckpt["state_dict"]["model.decoder.fpn_bottleneck.conv.weight"])
+    assert not torch.equal(fresh.model.neck.convs[0].conv.weight.cpu(), ckpt["state_dict"]["model.neck.convs.0.conv.weight"])
+    load_weights_from_checkpoint(fresh.model, best, map_location="cpu")
+    fresh.trainer = _Trainer(False)
+    fresh.eval(); task.eval()
+    dev = _to_dev(val[0])
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        a = fresh.validation_step(dev, 0)
+        bmask = task.validation_step(dev, 0)
+    assert torch.equal(a, bmask) and fresh.logged["val_loss"].item() == task.logged["val_loss"].item()
+
+
+def test_eval_after_train_sees_fresh_running_stats():
+    """The eval-mode BN fold is cached per layer; the single-GPU statistics kernel updates running_mean / running_var
+    through raw pointers.  Sequence of a Lightning run with sanity validation: eval (fills the cache) -> train forward
+    (moves the running stats, no optimizer step, affine parameters frozen or not) -> eval must use the NEW stats."""
+    ref, task = _dofa_task(freeze=("encoder", "neck", "decoder", "aux_head"))     # BN affine parameters frozen
+    model = task.model
+    batch = synthetic_batch(2, 3, 112, 5, 13)
+    x = batch["image"].to(DEV)
+    masks = [(torch.ones(2), torch.ones(2))] * TINY["depth"]
+    aux = torch.ones(2, 256)
+    model.eval(); ref.eval()
+    with torch.no_grad():
+        e0 = model(x, batch["wavelengths"]).out
+    model.train(); ref.train()
+    with torch.no_grad():
+        model(x, batch["wavelengths"], masks, aux)
+        ref(batch["image"], batch["wavelengths"], masks, aux)
+    model.eval(); ref.eval()
+    with torch.no_grad():
+        e1 = model(x, batch["wavelengths"]).out
+        o1 = ref(batch["image"], batch["wavelengths"]).out
+    assert (e1 - e0).abs().max().item() > 1e-3, "running statistics did not move the eval output"
+    assert (e1.cpu() - o1).abs().max().item() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ N > 1 on one GPU
+def _ddp_gpu_worker(rank, world, port, ret):
+    """One of two processes sharing GPU 0 (gloo backend on device tensors): HIP model under SyncBatchNorm + DDP on its
+    half of the batch."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ref = oracle.DOFASegmentationModel("dofa_tiny_test", (112, 112), num_classes=5, _encoder_kwargs=TINY,
+                                           freeze_layers=["encoder"])
+        sd = procedural_state_dict(ref, 7)
+        enc = DOFAv2(img_size=112, pretrained=False, **TINY)
+        m = DOFASegmentationModel(enc, (112, 112), num_classes=5, pretrained=False, freeze_layers=["encoder"])
+        m.load_state_dict(sd)
+        m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m.to(DEV).train())
+        ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], gradient_as_bucket_view=True)
+        batch, masks, aux = _ddp_case()
+        lo, hi = rank * 2, rank * 2 + 2
+        mk = [(a[lo:hi], b[lo:hi]) for a, b in masks]
+        r = ddp(batch["image"][lo:hi].to(DEV), batch["wavelengths"], mk, aux[lo:hi])
+        y = batch["mask"][lo:hi].squeeze(1).long().to(DEV)
+        crit = gnn.DiceLoss(mode="multiclass")
+        loss = crit(r.out, y) + 0.4 * crit(r.aux, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        ret[rank] = {"loss": loss.item(),
+                     "grads": {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None},
+                     "bufs": {n: b.detach().cpu() for n, b in m.named_buffers() if n.endswith(("running_mean", "running_var"))}}
+    finally:
+        dist.destroy_process_group()
+
+
+def _ddp_case():
+    batch = synthetic_batch(4, 3, 112, 5, 17)
+    g = np.random.default_rng(5)
+    masks = [(torch.from_numpy((g.uniform(size=4) < 0.8).astype(np.float32)),
+              torch.from_numpy((g.uniform(size=4) < 0.8).astype(np.float32))) for _ in range(TINY["depth"])]
+    aux = torch.from_numpy((g.uniform(size=(4, 256)) < 0.9).astype(np.float32))
+    return batch, masks, aux
+
+
+def test_ddp_syncbn_world2_on_one_gpu_matches_full_batch_oracle():
+    """DDP + SyncBatchNorm of the HIP path at world size 2 (configs/dofa_config_RGB.yaml:3-13), both ranks on this one
+    GPU over gloo: per-rank loss on half the batch, gradients averaged by DDP, batch statistics exchanged by
+    gnn.sync_batch_stats / sync_sum_pair.  Oracle: ONE process on the full batch (its BatchNorm sees all four tiles =
+    what SyncBN computes) with loss = mean of the two half-batch Dice losses (= what DDP's gradient averaging optimises)."""
+    import os
+    import torch.multiprocessing as mp
+    world, port = 2, 29900 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_ddp_gpu_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    ref = oracle.DOFASegmentationModel("dofa_tiny_test", (112, 112), num_classes=5, _encoder_kwargs=TINY,
+                                       freeze_layers=["encoder"]).train()
+    ref.load_state_dict(procedural_state_dict(ref, 7))
+    batch, masks, aux = _ddp_case()
+    o = ref(batch["image"], batch["wavelengths"], masks, aux)
+    y = batch["mask"].squeeze(1).long()
+    halves = [dice_loss_multiclass(o.out[s], y[s]) + 0.4 * dice_loss_multiclass(o.aux[s], y[s]) for s in (slice(0, 2), slice(2, 4))]
+    (0.5 * (halves[0] + halves[1])).backward()
+    r0, r1 = ret[0], ret[1]
+    assert abs(r0["loss"] - halves[0].item()) < 1e-5 and abs(r1["loss"] - halves[1].item()) < 1e-5
+    refp = dict(ref.named_parameters())
+    n = 0
+    for name, g0 in r0["grads"].items():
+        assert torch.equal(g0, r1["grads"][name]), name                     # all-reduced: identical on both ranks
+        rg = refp[name].grad
+        if name.endswith("conv.bias") and name.startswith("neck."):
+            continue
+        err, rn = (g0 - rg).norm().item(), rg.norm().item()
+        assert err <= 3e-2 * rn + 2e-6, (name, err, rn)
+        n += 1
+    assert n > 30
+    rb = dict(ref.named_buffers())
+    for name, b0 in r0["bufs"].items():
+        assert torch.equal(b0, r1["bufs"][name]), name
+        assert torch.allclose(b0, rb[name], atol=2e-5, rtol=1e-4), name

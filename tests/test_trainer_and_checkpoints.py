@@ -1,0 +1,188 @@
+"""MiniTrainer / train.py (the reference's ``train.py fit`` flow without Lightning, train.py:27-80) and the checkpoint
+formats either side of it (utils/models.py:10-66, dofa_v2.py:286-392) -- CPU tests on a toy task with the task classes'
+hook surface.  The GPU versions (real DOFA task through the same trainer) are in tests/test_hip_tasks.py."""
+
+import os
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import yaml
+
+from gdlhip.trainer import MiniTrainer, seed_everything
+from geo_deep_learning import train as gdl_train
+from geo_deep_learning.utils.models import load_weights_from_checkpoint
+
+import _toy_task as toy
+
+CONFIG = {
+    "seed_everything": True,
+    "trainer": {"max_epochs": 4, "gradient_clip_val": 1.0, "precision": "16-mixed", "sync_batchnorm": True,
+                "accelerator": "gpu", "devices": -1,
+                "strategy": {"class_path": "lightning.pytorch.strategies.DDPStrategy", "init_args": {"find_unused_parameters": False}},
+                "logger": {"class_path": "lightning.pytorch.loggers.mlflow.MLFlowLogger", "init_args": {"save_dir": "/nowhere"}},
+                "callbacks": [{"class_path": "lightning.pytorch.callbacks.EarlyStopping", "init_args": {"monitor": "val_loss", "patience": 20}},
+                              {"class_path": "lightning.pytorch.callbacks.ModelCheckpoint",
+                               "init_args": {"monitor": "val_loss", "mode": "min", "save_top_k": 1, "filename": "model-{epoch:02d}-{val_loss:.3f}"}},
+                              {"class_path": "tools.callbacks.segmentation_visualization.VisualizationCallback",
+                               "init_args": {"num_classes": "${model.init_args.num_classes}"}}]},
+    "model": {"class_path": "_toy_task.ToyTask",
+              "init_args": {"num_classes": 3, "mean": "${data.init_args.batch_size}",
+                            "loss": {"class_path": "torch.nn.CrossEntropyLoss"},
+                            "optimizer": {"class_path": "torch.optim.Adam", "init_args": {"lr": 0.05}},
+                            "scheduler": {"class_path": "torch.optim.lr_scheduler.ReduceLROnPlateau",
+                                          "init_args": {"mode": "min", "factor": 0.1, "patience": 0, "min_lr": 1e-6}},
+                            "scheduler_config": {"interval": "epoch", "frequency": 1, "monitor": "val_loss"}}},
+    "data": {"class_path": "_toy_task.ToyData", "init_args": {"batch_size": 4, "num_classes": 3}},
+    "ckpt_path": None,
+}
+
+
+def test_train_py_fit_checkpoints_and_post_fit_test(tmp_path):
+    cfg_path = tmp_path / "cfg.yaml"
+    cfg_path.write_text(yaml.safe_dump(CONFIG))
+    out = gdl_train.main(["fit", "--config", str(cfg_path), f"--trainer.default_root_dir={tmp_path}", "--trainer.max_epochs=5"])
+    best = Path(out["best_model_path"])
+    assert best.is_file() and best.parent == tmp_path / "checkpoints"
+    assert best.name.startswith("model-epoch=") is False and best.name.startswith("model-") and best.suffix == ".ckpt"
+    assert len(list(best.parent.iterdir())) == 1                          # save_top_k: 1
+    ckpt = torch.load(best)
+    assert all(k.startswith("model.") for k in ckpt["state_dict"])        # Lightning layout (utils/models.py:33)
+    assert {"model.encoder.weight", "model.norm.running_mean", "model.head.bias"} <= set(ckpt["state_dict"])
+    assert ckpt["hyper_parameters"]["num_classes"] == 3 and ckpt["hyper_parameters"]["mean"] == 4   # ${...} resolved
+    assert out["fit"]["val_loss"] < 1.0986 and "train_loss" in out["fit"]                            # learned something
+    assert set(out["test"]) == {"test_loss"} and abs(out["test"]["test_loss"] - out["fit"]["val_loss"]) < 0.5
+
+
+def test_minitrainer_hooks_scheduler_and_seed(tmp_path):
+    seed_everything(42)
+    a = torch.rand(3)
+    seed_everything(42)
+    assert torch.equal(a, torch.rand(3)) and os.environ["PL_GLOBAL_SEED"] == "42"
+    task = toy.ToyTask(3, torch.nn.CrossEntropyLoss(), optimizer=lambda p: torch.optim.SGD(p, lr=0.1),
+                       scheduler=lambda o: torch.optim.lr_scheduler.ReduceLROnPlateau(o, factor=0.5, patience=0),
+                       scheduler_config={"interval": "epoch", "monitor": "val_loss"})
+    data = toy.ToyData(train_batches=3)
+    tr = MiniTrainer(max_epochs=3, default_root_dir=str(tmp_path), gradient_clip_val=1.0, accumulate_grad_batches=1)
+    tr.fit(task, datamodule=data)
+    assert tr.global_step == 9 and tr.estimated_stepping_batches == 9
+    assert task.calls.count("train_epoch_end") == 3 and task.calls.count("val_epoch_end") == 3
+    assert task.calls.count("after:train") == 9 and task.calls.count("after:eval") == 6 and task.calls.count("before") == 15
+    assert set(tr.callback_metrics) == {"train_loss", "val_loss"}
+    # ReduceLROnPlateau is stepped with the monitored value: a scheduler monitoring a metric that is never logged fails
+    bad = toy.ToyTask(3, torch.nn.CrossEntropyLoss(), scheduler=lambda o: torch.optim.lr_scheduler.ReduceLROnPlateau(o),
+                      scheduler_config={"interval": "epoch", "monitor": "val_iou"})
+    with pytest.raises(KeyError, match="val_iou"):
+        MiniTrainer(max_epochs=1, default_root_dir=str(tmp_path)).fit(bad, datamodule=toy.ToyData(train_batches=1))
+    # accumulate_grad_batches: 6 batches -> 3 optimizer steps per epoch; interval "step" schedulers follow global_step
+    acc = toy.ToyTask(3, torch.nn.CrossEntropyLoss(), optimizer=lambda p: torch.optim.SGD(p, lr=1.0),
+                      scheduler=lambda o: torch.optim.lr_scheduler.StepLR(o, 1, gamma=0.5),
+                      scheduler_config={"interval": "step"})
+    tr = MiniTrainer(max_epochs=1, default_root_dir=str(tmp_path), accumulate_grad_batches=2)
+    tr.fit(acc, datamodule=toy.ToyData(train_batches=6))
+    assert tr.global_step == 3
+
+
+def test_checkpoint_round_trip_with_load_parts(tmp_path):
+    """save -> load_weights_from_checkpoint(load_parts=...) (utils/models.py:10-66): prefix filter, model. stripping."""
+    task = toy.ToyTask(3, torch.nn.CrossEntropyLoss())
+    task.configure_model()
+    tr = MiniTrainer(default_root_dir=str(tmp_path))
+    path = tmp_path / "a.ckpt"
+    tr.save_checkpoint(task, path)
+    fresh = toy.ToyNet(3)
+    res = load_weights_from_checkpoint(fresh, str(path), load_parts=["encoder", "norm"])
+    assert sorted(res.missing_keys) == ["head.bias", "head.weight"] and not res.unexpected_keys
+    assert torch.equal(fresh.encoder.weight, task.model.encoder.weight)
+    assert not torch.equal(fresh.head.weight, task.model.head.weight)
+    assert load_weights_from_checkpoint(fresh, str(path)) is None           # full, strict
+    assert torch.equal(fresh.head.weight, task.model.head.weight)
+    res = load_weights_from_checkpoint(toy.ToyNet(3), str(path), load_parts="nothing_here")
+    assert len(res.missing_keys) == len(fresh.state_dict()) - 1             # all but num_batches_tracked (not "missing")
+    torch.save(task.model.state_dict(), tmp_path / "bare.pth")              # a bare state dict (no "state_dict" key)
+    assert load_weights_from_checkpoint(toy.ToyNet(3), str(tmp_path / "bare.pth")) is None
+
+
+def test_dofa_pretrained_key_remap_and_pos_embed_resize(tmp_path, monkeypatch):
+    """dofa_v2.py:286-392 on a synthetic DOFA-style checkpoint: ``model.``-prefixed ViT keys are kept, other ``model.*``
+    keys dropped, ``patch_embed.*`` kept, a 16x16 position grid is resized bicubically to the model's grid (cls token
+    untouched), missing / unexpected keys fail.  ``pretrained=True`` reads the torch-hub cache location."""
+    from geo_deep_learning.models.encoders.dofa_v2 import DOFAv2
+    kw = dict(img_size=84, patch_size=14, embed_dim=64, depth=2, num_heads=2, out_indices=[0, 1])
+    enc = DOFAv2(pretrained=False, **kw)                                    # 6x6 grid: 37 tokens
+    g = torch.Generator().manual_seed(0)
+    src = {k: torch.randn(v.shape, generator=g) for k, v in enc.state_dict().items()}
+    ck = {}
+    for k, v in src.items():
+        ck[k if k.startswith("patch_embed.") else f"model.{k}"] = v
+    ck["model.pos_embed"] = torch.randn(1, 1 + 16 * 16, 64, generator=g)   # published checkpoints: 224 / 14 = 16
+    ck["model.fc_norm.weight"] = torch.zeros(64)                            # dropped: not blocks./norm./cls/pos
+    ck["model.head.weight"] = torch.zeros(10, 64)
+    missing, unexpected = enc.load_pretrained_state_dict({"model": dict(ck)})
+    assert not unexpected and set(missing) <= {"head.weight", "head.bias"}
+    sd = enc.state_dict()
+    for k in src:
+        if k != "pos_embed":
+            assert torch.equal(sd[k], src[k]), k
+    grid = ck["model.pos_embed"][:, 1:].reshape(1, 16, 16, 64).permute(0, 3, 1, 2)
+    want = torch.nn.functional.interpolate(grid, size=(6, 6), mode="bicubic", align_corners=False)
+    assert torch.equal(sd["pos_embed"][:, 0], ck["model.pos_embed"][:, 0])
+    assert torch.equal(sd["pos_embed"][:, 1:], want.permute(0, 2, 3, 1).reshape(1, 36, 64))
+    bad = dict(ck)
+    del bad["model.cls_token"]
+    with pytest.raises(RuntimeError, match="Missing required keys"):
+        DOFAv2(pretrained=False, **kw).load_pretrained_state_dict(bad)
+    with pytest.raises(RuntimeError, match="Unexpected keys"):
+        DOFAv2(pretrained=False, **kw).load_pretrained_state_dict({**ck, "patch_embed.extra": torch.zeros(1)})
+    # pretrained=True: the file torch.hub.load_state_dict_from_url would have cached
+    monkeypatch.setattr(torch.hub, "get_dir", lambda: str(tmp_path))
+    with pytest.raises(RuntimeError, match="dofav2_vit_base_e150.pth"):
+        DOFAv2(encoder_name="dofa_base", pretrained=True, **kw)
+    (tmp_path / "checkpoints").mkdir()
+    torch.save({"model": ck}, tmp_path / "checkpoints" / "dofav2_vit_base_e150.pth")
+    hot = DOFAv2(encoder_name="dofa_base", pretrained=True, **kw)
+    assert torch.equal(hot.state_dict()["blocks.1.mlp.fc2.weight"], src["blocks.1.mlp.fc2.weight"])
+
+
+def _ddp_worker(rank, world, port, tmp, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import _toy_task as toy
+        torch.manual_seed(0)
+        task = toy.ToyTask(3, torch.nn.CrossEntropyLoss(), optimizer=lambda p: torch.optim.SGD(p, lr=0.1), batchnorm=False)
+        trn = toy.make_batches(4, 8, 3, 1, rank, world)
+        val = toy.make_batches(2, 8, 3, 2, rank, world)
+        tr = MiniTrainer(max_epochs=2, default_root_dir=tmp)     # (torch's SyncBatchNorm needs GPU modules: GPU test)
+        tr.fit(task, train_dataloaders=trn, val_dataloaders=val)
+        inner = task.model.module
+        ret[rank] = {"w": inner.encoder.weight.detach().clone(), "val": tr.callback_metrics["val_loss"],
+                     "best": tr.checkpoint_callback.best_model_path}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_minitrainer_ddp_world2_matches_single_process(tmp_path):
+    """Two gloo ranks, each on half of every batch, under DDP == one process on the full batches (mean-reduced loss =>
+    averaged gradients), metrics averaged over ranks, one checkpoint written by rank 0 and known to both."""
+    world, port = 2, 29700 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, str(tmp_path), ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    task = toy.ToyTask(3, torch.nn.CrossEntropyLoss(), optimizer=lambda p: torch.optim.SGD(p, lr=0.1), batchnorm=False)
+    tr = MiniTrainer(max_epochs=2, default_root_dir=str(tmp_path / "single"))
+    tr.fit(task, train_dataloaders=toy.make_batches(4, 8, 3, 1), val_dataloaders=toy.make_batches(2, 8, 3, 2))
+    r0, r1 = ret[0], ret[1]
+    assert torch.equal(r0["w"], r1["w"]) and r0["best"] == r1["best"] and Path(r0["best"]).is_file()
+    assert torch.allclose(r0["w"], task.model.encoder.weight, atol=1e-5)
+    assert abs(r0["val"] - tr.callback_metrics["val_loss"]) < 1e-5 and abs(r0["val"] - r1["val"]) < 1e-12
+    sd = torch.load(r0["best"])["state_dict"]
+    assert "model.encoder.weight" in sd and not any("module." in k for k in sd)

@@ -16,7 +16,6 @@ lib = _lib.load()
 lib.gdl_debug_set_conv_probe.argtypes = [ctypes.c_void_p]
 lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
 lib.gdl_debug_set_conv_dbg.argtypes = [ctypes.c_int]
-lib.gdl_debug_set_conv_stagger.argtypes = [ctypes.c_int]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 bf = torch.bfloat16
 M = B * 1297
@@ -26,7 +25,7 @@ SHAPES = [("qkv 768->2304 bf16 out", M, 768, 2304, None, bf), ("proj 768->768 f3
 buf = torch.zeros(12288, device="cuda", dtype=torch.int64)
 
 
-def run(name, m, k, n, kind, odt, variant, dbg, stagger=1):
+def run(name, m, k, n, kind, odt, variant, dbg):
     conv = isinstance(m, tuple)            # (B, H, W): 3x3 / pad 1 convolution on an NHWC map
     if conv:
         x = torch.randn(*m, k, device="cuda").to(bf)
@@ -47,7 +46,6 @@ def run(name, m, k, n, kind, odt, variant, dbg, stagger=1):
         kw["shift"] = torch.zeros(n, device="cuda")
     lib.gdl_debug_force_conv_variant(variant)
     lib.gdl_debug_set_conv_dbg(dbg)
-    lib.gdl_debug_set_conv_stagger(stagger)
     fn = lambda: ops.conv_gemm(x, w, bias=bias, out=out, **kw)  # noqa: E731
     for _ in range(3):
         fn()
@@ -64,7 +62,6 @@ def run(name, m, k, n, kind, odt, variant, dbg, stagger=1):
     torch.cuda.synchronize()
     lib.gdl_debug_set_conv_probe(None)
     lib.gdl_debug_set_conv_dbg(0)
-    lib.gdl_debug_set_conv_stagger(1)
     lib.gdl_debug_force_conv_variant(-1)
     tm = 256 if variant in (2, 3, 4) else 128
     nb = min(2048, ((m + tm - 1) // tm) * ((n + tm - 1) // tm))
@@ -77,7 +74,7 @@ def run(name, m, k, n, kind, odt, variant, dbg, stagger=1):
     mhz = (kl[:, 0] / (kl[:, 1] / 100.0)).median().item()
     first = (tl[:, 0] - t0).sort().values / 100.0
     kt = kk // 64
-    print(f"{name:32s} v{variant} dbg{dbg} stagger{stagger}: {2 * m * kk * n / us / 1e6:7.1f} TF/s ({us:6.0f} us); blocks {nb}; "
+    print(f"{name:32s} v{variant} dbg{dbg}: {2 * m * kk * n / us / 1e6:7.1f} TF/s ({us:6.0f} us); blocks {nb}; "
           f"prologue+K loop {kl[:, 0].median():.0f} cyc ({kl[:, 0].median() / kt:.0f}/K-step), epilogue "
           f"{(tot - kl[:, 0]).median():.0f} cyc; block {dur.median():.1f} us (p10 {dur.quantile(0.1):.1f} p90 {dur.quantile(0.9):.1f}); "
           f"probe span {span:.0f} us; clock {mhz:.0f} MHz; start of block #256/#512/#1024: "
@@ -90,10 +87,8 @@ for shp in SHAPES:
         for dbg in ((0, 1, 2) if FULL else (0,)):
             if variant == 1 and dbg:
                 continue
-            for stagger in (0, 1):
-                run(*shp, variant, dbg, stagger)
+            run(*shp, variant, dbg)
 CONVS = [("neck 3x3 768->768 @144", (B, 144, 144), 768, 768, None, bf), ("fusion 3x3 1024->256 @144", (B, 144, 144), 1024, 256, None, bf),
          ("fpn 3x3 256->256 @144", (B, 144, 144), 256, 256, None, bf), ("neck 3x3 768->768 @72", (B, 72, 72), 768, 768, None, bf)]
 for shp in CONVS:
-    for stagger in (0, 1):
-        run(*shp, 4, 0, stagger)
+    run(*shp, 4, 0)
