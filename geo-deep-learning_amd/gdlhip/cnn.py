@@ -126,27 +126,30 @@ class _ConvBNTrain(Function):
         y = ops.conv_gemm(x, wq, R=r, S=s, stride=stride, pad=pad)
         world = _world(sync_group) if sync_group is not False else 1
         mean, var = ops.bn_stats(y)
+        p_local, p_share, total = y.numel() // npad, None, y.numel() // npad
         if world > 1:
-            mean, var = sync_batch_stats(mean, var, sync_group or None)
+            mean, var, total = sync_batch_stats(mean, var, sync_group or None, count=p_local)
+            p_share = p_local / total
         if running_mean is not None:
-            update_running_stats(running_mean, running_var, mean[:n], var[:n], momentum, y.numel() // npad * world)
+            update_running_stats(running_mean, running_var, mean[:n], var[:n], momentum, total)
         g, b = _padvec(gamma, npad), _padvec(beta, npad)
         out = ops.bn_apply(y, mean, var, g, b, eps, relu)
         ctx.save_for_backward(x, weight, y, mean, var, g, b)
-        ctx.cfg = (stride, pad, relu, eps, sync_group, world, cpad, npad)
+        ctx.cfg = (stride, pad, relu, eps, sync_group, world, cpad, npad, p_local, p_share)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         x, weight, y, mean, var, g, b = ctx.saved_tensors
-        stride, pad, relu, eps, sync_group, world, cpad, npad = ctx.cfg
+        stride, pad, relu, eps, sync_group, world, cpad, npad, p_local, p_share = ctx.cfg
         n, c, r, s = _wshape(weight)
         gout = _dense(gout if gout.dtype == y.dtype else to_compute(gout, y.dtype))
         dgamma, dbeta = ops.bn_bwd_reduce(y, gout, mean, var, g, b, eps, relu)
         sg, sb = dgamma, dbeta
         if world > 1:
             sg, sb = sync_sum_pair(dgamma, dbeta, sync_group or None)
-        dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, y.numel() // npad * world, out=y)
+            sg, sb = sg * p_share, sb * p_share      # see gdlhip.nn._ConvBNActTrain.backward
+        dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, p_local, out=y)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = _param_grad(ops.conv_wgrad(x, dy, R=r, S=s, stride=stride, pad=pad), weight, cpad)

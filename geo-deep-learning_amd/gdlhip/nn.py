@@ -114,26 +114,29 @@ def _world(group=None) -> int:
 
 
 # ------------------------------------------------------------------ SyncBatchNorm exchange
-def sync_batch_stats(mean: Tensor, var: Tensor, group=None) -> tuple[Tensor, Tensor]:
-    """Merge per-rank batch statistics into global ones (nn.SyncBatchNorm forward).
-
-    Every rank holds the same pixel count (fixed per-GPU batch, weak scaling), so the global mean
-    is the average of means and the global E[x^2] the average of (var + mean^2): ONE small
-    all-reduce of 2C floats per layer instead of torch's all_gather of [mean, invstd, count].
-    """
-    world = dist.get_world_size(group)
-    packed = torch.stack([mean, var + mean * mean])
+def sync_batch_stats(mean: Tensor, var: Tensor, group=None, count: int | None = None):
+    """Merge per-rank batch statistics into global ones (nn.SyncBatchNorm forward): count-weighted, so a
+    ragged last batch (ranks with different pixel counts) merges exactly like torch's all_gather of
+    [mean, invstd, count] does -- in ONE small all-reduce of 2C + 1 floats: sum_r n_r * [mean_r, E_r[x^2], 1].
+    Returns (global mean, global biased variance, global count); the count stays a 0-dim DEVICE tensor (no host
+    read-back: 21 layers per step would mean 21 stream syncs)."""
+    n = float(count if count is not None else 1)
+    packed = torch.cat([mean * n, (var + mean * mean) * n, mean.new_full((1,), n)])
     dist.all_reduce(packed, group=group)
-    packed /= world
-    gmean = packed[0].contiguous()
-    gvar = (packed[1] - gmean * gmean).clamp_min_(0).contiguous()
-    return gmean, gvar
+    c = mean.numel()
+    total = packed[2 * c]
+    gmean = (packed[:c] / total).contiguous()
+    gvar = (packed[c:2 * c] / total - gmean * gmean).clamp_min_(0).contiguous()
+    return gmean, gvar, total
 
 
-def update_running_stats(running_mean, running_var, mean, var, momentum: float, count: int) -> None:
-    """nn.BatchNorm2d running-stat update with the UNBIASED variance."""
+def update_running_stats(running_mean, running_var, mean, var, momentum: float, count) -> None:
+    """nn.BatchNorm2d running-stat update with the UNBIASED variance; ``count`` int or 0-dim tensor."""
     running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-    running_var.mul_(1 - momentum).add_(var, alpha=momentum * count / max(count - 1, 1))
+    if isinstance(count, Tensor):
+        running_var.mul_(1 - momentum).add_(var * (momentum * count / (count - 1).clamp_min(1)))
+    else:
+        running_var.mul_(1 - momentum).add_(var, alpha=momentum * count / max(count - 1, 1))
 
 
 def sync_sum_pair(a: Tensor, b: Tensor, group=None) -> tuple[Tensor, Tensor]:
@@ -159,11 +162,13 @@ class _ConvBNActTrain(Function):
         wq = gemm_weight(weight, cd)
         y = ops.conv_gemm(x, wq, R=r, S=s, pad=pad, bias=None if conv_bias is None else conv_bias.detach())
         world = _world(sync_group) if sync_group is not False else 1
+        p_local, p_share = y.numel() // n, None
         if world > 1:
             mean, var = ops.bn_stats(y)
-            mean, var = sync_batch_stats(mean, var, sync_group or None)
+            mean, var, total = sync_batch_stats(mean, var, sync_group or None, count=p_local)
             if running_mean is not None:
-                update_running_stats(running_mean, running_var, mean, var, momentum, y.numel() // n * world)
+                update_running_stats(running_mean, running_var, mean, var, momentum, total)
+            p_share = p_local / total          # this rank's share of the global pixel count (device scalar)
         else:
             mean, var = ops.bn_stats(y, running_mean, running_var, momentum)
             if running_mean is not None:     # written through raw pointers: invalidate the eval-mode fold cache
@@ -171,23 +176,24 @@ class _ConvBNActTrain(Function):
                 mark_updated(running_var)
         out = ops.bn_apply(y, mean, var, gamma.detach(), beta.detach(), eps, relu)
         ctx.save_for_backward(x, weight, y, mean, var, gamma, beta)
-        ctx.cfg = (pad, relu, eps, conv_bias is not None, sync_group, world)
+        ctx.cfg = (pad, relu, eps, conv_bias is not None, sync_group, world, p_local, p_share)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         x, weight, y, mean, var, gamma, beta = ctx.saved_tensors
-        pad, relu, eps, has_bias, sync_group, world = ctx.cfg
+        pad, relu, eps, has_bias, sync_group, world, p_local, p_share = ctx.cfg
         n, c, r, s = weight.shape
         if gout.dtype != y.dtype:
             gout = to_compute(gout, y.dtype)
         g, b = gamma.detach(), beta.detach()
         dgamma, dbeta = ops.bn_bwd_reduce(y, gout, mean, var, g, b, eps, relu)
-        p_local = y.numel() // n
         sg, sb = dgamma, dbeta
         if world > 1:
+            # the kernel divides the two sums by p_local: scaling them by p_local / P_global makes that the global mean
             sg, sb = sync_sum_pair(dgamma, dbeta, sync_group or None)
-        dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, p_local * world, out=y)
+            sg, sb = sg * p_share, sb * p_share
+        dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, p_local, out=y)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = ops.conv_wgrad(x, dy, R=r, S=s, pad=pad)
