@@ -12,6 +12,14 @@ A "step" is one pass of the hot path over one synthetic batch that is already re
   infer  = forward + softmax->argmax mask under no_grad.
 `value` is the TRAINING throughput of the whole job (tiles/s over all ranks); the inference
 throughput measured the same way is reported alongside.  Rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries (N = 1 only, all measured in this same process):
+  roofline      dominant MFMA kernel by HIP events on the launch stream; `traffic` = HBM bytes per launch from the
+                committed rocprofv3 PMC passes (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), see --help
+  hbm_kernels   the HBM-bound kernels of the step at their DOFA shapes: algorithmic GB/s vs the 8 TB/s peak
+  by_batch      the same train / inference step at the reference config's per-GPU batch 4 (dofa_config_RGB.yaml:85)
+  other_models  SegFormer-B2 (configs[2]) and UNet++/ResNet18 (configs[0]) steps at batch 32
+  cpu_baseline  the CPU oracle on this box's cores: 2 warm-ups, median of 5
 """
 
 from __future__ import annotations
@@ -19,6 +27,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 from pathlib import Path
@@ -33,10 +42,17 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (6.3 TB/s measured achievable), same table
 UNETPP_R18_FWD_GF = 128.04  # sum over convs of 2*K*C*R*S*Hout*Wout at 512x512 (counted on oracle/unetpp.py)
 RGB_MEAN = [0.3992, 0.4283, 0.3998]   # configs/dofa_config_RGB.yaml:91-98
 RGB_STD = [0.1672, 0.1800, 0.1584]
 WAVELENGTHS = [0.665, 0.549, 0.481]   # configs/dofa_config_RGB.yaml:50
+# whole-model algorithmic flops per tile: train (frozen encoder for DOFA, everything for the others), forward
+MODEL_GF = {"dofa": {"train": 1606.7, "infer": 726.7}, "segformer": {"train": 3 * 121.0, "infer": 121.0},
+            "unetpp": {"train": 3 * UNETPP_R18_FWD_GF, "infer": UNETPP_R18_FWD_GF}}
+MODEL_NAME = {"segformer": "SegFormer-B2 (MiT-B2 + MLP decoder)", "unetpp": "UNet++ (ResNet18 encoder)",
+              "dofa": "DOFA-base + UperNet"}
+PMC_TRAFFIC_FILE = ROOT / "profiles" / "pmc_dominant_kernel_traffic.json"   # written by tools/pmc_bench_traffic.py
 
 
 def parse():
@@ -57,6 +73,7 @@ def parse():
                     help="take the multi-GPU code path (RCCL group, SyncBatchNorm, DDP) even with one rank (self-test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip hbm_kernels / by_batch / other_models (profiling runs)")
     return ap.parse_args()
 
 
@@ -93,30 +110,159 @@ def timed(fn, steps: int, warmup: int, world: int, device) -> float:
     return dt
 
 
-def cpu_baseline():
-    """The oracle (CPU restatement of the reference path, validated against reference goldens)
-    timed on this box's host cores: ONE train step + ONE eval forward at batch 2, f32."""
+def build_task(model: str, device, dist_on: bool, local: int):
+    from gdlhip.nn import DiceLoss, FusedAdam
+    opt = lambda params: FusedAdam(params, lr=6e-5, max_grad_norm=1.0)  # noqa: E731
+    if model == "unetpp":
+        from tasks_with_models.segmentation_unetplus import SegmentationUnetPlus
+        task = SegmentationUnetPlus(encoder="resnet18", image_size=(512, 512), in_channels=3, num_classes=5,
+                                    max_samples=6, loss=DiceLoss(mode="multiclass"), optimizer=opt)
+    elif model == "segformer":
+        from tasks_with_models.segmentation_segformer import SegmentationSegformer
+        task = SegmentationSegformer(encoder="mit_b2", in_channels=3, num_classes=5, max_samples=6,
+                                     loss=DiceLoss(mode="multiclass"), optimizer=opt)
+    else:
+        from tasks_with_models.segmentation_dofa import SegmentationDOFA
+        task = SegmentationDOFA(encoder="dofa_base", pretrained=False, image_size=(512, 512), num_classes=5,
+                                max_samples=6, loss=DiceLoss(mode="multiclass"), freeze_layers=["encoder"], optimizer=opt)
+    task.configure_model()
+    task.to(device)
+    if dist_on:
+        # Lightning's `sync_batchnorm: true` + DDPStrategy(gradient_as_bucket_view=true)
+        task.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(task.model)
+        task.model = torch.nn.parallel.DistributedDataParallel(
+            task.model, device_ids=[local], gradient_as_bucket_view=True, find_unused_parameters=False)
+    (optimizer,), _ = task.configure_optimizers()
+    return task, optimizer
+
+
+def make_steps(task, optimizer, get_batch, use_bf16: bool):
+    def train_step():
+        task.train()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+            loss = task.training_step(get_batch(), 0)
+        loss.backward()
+        optimizer.step()
+
+    def infer_step():
+        task.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+            task.validation_step(get_batch(), 0)
+    return train_step, infer_step
+
+
+def side_measurement(model: str, batch_size: int, steps: int, warmup: int, device, use_bf16: bool) -> dict:
+    """Train + inference tiles/s of another model / batch size, measured like the headline (N = 1)."""
+    task, optimizer = build_task(model, device, False, 0)
+    batch = synthetic_batch(batch_size, device, 43)
+    train_step, infer_step = make_steps(task, optimizer, lambda: batch, use_bf16)
+    dt_t = timed(train_step, steps, warmup, 1, device)
+    dt_i = timed(infer_step, steps, warmup, 1, device)
+    peak = PEAK_BF16_TFLOPS if use_bf16 else PEAK_F32_TFLOPS
+    n = batch_size * steps
+    out = {"per_gpu_batch": batch_size, "train_tiles_per_s": round(n / dt_t, 2), "inference_tiles_per_s": round(n / dt_i, 2),
+           "train_ms_per_step": round(1e3 * dt_t / steps, 3), "inference_ms_per_step": round(1e3 * dt_i / steps, 3),
+           "model_flops_utilisation": {"train": round(MODEL_GF[model]["train"] * 1e-3 * n / dt_t / peak, 4),
+                                       "infer": round(MODEL_GF[model]["infer"] * 1e-3 * n / dt_i / peak, 4)}}
+    del task, optimizer, batch
+    torch.cuda.empty_cache()
+    return out
+
+
+def hbm_kernels(device, b: int = 32) -> dict:
+    """The HBM-bound kernels of one DOFA training step, each at its largest shape in the model (batch b), timed with
+    HIP events on torch's current stream (the stream the kernels are launched on).  Bytes are ALGORITHMIC: every operand
+    read once, every result written once at its stated dtype; fraction is of the 8 TB/s HBM3E peak."""
+    from gdlhip import ops
+    from gdlhip.nn import FusedAdam
+    bf = torch.bfloat16
+    res = {}
+
+    def run(name, fn, nbytes, iters=10):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        gbs = nbytes / us / 1e3
+        res[name] = {"us": round(us, 1), "algorithmic_mb": round(nbytes / 1e6, 1), "gb_per_s": round(gbs, 1),
+                     "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 3)}
+    tok = torch.randn(b * 1297, 768, device=device)
+    g, be = torch.ones(768, device=device), torch.zeros(768, device=device)
+    run("layernorm_fwd f32->bf16 [B*1297,768]", lambda: ops.layernorm(tok, g, be, 1e-5, bf), tok.numel() * 6)
+    y = torch.randn(b, 144, 144, 256, device=device).to(bf)
+    n = y.numel()
+    mean, var = ops.bn_stats(y)
+    ga, bb = torch.ones(256, device=device), torch.zeros(256, device=device)
+    run("bn_stats bf16 [B,144,144,256]", lambda: ops.bn_stats(y), n * 2)
+    run("bn_apply+relu bf16 [B,144,144,256]", lambda: ops.bn_apply(y, mean, var, ga, bb, 1e-5, True), n * 4)
+    dy = torch.randn_like(y)
+    run("bn_bwd_reduce bf16 [B,144,144,256]", lambda: ops.bn_bwd_reduce(y, dy, mean, var, ga, bb, 1e-5, True), n * 4)
+    sg, sb = ops.bn_bwd_reduce(y, dy, mean, var, ga, bb, 1e-5, True)
+    run("bn_bwd_dx bf16 [B,144,144,256]", lambda: ops.bn_bwd_dx(y, dy, mean, var, ga, bb, 1e-5, True, sg, sb, n // 256), n * 6)
+    x36 = torch.randn(b, 36, 36, 768, device=device).to(bf)
+    up = torch.empty(b, 144, 144, 768, device=device, dtype=bf)
+    run("bilinear_fwd bf16 36->144 x768", lambda: ops.bilinear(x36, (144, 144), out=up), (x36.numel() + up.numel()) * 2)
+    run("bilinear_bwd bf16 144->36 x768", lambda: ops.bilinear_bwd(up, (36, 36)), (x36.numel() + up.numel()) * 2)
+    low = torch.randn(b, 144, 144, 5, device=device)
+    run("upsample_logits f32 144->512 x5", lambda: ops.upsample_logits(low, (512, 512)), (low.numel() + b * 5 * 512 * 512) * 4)
+    logits = torch.randn(b, 5, 512, 512, device=device)
+    tgt = torch.randint(0, 5, (b, 512, 512), device=device)
+    run("dice_loss_fwd f32 [B,5,512,512]", lambda: ops.dice_loss_fwd(logits, tgt), logits.numel() * 4 + tgt.numel() * 8)
+    _, sums = ops.dice_loss_fwd(logits, tgt)
+    one = torch.ones((), device=device)
+    run("dice_loss_bwd f32 [B,5,512,512]", lambda: ops.dice_loss_bwd(logits, tgt, sums, one), logits.numel() * 8 + tgt.numel() * 8)
+    run("softmax_argmax f32 -> int64", lambda: ops.softmax_argmax(logits), logits.numel() * 4 + tgt.numel() * 8)
+    u8 = torch.randint(0, 256, (b, 3, 512, 512), device=device, dtype=torch.uint8)
+    m3, s3 = torch.tensor(RGB_MEAN, device=device), torch.tensor(RGB_STD, device=device)
+    run("normalize_u8 -> f32 [B,3,512,512]", lambda: ops.normalize_u8(u8, m3, s3), u8.numel() * 5)
+    p = torch.nn.Parameter(torch.randn(35_023_882, device=device))
+    p.grad = torch.randn_like(p)
+    opt = FusedAdam([p], lr=6e-5, max_grad_norm=1.0)
+    run("fused Adam + clip, 35.0 M params", opt.step, p.numel() * (4 + 28), iters=5)   # sumsq pass reads g once more
+    return res
+
+
+def cpu_baseline(warm: int = 2, reps: int = 5):
+    """The oracle (CPU restatement of the reference path, validated against reference goldens) timed on this box's
+    host cores at batch 2, f32: `warm` untimed + median of `reps` timed steps for training and for inference."""
     import oracle
     torch.manual_seed(0)
     threads = torch.get_num_threads()
     m = oracle.DOFASegmentationModel("dofa_base", (512, 512), num_classes=5, freeze_layers=["encoder"])
     b = oracle.synthetic_batch(2, 3, 512, 5, 42)
     opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=6e-5)
+
+    def train():
+        opt.zero_grad(set_to_none=True)
+        loss = oracle.model.training_loss(m(b["image"], b["wavelengths"]), b["mask"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+
+    def infer():
+        with torch.no_grad():
+            oracle.model.predict_mask(m(b["image"], b["wavelengths"]))
+
+    def med(fn):
+        ts = []
+        for i in range(warm + reps):
+            t0 = time.perf_counter()
+            fn()
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
     m.train()
-    t0 = time.perf_counter()
-    loss = oracle.model.training_loss(m(b["image"], b["wavelengths"]), b["mask"])
-    loss.backward()
-    torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
-    opt.step()
-    t_train = time.perf_counter() - t0
+    t_train = med(train)
     m.eval()
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        oracle.model.predict_mask(m(b["image"], b["wavelengths"]))
-    t_inf = time.perf_counter() - t0
+    t_inf = med(infer)
     return {"value": round(2 / t_train, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
-            "sample": f"1 train step (fwd+bwd+clip+Adam) at batch 2, f32, {t_train:.1f}s; "
-                      f"inference 1 forward+argmax at batch 2: {2 / t_inf:.3f} tiles/s",
+            "sample": f"train step (fwd+bwd+clip+Adam) at batch 2, f32: {warm} warm-ups, median of {reps} = {t_train:.2f} s; "
+                      f"inference (forward+argmax) at batch 2: median {t_inf:.2f} s = {2 / t_inf:.3f} tiles/s",
             "inference_value": round(2 / t_inf, 4)}
 
 
@@ -145,48 +291,12 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=device)
 
     from gdlhip import ops
-    from gdlhip.nn import DiceLoss, FusedAdam
-    from tasks_with_models.segmentation_dofa import SegmentationDOFA
-    from tasks_with_models.segmentation_segformer import SegmentationSegformer
 
     torch.manual_seed(42 + rank)  # train.py:67 seeds 42
-    if args.model == "unetpp":
-        from tasks_with_models.segmentation_unetplus import SegmentationUnetPlus
-        task = SegmentationUnetPlus(encoder="resnet18", image_size=(512, 512), in_channels=3, num_classes=5,
-                                    max_samples=6, loss=DiceLoss(mode="multiclass"),
-                                    optimizer=lambda params: FusedAdam(params, lr=6e-5, max_grad_norm=1.0))
-    elif args.model == "segformer":
-        task = SegmentationSegformer(encoder="mit_b2", in_channels=3, num_classes=5, max_samples=6,
-                                     loss=DiceLoss(mode="multiclass"),
-                                     optimizer=lambda params: FusedAdam(params, lr=6e-5, max_grad_norm=1.0))
-    else:
-        task = SegmentationDOFA(
-            encoder="dofa_base", pretrained=False, image_size=(512, 512), num_classes=5, max_samples=6,
-            loss=DiceLoss(mode="multiclass"), freeze_layers=["encoder"],
-            optimizer=lambda params: FusedAdam(params, lr=6e-5, max_grad_norm=1.0))
-    task.configure_model()
-    task.to(device)
-    if dist_on:
-        # Lightning's `sync_batchnorm: true` + DDPStrategy(gradient_as_bucket_view=true)
-        task.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(task.model)
-        task.model = torch.nn.parallel.DistributedDataParallel(
-            task.model, device_ids=[local], gradient_as_bucket_view=True, find_unused_parameters=False)
-    (optimizer,), _ = task.configure_optimizers()
+    task, optimizer = build_task(args.model, device, dist_on, local)
     batch = synthetic_batch(args.batch, device, 42 + rank)
     use_bf16 = args.dtype == "bf16"
-
-    def train_step():
-        task.train()
-        optimizer.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
-            loss = task.training_step(batch, 0)
-        loss.backward()
-        optimizer.step()
-
-    def infer_step():
-        task.eval()
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
-            task.validation_step(batch, 0)
+    train_step, infer_step = make_steps(task, optimizer, lambda: batch, use_bf16)
 
     timer = None
     res = {}
@@ -204,6 +314,16 @@ def main() -> None:
     if args.mode in ("both", "infer"):
         res["infer"] = timed(infer_step, args.steps, args.warmup, world, device)
 
+    ddp_info = None
+    if dist_on:
+        # the exchange step on its own: one all-reduce of the trainable gradients' bytes (what DDP's buckets move per step)
+        nparam = sum(p.numel() for p in task.parameters() if p.requires_grad)
+        buf = torch.zeros(nparam, device=device)
+        dt_c = timed(lambda: dist.all_reduce(buf), 5, 2, world, device)
+        ddp_info = {"backend": "nccl (RCCL)", "ranks": dist.get_world_size(), "grad_bytes": nparam * 4,
+                    "grad_allreduce_ms_alone": round(1e3 * dt_c / 5, 3)}
+        del buf
+
     pcie = None
     if args.with_input_stage and "train" in res:
         # host batches exactly as the dataset workers hand them over: raw uint8 tiles + int64 masks + sensor stats
@@ -218,14 +338,8 @@ def main() -> None:
         n_total = args.warmup + args.steps
         stage = DeviceInputStage((host[i % 3] for i in range(n_total)), device, depth=2)
         it = iter(stage)
-        resident = batch
-
-        def staged_step():
-            nonlocal batch
-            batch = next(it)
-            train_step()
-        dt = timed(staged_step, args.steps, args.warmup, world, device)
-        batch = resident
+        staged_train, _ = make_steps(task, optimizer, lambda: next(it), use_bf16)
+        dt = timed(staged_train, args.steps, args.warmup, world, device)
         pcie = {"train_tiles_per_s": round(args.batch * world * args.steps / dt, 3),
                 "h2d_bytes_per_tile": stage.bytes_h2d // (n_total * args.batch),
                 "note": "host uint8 tiles -> pinned ring -> copy stream (2 batches ahead) -> normalise kernel -> step"}
@@ -237,8 +351,7 @@ def main() -> None:
 
     tiles = args.batch * world * args.steps
     head = "train" if "train" in res else "infer"
-    model_name = {"segformer": "SegFormer-B2 (MiT-B2 + MLP decoder)", "unetpp": "UNet++ (ResNet18 encoder)",
-                  "dofa": "DOFA-base + UperNet"}[args.model]
+    model_name = MODEL_NAME[args.model]
     cfg_name = {"segformer": "configs[2]", "unetpp": "configs[0]", "dofa": "configs[1]"}[args.model]
     out = {
         "metric": f"512x512 tiles/s, {model_name}, {head} step",
@@ -263,9 +376,7 @@ def main() -> None:
     if "train" in res and "infer" in res:
         out["inference_tiles_per_s"] = round(tiles / res["infer"], 3)
         out["inference_ms_per_step"] = round(1e3 * res["infer"] / args.steps, 3)
-    # whole-model algorithmic flops: 1606.7 GF/tile train (frozen encoder), 726.7 fwd
-    gf = {"dofa": {"train": 1606.7, "infer": 726.7}, "segformer": {"train": 3 * 121.0, "infer": 121.0},
-          "unetpp": {"train": 3 * UNETPP_R18_FWD_GF, "infer": UNETPP_R18_FWD_GF}}[args.model]
+    gf = MODEL_GF[args.model]
     peak = PEAK_BF16_TFLOPS if use_bf16 else PEAK_F32_TFLOPS
     out["model_flops_utilisation"] = {
         k: round(gf[k] * 1e-3 * tiles / res[k] / world / peak, 4) for k in res}
@@ -274,9 +385,14 @@ def main() -> None:
         dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
         name, s = dom
         achieved = s["flops"] / (s["ms"] * 1e-3) / 1e12
+        traffic, traffic_note = None, "no PMC summary committed"
+        if PMC_TRAFFIC_FILE.is_file():
+            pm = json.loads(PMC_TRAFFIC_FILE.read_text())
+            if pm.get("kernel_substring", "\0") in name:
+                traffic, traffic_note = pm["hbm_bytes_per_launch"], pm["note"]
         out["roofline"] = {
             "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
             "launches": s["launches"], "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 2),
             "algorithmic_gflop_per_launch_avg": round(s["flops"] / s["launches"] / 1e9, 3),
             "share_of_step_time": round(s["ms"] * 1e-3 / res["train"], 4),
@@ -286,6 +402,15 @@ def main() -> None:
         }
     if pcie is not None:
         out["pcie_inclusive"] = pcie
+    if ddp_info is not None:
+        out["ddp"] = ddp_info
+    if world == 1 and not args.no_extras and args.model == "dofa" and use_bf16:
+        del task, optimizer
+        torch.cuda.empty_cache()
+        out["hbm_kernels"] = hbm_kernels(device, args.batch)
+        out["by_batch"] = {"4": side_measurement("dofa", 4, max(args.steps, 10), args.warmup, device, True)}
+        out["other_models"] = {m: side_measurement(m, args.batch, args.steps, args.warmup, device, True)
+                               for m in ("segformer", "unetpp")}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
     json_out.write(json.dumps(out) + "\n")

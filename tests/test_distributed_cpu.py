@@ -15,17 +15,29 @@ def _worker(rank, world, port, ret):
     try:
         from gdlhip import nn as gnn
         g = torch.Generator().manual_seed(5)
-        full = torch.randn(world * 6, 8, generator=g) * 2 + 0.7     # [pixels over all ranks, C]
-        mine = full[rank * 6:(rank + 1) * 6]
+        # RAGGED split (a short last batch on one rank): rank 0 holds 6 pixels, rank 1 holds 10
+        sizes = [6, 10][:world]
+        full = torch.randn(sum(sizes), 8, generator=g) * 2 + 0.7     # [pixels over all ranks, C]
+        lo = sum(sizes[:rank])
+        mine = full[lo:lo + sizes[rank]]
         mean, var = mine.mean(0), mine.var(0, unbiased=False)
-        gm, gv = gnn.sync_batch_stats(mean, var)
+        gm, gv, total = gnn.sync_batch_stats(mean, var, count=mine.shape[0])
         ok = torch.allclose(gm, full.mean(0), atol=1e-6) and torch.allclose(gv, full.var(0, unbiased=False), atol=1e-5)
+        ok = ok and isinstance(total, torch.Tensor) and float(total) == float(full.shape[0])
         rm, rv = torch.zeros(8), torch.ones(8)
-        gnn.update_running_stats(rm, rv, gm, gv, 0.1, full.shape[0])
+        gnn.update_running_stats(rm, rv, gm, gv, 0.1, total)         # count as a tensor: no host read-back
         ref = torch.nn.BatchNorm1d(8)
         ref.train()
         ref(full)
         ok = ok and torch.allclose(rm, ref.running_mean, atol=1e-6) and torch.allclose(rv, ref.running_var, atol=1e-5)
+        rm2, rv2 = torch.zeros(8), torch.ones(8)
+        gnn.update_running_stats(rm2, rv2, gm, gv, 0.1, full.shape[0])
+        ok = ok and torch.allclose(rm2, rm) and torch.allclose(rv2, rv)
+        # backward: the dx kernel divides the exchanged sums by the LOCAL count; scaled by p_local / P_global that is
+        # the global mean of dy (what SyncBatchNorm's backward uses)
+        share = mine.shape[0] / total
+        s1, _ = gnn.sync_sum_pair(mine.sum(0), (mine * mine).sum(0))
+        ok = ok and torch.allclose(s1 * share / mine.shape[0], full.mean(0), atol=1e-6)
         a, b = gnn.sync_sum_pair(mine.sum(0), (mine * mine).sum(0))
         ok = ok and torch.allclose(a, full.sum(0), atol=1e-5) and torch.allclose(b, (full * full).sum(0), atol=1e-4)
         # bench.py timing rule: the job time is the MAX over ranks
