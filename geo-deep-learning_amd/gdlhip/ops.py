@@ -450,11 +450,25 @@ def attention_unfused(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor
     return out
 
 
-def attention_flash(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
-    """Fused flash attention forward (bf16, head_dim 64); same argument convention."""
+def attention_flash(q: Tensor, k: Tensor, v: Tensor, num_heads: int, return_lse: bool = False):
+    """Fused flash attention forward (bf16, head_dim 64); same argument convention.  V is read row-major (transposed
+    inside the LDS).  ``return_lse``: also return the log-sum-exp of the scaled scores [B,H,Nq] f32, which the fused
+    backward recomputes the probabilities from."""
     B, Nq, Nkv, D, hd = _attn_check(q, k, v, num_heads)
     if q.dtype != torch.bfloat16 or hd != 64:
         raise ValueError("attention_flash: needs bf16 and head_dim 64")
+    out = torch.empty((B, Nq, D), device=q.device, dtype=q.dtype)
+    lse = torch.empty((B, num_heads, Nq), device=q.device, dtype=torch.float32) if return_lse else None
+    check(_lib.load().gdl_flash_attn_fwd2(_p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1),
+                                          _p(v), v.stride(0), v.stride(1), _p(out), out.stride(0), out.stride(1),
+                                          _p(lse), B, num_heads, Nq, Nkv, float(hd) ** -0.5, _stream()),
+          "gdl_flash_attn_fwd2")
+    return (out, lse) if return_lse else out
+
+
+def attention_flash_v1(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
+    """First-generation kernel (separate V^T pass); kept for A/B measurements."""
+    B, Nq, Nkv, D, hd = _attn_check(q, k, v, num_heads)
     npad = (Nkv + 63) // 64 * 64
     vt = _v_transposed(v, num_heads, hd, npad)
     out = torch.empty((B, Nq, D), device=q.device, dtype=q.dtype)
@@ -464,11 +478,33 @@ def attention_flash(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
     return out
 
 
-def attention(q: Tensor, k: Tensor, v: Tensor, num_heads: int) -> Tensor:
-    """Dispatch: flash kernel for bf16 / head_dim 64, materialised-score path otherwise."""
-    if q.dtype == torch.bfloat16 and q.shape[2] // num_heads == 64:
-        return attention_flash(q, k, v, num_heads)
-    return attention_unfused(q, k, v, num_heads)
+def flash_ok(q: Tensor, num_heads: int) -> bool:
+    return q.dtype == torch.bfloat16 and q.shape[2] // num_heads == 64
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, num_heads: int, return_lse: bool = False):
+    """Dispatch: flash kernel for bf16 / head_dim 64, materialised-score path otherwise (lse = None there)."""
+    if flash_ok(q, num_heads):
+        return attention_flash(q, k, v, num_heads, return_lse)
+    out = attention_unfused(q, k, v, num_heads)
+    return (out, None) if return_lse else out
+
+
+def attention_flash_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, lse: Tensor, num_heads: int,
+                        dq: Tensor, dk: Tensor, dv: Tensor) -> None:
+    """Fused attention backward (bf16, head_dim 64): dq / dk / dv written in place (strided slices allowed)."""
+    B, Nq, Nkv, D, hd = _attn_check(q, k, v, num_heads)
+    for t, n in ((o, Nq), (do, Nq), (dq, Nq), (dk, Nkv), (dv, Nkv)):
+        if t.shape != (B, n, D) or t.dtype != torch.bfloat16 or t.stride(2) != 1:
+            raise ValueError("attention_flash_bwd: tensor shape / dtype / stride mismatch")
+    if lse.shape != (B, num_heads, Nq) or lse.dtype != torch.float32 or not lse.is_contiguous():
+        raise ValueError("attention_flash_bwd: lse must be contiguous f32 [B,H,Nq]")
+    dvec = torch.empty_like(lse)
+    check(_lib.load().gdl_flash_attn_bwd(
+        _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
+        _p(o), o.stride(0), o.stride(1), _p(do), do.stride(0), do.stride(1), _p(lse), _p(dvec),
+        _p(dq), dq.stride(0), dq.stride(1), _p(dk), dk.stride(0), dk.stride(1), _p(dv), dv.stride(0), dv.stride(1),
+        B, num_heads, Nq, Nkv, float(hd) ** -0.5, _stream()), "gdl_flash_attn_bwd")
 
 
 def split_qkv(qkv: Tensor):
@@ -702,14 +738,20 @@ def _bwgrad(x: Tensor, x_sW: int, x_sZ: tuple[int, int], dy: Tensor, dy_sW: int,
 
 
 def attention_bwd(q: Tensor, k: Tensor, v: Tensor, do: Tensor, num_heads: int, dq: Tensor, dk: Tensor,
-                  dv: Tensor) -> None:
+                  dv: Tensor, o: Tensor | None = None, lse: Tensor | None = None) -> None:
     """Backward of softmax(q k^T / sqrt(hd)) v.  q/do/dq [B,Nq,D], k/v/dk/dv [B,Nkv,D]; all may be strided
     slices of packed qkv / kv tensors (unit channel stride); dq/dk/dv are written in place.
+
+    With the forward's output ``o`` and ``lse`` (bf16, head_dim 64) the fused kernels run (nothing of size Nq x Nkv in
+    HBM); otherwise -- the exact-f32 parity path and odd head dims -- the materialised path below.
 
     The probabilities are recomputed (the forward is the fused flash kernel and keeps none):
     S = scale q k^T -> P = softmax(S); dP = dO V^T; dS = P*(dP - rowsum(dP*P))*scale;
     dQ = dS K (batched GEMM against K^T); dK = dS^T Q, dV = P^T dO (batched weight-gradient kernels)."""
     B, Nq, Nkv, D, hd = _attn_check(q, k, v, num_heads)
+    if o is not None and lse is not None and flash_ok(q, num_heads):
+        attention_flash_bwd(q, k, v, o, do, lse, num_heads, dq, dk, dv)
+        return
     cdt = q.dtype
     al = 4 if cdt == torch.float32 else 8
     if hd % al != 0:

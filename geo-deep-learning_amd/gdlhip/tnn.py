@@ -255,7 +255,7 @@ class _MitBlock(Function):
         else:
             xn = h1
         kv = ops.linear(xn, gemm_weight(kvw, cd), d[5])
-        a = ops.attention(q, kv[..., :c], kv[..., c:], heads)
+        a, lse = ops.attention(q, kv[..., :c], kv[..., c:], heads, return_lse=True)
         x1 = torch.empty_like(x)
         ops.conv_gemm(a.view(b, 1, n, c), gemm_weight(pw, cd), bias=d[7], batch_scale=s1, resid=x.view(b, 1, n, c),
                       out=x1.view(b, 1, n, c))
@@ -267,13 +267,13 @@ class _MitBlock(Function):
         ops.conv_gemm(g.view(b, 1, n, -1), gemm_weight(f2w, cd), bias=d[15], batch_scale=s2,
                       resid=x1.view(b, 1, n, c), out=x2.view(b, 1, n, c))
         if any(ctx.needs_input_grad):
-            ctx.save_for_backward(x, s1, s2, h1, q, red, xn if sr > 1 else None, kv, a, x1, h2, u, g, w9, *prm)
+            ctx.save_for_backward(x, s1, s2, h1, q, red, xn if sr > 1 else None, kv, a, x1, h2, u, g, w9, lse, *prm)
             ctx.cfg = (hh, ww, heads, sr, eps1, eps_sr, cd)
         return x2
 
     @staticmethod
     def backward(ctx, gx2):
-        x, s1, s2, h1, q, red, xn, kv, a, x1, h2, u, g, w9, *prm = ctx.saved_tensors
+        x, s1, s2, h1, q, red, xn, kv, a, x1, h2, u, g, w9, lse, *prm = ctx.saved_tensors
         hh, ww, heads, sr, eps1, eps_sr, cd = ctx.cfg
         n1w, n1b, qw, qb, kvw, kvb, pw, pb, n2w, n2b, f1w, f1b, dww, dwb, f2w, f2b = prm[:16]
         b, n, c = x.shape
@@ -293,7 +293,7 @@ class _MitBlock(Function):
         da = linear_dx(dz1, pw)
         dq = torch.empty((b, n, c), device=x.device, dtype=cd)
         dkv = torch.empty_like(kv)
-        ops.attention_bwd(q, kv[..., :c], kv[..., c:], da, heads, dq, dkv[..., :c], dkv[..., c:])
+        ops.attention_bwd(q, kv[..., :c], kv[..., c:], da, heads, dq, dkv[..., :c], dkv[..., c:], o=a, lse=lse)
         kv_in = xn if sr > 1 else h1
         dkvw, dkvb = linear_dw(kv_in, dkv)
         dxn = linear_dx(dkv, kvw)
@@ -338,7 +338,7 @@ class _VitBlock(Function):
         h1 = ops.layernorm(x, d[0], d[1], eps, cd)
         qkv = ops.linear(h1, gemm_weight(qkvw, cd), d[3])
         qv, kv_, vv = ops.split_qkv(qkv)
-        a = ops.attention(qv, kv_, vv, heads)
+        a, lse = ops.attention(qv, kv_, vv, heads, return_lse=True)
         # the backward needs the branch outputs before LayerScale (z) and the GELU input (u): extra epilogue
         # stores that are skipped when nothing upstream or in the block wants a gradient (inference, frozen)
         train = any(ctx.needs_input_grad)
@@ -354,13 +354,13 @@ class _VitBlock(Function):
                       resid=x1.view(b, 1, n, c), out=x2.view(b, 1, n, c),
                       aux_out=z2.view(b, 1, n, c) if train else None)
         if train:
-            ctx.save_for_backward(x, s1, s2, h1, qkv, a, z1, x1, h2, u, f, z2, *prm)
+            ctx.save_for_backward(x, s1, s2, h1, qkv, a, z1, x1, h2, u, f, z2, lse, *prm)
             ctx.cfg = (heads, eps, cd)
         return x2
 
     @staticmethod
     def backward(ctx, gx2):
-        x, s1, s2, h1, qkv, a, z1, x1, h2, u, f, z2, *prm = ctx.saved_tensors
+        x, s1, s2, h1, qkv, a, z1, x1, h2, u, f, z2, lse, *prm = ctx.saved_tensors
         n1w, n1b, qkvw, qkvb, pw, pb, g1, n2w, n2b, f1w, f1b, f2w, f2b, g2 = prm
         heads, eps, cd = ctx.cfg
         b, n, c = x.shape
@@ -377,7 +377,7 @@ class _VitBlock(Function):
         dqkv = torch.empty_like(qkv)
         qv, kv_, vv = ops.split_qkv(qkv)
         dq_, dk_, dv_ = ops.split_qkv(dqkv)
-        ops.attention_bwd(qv, kv_, vv, da, heads, dq_, dk_, dv_)
+        ops.attention_bwd(qv, kv_, vv, da, heads, dq_, dk_, dv_, o=a, lse=lse)
         dqkvw, dqkvb = linear_dw(h1, dqkv)
         dh1 = linear_dx(dqkv, qkvw)
         gx, dn1w, dn1b = ops.layernorm_bwd(x, dh1, n1w.detach(), eps, dres=gx1)

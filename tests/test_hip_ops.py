@@ -191,6 +191,40 @@ def test_attention_flash(B, N, H):
     close(o, ref, dtype, "attention_flash")
 
 
+@pytest.mark.parametrize("B,Nq,Nkv,H", [(2, 70, 70, 2), (2, 300, 300, 4), (1, 1297, 1297, 8), (2, 333, 100, 4), (1, 64, 257, 3)])
+def test_attention_flash_lse_and_fused_backward(B, Nq, Nkv, H):
+    """Second-generation attention kernels: LSE output, V read row-major, and the fused backward (probabilities
+    recomputed from LSE, no [Nq, Nkv] tensor) vs torch autograd; packed / strided operands; both block orders
+    (B*H a multiple of 8 or not); separate query / key lengths (MiT spatial reduction); the v1 kernel as a cross-check."""
+    dtype, hd = torch.bfloat16, 64
+    D = H * hd
+    qf = q(rnd(B, Nq, D) * 1.2, dtype).requires_grad_()
+    kvf = q(rnd(B, Nkv, 2 * D, seed=1) * 1.2, dtype).requires_grad_()
+    do = q(rnd(B, Nq, D, seed=2), dtype)
+
+    def heads(t, n):
+        return t.reshape(B, n, H, hd).transpose(1, 2)
+    sc = heads(qf, Nq) @ heads(kvf[..., :D], Nkv).transpose(-1, -2) * hd ** -0.5
+    out = (sc.softmax(-1) @ heads(kvf[..., D:], Nkv)).transpose(1, 2).reshape(B, Nq, D)
+    out.backward(do)
+    qd, kvd = qf.detach().to(DEV, dtype), kvf.detach().to(DEV, dtype)
+    o, lse = ops.attention_flash(qd, kvd[..., :D], kvd[..., D:], H, return_lse=True)
+    close(o, out, dtype, "flash fwd2")
+    close(lse, torch.logsumexp(sc.detach(), -1), torch.float32, "lse", scale=max(1.0, sc.detach().abs().max().item()) * 20)
+    close(ops.attention_flash_v1(qd, kvd[..., :D], kvd[..., D:], H), out, dtype, "flash v1")
+    dq = torch.empty_like(qd)
+    dkv = torch.empty_like(kvd)
+    ops.attention_bwd(qd, kvd[..., :D], kvd[..., D:], do.to(DEV, dtype), H, dq, dkv[..., :D], dkv[..., D:], o=o, lse=lse)
+    close(dq, qf.grad, dtype, "fused dq")
+    close(dkv[..., :D], kvf.grad[..., :D], dtype, "fused dk")
+    close(dkv[..., D:], kvf.grad[..., D:], dtype, "fused dv")
+    # the materialised backward (no o / lse) agrees
+    dq2, dkv2 = torch.empty_like(qd), torch.empty_like(kvd)
+    ops.attention_bwd(qd, kvd[..., :D], kvd[..., D:], do.to(DEV, dtype), H, dq2, dkv2[..., :D], dkv2[..., D:])
+    close(dq, dq2, dtype, "fused vs materialised dq")
+    close(dkv, dkv2, dtype, "fused vs materialised dkv")
+
+
 def test_attention_flash_spike():
     """one dominant key late in the sequence forces the online-softmax rescale branch."""
     B, N, H, hd = 1, 300, 1, 64
