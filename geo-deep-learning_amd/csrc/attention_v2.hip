@@ -108,15 +108,18 @@ __device__ __forceinline__ f32x16_t zero16() {
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------------ forward
-// block = 4 waves x 64 queries; KV tile = 64 keys (K tile + V tile = 16 KiB per stage, two stages).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_fwd2_kernel(const Attn2Args f) {
+// block = NW waves x 64 queries (NW = 2, 3 or 4: the host picks the one that pads the query count least -- 1297 tokens are
+// 7 blocks of 192 (3.6 % idle rows) against 6 of 256 (18 %)); KV tile = 64 keys (K tile + V tile = 16 KiB per stage, two
+// stages).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_fwd2_kernel(const Attn2Args f) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];   // stage s: K at 2s, V at 2s+1
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int blk, bh;
-  decode_block((f.Nq + 255) / 256, f.B * f.H, blk, bh);
+  decode_block((f.Nq + 64 * NW - 1) / (64 * NW), f.B * f.H, blk, bh);
   const int b = bh / f.H, h = bh % f.H;
-  const int q0 = blk * 256 + wave * 64;
+  const int q0 = blk * (64 * NW) + wave * 64;
   const bool active = q0 < f.Nq;                                   // wave-uniform; idle waves still stage and sync
   const int frow = lane & 31, fhalf = lane >> 5;
   const uint16_t* qbase = f.q + (int64_t)b * f.q_sB + (int64_t)h * 64;
@@ -135,11 +138,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       qf[qt][kk] = __builtin_bit_cast(bf16x8_t, v);
     }
   }
-  auto issue = [&](int stage, int kv0) {   // 16 pieces per tile pair: wave w takes pieces 2w, 2w+1 of K and of V
+  auto issue = [&](int stage, int kv0) {   // 8 + 8 pieces per tile pair, dealt round-robin to the NW waves
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      stage_piece(srd_k, f.k_sN * 2, kv0, f.N, 2 * wave + i, lds_base + (2 * stage) * TILE_BYTES, lane);
-      stage_piece(srd_v, f.v_sN * 2, kv0, f.N, 2 * wave + i, lds_base + (2 * stage + 1) * TILE_BYTES, lane);
+    for (int i = 0; i < (8 + NW - 1) / NW; ++i) {
+      const int p = wave + NW * i;
+      if (p < 8) {
+        stage_piece(srd_k, f.k_sN * 2, kv0, f.N, p, lds_base + (2 * stage) * TILE_BYTES, lane);
+        stage_piece(srd_v, f.v_sN * 2, kv0, f.N, p, lds_base + (2 * stage + 1) * TILE_BYTES, lane);
+      }
     }
   };
   f32x16_t ot[2][2];   // O^T accumulators [query tile][channel tile]: rows = channels, column = query
@@ -470,7 +476,17 @@ extern "C" int gdl_flash_attn_fwd2(const void* q, int64_t q_sB, int64_t q_sN, co
   f.q_sB = q_sB; f.q_sN = q_sN; f.k_sB = k_sB; f.k_sN = k_sN; f.v_sB = v_sB; f.v_sN = v_sN; f.o_sB = o_sB; f.o_sN = o_sN;
   f.B = B; f.H = H; f.Nq = Nq; f.N = Nkv;
   f.scale = scale; f.scale_log2e = scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(flash_fwd2_kernel, dim3((unsigned)((Nq + 255) / 256 * B * H)), dim3(256), 0, (hipStream_t)stream, f);
+  // waves per block: least padded query rows, larger blocks on ties
+  int nw = 4;
+  int64_t best = -1;
+  for (int c = 4; c >= 2; --c) {
+    const int64_t pad = (int64_t)((Nq + 64 * c - 1) / (64 * c)) * 64 * c;
+    if (best < 0 || pad < best) { best = pad; nw = c; }
+  }
+  const unsigned grid = (unsigned)((Nq + 64 * nw - 1) / (64 * nw) * B * H);
+  if (nw == 4) hipLaunchKernelGGL(flash_fwd2_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, f);
+  else if (nw == 3) hipLaunchKernelGGL(flash_fwd2_kernel<3>, dim3(grid), dim3(192), 0, (hipStream_t)stream, f);
+  else hipLaunchKernelGGL(flash_fwd2_kernel<2>, dim3(grid), dim3(128), 0, (hipStream_t)stream, f);
   GDL_CHECK_LAUNCH("gdl_flash_attn_fwd2");
   return GDL_OK;
 }
