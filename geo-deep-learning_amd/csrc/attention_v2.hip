@@ -108,9 +108,8 @@ __device__ __forceinline__ f32x16_t zero16() {
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------------ forward
-// block = NW waves x 64 queries (NW = 2, 3 or 4: the host picks the one that pads the query count least -- 1297 tokens are
-// 7 blocks of 192 (3.6 % idle rows) against 6 of 256 (18 %)); KV tile = 64 keys (K tile + V tile = 16 KiB per stage, two
-// stages).
+// block = NW waves x 64 queries (NW = 4; 2 for query ranges of at most 128 rows); KV tile = 64 keys (K tile + V tile =
+// 16 KiB per stage, two stages).
 template <int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void flash_fwd2_kernel(const Attn2Args f) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];   // stage s: K at 2s, V at 2s+1
@@ -476,16 +475,11 @@ extern "C" int gdl_flash_attn_fwd2(const void* q, int64_t q_sB, int64_t q_sN, co
   f.q_sB = q_sB; f.q_sN = q_sN; f.k_sB = k_sB; f.k_sN = k_sN; f.v_sB = v_sB; f.v_sN = v_sN; f.o_sB = o_sB; f.o_sN = o_sN;
   f.B = B; f.H = H; f.Nq = Nq; f.N = Nkv;
   f.scale = scale; f.scale_log2e = scale * 1.4426950408889634f;
-  // waves per block: least padded query rows, larger blocks on ties
-  int nw = 4;
-  int64_t best = -1;
-  for (int c = 4; c >= 2; --c) {
-    const int64_t pad = (int64_t)((Nq + 64 * c - 1) / (64 * c)) * 64 * c;
-    if (best < 0 || pad < best) { best = pad; nw = c; }
-  }
+  // waves per block: 4 (two resident blocks fill the CU's eight wave slots; measured 285 us vs 319 us for the
+  // less-padded 3-wave blocks at N = 1297), fewer only when the whole query range is shorter than that
+  const int nw = Nq > 128 ? 4 : 2;
   const unsigned grid = (unsigned)((Nq + 64 * nw - 1) / (64 * nw) * B * H);
   if (nw == 4) hipLaunchKernelGGL(flash_fwd2_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, f);
-  else if (nw == 3) hipLaunchKernelGGL(flash_fwd2_kernel<3>, dim3(grid), dim3(192), 0, (hipStream_t)stream, f);
   else hipLaunchKernelGGL(flash_fwd2_kernel<2>, dim3(grid), dim3(128), 0, (hipStream_t)stream, f);
   GDL_CHECK_LAUNCH("gdl_flash_attn_fwd2");
   return GDL_OK;

@@ -21,13 +21,7 @@ using namespace gdlconv;
 
 namespace {
 
-// SPREAD: every wave stages 1/8 of the DMA pieces, and the waves issue them at three different points of the K-step
-// (waves 0-2 right after the barrier, 3-5 one MFMA group later, 6-7 two groups later; SIMD partners w / w+4 never in
-// the same slot).  A piece costs its wave ~45 cycles of texture-address time when it has the unit to itself, but the
-// four loader waves of the ping-pong scheme issue together and each waits for all of them: the loader half is blocked
-// ~1980 cycles per K-step and only THEN starts its own 1024 cycles of MFMAs (measured 2923 cycles per K-step against
-// 2048 of MFMA issue).  Spread out, a wave is blocked ~300-500 cycles per K-step while its SIMD partner computes.
-template <typename T, bool SPREAD>
+template <typename T>
 __global__ __launch_bounds__(512) void conv3x3_sf_kernel(const KArgs k) {
   constexpr int ES = TileTraits<T>::ES;
   constexpr int BKE = TileTraits<T>::BKE;
@@ -96,45 +90,6 @@ __global__ __launch_bounds__(512) void conv3x3_sf_kernel(const KArgs k) {
     if (t + 2 < KT) issue_b(t + 2);
     const int u = t + 1, g = u / 3 + 1;
     if (g < n_macro) issue_a(g, u - 3 * (u / 3));
-  };
-
-  // ---- SPREAD variant: wave w stages weight pieces {w, w+8, w+16, w+24} of every K-step and activation pieces
-  // {12*part + w} (+ {12*part + 8 + w} for w < 4) of every macro-step third
-  unsigned sb_voff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (i * 8 + wave) * 8 + lrow;
-    const int chunk = lslot ^ ((r >> 1) & 7);
-    const int n = n0 + r;
-    sb_voff[i] = n < a.N ? (unsigned)((n * a.w_sN + chunk * (16 / ES)) * ES) : kOob;
-  }
-  const int my_slot = wave < 3 ? 0 : (wave < 6 ? 1 : 2);
-  auto spread_issue = [&](int t) {       // the DMA work that belongs to the barrier of K-step t, this wave's share
-    if (k.dbg == 1) return;
-    if (t + 2 < KT) {
-      const int t2 = t + 2, g = t2 / 3, s2 = t2 - 3 * g, cc = g / 3, r = g - 3 * cc;
-      const unsigned wk = (unsigned)(((r * 3 + s2) * a.C + cc * BKE) * ES);
-      const unsigned lds = lds_base + 2 * A_BYTES + (t2 & 1) * B_BYTES + wave * 1024;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dma16_buf(sb_voff[i], srd_b, wk, lds + i * 8 * 1024);
-    }
-    const int u = t + 1, g = u / 3 + 1;
-    if (g < n_macro) {
-      const int part = u - 3 * (u / 3);
-      const int cc = g / 3, r = g - 3 * cc;
-      const int q0 = m0 - 1 + (r - 1) * W;
-      const unsigned lds = lds_base + (g & 1) * A_BYTES;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (i == 1 && wave >= 4) break;
-        const int p = part * 12 + i * 8 + wave;
-        const int j = p * 8 + lrow;
-        const int chunk = lslot ^ ((j >> 1) & 7);
-        const int q = q0 + j;
-        const unsigned v = (unsigned)q < (unsigned)k.M ? (unsigned)((q * a.in_sW + cc * BKE + chunk * (16 / ES)) * ES) : kOob;
-        dma16_buf(v, srd_a, 0u, lds + p * 1024);
-      }
-    }
   };
 
   // ---- per-lane tap validity of the output rows this lane feeds as MFMA operand (row = lane & 31 of tile i)
@@ -209,8 +164,7 @@ __global__ __launch_bounds__(512) void conv3x3_sf_kernel(const KArgs k) {
   if (half == 0) { issue_b(0); issue_a(0, 0); } else { issue_a(0, 1); issue_a(0, 2); }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if constexpr (SPREAD) spread_issue(-1);
-  else slot(-1);      // t = -1: half 1 loads the weights of step 1 and the first third of macro step 1
+  slot(-1);           // t = -1: half 1 loads the weights of step 1 and the first third of macro step 1
   // all scalar (kernel-argument) loads are complete here: tell the waitcnt inserter, so that inside the loop it can
   // wait for the OLDER fragment reads only (lgkmcnt(6)) instead of draining every LDS read before the first MFMAs
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
@@ -226,9 +180,6 @@ __global__ __launch_bounds__(512) void conv3x3_sf_kernel(const KArgs k) {
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
         fetch(g, t, s, kk + 1, (kk + 1) & 1);
-        if constexpr (SPREAD) {          // slots 1 and 2 of the DMA work that belongs to the barrier of step t - 1
-          if (kk < 2 && my_slot == kk + 1 && t > 0) spread_issue(t - 1);
-        }
         __builtin_amdgcn_sched_barrier(0);
         mfmas(kk & 1, bit);
         __builtin_amdgcn_sched_barrier(0);
@@ -236,8 +187,7 @@ __global__ __launch_bounds__(512) void conv3x3_sf_kernel(const KArgs k) {
       if (t + 1 < KT) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for step t+1 (weights / activations) landed
         __syncthreads();                                   // ... everyone's; the stages of step t are free
-        if constexpr (SPREAD) { if (my_slot == 0) spread_issue(t); }
-        else slot(t);
+        slot(t);
         if (s < 2) fetch(g, t + 1, s + 1, 0, 0);
         else fetch(g + 1, t + 1, 0, 0, 0);
       }
@@ -261,9 +211,6 @@ __global__ __launch_bounds__(512) void conv3x3_sf_kernel(const KArgs k) {
 
 }  // namespace
 
-static int g_sf_spread = 0;
-extern "C" void gdl_debug_set_conv_sf_spread(int on) { g_sf_spread = on; }   // A/B hook: DMA issue spread over all waves
-
 namespace gdlconv {
 
 // Can this call run on the shared-staging kernel?
@@ -279,13 +226,15 @@ int conv3x3_sf_launch(const KArgs& k, hipStream_t stream) {
   kk.tiles_n = (k.a.N + 255) / 256;
   const size_t lds = 2 * 36 * 1024 + 2 * 256 * 128;
   dim3 grid(kk.tiles_m * kk.tiles_n), block(512);
-  auto go = [&](auto kern) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, kk);
-  };
-  const bool spread = g_sf_spread != 0;
-  if (k.a.dtype == GDL_BF16) { if (spread) go(conv3x3_sf_kernel<bf16_tag, true>); else go(conv3x3_sf_kernel<bf16_tag, false>); }
-  else { if (spread) go(conv3x3_sf_kernel<float, true>); else go(conv3x3_sf_kernel<float, false>); }
+  if (k.a.dtype == GDL_BF16) {
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_sf_kernel<bf16_tag>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    hipLaunchKernelGGL(conv3x3_sf_kernel<bf16_tag>, grid, block, lds, stream, kk);
+  } else {
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_sf_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    hipLaunchKernelGGL(conv3x3_sf_kernel<float>, grid, block, lds, stream, kk);
+  }
   GDL_CHECK_LAUNCH("gdl_conv_gemm(3x3 shared staging)");
   return GDL_OK;
 }

@@ -622,7 +622,6 @@ struct WRows {
   int ntiles, cchunks;         // ceil(N / 64), ceil(C / 64)
   int seglen, segs_per_row;    // pixels per row segment (multiple of 16, <= 64), ceil(W / seglen)
   int nsegs, segs_per_split;
-  int xcd_major;               // block order, see the kernel
 };
 
 // Work split: 4 waves, wave (i, j) owns the 32 (n) x 32 (c) quadrant of the 64 x 64 tile for ALL nine taps
@@ -640,17 +639,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wi = wave & 1, wj = wave >> 1;            // n half, c half
-  // Work item = (split, c chunk, n tile), n fastest.  XCD x (= block id % 8) takes a CONTIGUOUS eighth of that list:
-  // its ~64 resident blocks then share one pixel range, a few c chunks of x (each read by all its n tiles) and the dy
-  // rows (read by all its c chunks) out of that XCD's L2 -- in launch order every XCD streamed all of x and dy itself.
-  int wid = blockIdx.x;
-  if (kk.xcd_major) {
-    const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = wid & 7, idx = wid >> 3;
-    wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tiles = kk.ntiles * kk.cchunks;
-  const int split = wid / tiles, tile = wid - split * tiles;
-  const int n0 = (tile % kk.ntiles) * 64, c0 = (tile / kk.ntiles) * 64;
+  const int n0 = (blockIdx.x % kk.ntiles) * 64, c0 = (blockIdx.x / kk.ntiles) * 64;
+  const int split = blockIdx.y;
   const unsigned xpix = (unsigned)(a.in_sW * 2), dypix = (unsigned)(a.dy_sW * 2);
   const srd_t srd_x = make_srd((const unsigned char*)a.in - xpix, kk.in_span + xpix);
   const srd_t srd_dy = make_srd((const unsigned char*)a.dy, kk.dy_span);
@@ -847,7 +837,7 @@ int64_t span_bytes(int B, int H, int W, int C, int64_t sB, int64_t sH, int64_t s
   return (((int64_t)B - 1) * sB + ((int64_t)H - 1) * sH + ((int64_t)W - 1) * sW + C) * es;
 }
 
-int g_wgrad_force_small = 0;   // A/B hook: bit 0 = never use the 256^2 kernel, bit 1 = never use the row-segment kernel, bit 3 = N, C >= 256 layers on the 256^2 kernel, bit 4 = row-segment kernel in launch order (no XCD-major remap)
+int g_wgrad_force_small = 0;   // A/B hook: bit 0 = never use the 256^2 kernel, bit 1 = never use the row-segment kernel, bit 3 = N, C >= 256 layers on the 256^2 kernel
 
 // 256^2 tiles for wide bf16 layers whose operands fit 32-bit buffer offsets
 int wgrad_tile(const gdl_wgrad_args& a) {
@@ -964,8 +954,7 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
       (void)hipFuncSetAttribute((const void*)wgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 35840);
       rows_attr_set = true;
     }
-    kr.xcd_major = !(g_wgrad_force_small & 16);   // A/B hook
-    hipLaunchKernelGGL(wgrad_rows_kernel, dim3(kr.ntiles * kr.cchunks * k.splits), dim3(256), 2 * 35840, s, kr);
+    hipLaunchKernelGGL(wgrad_rows_kernel, dim3(kr.ntiles * kr.cchunks, k.splits), dim3(256), 2 * 35840, s, kr);
   } else if (wgrad_tile(a) == 256 && !g_wgrad_force_v1) {
     W256 kb;
     kb.w = k;

@@ -29,3 +29,106 @@ def test_structure_and_shapes():
     with torch.no_grad():
         y = m(torch.zeros(1, 3, 64, 64))
     assert y.shape == (1, 5, 64, 64)
+
+
+def _hf_resnet(name):
+    """An independent implementation of the same encoder: ``transformers`` ResNet with BasicBlock ("basic") layers --
+    the torchvision resnet18 / resnet34 topology (stem 7x7/2 + BN + ReLU + max-pool 3x3/2, stages of two 3x3 convs with
+    a 1x1 stride-2 projection shortcut at the start of stages 2-4, ReLU after the residual sum)."""
+    import pytest
+    transformers = pytest.importorskip("transformers")
+    from oracle.unetpp import RESNET_LAYERS
+    cfg = transformers.ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[64, 128, 256, 512],
+                                    depths=RESNET_LAYERS[name], layer_type="basic", hidden_act="relu",
+                                    downsample_in_first_stage=False)
+    return transformers.ResNetModel(cfg).eval()
+
+
+def _copy_hf_to_oracle(hf, enc):
+    """HF names -> torchvision / smp names (the oracle's)."""
+    src = hf.state_dict()
+    dst = {}
+
+    def bn(dprefix, sprefix):
+        for k in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+            dst[f"{dprefix}.{k}"] = src[f"{sprefix}.normalization.{k}"]
+    dst["conv1.weight"] = src["embedder.embedder.convolution.weight"]
+    bn("bn1", "embedder.embedder")
+    for si in range(4):
+        j = 0
+        while f"encoder.stages.{si}.layers.{j}.layer.0.convolution.weight" in src:
+            s, d = f"encoder.stages.{si}.layers.{j}", f"layer{si + 1}.{j}"
+            dst[f"{d}.conv1.weight"] = src[f"{s}.layer.0.convolution.weight"]
+            bn(f"{d}.bn1", f"{s}.layer.0")
+            dst[f"{d}.conv2.weight"] = src[f"{s}.layer.1.convolution.weight"]
+            bn(f"{d}.bn2", f"{s}.layer.1")
+            if f"{s}.shortcut.convolution.weight" in src:
+                dst[f"{d}.downsample.0.weight"] = src[f"{s}.shortcut.convolution.weight"]
+                bn(f"{d}.downsample.1", f"{s}.shortcut")
+            j += 1
+    missing, unexpected = enc.load_state_dict(dst, strict=True), None
+    return missing, unexpected
+
+
+def test_resnet_encoder_matches_an_independent_implementation():
+    """Numeric cross-check of the encoder half of the UNet++ oracle (the way Dinov2 pins the ViT block): same weights
+    in ``transformers``' ResNet and in oracle.unetpp.ResNetEncoder -> the same five feature maps (strides 2..32)."""
+    import pytest
+    from oracle.unetpp import ResNetEncoder
+    for name in ("resnet18", "resnet34"):
+        hf = _hf_resnet(name)
+        g = torch.Generator().manual_seed(3)
+        with torch.no_grad():
+            for n, p in hf.named_parameters():                      # non-trivial BN affine / running statistics
+                p.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() == 4 else 0.5) + (1.0 if n.endswith("normalization.weight") else 0.0))
+            for n, b in hf.named_buffers():
+                if n.endswith("running_mean"):
+                    b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+                elif n.endswith("running_var"):
+                    b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+        enc = ResNetEncoder(name, 3).eval()
+        _copy_hf_to_oracle(hf, enc)
+        assert len(enc.state_dict()) == len(hf.state_dict())           # every tensor has a counterpart
+        x = torch.randn(2, 3, 96, 96, generator=g)
+        with torch.no_grad():
+            feats = enc(x)
+            out = hf(x, output_hidden_states=True)
+            stem = hf.embedder.embedder(x)                              # conv + BN + ReLU, before the max-pool
+        assert torch.equal(feats[0], x)
+        assert torch.allclose(feats[1], stem, atol=1e-5, rtol=1e-5)
+        # hidden_states[0] = after the max-pool; [1..4] = the four stages
+        assert [tuple(f.shape[1:]) for f in feats[1:]] == [(64, 48, 48), (64, 24, 24), (128, 12, 12), (256, 6, 6), (512, 3, 3)]
+        for i in range(4):
+            assert torch.allclose(feats[2 + i], out.hidden_states[1 + i], atol=2e-5, rtol=1e-4), (name, i)
+    pytest.importorskip("transformers")
+
+
+def test_smp_state_dict_key_list_is_exact():
+    """The COMPLETE key list of smp 0.5.0 ``UnetPlusPlus("resnet34", classes=2)`` as its published code generates it
+    (torchvision ResNet names under ``encoder.``, ``decoder.blocks.x_{depth}_{layer}.conv{1,2}.{0,1}`` for the eleven
+    nested blocks, ``segmentation_head.0``): 36 encoder conv / downsample weights + 36 BN layers x 5 tensors ... --
+    derived here from the naming rules, not from the oracle, and compared with the oracle's keys."""
+    m = UnetPlusPlus("resnet34", 3, 2)
+    want = ["encoder.conv1.weight"] + [f"encoder.bn1.{k}" for k in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")]
+    bnk = ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")
+    for li, blocks in enumerate([3, 4, 6, 3], start=1):
+        for j in range(blocks):
+            p = f"encoder.layer{li}.{j}"
+            want += [f"{p}.conv1.weight"] + [f"{p}.bn1.{k}" for k in bnk] + [f"{p}.conv2.weight"] + [f"{p}.bn2.{k}" for k in bnk]
+            if j == 0 and li > 1:
+                want += [f"{p}.downsample.0.weight"] + [f"{p}.downsample.1.{k}" for k in bnk]
+    # smp decoder: blocks[f"x_{depth_idx}_{layer_idx}"] for layer_idx in 0..3, depth_idx in 0..layer_idx, then x_0_4
+    names = [f"x_{d}_{l}" for l in range(4) for d in range(l + 1)] + ["x_0_4"]
+    for nme in names:
+        for c in ("conv1", "conv2"):
+            want += [f"decoder.blocks.{nme}.{c}.0.weight"] + [f"decoder.blocks.{nme}.{c}.1.{k}" for k in bnk]
+    want += ["segmentation_head.0.weight", "segmentation_head.0.bias"]
+    assert sorted(m.state_dict().keys()) == sorted(want)
+    # channel plan of the dense grid (smp decoder.py: in = skip_channels[l-1] for depth > 0; skip = skip_ch[l] * (l + 1 - depth))
+    b = m.decoder.blocks
+    plan = {"x_0_0": (512 + 256, 256), "x_0_1": (256 + 128 * 2, 128), "x_1_1": (256 + 128, 128), "x_0_2": (128 + 64 * 3, 64),
+            "x_1_2": (128 + 64 * 2, 64), "x_2_2": (128 + 64, 64), "x_0_3": (64 + 64 * 4, 32), "x_1_3": (64 + 64 * 3, 64),
+            "x_2_3": (64 + 64 * 2, 64), "x_3_3": (64 + 64, 64), "x_0_4": (32, 16)}
+    for k, (cin, cout) in plan.items():
+        assert b[k].conv1[0].weight.shape[:2] == (cout, cin), (k, tuple(b[k].conv1[0].weight.shape))
+        assert b[k].conv2[0].weight.shape[:2] == (cout, cout), k

@@ -60,7 +60,7 @@ def timeit(fn, rounds=5, inner=3):
 def main():
     lib = _lib.load()
     lib.gdl_debug_force_wgrad_small.argtypes = [ctypes.c_int]
-    print(f"batch {B}: TF/s (us)  auto (row-segment kernel, XCD-major block order) | same in launch order | wide layers on the 256^2 per-tap kernel | per-tap 128^2")
+    print(f"batch {B}: TF/s (us)  auto | wide layers on the 256^2 per-tap kernel | per-tap 128^2")
     for name, h, w, c, n in LAYERS:
         b = B if h * w * max(c, n) * B * 2 < (1 << 31) else B // 2
         x = torch.randn(b, h, w, c, device=DEV).to(bf)
@@ -68,7 +68,7 @@ def main():
         flops = 2 * b * h * w * n * 9 * c
         out = []
         ref = None
-        for mode in (0, 16, 8, 3):
+        for mode in (0, 8, 3):
             lib.gdl_debug_force_wgrad_small(mode)
             try:
                 t = timeit(lambda: ops.conv_wgrad(x, dy, R=3, S=3, pad=1))

@@ -16,7 +16,6 @@ lib = _lib.load()
 lib.gdl_debug_set_conv_probe.argtypes = [ctypes.c_void_p]
 lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
 lib.gdl_debug_set_conv_dbg.argtypes = [ctypes.c_int]
-lib.gdl_debug_set_conv_sf_spread.argtypes = [ctypes.c_int]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 bf = torch.bfloat16
 M = B * 1297
@@ -92,11 +91,7 @@ for shp in ([] if len(sys.argv) > 2 and sys.argv[2] == "convs" else SHAPES):
 CONVS = [("neck 3x3 768->768 @144", (B, 144, 144), 768, 768, None, bf), ("fusion 3x3 1024->256 @144", (B, 144, 144), 1024, 256, None, bf),
          ("fpn 3x3 256->256 @144", (B, 144, 144), 256, 256, None, bf), ("neck 3x3 768->768 @72", (B, 72, 72), 768, 768, None, bf)]
 for shp in CONVS:
-    for spread in (0, 1, 0, 1):
-        lib.gdl_debug_set_conv_sf_spread(spread)
-        print(f"[sf spread {spread}]", end=" ")
-        run(*shp, 4, 0)
-        if FULL:
-            run(*shp, 4, 1)
-            run(*shp, 4, 2)
-lib.gdl_debug_set_conv_sf_spread(0)
+    run(*shp, 4, 0)
+    if FULL:
+        run(*shp, 4, 1)
+        run(*shp, 4, 2)
