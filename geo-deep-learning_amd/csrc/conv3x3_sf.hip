@@ -227,12 +227,10 @@ int conv3x3_sf_launch(const KArgs& k, hipStream_t stream) {
   const size_t lds = 2 * 36 * 1024 + 2 * 256 * 128;
   dim3 grid(kk.tiles_m * kk.tiles_n), block(512);
   if (k.a.dtype == GDL_BF16) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_sf_kernel<bf16_tag>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    GDL_SET_MAX_LDS_ONCE(conv3x3_sf_kernel<bf16_tag>, lds);
     hipLaunchKernelGGL(conv3x3_sf_kernel<bf16_tag>, grid, block, lds, stream, kk);
   } else {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)conv3x3_sf_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    GDL_SET_MAX_LDS_ONCE(conv3x3_sf_kernel<float>, lds);
     hipLaunchKernelGGL(conv3x3_sf_kernel<float>, grid, block, lds, stream, kk);
   }
   GDL_CHECK_LAUNCH("gdl_conv_gemm(3x3 shared staging)");

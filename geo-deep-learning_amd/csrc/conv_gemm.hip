@@ -287,11 +287,7 @@ int launch_x(const KArgs& k, hipStream_t stream) {
   kk.tiles_n = (k.a.N + BN - 1) / BN;
   const size_t lds = 2 * (BM + BN) * 128;
   auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA, PP, CT, TP>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  GDL_SET_MAX_LDS_ONCE(kern, lds);   // one flag per template instantiation of launch_x
   dim3 grid(kk.tiles_m * kk.tiles_n, k.a.nz), block(64 * WARPS_M * WARPS_N);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, kk);
   GDL_CHECK_LAUNCH("gdl_conv_gemm");
@@ -311,10 +307,12 @@ int launch(const KArgs& k, hipStream_t stream) {
 
 }  // namespace
 
-static int g_tap_inner = 1, g_dbg = 0, g_tap_packing = 1;
+// tuning hooks (gdl_debug_*): process-global words, written only by the tools/ scripts, read with relaxed atomics
+#include <atomic>
+static std::atomic<int> g_tap_inner{1}, g_dbg{0}, g_tap_packing{1};
 extern "C" void gdl_debug_set_conv_tap_packing(int on) { g_tap_packing = on; }  // A/B hook
 extern "C" void gdl_debug_set_conv_dbg(int mode) { g_dbg = mode; }
-static unsigned long long* g_probe = nullptr;
+static std::atomic<unsigned long long*> g_probe{nullptr};
 extern "C" void gdl_debug_set_conv_probe(void* dev_buf_2048x2_u64) { g_probe = (unsigned long long*)dev_buf_2048x2_u64; }
 extern "C" void gdl_debug_set_conv_korder(int tap_inner) { g_tap_inner = tap_inner; }  // A/B hook
 
@@ -409,8 +407,8 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
 // Tile selection by available parallelism (256 CUs) and output width: 256x256 tiles / 8 waves (variants 2-4) when
 // they still give >= 512 blocks, 128x128 / 4 waves (variant 1) when that gives >= 256 blocks,
 // else 64x64 (variant 0).  Also reports the ALGORITHMIC flops of the call (2*M*N*K, no padding).
-static int g_forced_variant = -1;
-static int g_sf_enabled = 1;
+static std::atomic<int> g_forced_variant{-1};
+static std::atomic<int> g_sf_enabled{1};
 extern "C" void gdl_debug_set_conv_sf(int on) { g_sf_enabled = on; }  // A/B hook: 3x3 shared-staging kernel
 extern "C" void gdl_debug_force_conv_variant(int v) { g_forced_variant = v; }  // tuning hook (-1 = auto)
 

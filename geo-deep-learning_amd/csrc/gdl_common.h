@@ -31,6 +31,17 @@ void gdl_set_error(const char* fmt, ...);
 
 static inline size_t gdl_elem_size(int dtype) { return dtype == GDL_BF16 ? 2 : 4; }
 
+// Raise a kernel's dynamic-LDS limit exactly once per process, thread-safely: forward calls come from the Python main
+// thread, backward calls from autograd's device thread (INTEGRATION.md "threading").  One flag per call site.
+#include <mutex>
+#define GDL_SET_MAX_LDS_ONCE(kernel, bytes)                                                                  \
+  do {                                                                                                       \
+    static std::once_flag once__;                                                                            \
+    std::call_once(once__, [&] {                                                                             \
+      (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+    });                                                                                                      \
+  } while (0)
+
 // ---- bf16 <-> f32 (round-to-nearest-even, like torch) ----
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);

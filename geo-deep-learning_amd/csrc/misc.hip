@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void iou_counts_kernel(const int64_t* __restri
 }
 
 // ------------------------------------------------------------------ classifier tail
-// 1x1 conv to K<=8 classes: one wave per pixel, 4 channels per lane per step.
+// 1x1 conv to K<=16 classes: one wave per pixel, 4 channels per lane per step.
 template <typename T, int K>
 __global__ __launch_bounds__(256) void head_1x1_kernel(const void* __restrict__ feat, int64_t P, int C, int64_t f_sP,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
@@ -516,17 +516,18 @@ __global__ __launch_bounds__(256) void dice_partial_kernel(const float* __restri
 template <int K>
 __global__ __launch_bounds__(256) void dice_final_kernel(const float* __restrict__ ws, int nblk, float eps,
                                                          float* __restrict__ sums, float* __restrict__ loss) {
-  __shared__ double part[8][32];
-  __shared__ double tot[32];
-  const int t = threadIdx.x, v = t & 31, grp = t >> 5;   // 8 groups of 32 value slots (3K <= 24)
+  __shared__ double part[4][64];
+  __shared__ double tot[64];
+  const int t = threadIdx.x, v = t & 63, grp = t >> 6;   // 4 groups of 64 value slots (3K <= 48)
+  static_assert(3 * K <= 64, "dice_final_kernel: at most 21 classes");
   double s = 0;
   if (v < 3 * K)
-    for (int i = grp; i < nblk; i += 8) s += ws[(int64_t)i * 3 * K + v];
+    for (int i = grp; i < nblk; i += 4) s += ws[(int64_t)i * 3 * K + v];
   part[grp][v] = s;
   __syncthreads();
   if (t < 3 * K) {
     double r = 0;
-    for (int g = 0; g < 8; ++g) r += part[g][t];
+    for (int g = 0; g < 4; ++g) r += part[g][t];
     tot[t] = r;
     sums[t] = (float)r;
   }
@@ -887,7 +888,15 @@ extern "C" int gdl_scale_outer(void* x, int dtype, const float* s, int64_t outer
     case 6: { constexpr int KK = 6; __VA_ARGS__; } break;                    \
     case 7: { constexpr int KK = 7; __VA_ARGS__; } break;                    \
     case 8: { constexpr int KK = 8; __VA_ARGS__; } break;                    \
-    default: gdl_set_error("num classes K=%d unsupported (1..8)", K); return GDL_ERR_UNSUPPORTED; \
+    case 9: { constexpr int KK = 9; __VA_ARGS__; } break;                    \
+    case 10: { constexpr int KK = 10; __VA_ARGS__; } break;                  \
+    case 11: { constexpr int KK = 11; __VA_ARGS__; } break;                  \
+    case 12: { constexpr int KK = 12; __VA_ARGS__; } break;                  \
+    case 13: { constexpr int KK = 13; __VA_ARGS__; } break;                  \
+    case 14: { constexpr int KK = 14; __VA_ARGS__; } break;                  \
+    case 15: { constexpr int KK = 15; __VA_ARGS__; } break;                  \
+    case 16: { constexpr int KK = 16; __VA_ARGS__; } break;                  \
+    default: gdl_set_error("num classes K=%d unsupported (1..16)", K); return GDL_ERR_UNSUPPORTED; \
   }
 
 extern "C" int gdl_head_1x1(const void* feat, int dtype, int64_t P, int C, int64_t f_sP, const float* w,

@@ -8,6 +8,8 @@
 // with ds_write_b128 into the SAME swizzled 128-byte-row LDS tile format as the forward kernel,
 // so the fragment fetch + MFMA core is identical.  One block = one (n-tile, tap, c-tile, split);
 // split-K partials go to a workspace and are reduced deterministically.
+#include <atomic>
+
 #include "gdl_common.h"
 
 namespace {
@@ -837,7 +839,7 @@ int64_t span_bytes(int B, int H, int W, int C, int64_t sB, int64_t sH, int64_t s
   return (((int64_t)B - 1) * sB + ((int64_t)H - 1) * sH + ((int64_t)W - 1) * sW + C) * es;
 }
 
-int g_wgrad_force_small = 0;   // A/B hook: bit 0 = never use the 256^2 kernel, bit 1 = never use the row-segment kernel, bit 3 = N, C >= 256 layers on the 256^2 kernel
+std::atomic<int> g_wgrad_force_small{0};   // A/B hook: bit 0 = never use the 256^2 kernel, bit 1 = never use the row-segment kernel, bit 3 = N, C >= 256 layers on the 256^2 kernel
 
 // 256^2 tiles for wide bf16 layers whose operands fit 32-bit buffer offsets
 int wgrad_tile(const gdl_wgrad_args& a) {
@@ -891,7 +893,7 @@ int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
 
 }  // namespace
 
-static int g_wgrad_force_v1 = 0;
+static std::atomic<int> g_wgrad_force_v1{0};
 extern "C" void gdl_debug_force_wgrad_small(int on) { g_wgrad_force_small = on; }  // A/B hook: 128^2 tiles only
 extern "C" void gdl_debug_force_wgrad_v1(int on) { g_wgrad_force_v1 = on; }  // A/B hook: register-transpose kernel
 
@@ -949,11 +951,7 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
     kr.segs_per_row = (a.W + kr.seglen - 1) / kr.seglen;
     kr.nsegs = a.B * a.H * kr.segs_per_row;
     kr.segs_per_split = (kr.nsegs + k.splits - 1) / k.splits;
-    static bool rows_attr_set = false;
-    if (!rows_attr_set) {
-      (void)hipFuncSetAttribute((const void*)wgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 35840);
-      rows_attr_set = true;
-    }
+    GDL_SET_MAX_LDS_ONCE(wgrad_rows_kernel, 2 * 35840);
     hipLaunchKernelGGL(wgrad_rows_kernel, dim3(kr.ntiles * kr.cchunks, k.splits), dim3(256), 2 * 35840, s, kr);
   } else if (wgrad_tile(a) == 256 && !g_wgrad_force_v1) {
     W256 kb;
@@ -961,11 +959,7 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
     kb.w.ctiles = (a.C + 255) / 256;
     kb.in_span = (unsigned)span_bytes(a.B, a.H, a.W, a.C, a.in_sB, a.in_sH, a.in_sW, 2);
     kb.dy_span = (unsigned)span_bytes(a.B, a.Ho, a.Wo, a.N, a.dy_sB, a.dy_sH, a.dy_sW, 2);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)wgrad_tr256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      attr_set = true;
-    }
+    GDL_SET_MAX_LDS_ONCE(wgrad_tr256_kernel, 128 * 1024);
     kb.tiles_n = (a.N + 255) / 256;
     kb.tiles_y = a.R * a.S * kb.w.ctiles;
     dim3 gridb((unsigned)((int64_t)kb.tiles_n * kb.tiles_y * a.nz * k.splits));

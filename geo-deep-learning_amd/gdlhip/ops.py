@@ -1022,7 +1022,7 @@ def scale_outer(x: Tensor, s: Tensor) -> Tensor:
 
 # ------------------------------------------------------------------ classifier tail
 def head_1x1(feat: Tensor, w: Tensor, bias: Tensor | None, chan_scale: Tensor | None = None) -> Tensor:
-    """NHWC features -> f32 NHWC logits [B,H,W,K] (K <= 8)."""
+    """NHWC features -> f32 NHWC logits [B,H,W,K] (K <= 16)."""
     f4 = _nhwc4(feat, "head feat")
     B, H, W, Cc = f4.shape
     P, _, sP = _pix(f4, "head feat")

@@ -42,6 +42,7 @@ class DeviceInputStage:
         self.augment = augment      # gdlhip.augment.AugmentationSequential: fused with the normalise kernel
         self._copy_stream = torch.cuda.Stream(device=self.device)
         self._pinned: dict = {}      # (key, shape, dtype) -> ring of pinned host buffers
+        self._slot_events: list = [None] * (self.depth + 1)   # copy-done event of the batch that last used a ring slot
         self._slot = 0
         self.bytes_h2d = 0
 
@@ -57,6 +58,11 @@ class DeviceInputStage:
     def _stage(self, batch: dict[str, Any]):
         """Enqueue the H2D copies of one batch on the copy stream; returns (device dict, event)."""
         dev: dict[str, Any] = {}
+        # the pinned buffers of this ring slot were the SOURCE of an asynchronous H2D copy depth + 1 batches ago: the host
+        # must not overwrite them before that copy has finished (only the compute stream waits on the event otherwise)
+        slot = self._slot % (self.depth + 1)
+        if self._slot_events[slot] is not None:
+            self._slot_events[slot].synchronize()
         with torch.cuda.stream(self._copy_stream):
             for k, v in batch.items():
                 if isinstance(v, torch.Tensor) and not v.is_cuda and k != "wavelengths":
@@ -71,6 +77,7 @@ class DeviceInputStage:
                     dev[k] = v        # wavelengths stay on the host (the encoder reads them there), strings, ...
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
+        self._slot_events[slot] = ev
         self._slot += 1
         return dev, ev
 

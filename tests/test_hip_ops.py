@@ -388,8 +388,9 @@ def test_wgrad_row_segment_kernel(B, H, W, C, N):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_head_and_logit_upsample(dtype):
-    B, H, W, C, K, HO = 2, 9, 9, 256, 5, 32
+@pytest.mark.parametrize("K", [5, 1, 12, 16])
+def test_head_and_logit_upsample(dtype, K):
+    B, H, W, C, HO = 2, 9, 9, 256, 32
     feat = q(rnd(B, H, W, C), dtype)
     w, bias = rnd(K, C, seed=1) * 0.1, rnd(K, seed=2)
     cs = (torch.rand(B, C, generator=torch.Generator().manual_seed(3)) < 0.9).float() / 0.9
@@ -408,6 +409,26 @@ def test_head_and_logit_upsample(dtype):
     close(dfeat.permute(0, 3, 1, 2), fr.grad, dtype, "head dfeat")
     close(dw, wr.grad, dtype, "head dw")
     close(db, br.grad, dtype, "head db")
+
+
+@pytest.mark.parametrize("K", [2, 9, 16])
+def test_classifier_tail_many_classes(K):
+    """Dice loss, softmax->argmax and class probabilities beyond 8 classes (land-cover legends): up to 16."""
+    import oracle
+    B, H = 2, 40
+    logits = (rnd(B, K, H, H) * 2).requires_grad_(True)
+    y = torch.randint(0, K, (B, H, H), generator=torch.Generator().manual_seed(K))
+    ref = oracle.model.dice_loss_multiclass(logits, y)
+    ref.backward()
+    ld = logits.detach().to(DEV).requires_grad_(True)
+    loss = gnn.DiceLoss()(ld, y.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6
+    close(ld.grad, logits.grad, torch.float32, "dice grad")
+    assert torch.equal(ops.softmax_argmax(ld.detach()).cpu(), logits.detach().softmax(1).argmax(1))
+    close(ops.class_probs(ld.detach()), logits.detach().softmax(1), torch.float32, "class probs")
+    with pytest.raises(ValueError, match="1..16"):
+        ops.softmax_argmax(torch.zeros(1, 17, 8, 8, device=DEV))
 
 
 def test_softmax_argmax_bit_exact():
