@@ -427,7 +427,8 @@ def test_classifier_tail_many_classes(K):
     close(ld.grad, logits.grad, torch.float32, "dice grad")
     assert torch.equal(ops.softmax_argmax(ld.detach()).cpu(), logits.detach().softmax(1).argmax(1))
     close(ops.class_probs(ld.detach()), logits.detach().softmax(1), torch.float32, "class probs")
-    with pytest.raises(ValueError, match="1..16"):
+    from gdlhip._lib import GdlHipError
+    with pytest.raises(GdlHipError, match="1..16"):            # a loud, typed failure -- never a silent fallback
         ops.softmax_argmax(torch.zeros(1, 17, 8, 8, device=DEV))
 
 
