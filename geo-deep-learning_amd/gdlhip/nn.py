@@ -146,6 +146,9 @@ def sync_sum_pair(a: Tensor, b: Tensor, group=None) -> tuple[Tensor, Tensor]:
     return packed[0].contiguous(), packed[1].contiguous()
 
 
+FUSE_UP4 = True   # A/B switch: False = materialise the x4 upsample and run the ordinary 3x3 kernel
+
+
 # ------------------------------------------------------------------ conv -> BN -> ReLU
 class _ConvBNActTrain(Function):
     """Training-mode ConvModule: conv(+bias) -> BatchNorm(batch stats) -> ReLU.
@@ -156,11 +159,14 @@ class _ConvBNActTrain(Function):
 
     @staticmethod
     def forward(ctx, x, weight, conv_bias, gamma, beta, running_mean, running_var, momentum, eps,
-                pad, relu, sync_group):
+                pad, relu, sync_group, up4=False):
         cd = x.dtype
         n, c, r, s = weight.shape
-        wq = gemm_weight(weight, cd)
-        y = ops.conv_gemm(x, wq, R=r, S=s, pad=pad, bias=None if conv_bias is None else conv_bias.detach())
+        cb = None if conv_bias is None else conv_bias.detach()
+        if up4:   # conv3x3(bilinear_x4(x)) without the upsampled intermediate (ops.up4_conv3x3)
+            y = ops.up4_conv3x3(x, subpix4_weight(weight, cd), bias=cb)
+        else:
+            y = ops.conv_gemm(x, gemm_weight(weight, cd), R=r, S=s, pad=pad, bias=cb)
         world = _world(sync_group) if sync_group is not False else 1
         p_local, p_share = y.numel() // n, None
         if world > 1:
@@ -176,14 +182,17 @@ class _ConvBNActTrain(Function):
                 mark_updated(running_var)
         out = ops.bn_apply(y, mean, var, gamma.detach(), beta.detach(), eps, relu)
         ctx.save_for_backward(x, weight, y, mean, var, gamma, beta)
-        ctx.cfg = (pad, relu, eps, conv_bias is not None, sync_group, world, p_local, p_share)
+        ctx.cfg = (pad, relu, eps, conv_bias is not None, sync_group, world, p_local, p_share, up4)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         x, weight, y, mean, var, gamma, beta = ctx.saved_tensors
-        pad, relu, eps, has_bias, sync_group, world, p_local, p_share = ctx.cfg
+        pad, relu, eps, has_bias, sync_group, world, p_local, p_share, up4 = ctx.cfg
         n, c, r, s = weight.shape
+        lo = (x.shape[1], x.shape[2])
+        if up4:   # the backward works on the upsampled map: recomputed here (one HBM-bound pass) instead of saved
+            x = ops.bilinear(x, (4 * lo[0], 4 * lo[1]))
         if gout.dtype != y.dtype:
             gout = to_compute(gout, y.dtype)
         g, b = gamma.detach(), beta.detach()
@@ -206,13 +215,26 @@ class _ConvBNActTrain(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv_gemm(dy, dgrad_weight(weight, x.dtype), R=r, S=s, pad=r - 1 - pad)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None
+            if up4:
+                dx = ops.bilinear_bwd(dx, lo)
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
-def conv_bn_act(x: Tensor, conv: nn.Conv2d, norm: nn.Module, *, relu: bool = True) -> Tensor:
-    """ConvModule forward on an NHWC tensor (in the compute dtype); returns NHWC."""
+def subpix4_weight(weight: Tensor, cd: torch.dtype) -> dict:
+    """Phase weight sets of conv3x3(bilinear_x4(.)) for a [N,C,3,3] conv parameter (cached per parameter version)."""
+    def build():
+        w = conv_weight_matrix(weight)
+        return ops.subpix4_weights(w.float().contiguous(), weight.shape[1], cd)
+    return cached((weight,), f"subpix4:{cd}", build)
+
+
+def conv_bn_act(x: Tensor, conv: nn.Conv2d, norm: nn.Module, *, relu: bool = True, up4: bool = False) -> Tensor:
+    """ConvModule forward on an NHWC tensor (in the compute dtype); returns NHWC.  ``up4``: the input is bilinearly
+    upsampled x4 first (MultiLevelNeck's finest level) -- fused, see ops.up4_conv3x3."""
     r = conv.kernel_size[0]
     pad = conv.padding[0]
+    if up4 and not (r == 3 and pad == 1 and x.shape[1] >= 2 and x.shape[2] >= 2 and FUSE_UP4):
+        x, up4 = bilinear(x, (4 * x.shape[1], 4 * x.shape[2])), False
     training = norm.training
     if training:
         if isinstance(norm, nn.SyncBatchNorm):
@@ -222,7 +244,7 @@ def conv_bn_act(x: Tensor, conv: nn.Conv2d, norm: nn.Module, *, relu: bool = Tru
         momentum = 0.1 if norm.momentum is None else norm.momentum
         out = _ConvBNActTrain.apply(x, conv.weight, conv.bias, norm.weight, norm.bias,
                                     norm.running_mean, norm.running_var, momentum, norm.eps, pad,
-                                    relu, sync_group)
+                                    relu, sync_group, up4)
         if norm.num_batches_tracked is not None:
             norm.num_batches_tracked.add_(1)
         return out
@@ -234,6 +256,9 @@ def conv_bn_act(x: Tensor, conv: nn.Conv2d, norm: nn.Module, *, relu: bool = Tru
     scale, shift = cached((norm.weight, norm.bias, norm.running_mean, norm.running_var), "bnfold",
                           lambda: ops.bn_fold(norm.weight.detach(), norm.bias.detach(),
                                               norm.running_mean, norm.running_var, norm.eps))
+    if up4:
+        return ops.up4_conv3x3(x, subpix4_weight(conv.weight, cd), bias=None if conv.bias is None else conv.bias.detach(),
+                               scale=scale, shift=shift, act=ACT_RELU if relu else ACT_NONE)
     return ops.conv_gemm(x, gemm_weight(conv.weight, cd), R=r, S=r, pad=pad,
                          bias=None if conv.bias is None else conv.bias.detach(), scale=scale,
                          shift=shift, act=ACT_RELU if relu else ACT_NONE)

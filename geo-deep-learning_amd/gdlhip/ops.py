@@ -384,6 +384,80 @@ def adaptive_avgpool_bwd(dout: Tensor, in_size: tuple[int, int], din: Tensor | N
     return din
 
 
+# ------------------------------------------------------------------ fused bilinear x4 upsample -> 3x3 conv
+def pad_nhwc(x: Tensor, pad_h: int, pad_w: int, zero: bool = False) -> Tensor:
+    """NHWC border padding: replicate (default) or zeros."""
+    _need_cuda(x)
+    x4 = _nhwc4(x, "pad_nhwc x")
+    B, H, W, Cc = x4.shape
+    out = torch.empty((B, H + 2 * pad_h, W + 2 * pad_w, Cc), device=x.device, dtype=x.dtype)
+    check(_lib.load().gdl_pad_nhwc(_p(x4), dt(x4), B, H, W, Cc, x4.stride(0), x4.stride(1), x4.stride(2), _p(out),
+                                   pad_h, pad_w, int(zero), _stream()), "gdl_pad_nhwc")
+    return out
+
+
+def subpix4_weights(w32: Tensor, Cc: int, out_dtype: torch.dtype) -> dict:
+    """Phase weights of (bilinear x4 upsample -> 3x3 conv) from w32 [N, 9*C] f32 (K order dy,dx,c); csrc/subpixel.hip."""
+    _need_cuda(w32)
+    N = w32.shape[0]
+    if w32.dtype != torch.float32 or not w32.is_contiguous() or w32.shape[1] != 9 * Cc:
+        raise ValueError("subpix4_weights: contiguous f32 [N, 9*C] expected")
+    mk = lambda taps: torch.empty((4, N, taps * Cc), device=w32.device, dtype=out_dtype)  # noqa: E731
+    out = {"g22": mk(4), "g23": mk(6), "g32": mk(6), "g33": mk(9), "lines": mk(3)}
+    check(_lib.load().gdl_subpix4_weights(_p(w32), N, Cc, dt(out["g22"]), _p(out["g22"]), _p(out["g23"]), _p(out["g32"]),
+                                          _p(out["g33"]), _p(out["lines"]), _stream()), "gdl_subpix4_weights")
+    return out
+
+
+def up4_conv3x3(x: Tensor, wsets: dict, *, bias: Tensor | None = None, scale: Tensor | None = None,
+                shift: Tensor | None = None, act: int = ACT_NONE) -> Tensor:
+    """conv3x3(pad 1)(bilinear_x4(x)) on NHWC x [B,H,W,C] WITHOUT materialising the upsampled map: 16 phase
+    convolutions of the replicate-padded low-res map (four batched launches, 6.25 low-res taps on average instead of 9
+    high-res ones) written into the strided phase positions of the output, then the four outermost output lines --
+    the only ones the convolution's zero padding touches -- recomputed exactly by 1x3 line convolutions.
+    Reference: multilevel_neck.py:157-158 with scale 4 (+ models/utils.py:131-137)."""
+    _need_cuda(x)
+    x4 = _nhwc4(x, "up4_conv3x3 x")
+    B, H, W, Cc = x4.shape
+    N = wsets["g22"].shape[1]
+    es = x4.element_size()
+    xp = pad_nhwc(x4, 1, 1)                                   # replicate: the bilinear index clamping
+    Hp, Wp = H + 2, W + 2
+    y = torch.empty((B, 4 * H, 4 * W, N), device=x.device, dtype=x.dtype)
+    f32 = lambda t, name: None if t is None else _f32vec(t, N, name).data_ptr()  # noqa: E731
+    for gy, R in ((0, 2), (1, 3)):
+        for gx, S in ((0, 2), (1, 3)):
+            wg = wsets[f"g{R}{S}"]
+            py0, dpy = (0, 3) if R == 2 else (1, 1)
+            px0, dpx = (0, 3) if S == 2 else (1, 1)
+            a = ConvArgs()
+            a.inp, a.dtype = xp.data_ptr(), dt(xp)
+            a.B, a.H, a.W, a.C = B, H + R - 1, W + S - 1, Cc
+            a.in_sB, a.in_sH, a.in_sW = Hp * Wp * Cc, Wp * Cc, Cc
+            a.Ho, a.Wo, a.R, a.S, a.stride, a.pad = H, W, R, S, 1, 0
+            a.w, a.w_sN, a.N = wg.data_ptr(), R * S * Cc, N
+            a.out = y.data_ptr() + (py0 * 4 * W * N + px0 * N) * es
+            a.out_dtype = dt(y)
+            a.out_sB, a.out_sH, a.out_sW = 16 * H * W * N, 16 * W * N, 4 * N
+            a.alpha, a.act = 1.0, act
+            a.bias, a.scale, a.shift = f32(bias, "bias"), f32(scale, "scale"), f32(shift, "shift")
+            a.nz, a.nz_inner = 4, 2                           # z = (row phase index, column phase index)
+            a.in_sZ0, a.in_sZ1 = (Wp * Cc if R == 2 else 0), (Cc if S == 2 else 0)
+            a.w_sZ0, a.w_sZ1 = 2 * N * R * S * Cc, N * R * S * Cc
+            a.out_sZ0, a.out_sZ1 = dpy * 4 * W * N, dpx * N
+            batched_gemm_raw(a)
+    lines = wsets["lines"]
+    kw = dict(bias=bias, scale=scale, shift=shift, act=act)
+    for side, src, dst in ((0, x4[:, 0:1], y[:, 0:1]), (1, x4[:, H - 1:H], y[:, 4 * H - 1:4 * H])):
+        ln = pad_nhwc(bilinear(src, (1, 4 * W)), 0, 1, zero=True)               # [B,1,4W+2,C]
+        conv_gemm(ln, lines[side], R=1, S=3, out=dst, **kw)
+    for side, src, col in ((2, x4[:, :, 0:1], 0), (3, x4[:, :, W - 1:W], 4 * W - 1)):
+        ln = bilinear(src, (4 * H, 1)).view(B, 1, 4 * H, Cc)                    # the column as a line
+        ln = pad_nhwc(ln, 0, 1, zero=True)
+        conv_gemm(ln, lines[side], R=1, S=3, out=y[:, :, col, :].unsqueeze(1), **kw)
+    return y
+
+
 # ------------------------------------------------------------------ attention (unfused + fused)
 def _attn_check(q: Tensor, k: Tensor, v: Tensor, num_heads: int):
     _need_cuda(q, k, v)

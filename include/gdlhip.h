@@ -380,6 +380,16 @@ int gdl_dice_binary_loss_bwd(const float* logits, const int64_t* target, int64_t
                              const float* sums, const float* upstream, float grad_scale, float* dlogits,
                              int accumulate, gdl_stream_t stream);
 
+/* ---- fused bilinear x4 upsample -> 3x3 conv (multilevel_neck.py:157-158, scale 4) -------------------------------
+ * gdl_pad_nhwc: NHWC border padding by (pad_h, pad_w), replicate (zero_mode 0) or zeros (1): out [B,H+2ph,W+2pw,C] dense.
+ * gdl_subpix4_weights: the 16 phase weight sets of the sub-pixel decomposition from the 3x3 weights w [N][9*C]
+ * (f32, K order (dy,dx,c)): g22 / g23 / g32 / g33 = [4 phases][N][R*S*C] for the phase groups with R x S low-res
+ * taps, lines = [4][N][3*C] (top, bottom, left, right border-line convolutions); see csrc/subpixel.hip. */
+int gdl_pad_nhwc(const void* in, int dtype, int B, int H, int W, int C, int64_t in_sB, int64_t in_sH, int64_t in_sW,
+                 void* out, int pad_h, int pad_w, int zero_mode, gdl_stream_t stream);
+int gdl_subpix4_weights(const float* w, int N, int C, int out_dtype, void* g22, void* g23, void* g32, void* g33,
+                        void* lines, gdl_stream_t stream);
+
 /* ---- optimizer -------------------------------------------------------------------------
  * torch.optim.Adam step (configs/dofa_config_RGB.yaml:62-65) on one flat f32 tensor, with the
  * global-norm clip coefficient read from device memory (gradient_clip_val 1.0, :11). */

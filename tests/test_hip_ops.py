@@ -120,6 +120,54 @@ def test_conv_epilogue_row_segments(dtype, variant):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 9, 9, 64, 256), (1, 36, 36, 128, 256), (3, 5, 7, 64, 64), (1, 2, 2, 64, 128)])
+def test_up4_conv3x3_matches_upsample_then_conv(dtype, B, H, W, C, N):
+    """The fused sub-pixel form of conv3x3(pad 1)(bilinear x4 (align_corners=False)) (multilevel_neck.py:157-158) vs
+    torch's two ops, every pixel including the border lines the convolution's zero padding touches; with the folded-BN
+    + ReLU epilogue of the eval path; and through the training ConvModule node against the unfused path."""
+    x, w = q(rnd(B, H, W, C), dtype), q(rnd(N, C, 3, 3, seed=1) * 0.1, dtype)
+    bias, scale, shift = rnd(N, seed=2), rnd(N, seed=3), rnd(N, seed=4)
+    up = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=4, mode="bilinear", align_corners=False)
+    ref = F.conv2d(up, w, bias, padding=1).permute(0, 2, 3, 1)
+    wm = w.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous()
+    ws = ops.subpix4_weights(wm.to(DEV), C, dtype)
+    y = ops.up4_conv3x3(x.to(DEV, dtype), ws, bias=bias.to(DEV))
+    assert y.shape == (B, 4 * H, 4 * W, N)
+    # bf16: the reference rounds the upsampled map to bf16, the fused form rounds the combined weights instead
+    close(y, ref, dtype, "up4 conv", scale=None if dtype == torch.float32 else 2 * ref.abs().max().item())
+    for name, sl in (("top", (slice(None), 0)), ("bottom", (slice(None), -1)), ("left", (slice(None), slice(None), 0)),
+                     ("right", (slice(None), slice(None), -1))):
+        close(y[sl], ref[sl], dtype, f"up4 conv {name} line", scale=ref.abs().max().item() * (1 if dtype == torch.float32 else 2))
+    y = ops.up4_conv3x3(x.to(DEV, dtype), ws, bias=bias.to(DEV), scale=scale.to(DEV), shift=shift.to(DEV), act=ops.ACT_RELU)
+    close(y, F.relu(ref * scale + shift), dtype, "up4 conv + folded BN + ReLU",
+          scale=None if dtype == torch.float32 else 2 * ref.abs().max().item())
+    if B < 2:
+        return
+    # training node: same gradients as the unfused path (the backward runs on the recomputed upsampled map)
+    conv = torch.nn.Conv2d(C, N, 3, padding=1).to(DEV).to(memory_format=torch.channels_last)
+    norm = torch.nn.BatchNorm2d(N).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w.to(DEV))
+    got = {}
+    for fuse in (True, False):
+        gnn.FUSE_UP4 = fuse
+        try:
+            for p in list(conv.parameters()) + list(norm.parameters()):
+                p.grad = None
+            norm.reset_running_stats()
+            xd = x.to(DEV, dtype).requires_grad_()
+            out = gnn.conv_bn_act(xd, conv, norm.train(), relu=True, up4=True)
+            out.float().square().mean().backward()
+            got[fuse] = (out.detach().float(), xd.grad.float(), conv.weight.grad.float().clone(), norm.weight.grad.clone(),
+                         norm.running_var.clone())
+        finally:
+            gnn.FUSE_UP4 = True
+    tol_dt = dtype
+    for a, b, what in zip(got[True], got[False], ("out", "dx", "dw", "dgamma", "running_var")):
+        close(a, b, tol_dt, f"fused vs unfused {what}", scale=None if dtype == torch.float32 else 4 * b.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,C,N,R", [(2, 10, 12, 64, 96, 3), (1, 18, 18, 128, 256, 3), (2, 7, 5, 64, 64, 1),
                                          (3, 36, 36, 64, 128, 3),
                                          # channel tails (C not a multiple of the K chunk: MiT-B0's 32 / 160 channels)
