@@ -191,8 +191,7 @@ class _ConvBNActTrain(Function):
         pad, relu, eps, has_bias, sync_group, world, p_local, p_share, up4 = ctx.cfg
         n, c, r, s = weight.shape
         lo = (x.shape[1], x.shape[2])
-        if up4:   # the backward works on the upsampled map: recomputed here (one HBM-bound pass) instead of saved
-            x = ops.bilinear(x, (4 * lo[0], 4 * lo[1]))
+        x_lo = x
         if gout.dtype != y.dtype:
             gout = to_compute(gout, y.dtype)
         g, b = gamma.detach(), beta.detach()
@@ -203,20 +202,21 @@ class _ConvBNActTrain(Function):
             sg, sb = sync_sum_pair(dgamma, dbeta, sync_group or None)
             sg, sb = sg * p_share, sb * p_share
         dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, p_local, out=y)
-        dw = None
-        if ctx.needs_input_grad[1]:
-            dw = ops.conv_wgrad(x, dy, R=r, S=s, pad=pad)
-            # same strides as the channels-last parameter (for 1x1 kernels torch keeps (C,1,1,1))
-            dw = dw.view(n, c, 1, 1) if r == 1 and s == 1 else dw.view(n, r, s, c).permute(0, 3, 1, 2)
         dbias = None
         if has_bias and ctx.needs_input_grad[2]:
             # a bias feeding train-mode BN has an analytically zero gradient
             dbias = torch.zeros(n, device=x.device, dtype=torch.float32)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0]:   # (before the weight gradient: the fused x4 path consumes dy's border lines)
             dx = ops.conv_gemm(dy, dgrad_weight(weight, x.dtype), R=r, S=s, pad=r - 1 - pad)
             if up4:
                 dx = ops.bilinear_bwd(dx, lo)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            # up4: phase weight gradients on the low-res map (31 % fewer MACs, no upsampled tensor); dy is dead afterwards
+            dw = ops.up4_conv3x3_wgrad(x_lo, dy) if up4 else ops.conv_wgrad(x, dy, R=r, S=s, pad=pad)
+            # same strides as the channels-last parameter (for 1x1 kernels torch keeps (C,1,1,1))
+            dw = dw.view(n, c, 1, 1) if r == 1 and s == 1 else dw.view(n, r, s, c).permute(0, 3, 1, 2)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
