@@ -482,10 +482,12 @@ def up4_conv3x3_wgrad(x: Tensor, dy: Tensor) -> Tensor:
         raise ValueError("up4_conv3x3_wgrad: dy must be a contiguous [B,4H,4W,N] tensor of x's dtype")
     dev = x.device
     dlines = torch.empty((4, N, 3 * Cc), device=dev, dtype=torch.float32)
-    for i, (ln, view) in enumerate(zip(_up4_lines(x4), _up4_line_views(dy))):
-        conv_wgrad(ln, view, R=1, S=3, dw=dlines[i])
-    for view in _up4_line_views(dy):
-        view.zero_()
+    # the forward writes the columns last, so the four corner pixels belong to the column convolutions: columns first,
+    # zeroed, then the rows (whose corners are zero by then)
+    lns, views = _up4_lines(x4), _up4_line_views(dy)
+    for i in (2, 3, 0, 1):
+        conv_wgrad(lns[i], views[i], R=1, S=3, dw=dlines[i])
+        views[i].zero_()
     xp = pad_nhwc(x4, 1, 1)
     Hp, Wp = H + 2, W + 2
     es = dy.element_size()
