@@ -40,8 +40,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // instead of one zero-padded tap, so a 3x3 conv on 16 channels takes 3 K-steps instead of 9.  The weight rows
 // [N][(tap, c)] are already contiguous in that order; on the activation side a lane's 16-byte piece belongs to tap
 // (chunk's first tap + piece / pieces-per-tap), which only shifts its pixel offset and its halo bit.
+// TL ("timeline", tuning only, dbg mode 7): per-wave shader-cycle totals of the K loop's phases -> k.probe[10240 + wave*8 + i]
+// of block 0: i = 0 MFMA groups 0-2 (with their fragment reads), 1 wait for own DMA, 2 barrier, 3 DMA issue, 4 last group.
 template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false, bool CT = false,
-          bool TP = false>
+          bool TP = false, bool TL = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const KArgs k) {
   constexpr int ES = TileTraits<T>::ES;
   constexpr int BKE = TileTraits<T>::BKE;
@@ -245,6 +247,17 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   // wait for the OLDER fragment reads only (lgkmcnt(6)) instead of draining every LDS read before the first MFMAs
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
   fetch(smem, 0, 0);
+  unsigned long long tl[5] = {0, 0, 0, 0, 0}, tl_t = 0;
+  auto stamp = [&](int i) {
+    if constexpr (TL) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_readcyclecounter();
+      tl[i] += now - tl_t;
+      tl_t = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if constexpr (TL) { __builtin_amdgcn_sched_barrier(0); tl_t = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
   for (int kt = 0; kt < k.KT; ++kt) {
     const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
@@ -254,15 +267,26 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
       mfmas(kk & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    stamp(0);
     if (kt + 1 < k.KT) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt+1 has landed
+      stamp(1);
       __syncthreads();                                   // ... and everyone's; nobody reads tile kt's stage any more
+      stamp(2);
       if (kt + 2 < k.KT) issue(kt & 1, (!PP || half == (kt & 1)) && k.dbg != 1);
+      stamp(3);
       fetch(smem + ((kt + 1) & 1) * STAGE_BYTES, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     mfmas(1);
     __builtin_amdgcn_sched_barrier(0);
+    stamp(4);
+  }
+  if constexpr (TL) {
+    if (k.probe && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) k.probe[10240 + wave * 8 + i] = tl[i];
+    }
   }
 
   if (k.probe && tid == 0 && blockIdx.x < 2048) {
@@ -279,14 +303,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
 }
 
 template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false, bool CT = false,
-          bool TP = false>
+          bool TP = false, bool TL = false>
 int launch_x(const KArgs& k, hipStream_t stream) {
   constexpr int BM = WARPS_M * TM * 32, BN = WARPS_N * TN * 32;
   KArgs kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.a.N + BN - 1) / BN;
   const size_t lds = 2 * (BM + BN) * 128;
-  auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA, PP, CT, TP>;
+  auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA, PP, CT, TP, TL>;
   GDL_SET_MAX_LDS_ONCE(kern, lds);   // one flag per template instantiation of launch_x
   dim3 grid(kk.tiles_m * kk.tiles_n, k.a.nz), block(64 * WARPS_M * WARPS_N);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, kk);
@@ -388,6 +412,7 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   }
   if (a.dtype == GDL_BF16) {
     if (variant == 4) return conv3x3_sf_launch(k, s);
+    if (variant == 3 && k.dbg == 7) return launch_x<bf16_tag, 2, 4, 4, 2, false, true, false, false, true>(k, s);
     if (variant == 3) return launch_x<bf16_tag, 2, 4, 4, 2, false, true>(k, s);
     if (variant == 2) return launch_x<bf16_tag, 2, 4, 4, 2, false>(k, s);
     if (variant == 5 && tap_packed) return launch_x<bf16_tag, 4, 1, 2, 2, false, false, false, true>(k, s);

@@ -83,8 +83,8 @@ def test_conv_epilogue_row_segments(dtype, variant):
     lib = _lib.load()
     lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
     B, T, K, N = 3, 1297, 128, 208          # M = 3891 (tail of 51 rows), N % 64 = 16, N % 256 != 0
-    if variant == 3:
-        N = 512                              # the 256^2 tile needs N % 256 == 0
+    if variant >= 3:
+        N = 512                              # the 256^2 tiles need N % 256 == 0
     x, w = q(rnd(B, T, K), dtype), q(rnd(N, K, seed=1), dtype) * 0.1
     bias, scale, shift = rnd(N, seed=2), rnd(N, seed=3), rnd(N, seed=4)
     resid, bs = rnd(B, T, N, seed=5), torch.tensor([0.0, 1.25, 0.5])

@@ -74,6 +74,11 @@ def run(name, m, k, n, kind, odt, variant, dbg):
     mhz = (kl[:, 0] / (kl[:, 1] / 100.0)).median().item()
     first = (tl[:, 0] - t0).sort().values / 100.0
     kt = kk // 64
+    if dbg == 7:
+        ph = buf[10240:10240 + 64].view(8, 8)[:, :5].double().cpu() / kt
+        names = ("groups 0-2", "wait own DMA", "barrier", "DMA issue", "group 3")
+        for w in range(8):
+            print(f"    wave {w}: " + ", ".join(f"{n} {ph[w, i]:.0f}" for i, n in enumerate(names)) + f"  (sum {ph[w].sum():.0f} cyc/K-step)")
     print(f"{name:32s} v{variant} dbg{dbg}: {2 * m * kk * n / us / 1e6:7.1f} TF/s ({us:6.0f} us); blocks {nb}; "
           f"prologue+K loop {kl[:, 0].median():.0f} cyc ({kl[:, 0].median() / kt:.0f}/K-step), epilogue "
           f"{(tot - kl[:, 0]).median():.0f} cyc; block {dur.median():.1f} us (p10 {dur.quantile(0.1):.1f} p90 {dur.quantile(0.9):.1f}); "
@@ -82,7 +87,7 @@ def run(name, m, k, n, kind, odt, variant, dbg):
 
 
 FULL = len(sys.argv) > 2 and sys.argv[2] == "full"
-for shp in ([] if len(sys.argv) > 2 and sys.argv[2] == "convs" else SHAPES):
+for shp in ([] if len(sys.argv) > 2 and sys.argv[2] in ("convs", "phases") else SHAPES):
     for variant in (3, 1):
         for dbg in ((0, 1, 2) if FULL else (0,)):
             if variant == 1 and dbg:
@@ -90,8 +95,14 @@ for shp in ([] if len(sys.argv) > 2 and sys.argv[2] == "convs" else SHAPES):
             run(*shp, variant, dbg)
 CONVS = [("neck 3x3 768->768 @144", (B, 144, 144), 768, 768, None, bf), ("fusion 3x3 1024->256 @144", (B, 144, 144), 1024, 256, None, bf),
          ("fpn 3x3 256->256 @144", (B, 144, 144), 256, 256, None, bf), ("neck 3x3 768->768 @72", (B, 72, 72), 768, 768, None, bf)]
+if len(sys.argv) > 2 and sys.argv[2] == "phases":
+    run(*SHAPES[0], 3, 7)
+    run(*SHAPES[3], 3, 7)
+    run(*CONVS[0], 3, 7)
+    sys.exit(0)
 for shp in CONVS:
     run(*shp, 4, 0)
+    run(*shp, 3, 0)
     if FULL:
         run(*shp, 4, 1)
         run(*shp, 4, 2)

@@ -93,6 +93,84 @@ static void run(const char* name, const char* d, unsigned region, int grid, int 
          bytes * grid / (ms * 1e-3) / 1e12, ms);
 }
 
+
+// Same loop, LDS-DMA only, but the source of a piece is NOT 1 KiB of contiguous memory: it is 1024/ROWB row segments of
+// ROWB bytes, `stride` bytes apart (an NHWC activation tile: rows = pixels, 128 B of K per pixel, stride = C * 2 bytes).
+template <int ROWB, bool TO_LDS>
+__global__ __launch_bounds__(512) void ks(const char* src, unsigned stride, unsigned nrows, int iters, unsigned long long* out) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
+  const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds);
+  const unsigned region = stride * nrows;
+  unsigned long long a = (unsigned long long)(src + (size_t)blockIdx.x * region);
+  srd_t s;
+  s.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  s.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffff);
+  s.z = region;
+  s.w = 0x00020000;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, region, 0x00020000);
+  constexpr unsigned LPR = ROWB / 16, RPP = 1024 / ROWB;    // lanes per row segment, row segments per piece
+  unsigned voff[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const unsigned row = ((wave * 8 + p) * RPP + lane / LPR) % nrows;
+    voff[p] = row * stride + (lane % LPR) * 16;
+  }
+  u4 cur[8], nxt[8];
+  unsigned acc = 0;
+  __syncthreads();
+  const unsigned long long t0 = clock64(), r0 = wall_clock64();
+  auto issue = [&](int it, u4* dst) {
+    const unsigned so = __builtin_amdgcn_readfirstlane(((unsigned)it * ROWB) % stride);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      if (TO_LDS) dma16(voff[p], s, so, base + wave * 8192 + p * 1024);
+      else dst[p] = ld16(voff[p], rs, so);
+    }
+  };
+  auto consume = [&](u4* r) {
+    if (TO_LDS) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) acc ^= r[p].x ^ r[p].w;
+    }
+    __syncthreads();
+  };
+  issue(0, cur);
+  for (int it = 1; it <= iters; it += 2) {
+    issue(it, nxt);
+    consume(cur);
+    issue(it + 1, cur);
+    consume(nxt);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t1 = clock64(), r1 = wall_clock64();
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = t1 - t0; out[2 * blockIdx.x + 1] = r1 - r0; }
+  if (acc == 0x12345678u || lds[threadIdx.x] == 0x5a) out[0] += 1;
+}
+
+template <int ROWB, bool TO_LDS>
+static void run_s(const char* d, unsigned stride, unsigned nrows, int grid, int iters, unsigned long long* dout) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((ks<ROWB, TO_LDS>), dim3(grid), dim3(512), 0, 0, d, stride, nrows, iters, dout);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL((ks<ROWB, TO_LDS>), dim3(grid), dim3(512), 0, 0, d, stride, nrows, iters, dout);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(2 * grid);
+  hipMemcpy(h.data(), dout, 16 * grid, hipMemcpyDeviceToHost);
+  double cyc = 0, real = 0;
+  for (int b = 0; b < grid; ++b) { cyc += h[2 * b]; real += h[2 * b + 1]; }
+  cyc /= grid; real /= grid;
+  const double bytes = 65536.0 * iters;
+  printf("%s row segments of %4d B, stride %5u B, %4u rows/block, grid %4d: %7.1f cyc / 64 KiB = %5.1f B/clk/CU (%4.1f cyc per segment), "
+         "clock %4.0f MHz; chip %6.2f TB/s\n", TO_LDS ? "LDS-DMA  " : "VGPR only", ROWB, stride, nrows, grid, cyc / iters, bytes / cyc,
+         cyc / iters / (65536.0 / ROWB), cyc / (real * 10.0) * 1000.0, bytes * grid / (ms * 1e-3) / 1e12);
+}
+
 int main() {
   const size_t total = (size_t)256 * (4u << 20);
   char* d; unsigned long long* o;
@@ -106,6 +184,17 @@ int main() {
       run<2>("VGPR only", d, region, grid, iters, o);
       run<3>("half DMA, half VGPR + ds_write", d, region, grid, iters, o);
     }
+  }
+  // strided row segments, L2-resident footprint (256 blocks x 64 rows x stride <= 24 MiB)
+  for (int grid : {1, 256}) {
+    for (unsigned stride : {1536u, 2048u, 512u}) {
+      run_s<64, true>(d, stride, 64, grid, iters, o);
+      run_s<128, true>(d, stride, 64, grid, iters, o);
+      run_s<256, true>(d, stride, 64, grid, iters, o);
+      run_s<512, true>(d, stride, 64, grid, iters, o);
+      run_s<128, false>(d, stride, 64, grid, iters, o);
+    }
+    run_s<128, true>(d, 1536u, 2048, grid, iters, o);    // 3 MiB per block: streamed
   }
   return 0;
 }
