@@ -82,12 +82,22 @@ def _grad_check(name, grad, ref_norm, ref_sample, n):
     assert bad.mean() <= 0.01, (name, float(bad.mean()))
 
 
-def _mask_check(got_mask, ref_logits, ref_mask):
+def _mask_check(got_mask, ref_logits, ref_mask, max_mismatch=None):
+    """Bit-exact wherever the reference's top-2 margin exceeds the logit tolerance; the mismatches that remain (pixels
+    whose two best logits are closer than any two f32 summation orders can resolve) are COUNTED, printed (pytest -s / the
+    failure message) and bounded: at most 1e-4 of the pixels, or ``max_mismatch`` pixels when the caller pins a count."""
     top2 = ref_logits.topk(2, dim=1).values
-    decided = ((top2[:, 0] - top2[:, 1]) > LOGIT_TOL).numpy()
+    margin = (top2[:, 0] - top2[:, 1]).numpy()
+    decided = margin > LOGIT_TOL
     got = got_mask.cpu().numpy()
-    assert (got == ref_mask)[decided].all(), "argmax differs where the oracle's margin exceeds the tolerance"
-    assert (got != ref_mask).mean() < 1e-4
+    diff = got != ref_mask
+    n_bad, n_pix, n_undecided = int(diff.sum()), diff.size, int((~decided).sum())
+    worst = float(margin[diff].max()) if n_bad else 0.0
+    print(f"mask check: {n_bad} of {n_pix} pixels differ ({n_undecided} pixels have a top-2 margin <= {LOGIT_TOL:g}; "
+          f"largest margin among the differing pixels {worst:.2e})")
+    assert not (diff & decided).any(), f"argmax differs at a pixel whose margin {worst:.2e} exceeds the tolerance {LOGIT_TOL:g}"
+    bound = max_mismatch if max_mismatch is not None else int(1e-4 * n_pix)
+    assert n_bad <= bound, f"{n_bad} mismatching pixels of {n_pix} (bound {bound}, {n_undecided} undecidable)"
 
 
 @pytest.fixture(scope="module")

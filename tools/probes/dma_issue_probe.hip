@@ -20,7 +20,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 // MF: MFMAs (32x32x16 bf16, 8 independent accumulators) every wave issues per iteration after its DMA burst / reads;
 // MF_FIRST: waves 4-7 (the SIMD partners of the issuing waves 0-3) do their MFMAs at the START of the iteration instead
-template <int P, bool LOOKAHEAD, int READS = 0, int MF = 0>
+template <int P, bool LOOKAHEAD, int READS = 0, int MF = 0, int RDPAT = 0>
 __global__ __launch_bounds__(512) void k(const char* src, unsigned wmask, int iters, unsigned long long* out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -62,7 +62,9 @@ __global__ __launch_bounds__(512) void k(const char* src, unsigned wmask, int it
       uint4 v[READS ? READS : 1];
 #pragma unroll
       for (int r = 0; r < READS; ++r)      // all reads in flight together (throughput, not latency)
-        v[r] = *(const uint4*)(st + ((rd0 + (r & 7) * 4096) ^ (((r >> 3) & 3) << 5)));
+        v[r] = RDPAT == 1 ? *(const uint4*)(st + lane * 16 + r * 1024 + (wave & 1) * 32768)     // linear: 1 KiB contiguous per read
+                          : RDPAT == 2 ? *(const uint4*)(st + (lane & 31) * 128 + (lane >> 5) * 16 + (r & 7) * 4096 + ((r >> 3) & 3) * 32)   // rows of 128 B, no swizzle (8-way conflicts)
+                                       : *(const uint4*)(st + ((rd0 + (r & 7) * 4096) ^ (((r >> 3) & 3) << 5)));
 #pragma unroll
       for (int r = 0; r < READS; ++r) { sink.x ^= v[r].x; sink.y ^= v[r].y; sink.z ^= v[r].z; sink.w ^= v[r].w; }
     }
@@ -85,10 +87,10 @@ __global__ __launch_bounds__(512) void k(const char* src, unsigned wmask, int it
   if ((sink.x ^ sink.y ^ sink.z ^ sink.w) == 0x12345u || t == 1.2345f) out[15] = 1;
 }
 
-template <int P, bool LOOKAHEAD, int READS = 0, int MF = 0>
+template <int P, bool LOOKAHEAD, int READS = 0, int MF = 0, int RDPAT = 0>
 static void run(const char* d, unsigned wmask, unsigned long long* dout, int grid) {
   const int iters = 2000;
-  auto kern = k<P, LOOKAHEAD, READS, MF>;
+  auto kern = k<P, LOOKAHEAD, READS, MF, RDPAT>;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 131072, 0, d, wmask, iters, dout);
   hipDeviceSynchronize();
@@ -99,21 +101,20 @@ static void run(const char* d, unsigned wmask, unsigned long long* dout, int gri
   int nw = 0, first = -1;
   for (int w = 0; w < 8; ++w) if ((wmask >> w) & 1u) { ++nw; if (first < 0) first = w; }
   const double per_iter = (double)h[0] / iters, per_piece = first < 0 ? 0.0 : (double)h[2 * first + 1] / iters / P;
-  printf("%2d MFMA + %2d ds_read_b128 per wave, waves 0x%02x (%d issuing) x %2d pieces, %s, grid %3d: burst %6.1f cyc/piece (wave %d), iteration %7.1f cyc = %5.1f B/clk/CU\n",
-         MF, READS, wmask, nw, P, LOOKAHEAD ? "one burst of lookahead" : "wait for own burst    ", grid, per_piece, first, per_iter, nw * P * 1024.0 / per_iter);
+  printf("[read pattern %d] %2d MFMA + %2d ds_read_b128 per wave, waves 0x%02x (%d issuing) x %2d pieces, %s, grid %3d: burst %6.1f cyc/piece (wave %d), iteration %7.1f cyc = %5.1f B/clk/CU\n",
+         RDPAT, MF, READS, wmask, nw, P, LOOKAHEAD ? "one burst of lookahead" : "wait for own burst    ", grid, per_piece, first, per_iter, nw * P * 1024.0 / per_iter);
 }
 
 int main() {
   char* d; unsigned long long* o;
   hipMalloc(&d, (size_t)256 * 131072); hipMemset(d, 1, (size_t)256 * 131072);
   hipMalloc(&o, 256);
-  // LDS fragment-read throughput with and without LDS-DMA writes landing at the same time (no MFMAs)
-  run<16, false, 24, 0>(d, 0x00u, o, 256);
-  run<16, false, 24, 0>(d, 0x0fu, o, 256);
-  run<16, true, 24, 0>(d, 0x0fu, o, 256);
-  run<8, true, 24, 0>(d, 0xffu, o, 256);
-  run<16, false, 0, 0>(d, 0x0fu, o, 256);
-  run<16, false, 12, 0>(d, 0x00u, o, 256);
-  run<16, false, 12, 0>(d, 0x0fu, o, 256);
+  // ds_read_b128 throughput by address pattern (0 = the GEMM's swizzled rows, 1 = linear, 2 = unswizzled rows)
+  run<16, false, 24, 0, 0>(d, 0x00u, o, 256);
+  run<16, false, 24, 0, 1>(d, 0x00u, o, 256);
+  run<16, false, 24, 0, 2>(d, 0x00u, o, 256);
+  run<16, false, 48, 0, 0>(d, 0x00u, o, 256);
+  run<16, false, 48, 0, 1>(d, 0x00u, o, 256);
+  run<16, false, 24, 0, 1>(d, 0x0fu, o, 256);
   return 0;
 }
