@@ -154,3 +154,21 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
+
+// Sum of f(i) for i = begin, begin + step, ... < end, added in exactly that order (deterministic, same result as the plain
+// loop) but with EIGHT loads in flight: the final-reduction kernels walk a few dozen partials per thread and were bound by one
+// memory latency per partial.
+template <typename ACC, typename F>
+__device__ __forceinline__ ACC ordered_sum8(int begin, int end, int step, F f) {
+  ACC s = 0;
+  int i = begin;
+  for (; i + 7 * step < end; i += 8 * step) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = f(i + u * step);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; i < end; i += step) s += f(i);
+  return s;
+}

@@ -142,19 +142,22 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const void* __restrict__
 __global__ void bn_stats_final(const float* __restrict__ ws, int nsplit, int C, int64_t P,
                                float* __restrict__ mean, float* __restrict__ var, float* running_mean,
                                float* running_var, float momentum) {
-  // block = 8 channels x 32 split groups: the nsplit partials are summed 32-wide, then via LDS
-  __shared__ double ps[32][8], pq[32][8];
-  const int cl = threadIdx.x & 7, grp = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cl;
+  // block = 4 channels x 64 split groups: the nsplit partials are summed 64-wide (eight loads in flight per thread), then
+  // via LDS in a fixed order
+  __shared__ double ps[64][4], pq[64][4];
+  const int cl = threadIdx.x & 3, grp = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   double s = 0, q = 0;
-  if (c < C)
-    for (int i = grp; i < nsplit; i += 32) { s += ws[((int64_t)i * 2) * C + c]; q += ws[((int64_t)i * 2 + 1) * C + c]; }
+  if (c < C) {
+    s = ordered_sum8<double>(grp, nsplit, 64, [&](int i) { return ws[((int64_t)i * 2) * C + c]; });
+    q = ordered_sum8<double>(grp, nsplit, 64, [&](int i) { return ws[((int64_t)i * 2 + 1) * C + c]; });
+  }
   ps[grp][cl] = s; pq[grp][cl] = q;
   __syncthreads();
   if (grp != 0 || c >= C) return;
   s = 0; q = 0;
 #pragma unroll
-  for (int g = 0; g < 32; ++g) { s += ps[g][cl]; q += pq[g][cl]; }
+  for (int g = 0; g < 64; ++g) { s += ps[g][cl]; q += pq[g][cl]; }
   const double m = s / (double)P;
   double v = q / (double)P - m * m;
   v = v > 0 ? v : 0;
@@ -265,18 +268,20 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const void* __restrict__ x
 
 __global__ void bn_bwd_final(const float* __restrict__ ws, int nsplit, int C, float* __restrict__ dgamma,
                              float* __restrict__ dbeta) {
-  __shared__ double ps[32][8], pq[32][8];
-  const int cl = threadIdx.x & 7, grp = threadIdx.x >> 3;
-  const int c = blockIdx.x * 8 + cl;
+  __shared__ double ps[64][4], pq[64][4];
+  const int cl = threadIdx.x & 3, grp = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   double s = 0, q = 0;
-  if (c < C)
-    for (int i = grp; i < nsplit; i += 32) { s += ws[((int64_t)i * 2) * C + c]; q += ws[((int64_t)i * 2 + 1) * C + c]; }
+  if (c < C) {
+    s = ordered_sum8<double>(grp, nsplit, 64, [&](int i) { return ws[((int64_t)i * 2) * C + c]; });
+    q = ordered_sum8<double>(grp, nsplit, 64, [&](int i) { return ws[((int64_t)i * 2 + 1) * C + c]; });
+  }
   ps[grp][cl] = s; pq[grp][cl] = q;
   __syncthreads();
   if (grp != 0 || c >= C) return;
   s = 0; q = 0;
 #pragma unroll
-  for (int g = 0; g < 32; ++g) { s += ps[g][cl]; q += pq[g][cl]; }
+  for (int g = 0; g < 64; ++g) { s += ps[g][cl]; q += pq[g][cl]; }
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
 }
@@ -373,7 +378,7 @@ extern "C" int gdl_bn_stats(const void* x, int dtype, int64_t P, int C, int64_t 
   dim3 grid((C + 255) / 256, nsplit);
   if (dtype == GDL_BF16) hipLaunchKernelGGL(bn_stats_partial<uint16_t>, grid, dim3(256), 0, s, x, P, C, x_sP, ws);
   else hipLaunchKernelGGL(bn_stats_partial<float>, grid, dim3(256), 0, s, x, P, C, x_sP, ws);
-  hipLaunchKernelGGL(bn_stats_final, dim3((C + 7) / 8), dim3(256), 0, s, ws, nsplit, C, P, mean, var, running_mean, running_var, momentum);
+  hipLaunchKernelGGL(bn_stats_final, dim3((C + 3) / 4), dim3(256), 0, s, ws, nsplit, C, P, mean, var, running_mean, running_var, momentum);
   GDL_CHECK_LAUNCH("gdl_bn_stats");
   return GDL_OK;
 }
@@ -409,7 +414,7 @@ extern "C" int gdl_bn_bwd_reduce(const void* x, const void* dy, int dtype, int64
     hipLaunchKernelGGL(bn_bwd_partial<uint16_t>, grid, dim3(256), 0, s, x, dy, P, C, x_sP, dy_sP, mean, var, gamma, beta, eps, relu, ws);
   else
     hipLaunchKernelGGL(bn_bwd_partial<float>, grid, dim3(256), 0, s, x, dy, P, C, x_sP, dy_sP, mean, var, gamma, beta, eps, relu, ws);
-  hipLaunchKernelGGL(bn_bwd_final, dim3((C + 7) / 8), dim3(256), 0, s, ws, nsplit, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_final, dim3((C + 3) / 4), dim3(256), 0, s, ws, nsplit, C, dgamma, dbeta);
   GDL_CHECK_LAUNCH("gdl_bn_bwd_reduce");
   return GDL_OK;
 }

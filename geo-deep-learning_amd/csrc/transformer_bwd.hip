@@ -13,8 +13,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   const int cl = threadIdx.x & 7, grp = threadIdx.x >> 3;
   const int i = blockIdx.x * 8 + cl;
   double s = 0;
-  if (i < total)
-    for (int b = grp; b < nblk; b += 32) s += ws[(int64_t)b * stride + i];
+  if (i < total) s = ordered_sum8<double>(grp, nblk, 32, [&](int b) { return ws[(int64_t)b * stride + i]; });
   part[grp][cl] = s;
   __syncthreads();
   if (grp != 0 || i >= total) return;

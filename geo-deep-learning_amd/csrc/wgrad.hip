@@ -807,8 +807,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __r
   const int64_t total = (int64_t)N * K;
   const int64_t i = (int64_t)blockIdx.x * 32 + col;
   float s = 0.f;
-  if (i < total)
-    for (int sp = grp; sp < splits; sp += 8) s += ws[(int64_t)sp * total + i];
+  if (i < total) s = ordered_sum8<float>(grp, splits, 8, [&](int sp) { return ws[(int64_t)sp * total + i]; });
   part[grp][col] = s;
   __syncthreads();
   if (grp != 0 || i >= total) return;
@@ -827,8 +826,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   ws += (int64_t)zb * splits * total;
   dw += (zb / nz_inner) * dw_sZ0 + (zb % nz_inner) * dw_sZ1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += ws[(int64_t)sp * total + i];
+    const float s = ordered_sum8<float>(0, splits, 1, [&](int sp) { return ws[(int64_t)sp * total + i]; });
     const int64_t n = i / K, kk = i - n * K;
     float* q = dw + n * dw_sN + kk;
     *q = accumulate ? *q + s : s;
