@@ -15,7 +15,7 @@ from torch import Tensor, nn
 from torch.autograd import Function
 
 from . import ops
-from .nn import (_world, cached, conv_weight_matrix, sync_batch_stats, sync_sum_pair, to_compute,
+from .nn import (_world, cached, mark_updated, conv_weight_matrix, sync_batch_stats, sync_sum_pair, to_compute,
                  update_running_stats)
 from .ops import ACT_NONE, ACT_RELU, ACT_RESID_RELU
 from .tnn import _dense
@@ -125,12 +125,16 @@ class _ConvBNTrain(Function):
         wq, _ = padded_operands(weight, cd, cpad, npad)
         y = ops.conv_gemm(x, wq, R=r, S=s, stride=stride, pad=pad)
         world = _world(sync_group) if sync_group is not False else 1
-        mean, var = ops.bn_stats(y)
         p_local, p_share, total = y.numel() // npad, None, y.numel() // npad
+        in_kernel = world == 1 and running_mean is not None and npad == n   # the statistics kernel updates the buffers itself
+        mean, var = ops.bn_stats(y, running_mean, running_var, momentum) if in_kernel else ops.bn_stats(y)
         if world > 1:
             mean, var, total = sync_batch_stats(mean, var, sync_group or None, count=p_local)
             p_share = p_local / total
-        if running_mean is not None:
+        if in_kernel:     # written through raw pointers: invalidate the eval-mode fold cache
+            mark_updated(running_mean)
+            mark_updated(running_var)
+        elif running_mean is not None:
             update_running_stats(running_mean, running_var, mean[:n], var[:n], momentum, total)
         g, b = _padvec(gamma, npad), _padvec(beta, npad)
         out = ops.bn_apply(y, mean, var, g, b, eps, relu)
