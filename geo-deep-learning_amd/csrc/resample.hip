@@ -96,6 +96,52 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const void* __restric
   }
 }
 
+// out = sum_k bilinear(src_k -> Ho x Wo), up to three dense NHWC sources of different sizes with the same channel count,
+// ONE write of the output.  Used where a 1x1 convolution over a concat of upsampled pyramid levels is evaluated per
+// level at the level's own resolution (a 1x1 convolution and a bilinear resize commute), SegFormer's linear_fuse:
+// the upsampled partial results are summed here instead of being written one by one.  Source maps are small (L2-resident).
+struct SumSrc { const void* p[3]; int H[3], W[3]; };
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bilinear_sum_kernel(SumSrc src, int nsrc, int B, int C, void* out, int Ho, int Wo) {
+  const int cv = C / VEC;
+  const int64_t total = (int64_t)B * Ho * Wo * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cv) * VEC;
+    int64_t t = i / cv;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = 0.f;
+    for (int k = 0; k < nsrc; ++k) {
+      const int Hi = src.H[k], Wi = src.W[k];
+      int y0, y1, x0, x1; float ly, lx;
+      src_index((float)Hi / (float)Ho, oy, Hi, y0, y1, ly);
+      src_index((float)Wi / (float)Wo, ox, Wi, x0, x1, lx);
+      const int64_t base = (int64_t)b * Hi * Wi * C + c;
+      float a[VEC], bb[VEC], cc[VEC], d[VEC];
+      if constexpr (VEC == 8) {
+        V8::ld(src.p[k], base + ((int64_t)y0 * Wi + x0) * C, a);
+        V8::ld(src.p[k], base + ((int64_t)y0 * Wi + x1) * C, bb);
+        V8::ld(src.p[k], base + ((int64_t)y1 * Wi + x0) * C, cc);
+        V8::ld(src.p[k], base + ((int64_t)y1 * Wi + x1) * C, d);
+      } else {
+        V4<T>::ld(src.p[k], base + ((int64_t)y0 * Wi + x0) * C, a);
+        V4<T>::ld(src.p[k], base + ((int64_t)y0 * Wi + x1) * C, bb);
+        V4<T>::ld(src.p[k], base + ((int64_t)y1 * Wi + x0) * C, cc);
+        V4<T>::ld(src.p[k], base + ((int64_t)y1 * Wi + x1) * C, d);
+      }
+      const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] += hy * (hx * a[j] + lx * bb[j]) + ly * (hx * cc[j] + lx * d[j]);
+    }
+    const int64_t ooff = (((int64_t)b * Ho + oy) * Wo + ox) * C + c;
+    if constexpr (VEC == 8) V8::st(out, ooff, o);
+    else V4<T>::st(out, ooff, o);
+  }
+}
+
 // Backward (gather): din[iy,ix] (+)= sum over outputs whose taps touch (iy,ix).
 // Candidate outputs: src in (i-1, i+1)  =>  dst in ((i-0.5)/ratio - 0.5, (i+1.5)/ratio - 0.5).
 template <typename TO_, typename TI_>  // TO_ = dtype of dout, TI_ = dtype of din
@@ -465,6 +511,30 @@ extern "C" int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int
   DISPATCH2(bilinear_fwd_kernel, in_dtype, out_dtype, dim3(grid_for(total)), dim3(256), 0,
             (hipStream_t)stream, in, B, Hi, Wi, C, isB, isH, isW, out, Ho, Wo, osB, osH, osW, accumulate);
   GDL_CHECK_LAUNCH("gdl_bilinear_fwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_bilinear_sum_fwd(const void* const* srcs, const int* hs, const int* ws, int nsrc, int dtype, int B, int C,
+                                    void* out, int Ho, int Wo, gdl_stream_t stream) {
+  GDL_CHECK_ARG(srcs && hs && ws && out && nsrc >= 1 && nsrc <= 3, "gdl_bilinear_sum_fwd: 1..3 sources");
+  GDL_CHECK_ARG(dtype == GDL_F32 || dtype == GDL_BF16, "gdl_bilinear_sum_fwd: bad dtype");
+  GDL_CHECK_ARG(B > 0 && Ho > 0 && Wo > 0 && C > 0 && C % (dtype == GDL_BF16 ? 8 : 4) == 0,
+                "gdl_bilinear_sum_fwd: C must be a multiple of the 16-byte vector");
+  SumSrc s;
+  for (int k = 0; k < 3; ++k) {
+    s.p[k] = k < nsrc ? srcs[k] : nullptr;
+    s.H[k] = k < nsrc ? hs[k] : 1;
+    s.W[k] = k < nsrc ? ws[k] : 1;
+    GDL_CHECK_ARG(k >= nsrc || (srcs[k] && hs[k] > 0 && ws[k] > 0 && (uintptr_t)srcs[k] % 16 == 0), "gdl_bilinear_sum_fwd: bad source %d", k);
+  }
+  GDL_CHECK_ARG((uintptr_t)out % 16 == 0, "gdl_bilinear_sum_fwd: out must be 16-byte aligned");
+  const int vec = dtype == GDL_BF16 ? 8 : 4;
+  const int64_t total = (int64_t)B * Ho * Wo * (C / vec);
+  if (dtype == GDL_BF16)
+    hipLaunchKernelGGL((bilinear_sum_kernel<uint16_t, 8>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, s, nsrc, B, C, out, Ho, Wo);
+  else
+    hipLaunchKernelGGL((bilinear_sum_kernel<float, 4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, s, nsrc, B, C, out, Ho, Wo);
+  GDL_CHECK_LAUNCH("gdl_bilinear_sum_fwd");
   return GDL_OK;
 }
 

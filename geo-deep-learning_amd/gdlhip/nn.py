@@ -15,7 +15,7 @@ from torch import Tensor, nn
 from torch.autograd import Function
 
 from . import ops
-from .ops import ACT_GELU, ACT_NONE, ACT_RELU  # noqa: F401
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU, ACT_RESID_RELU  # noqa: F401
 
 
 # ------------------------------------------------------------------ precision policy
@@ -218,6 +218,125 @@ class _ConvBNActTrain(Function):
             # same strides as the channels-last parameter (for 1x1 kernels torch keeps (C,1,1,1))
             dw = dw.view(n, c, 1, 1) if r == 1 and s == 1 else dw.view(n, r, s, c).permute(0, 3, 1, 2)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+FUSE_PYRAMID = True   # A/B switch: False = upsample every level into a concat buffer and run one wide 1x1 convolution
+
+
+def _bn_train_stats(y, n, running_mean, running_var, momentum, sync_group):
+    """Batch statistics of a conv output (+ cross-rank merge and the running-stat update): (mean, var, world, p_local, p_share)."""
+    world = _world(sync_group) if sync_group is not False else 1
+    p_local, p_share = y.numel() // n, None
+    if world > 1:
+        mean, var = ops.bn_stats(y)
+        mean, var, total = sync_batch_stats(mean, var, sync_group or None, count=p_local)
+        if running_mean is not None:
+            update_running_stats(running_mean, running_var, mean, var, momentum, total)
+        p_share = p_local / total
+    else:
+        mean, var = ops.bn_stats(y, running_mean, running_var, momentum)
+        if running_mean is not None:
+            mark_updated(running_mean)
+            mark_updated(running_var)
+    return mean, var, world, p_local, p_share
+
+
+def _bn_train_backward(y, gout, mean, var, g, b, eps, relu, sync_group, world, p_local, p_share):
+    """(dy written over y, dgamma, dbeta) of BatchNorm(batch stats) (+ ReLU)."""
+    if gout.dtype != y.dtype:
+        gout = to_compute(gout, y.dtype)
+    dgamma, dbeta = ops.bn_bwd_reduce(y, gout, mean, var, g, b, eps, relu)
+    sg, sb = dgamma, dbeta
+    if world > 1:
+        sg, sb = sync_sum_pair(dgamma, dbeta, sync_group or None)
+        sg, sb = sg * p_share, sb * p_share
+    dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, p_local, out=y)
+    return dy, dgamma, dbeta
+
+
+class _PyramidFuseBNTrain(Function):
+    """conv1x1(cat([bilinear(l_0 -> size), ..., bilinear(l_{k-1} -> size), l_k])) -> BatchNorm(batch stats) -> ReLU
+    (segformer_mlp.py:97-125 `linear_fuse`), evaluated PER LEVEL: a 1x1 convolution acts per pixel and a bilinear resize
+    per channel, so they commute -- W_j is applied to level j at the level's own resolution (1/4, 1/16, 1/64 of the
+    pixels), the small results are upsampled and summed in one pass (ops.bilinear_sum) and enter the last level's GEMM as
+    its residual operand.  Neither the upsampled levels nor the concat buffer exist; forward, data-gradient and
+    weight-gradient GEMMs shrink from K = sum(E_j) at full resolution to one K = E_k GEMM at full resolution plus small
+    ones.  Backward: dz_j = bilinear^T(dy) per level, then the level's own dgrad / wgrad."""
+
+    @staticmethod
+    def forward(ctx, weight, gamma, beta, running_mean, running_var, momentum, eps, relu, sync_group, *levels):
+        cd = levels[0].dtype
+        n = weight.shape[0]
+        wq = gemm_weight(weight, cd)
+        size = (levels[-1].shape[1], levels[-1].shape[2])
+        offs, off = [], 0
+        for lv in levels:
+            offs.append(off)
+            off += lv.shape[3]
+        zs = [ops.conv_gemm(lv, wq[:, o:o + lv.shape[3]]) for lv, o in zip(levels[:-1], offs[:-1])]
+        y = ops.conv_gemm(levels[-1], wq[:, offs[-1]:], resid=ops.bilinear_sum(zs, size))
+        mean, var, world, p_local, p_share = _bn_train_stats(y, n, running_mean, running_var, momentum, sync_group)
+        out = ops.bn_apply(y, mean, var, gamma.detach(), beta.detach(), eps, relu)
+        ctx.save_for_backward(weight, y, mean, var, gamma, beta, *levels)
+        ctx.cfg = (relu, eps, sync_group, world, p_local, p_share, offs)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        weight, y, mean, var, gamma, beta, *levels = ctx.saved_tensors
+        relu, eps, sync_group, world, p_local, p_share, offs = ctx.cfg
+        n, ctot = weight.shape[0], weight.shape[1]
+        cd = y.dtype
+        dy, dgamma, dbeta = _bn_train_backward(y, gout, mean, var, gamma.detach(), beta.detach(), eps, relu, sync_group,
+                                               world, p_local, p_share)
+        dzs = [ops.bilinear_bwd(dy, (lv.shape[1], lv.shape[2])) for lv in levels[:-1]] + [dy]
+        wd = dgrad_weight(weight, cd)                       # [sum(E_j), N]: rows of level j are contiguous
+        dls = []
+        for j, (lv, dz, o) in enumerate(zip(levels, dzs, offs)):
+            dls.append(ops.conv_gemm(dz, wd[o:o + lv.shape[3]]) if ctx.needs_input_grad[9 + j] else None)
+        dw = None
+        if ctx.needs_input_grad[0]:
+            dw = torch.empty((n, ctot), device=y.device, dtype=torch.float32)
+            for lv, dz, o in zip(levels, dzs, offs):
+                ops.conv_wgrad(lv, dz, R=1, S=1, dw=dw[:, o:o + lv.shape[3]])
+            dw = dw.view(n, ctot, 1, 1)
+        return (dw, dgamma, dbeta, None, None, None, None, None, None, *dls)
+
+
+def pyramid_fuse_bn_act(levels: list[Tensor], conv: nn.Conv2d, norm: nn.Module, *, relu: bool = True) -> Tensor:
+    """ConvModule(1x1, no bias) over cat([bilinear(l -> size of levels[-1]) for l in levels[:-1]] + [levels[-1]]) on NHWC
+    maps, without the concat (see _PyramidFuseBNTrain).  Eval mode: the folded BN scale goes into the weights, so that every
+    level's partial result is already scaled and the last GEMM's epilogue is relu(acc + shift + residual)."""
+    ok = (FUSE_PYRAMID and conv.kernel_size == (1, 1) and conv.bias is None and 2 <= len(levels) <= 4
+          and all(lv.is_contiguous() for lv in levels))
+    size = (levels[-1].shape[1], levels[-1].shape[2])
+    if not ok:
+        return conv_bn_act(concat_upsample(levels, size), conv, norm, relu=relu)
+    if norm.training:
+        sync_group = norm.process_group if isinstance(norm, nn.SyncBatchNorm) else False
+        momentum = 0.1 if norm.momentum is None else norm.momentum
+        out = _PyramidFuseBNTrain.apply(conv.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var,
+                                        momentum, norm.eps, relu, sync_group, *levels)
+        if norm.num_batches_tracked is not None:
+            norm.num_batches_tracked.add_(1)
+        return out
+    if torch.is_grad_enabled() and (conv.weight.requires_grad or any(lv.requires_grad for lv in levels)):
+        msg = ("gdlhip: autograd through eval-mode BatchNorm is not implemented; call under "
+               "torch.no_grad() for inference or model.train() for training")
+        raise NotImplementedError(msg)
+    cd = levels[0].dtype
+
+    def fold():
+        scale, shift = ops.bn_fold(norm.weight.detach(), norm.bias.detach(), norm.running_mean, norm.running_var, norm.eps)
+        w = conv_weight_matrix(conv.weight).float() * scale[:, None]
+        return (w.contiguous() if cd == torch.float32 else ops.cast(w.contiguous(), cd)), shift
+    wq, shift = cached((conv.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var), f"pyrfold:{cd}", fold)
+    off, zs = 0, []
+    for lv in levels[:-1]:
+        zs.append(ops.conv_gemm(lv, wq[:, off:off + lv.shape[3]]))
+        off += lv.shape[3]
+    return ops.conv_gemm(levels[-1], wq[:, off:], bias=shift, resid=ops.bilinear_sum(zs, size),
+                         act=ACT_RESID_RELU if relu else ACT_NONE)
 
 
 def subpix4_weight(weight: Tensor, cd: torch.dtype) -> dict:

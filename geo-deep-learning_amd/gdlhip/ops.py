@@ -343,6 +343,26 @@ def bilinear(x: Tensor, size: tuple[int, int], out: Tensor | None = None,
     return out
 
 
+def bilinear_sum(xs: list[Tensor], size: tuple[int, int]) -> Tensor:
+    """sum_k bilinear(xs[k] -> size) for 1..3 dense NHWC maps with equal batch / channels / dtype, one output write."""
+    _need_cuda(*xs)
+    if not 1 <= len(xs) <= 3:
+        raise ValueError("bilinear_sum: 1..3 sources")
+    x4s = [_nhwc4(x, "bilinear_sum source") for x in xs]
+    B, _, _, Cc = x4s[0].shape
+    for x in x4s:
+        if x.shape[0] != B or x.shape[3] != Cc or x.dtype != x4s[0].dtype or not x.is_contiguous():
+            raise ValueError("bilinear_sum: sources must be contiguous NHWC maps with equal batch, channels and dtype")
+    out = torch.empty((B, size[0], size[1], Cc), device=xs[0].device, dtype=xs[0].dtype)
+    n = len(x4s)
+    ptrs = (C.c_void_p * 3)(*([x.data_ptr() for x in x4s] + [None] * (3 - n)))
+    hs = (C.c_int * 3)(*([x.shape[1] for x in x4s] + [1] * (3 - n)))
+    ws = (C.c_int * 3)(*([x.shape[2] for x in x4s] + [1] * (3 - n)))
+    check(_lib.load().gdl_bilinear_sum_fwd(ptrs, hs, ws, n, dt(x4s[0]), B, Cc, _p(out), size[0], size[1], _stream()),
+          "gdl_bilinear_sum_fwd")
+    return out
+
+
 def bilinear_bwd(dout: Tensor, in_size: tuple[int, int], din: Tensor | None = None,
                  din_dtype: torch.dtype | None = None, accumulate: bool = False) -> Tensor:
     d4 = _nhwc4(dout, "bilinear_bwd dout")

@@ -29,7 +29,8 @@ class MLP(nn.Module):
 
 class Decoder(nn.Module):
     """segformer_mlp.py:22-130: 4 x Linear -> bilinear to 1/4 res -> concat -> 1x1 conv + BN + ReLU ->
-    Dropout2d -> 1x1 classifier.  The upsamples write straight into the concat buffer."""
+    Dropout2d -> 1x1 classifier.  The 1x1 fusion convolution commutes with the resizes: it runs per level at the level's
+    own resolution and the upsampled partial results are summed (gdlhip.nn.pyramid_fuse_bn_act) -- no concat buffer."""
 
     def __init__(self, encoder: str = "mit_b2", in_channels: list[int] | None = None,
                  feature_strides: list[int] | None = None, embedding_dim: int = 768, num_classes: int = 1,
@@ -68,8 +69,8 @@ class Decoder(nn.Module):
         c1, c2, c3, c4 = feats
         lv = [self.linear_c4.forward_nhwc(c4), self.linear_c3.forward_nhwc(c3), self.linear_c2.forward_nhwc(c2),
               self.linear_c1.forward_nhwc(c1)]
-        cat = gnn.concat_upsample(lv, (c1.shape[1], c1.shape[2]))
-        fused = gnn.conv_bn_act(cat, self.linear_fuse[0], self.linear_fuse[1], relu=True)
+        # linear_fuse over the concat of the upsampled levels, evaluated per level at the level's own resolution
+        fused = gnn.pyramid_fuse_bn_act(lv, self.linear_fuse[0], self.linear_fuse[1], relu=True)
         chan_scale = None
         if self.training and self.dropout_ratio > 0:
             keep = 1.0 - self.dropout_ratio

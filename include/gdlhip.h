@@ -247,6 +247,12 @@ int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int Wi, int C,
                      int64_t in_sH, int64_t in_sW, void* out, int out_dtype, int Ho, int Wo,
                      int64_t out_sB, int64_t out_sH, int64_t out_sW, int accumulate,
                      gdl_stream_t stream);
+/* out = sum_k bilinear(src_k -> Ho x Wo) for 1..3 DENSE sources [B, hs[k], ws[k], C] of one dtype, written once (dense
+ * [B,Ho,Wo,C], same dtype).  segformer_mlp.py:97-125: `linear_fuse(cat([resize(_c4), resize(_c3), resize(_c2), _c1]))` is
+ * evaluated per level at the level's own resolution (a 1x1 convolution commutes with the resize); this sums the upsampled
+ * partial results, which then enter the finest level's GEMM as its residual operand. */
+int gdl_bilinear_sum_fwd(const void* const* srcs, const int* hs, const int* ws, int nsrc, int dtype, int B, int C,
+                         void* out, int Ho, int Wo, gdl_stream_t stream);
 /* din (+)= bilinear^T(dout) */
 int gdl_bilinear_bwd(const void* dout, int dout_dtype, int B, int Ho, int Wo, int C,
                      int64_t dout_sB, int64_t dout_sH, int64_t dout_sW, void* din, int din_dtype,

@@ -718,3 +718,72 @@ def test_conv_narrow_output_tile(dtype, B, H, W, C, N, R):
         lib.gdl_debug_force_conv_variant(-1)
     close(outs[5].permute(0, 3, 1, 2), ref, dtype, "256x64 tile")
     assert (outs[5] - outs[0]).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("training", [True, False])
+def test_pyramid_fuse_matches_concat_conv(dtype, training):
+    """conv1x1(cat(upsampled levels)) + BN + ReLU evaluated per level (gdlhip.nn.pyramid_fuse_bn_act, SegFormer's
+    linear_fuse, segformer_mlp.py:97-125) vs torch's interpolate -> cat -> conv2d -> batch_norm -> relu: output, running
+    statistics and every gradient (levels, 1x1 weight, BN affine); and vs the build's own unfused path."""
+    from torch import nn
+    from gdlhip import nn as gnn
+    B, E, N = 2, 64, 256
+    sizes = [(3, 5), (6, 10), (12, 20), (24, 40)]
+    lv = [q(rnd(B, E, h, w, seed=10 + i), dtype) for i, (h, w) in enumerate(sizes)]
+    conv = nn.Conv2d(4 * E, N, 1, bias=False)
+    bn = nn.BatchNorm2d(N)
+    with torch.no_grad():
+        conv.weight.copy_(q(rnd(N, 4 * E, 1, 1, seed=1) * 0.1, dtype))
+        bn.weight.copy_(rnd(N, seed=2).abs() + 0.5)
+        bn.bias.copy_(rnd(N, seed=3) * 0.1)
+        bn.running_mean.copy_(rnd(N, seed=4) * 0.1)
+        bn.running_var.copy_(rnd(N, seed=5).abs() + 0.5)
+    conv.train(training), bn.train(training)
+    gout = rnd(B, N, *sizes[-1], seed=7)
+    # torch reference (f32, CPU)
+    ref_in = [t.clone().requires_grad_(training) for t in lv]
+    cat = torch.cat([F.interpolate(t, size=sizes[-1], mode="bilinear", align_corners=False) for t in ref_in[:-1]] + [ref_in[-1]], 1)
+    import copy
+    rconv, rbn = copy.deepcopy(conv), copy.deepcopy(bn)
+    ref = F.relu(rbn(rconv(cat)))
+    if training:
+        ref.backward(gout)
+    outs = {}
+    for fused in (True, False):
+        gnn.FUSE_PYRAMID = fused
+        try:
+            c, n = copy.deepcopy(conv).to(DEV).to(memory_format=torch.channels_last), copy.deepcopy(bn).to(DEV)
+            xs = [t.permute(0, 2, 3, 1).contiguous().to(DEV, dtype).requires_grad_(training) for t in lv]
+            with torch.set_grad_enabled(training):
+                y = gnn.pyramid_fuse_bn_act(xs, c, n, relu=True)
+            if training:
+                y.backward(gout.permute(0, 2, 3, 1).contiguous().to(DEV, dtype))
+            outs[fused] = (y, xs, c, n)
+        finally:
+            gnn.FUSE_PYRAMID = True
+    y, xs, c, n = outs[True]
+    close(y.permute(0, 3, 1, 2), ref, dtype, "pyramid fuse output")
+    close(y, outs[False][0], dtype, "fused vs concat path")
+    if training:
+        close(n.running_mean, rbn.running_mean, dtype, "running_mean")
+        close(n.running_var, rbn.running_var, dtype, "running_var")
+        def grad_ok(got, ref, other, what):
+            """f32: element-wise.  bf16: conv output, dy and the resized dz are all stored in bf16 -- a gradient is held in
+            the L2 norm to the f32 reference, no worse than 1.5 x the error of the build's own concat path, and the two
+            paths agree with each other."""
+            got, ref, other = got.float().cpu(), ref.float().cpu(), other.float().cpu()
+            if dtype == torch.float32:
+                close(got, ref, dtype, what, scale=ref.abs().max().item())
+                return
+            rel, rel_other = float((got - ref).norm() / ref.norm()), float((other - ref).norm() / ref.norm())
+            rel_paths = float((got - other).norm() / other.norm())
+            print(f"{what}: fused vs f32 reference {rel:.4f}, concat path vs reference {rel_other:.4f}, fused vs concat {rel_paths:.4f}")
+            assert rel <= max(2e-2, 1.5 * rel_other) and rel_paths <= 6e-2, (what, rel, rel_other, rel_paths)
+
+        _, xs_u, c_u, n_u = outs[False]
+        for i, (x, r, xu) in enumerate(zip(xs, ref_in, xs_u)):
+            grad_ok(x.grad.permute(0, 3, 1, 2), r.grad, xu.grad.permute(0, 3, 1, 2), f"level {i} gradient")
+        grad_ok(c.weight.grad, rconv.weight.grad, c_u.weight.grad, "1x1 weight gradient")
+        grad_ok(n.weight.grad, rbn.weight.grad, n_u.weight.grad, "gamma gradient")
+        grad_ok(n.bias.grad, rbn.bias.grad, n_u.bias.grad, "beta gradient")
