@@ -410,6 +410,7 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
     k.KT = k.kc;
     k.c_tail = 0;
   }
+  if (variant == 7) return conv3x3_narrow_launch(k, s);
   if (a.dtype == GDL_BF16) {
     if (variant == 4) return conv3x3_sf_launch(k, s);
     if (variant == 3 && k.dbg == 7) return launch_x<bf16_tag, 2, 4, 4, 2, false, true, false, false, true>(k, s);
@@ -434,6 +435,8 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
 // else 64x64 (variant 0).  Also reports the ALGORITHMIC flops of the call (2*M*N*K, no padding).
 static std::atomic<int> g_forced_variant{-1};
 static std::atomic<int> g_sf_enabled{1};
+static std::atomic<int> g_narrow_enabled{1};
+extern "C" void gdl_debug_set_conv_narrow(int on) { g_narrow_enabled = on; }  // A/B hook: direct narrow 3x3 kernel
 extern "C" void gdl_debug_set_conv_sf(int on) { g_sf_enabled = on; }  // A/B hook: 3x3 shared-staging kernel
 extern "C" void gdl_debug_force_conv_variant(int v) { g_forced_variant = v; }  // tuning hook (-1 = auto)
 
@@ -445,8 +448,11 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   if (g_forced_variant >= 0 && !(g_forced_variant >= 2 && (a.aux_out || a.act == GDL_ACT_MUL_GELU_GRAD)) &&
       !(g_forced_variant >= 2 && g_forced_variant != 5 && a.C % (a.dtype == GDL_BF16 ? 64 : 32) != 0) &&
       !(g_forced_variant == 5 && a.N > 64) &&
-      !(g_forced_variant == 4 && !conv3x3_sf_applicable(a)))
+      !(g_forced_variant == 4 && !conv3x3_sf_applicable(a)) &&
+      !(g_forced_variant == 7 && !conv3x3_narrow_applicable(a)))
     return g_forced_variant;
+  // narrow 3x3 layers on large maps: direct kernel, one staged window per 4 x 64 pixels (HBM-bound layers)
+  if (g_narrow_enabled && conv3x3_narrow_applicable(a)) return 7;
   const int64_t t256 = ((M + 255) / 256) * ((a.N + 255) / 256) * a.nz;
   const int64_t t128 = ((M + 127) / 128) * ((a.N + 127) / 128) * a.nz;
   const int64_t ksteps = (int64_t)a.R * a.S * a.C * (int64_t)gdl_elem_size(a.dtype) / 128;

@@ -101,45 +101,43 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const void* __restric
 // level at the level's own resolution (a 1x1 convolution and a bilinear resize commute), SegFormer's linear_fuse:
 // the upsampled partial results are summed here instead of being written one by one.  Source maps are small (L2-resident).
 struct SumSrc { const void* p[3]; int H[3], W[3]; };
+// grid = (ceil(Wo * C/VEC / 256), B * Ho): one block per output-row segment, so the batch / row decomposition and every
+// source's row pair + vertical weight are block-uniform; a thread only derives its column pair.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bilinear_sum_kernel(SumSrc src, int nsrc, int B, int C, void* out, int Ho, int Wo) {
   const int cv = C / VEC;
-  const int64_t total = (int64_t)B * Ho * Wo * cv;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % cv) * VEC;
-    int64_t t = i / cv;
-    const int ox = (int)(t % Wo); t /= Wo;
-    const int oy = (int)(t % Ho);
-    const int b = (int)(t / Ho);
-    float o[VEC];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= Wo * cv) return;
+  const int ox = j / cv, c = (j - ox * cv) * VEC;
+  const int b = blockIdx.y / Ho, oy = blockIdx.y - b * Ho;
+  float o[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o[j] = 0.f;
-    for (int k = 0; k < nsrc; ++k) {
-      const int Hi = src.H[k], Wi = src.W[k];
-      int y0, y1, x0, x1; float ly, lx;
-      src_index((float)Hi / (float)Ho, oy, Hi, y0, y1, ly);
-      src_index((float)Wi / (float)Wo, ox, Wi, x0, x1, lx);
-      const int64_t base = (int64_t)b * Hi * Wi * C + c;
-      float a[VEC], bb[VEC], cc[VEC], d[VEC];
-      if constexpr (VEC == 8) {
-        V8::ld(src.p[k], base + ((int64_t)y0 * Wi + x0) * C, a);
-        V8::ld(src.p[k], base + ((int64_t)y0 * Wi + x1) * C, bb);
-        V8::ld(src.p[k], base + ((int64_t)y1 * Wi + x0) * C, cc);
-        V8::ld(src.p[k], base + ((int64_t)y1 * Wi + x1) * C, d);
-      } else {
-        V4<T>::ld(src.p[k], base + ((int64_t)y0 * Wi + x0) * C, a);
-        V4<T>::ld(src.p[k], base + ((int64_t)y0 * Wi + x1) * C, bb);
-        V4<T>::ld(src.p[k], base + ((int64_t)y1 * Wi + x0) * C, cc);
-        V4<T>::ld(src.p[k], base + ((int64_t)y1 * Wi + x1) * C, d);
-      }
-      const float hy = 1.f - ly, hx = 1.f - lx;
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) o[j] += hy * (hx * a[j] + lx * bb[j]) + ly * (hx * cc[j] + lx * d[j]);
+  for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+  for (int k = 0; k < nsrc; ++k) {
+    const int Hi = src.H[k], Wi = src.W[k];
+    int y0, y1, x0, x1; float ly, lx;
+    src_index((float)Hi / (float)Ho, oy, Hi, y0, y1, ly);
+    src_index((float)Wi / (float)Wo, ox, Wi, x0, x1, lx);
+    const int64_t r0 = ((int64_t)b * Hi + y0) * Wi * C + c, r1 = ((int64_t)b * Hi + y1) * Wi * C + c;
+    float a[VEC], bb[VEC], cc[VEC], d[VEC];
+    if constexpr (VEC == 8) {
+      V8::ld(src.p[k], r0 + (int64_t)x0 * C, a);
+      V8::ld(src.p[k], r0 + (int64_t)x1 * C, bb);
+      V8::ld(src.p[k], r1 + (int64_t)x0 * C, cc);
+      V8::ld(src.p[k], r1 + (int64_t)x1 * C, d);
+    } else {
+      V4<T>::ld(src.p[k], r0 + (int64_t)x0 * C, a);
+      V4<T>::ld(src.p[k], r0 + (int64_t)x1 * C, bb);
+      V4<T>::ld(src.p[k], r1 + (int64_t)x0 * C, cc);
+      V4<T>::ld(src.p[k], r1 + (int64_t)x1 * C, d);
     }
-    const int64_t ooff = (((int64_t)b * Ho + oy) * Wo + ox) * C + c;
-    if constexpr (VEC == 8) V8::st(out, ooff, o);
-    else V4<T>::st(out, ooff, o);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] += hy * (hx * a[e] + lx * bb[e]) + ly * (hx * cc[e] + lx * d[e]);
   }
+  const int64_t ooff = (((int64_t)b * Ho + oy) * Wo + ox) * C + c;
+  if constexpr (VEC == 8) V8::st(out, ooff, o);
+  else V4<T>::st(out, ooff, o);
 }
 
 // Backward (gather): din[iy,ix] (+)= sum over outputs whose taps touch (iy,ix).
@@ -529,11 +527,12 @@ extern "C" int gdl_bilinear_sum_fwd(const void* const* srcs, const int* hs, cons
   }
   GDL_CHECK_ARG((uintptr_t)out % 16 == 0, "gdl_bilinear_sum_fwd: out must be 16-byte aligned");
   const int vec = dtype == GDL_BF16 ? 8 : 4;
-  const int64_t total = (int64_t)B * Ho * Wo * (C / vec);
+  GDL_CHECK_ARG((int64_t)B * Ho <= 65535, "gdl_bilinear_sum_fwd: B * Ho must fit one grid dimension");
+  const dim3 grid((unsigned)((Wo * (C / vec) + 255) / 256), (unsigned)(B * Ho));
   if (dtype == GDL_BF16)
-    hipLaunchKernelGGL((bilinear_sum_kernel<uint16_t, 8>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, s, nsrc, B, C, out, Ho, Wo);
+    hipLaunchKernelGGL((bilinear_sum_kernel<uint16_t, 8>), grid, dim3(256), 0, (hipStream_t)stream, s, nsrc, B, C, out, Ho, Wo);
   else
-    hipLaunchKernelGGL((bilinear_sum_kernel<float, 4>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, s, nsrc, B, C, out, Ho, Wo);
+    hipLaunchKernelGGL((bilinear_sum_kernel<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, s, nsrc, B, C, out, Ho, Wo);
   GDL_CHECK_LAUNCH("gdl_bilinear_sum_fwd");
   return GDL_OK;
 }

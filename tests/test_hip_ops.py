@@ -787,3 +787,36 @@ def test_pyramid_fuse_matches_concat_conv(dtype, training):
         grad_ok(c.weight.grad, rconv.weight.grad, c_u.weight.grad, "1x1 weight gradient")
         grad_ok(n.weight.grad, rbn.weight.grad, n_u.weight.grad, "gamma gradient")
         grad_ok(n.bias.grad, rbn.bias.grad, n_u.bias.grad, "beta gradient")
+
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 8, 64, 16, 16), (1, 12, 128, 32, 32), (2, 4, 64, 8, 16), (1, 8, 64, 16, 5),
+                                       (1, 16, 192, 32, 16), (3, 4, 64, 16, 32)])
+def test_conv3x3_narrow_direct_kernel(B, H, W, C, N):
+    """The direct 3x3 kernel for narrow layers on large maps (C in {8,16,32}, N <= 32; chosen by the planner whenever it
+    applies): image borders (hardware zero fill of the staged window), several tiles per image and per batch, N tails
+    (5 classes), bias + ReLU + residual epilogue with f32 and bf16 outputs, vs F.conv2d and vs the implicit-GEMM tile."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_set_conv_narrow.argtypes = [ctypes.c_int]
+    lib.gdl_conv_gemm_plan.restype = ctypes.c_int
+    dtype = torch.bfloat16
+    x, w = q(rnd(B, C, H, W), dtype), q(rnd(N, C, 3, 3, seed=1) * 0.1, dtype)
+    bias, resid = rnd(N, seed=2), q(rnd(B, N, H, W, seed=3), dtype)
+    ref = F.relu(F.conv2d(x, w, bias, padding=1)) + resid
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    wq = w.permute(0, 2, 3, 1).reshape(N, -1).contiguous().to(DEV, dtype)
+    rn = resid.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    outs = {}
+    try:
+        for on in (1, 0):
+            lib.gdl_debug_set_conv_narrow(on)
+            outs[on] = ops.conv_gemm(xn, wq, R=3, S=3, pad=1, bias=bias.to(DEV), act=ops.ACT_RELU, resid=rn,
+                                     out_dtype=torch.float32)
+    finally:
+        lib.gdl_debug_set_conv_narrow(1)
+    close(outs[1].permute(0, 3, 1, 2), ref, dtype, "direct narrow 3x3")
+    assert (outs[1] - outs[0]).abs().max().item() <= 1e-4 * ref.abs().max().item()    # same bf16 products, other K order
+    yb = ops.conv_gemm(xn, wq, R=3, S=3, pad=1)                                         # plain bf16 output
+    close(yb.permute(0, 3, 1, 2), F.conv2d(x, w, padding=1), dtype, "direct narrow 3x3, bf16 out")
