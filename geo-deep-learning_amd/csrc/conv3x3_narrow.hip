@@ -1,6 +1,7 @@
-// Direct 3x3 / stride-1 / pad-1 convolution for NARROW layers on large maps: C in {8, 16, 32} input channels, at most 32
-// output channels, dense NHWC input (UNet++'s 512^2 / 256^2 decoder stages and their data gradients, the 16 -> classes
-// head; smp DecoderBlock / SegmentationHead, reference call site tasks_with_models/segmentation_unetplus.py:126-131).
+// Direct 3x3 / stride-1 / pad-1 convolution for NARROW-INPUT layers on large maps: C in {8, 16, 32} input channels, dense
+// NHWC input, any number of output channels in 32-wide slices (blockIdx.y) -- UNet++'s 512^2 / 256^2 decoder stages and
+// their data gradients (e.g. 32 -> 320 channels), the 16 -> classes head; smp DecoderBlock / SegmentationHead, reference
+// call site tasks_with_models/segmentation_unetplus.py:126-131.
 //
 // These layers are HBM-bound (32 + 32 bytes per pixel at C = N = 16 against 4.6 kFLOP), but the implicit-GEMM tiles treat
 // them as GEMMs with K = 9 C: every filter tap re-stages the activation tile (9 x the bytes through LDS-DMA) and a
@@ -8,7 +9,7 @@
 // ~0.15 ms of memory time (tools/log_conv_plans.py).  Here a block owns 4 rows x 64 columns of one image:
 //   * the (4+2) x (64+2) pixel window is staged ONCE by LDS-DMA (out-of-image pixels arrive as hardware zeros = the
 //     convolution's zero padding), 6 / 13 / 25 KiB for C = 8 / 16 / 32;
-//   * the whole filter ([N <= 32][9 C] bf16) sits in registers as MFMA operand fragments for the block's lifetime;
+//   * the block's 32-output-channel slice of the filter ([32][9 C] bf16) sits in registers as MFMA operand fragments;
 //   * a wave computes 32 consecutive pixels of one row per unit: per k16 group one ds_read_b128 of the window (the tap is
 //     a byte offset) and one v_mfma_f32_32x32x16_bf16, 5 / 9 / 18 groups per unit, then the common epilogue
 //     (bias, folded BN, ReLU, residual, bf16 / f32 output).
@@ -55,12 +56,13 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const KArgs k) {
 
   // ---- the filter as MFMA fragments: lane (n = lane & 31, half = lane >> 5) holds k = 16 g + 8 half .. + 7 of row n
   const int frow = lane & 31, fhalf = lane >> 5;
+  const int n0 = blockIdx.y * 32;
   bf16x8_t wf[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int kidx = g * 16 + fhalf * 8;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (frow < a.N && kidx < 9 * CIN) v = *(const uint4*)((const uint16_t*)a.w + (int64_t)frow * a.w_sN + kidx);
+    if (n0 + frow < a.N && kidx < 9 * CIN) v = *(const uint4*)((const uint16_t*)a.w + (int64_t)(n0 + frow) * a.w_sN + kidx);
     wf[g] = __builtin_bit_cast(bf16x8_t, v);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const KArgs k) {
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g], __builtin_bit_cast(bf16x8_t, v), acc[0][0], 0, 0, 0);
     }
     const int m0 = ((b * a.H + y0 + urow) * a.W) + x0 + ucol;
-    conv_epilogue<1, 1, false>(k, acc, m0, 0, 0, 0, lane, 0);
+    conv_epilogue<1, 1, false>(k, acc, m0, n0, 0, 0, lane, 0);
   }
 }
 
@@ -94,7 +96,7 @@ namespace gdlconv {
 
 bool conv3x3_narrow_applicable(const gdl_conv_args& a) {
   return a.dtype == GDL_BF16 && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.nz == 1 && a.Ho == a.H &&
-         a.Wo == a.W && (a.C == 8 || a.C == 16 || a.C == 32) && a.N <= 32 && a.in_sW == a.C &&
+         a.Wo == a.W && (a.C == 8 || a.C == 16 || a.C == 32) && a.N <= 32 * 65535 && a.in_sW == a.C &&
          a.in_sH == (int64_t)a.W * a.C && a.in_sB == (int64_t)a.H * a.W * a.C && a.W % TW == 0 && a.H % TH == 0 &&
          a.w_sN % 8 == 0 && !a.aux_out && a.act != GDL_ACT_MUL_GELU_GRAD &&
          (int64_t)a.B * (a.H / TH) * (a.W / TW) < (1ll << 31);
@@ -102,7 +104,7 @@ bool conv3x3_narrow_applicable(const gdl_conv_args& a) {
 
 int conv3x3_narrow_launch(const KArgs& k, hipStream_t stream) {
   const gdl_conv_args& a = k.a;
-  dim3 grid((unsigned)((int64_t)a.B * (a.H / TH) * (a.W / TW))), block(256);
+  dim3 grid((unsigned)((int64_t)a.B * (a.H / TH) * (a.W / TW)), (unsigned)((a.N + 31) / 32)), block(256);
   if (a.C == 8) hipLaunchKernelGGL(conv3x3_narrow_kernel<8>, grid, block, 0, stream, k);
   else if (a.C == 16) hipLaunchKernelGGL(conv3x3_narrow_kernel<16>, grid, block, 0, stream, k);
   else hipLaunchKernelGGL(conv3x3_narrow_kernel<32>, grid, block, 0, stream, k);

@@ -74,7 +74,7 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // 3x3 shared-staging kernel (conv3x3_sf.hip)
 bool conv3x3_sf_applicable(const gdl_conv_args& a);
 int conv3x3_sf_launch(const KArgs& k, hipStream_t stream);
-// direct 3x3 kernel for C in {8,16,32}, N <= 32 on large dense maps (conv3x3_narrow.hip)
+// direct 3x3 kernel for C in {8,16,32} on large dense maps, outputs in 32-channel slices (conv3x3_narrow.hip)
 bool conv3x3_narrow_applicable(const gdl_conv_args& a);
 int conv3x3_narrow_launch(const KArgs& k, hipStream_t stream);
 

@@ -20,3 +20,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _seed_global_rng(request):
+    """Every test starts from a torch global-RNG state derived from its own node id: parameter initialisations of
+    nn.Module constructors and unseeded draws are the same on every run (an unseeded bf16 case used to miss its tolerance on
+    about one run in four), independent of test order and of `-k` selections."""
+    import zlib
+
+    import torch
+    torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF)
+    yield

@@ -175,7 +175,7 @@ def _conv_args(B, H, W, C, N, R, dtype=1, stride=1, aux=False):
 
 def test_conv_tile_selection(lib):
     """gdl_conv_gemm_plan: which tile a layer gets (0 = 64^2, 1 = 128^2, 3 = 256^2 ping-pong, 4 = 3x3 shared staging,
-    5 = 256x64) and the algorithmic flops it reports."""
+    5 = 256x64, 7 = direct 3x3 for C <= 32 on large dense maps) and the algorithmic flops it reports."""
     import ctypes as C
 
     def plan(*a, **k):
@@ -187,7 +187,9 @@ def test_conv_tile_selection(lib):
     assert plan(32, 144, 144, 768, 256, 1)[0] == 3           # lateral 1x1: 256^2 ping-pong
     assert plan(1, 1, 32 * 1297, 768, 2304, 1)[0] == 3       # ViT qkv
     assert plan(32, 256, 256, 64, 64, 3)[0] == 5             # UNet++ decoder: narrow output on a large map
-    assert plan(32, 512, 512, 32, 16, 3)[0] == 5             # 32 -> 16 channels at 512^2 (tap-packed K chunks)
+    assert plan(32, 512, 512, 32, 16, 3)[0] == 7             # 32 -> 16 channels at 512^2: direct kernel, one staged window
+    assert plan(32, 256, 256, 32, 320, 3)[0] == 7            # its data gradient's shape: outputs in 32-channel slices
+    assert plan(2, 36, 36, 32, 16, 3)[0] != 7                # map width not a multiple of the 64-pixel window
     assert plan(2, 16, 16, 64, 64, 3)[0] == 0                # too few pixels for 256-row tiles
     assert plan(32, 128, 128, 160, 256, 1)[0] in (0, 1)      # channel tail (MiT-B0 width): small tiles only
     assert plan(32, 128, 128, 768, 3072, 1, aux=True)[0] in (0, 1)   # training epilogue: never the 256^2 tiles

@@ -791,10 +791,10 @@ def test_pyramid_fuse_matches_concat_conv(dtype, training):
 
 
 @pytest.mark.parametrize("B,H,W,C,N", [(2, 8, 64, 16, 16), (1, 12, 128, 32, 32), (2, 4, 64, 8, 16), (1, 8, 64, 16, 5),
-                                       (1, 16, 192, 32, 16), (3, 4, 64, 16, 32)])
+                                       (1, 16, 192, 32, 16), (3, 4, 64, 16, 32), (1, 8, 64, 32, 320), (2, 4, 64, 16, 72)])
 def test_conv3x3_narrow_direct_kernel(B, H, W, C, N):
-    """The direct 3x3 kernel for narrow layers on large maps (C in {8,16,32}, N <= 32; chosen by the planner whenever it
-    applies): image borders (hardware zero fill of the staged window), several tiles per image and per batch, N tails
+    """The direct 3x3 kernel for narrow layers on large maps (C in {8,16,32}, outputs in 32-channel slices; chosen by the planner
+    whenever it applies): image borders (hardware zero fill of the staged window), several tiles per image and per batch, N tails
     (5 classes), bias + ReLU + residual epilogue with f32 and bf16 outputs, vs F.conv2d and vs the implicit-GEMM tile."""
     import ctypes
     from gdlhip import _lib

@@ -74,6 +74,8 @@ def test_conv_bn_node_padded(dtype, cin, cout, stride, k):
     """conv-BN-ReLU training node with narrow channels (K-chunk tails), output padding to the 16-byte granularity
     and stride vs torch autograd."""
     B, H = 2, 12
+    # (the parameters come from torch's global generator, seeded per test id by conftest.py: unseeded, about one in four bf16
+    #  instances of the 6 x 6-output case flipped a ReLU mask at a near-zero pre-activation and missed the tolerance)
     conv = torch.nn.Conv2d(cin, cout, k, stride, k // 2, bias=False)
     bn = torch.nn.BatchNorm2d(cout)
     with torch.no_grad():
