@@ -5,7 +5,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02z
 mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|Error" | tail -5 > $O/pytest_gpu.txt
+case " $* " in *" notest "*) echo "(pytest skipped)" > $O/pytest_gpu.txt ;; *)
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|Error" | tail -5 > $O/pytest_gpu.txt ;; esac
 cat $O/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $O/smoke.txt
 timeout 900 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
@@ -15,5 +16,5 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- p
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 find $O/prof -name "*.csv" -size +4M -delete
 head -12 $O/kernel_stats.csv
-[ "$1" = "pmc" ] && bash $R/tools/pmc_bench_traffic.sh > $O/pmc.log 2>&1
+case " $* " in *" pmc "*) bash $R/tools/pmc_bench_traffic.sh > $O/pmc.log 2>&1 ;; esac
 tail -30 $O/pmc.log
