@@ -50,4 +50,11 @@ for name, hi, ho, c in (("neck 36->144 x768", 36, 144, 768), ("neck 36->72 x768"
     lib.gdl_debug_set_flat_resample(1)
     same = torch.equal(a, ops.bilinear(x, (ho, ho))) and torch.equal(g, ops.bilinear_bwd(a, (hi, hi)))
     lib.gdl_debug_set_flat_resample(0)
-    print(f"{name:24s} rows: {out[0]} | flat: {out[1]} | bit-identical {same}", flush=True)
+    # separable backward: vertical pass to [B, hi, ho, C], then horizontal pass (bilinear interpolation is a product of two
+    # 1-D interpolations, so is its transpose); bf16 intermediate
+    def two_pass():
+        t = ops.bilinear_bwd(y, (hi, ho))
+        return ops.bilinear_bwd(t, (hi, hi))
+    t2 = timeit(two_pass) if ho > hi else float("nan")
+    err = (two_pass().float() - g.float()).abs().max().item() / g.float().abs().max().item() if ho > hi else 0.0
+    print(f"{name:24s} rows: {out[0]} | flat: {out[1]} | bit-identical {same} | two-pass bwd {t2:6.0f} us (rel dev {err:.1e})", flush=True)
