@@ -56,6 +56,8 @@ struct Attn2Args {
   float* dvec;                                  // [B, H, Nq]  rowsum(dO * O)
   int B, H, Nq, N;                              // N = number of keys
   float scale, scale_log2e;
+  int qsplit;                                   // dK/dV kernel: query range cut into qsplit parts (blockIdx.y)
+  float* dkv_part;                              // qsplit > 1: f32 partials [qsplit][B*H][N][dK 64 | dV 64]
 };
 
 // One wave stages pieces of a [64 tokens][64 ch] tile: piece p (0..7) = token rows 8p..8p+7.
@@ -399,12 +401,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
   f32x16_t dvt[2] = {zero16(), zero16()}, dkt[2] = {zero16(), zero16()};   // rows = channels (tile ct), column = key
-  const int ntiles = (f.Nq + 63) / 64;
-  issue(0, 0);
-  for (int t = 0; t < ntiles; ++t) {
+  // query tiles [t_lo, t_hi) of this block: with few keys (MiT's spatial reduction: 256 keys for up to 16384 queries) the
+  // key blocks alone are 2 x B x H workgroups, so the query range is cut into blockIdx.y parts whose f32 partial sums a
+  // second kernel adds in a fixed order
+  const int ntiles_all = (f.Nq + 63) / 64;
+  const int per = (ntiles_all + f.qsplit - 1) / f.qsplit;
+  const int t_lo = blockIdx.y * per, t_hi = t_lo + per < ntiles_all ? t_lo + per : ntiles_all;
+  if (t_lo < t_hi) issue(t_lo & 1, t_lo * 64);
+  for (int t = t_lo; t < t_hi; ++t) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < ntiles) issue((t + 1) & 1, (t + 1) * 64);
+    if (t + 1 < t_hi) issue((t + 1) & 1, (t + 1) * 64);
     if (!active) continue;
     const unsigned char* sq = smem + (2 * (t & 1)) * TILE_BYTES;
     const unsigned char* sd = sq + TILE_BYTES;
@@ -444,6 +451,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   if (!active || !kok) return;
+  if (f.qsplit > 1) {
+    float* part = f.dkv_part + (((int64_t)blockIdx.y * f.B * f.H + bh) * f.N + key) * 128;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = ct * 32 + 8 * g + 4 * fhalf;
+        *(float4*)(part + d) = make_float4(dkt[ct][4 * g], dkt[ct][4 * g + 1], dkt[ct][4 * g + 2], dkt[ct][4 * g + 3]);
+        *(float4*)(part + 64 + d) = make_float4(dvt[ct][4 * g], dvt[ct][4 * g + 1], dvt[ct][4 * g + 2], dvt[ct][4 * g + 3]);
+      }
+    return;
+  }
   uint16_t* rk = f.dk + (int64_t)b * f.dk_sB + (int64_t)key * f.dk_sN + (int64_t)h * 64;
   uint16_t* rv = f.dv + (int64_t)b * f.dv_sB + (int64_t)key * f.dv_sN + (int64_t)h * 64;
 #pragma unroll
@@ -454,6 +473,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       *(uint2*)(rk + d) = make_uint2(pack_bf16x2(dkt[ct][4 * g], dkt[ct][4 * g + 1]), pack_bf16x2(dkt[ct][4 * g + 2], dkt[ct][4 * g + 3]));
       *(uint2*)(rv + d) = make_uint2(pack_bf16x2(dvt[ct][4 * g], dvt[ct][4 * g + 1]), pack_bf16x2(dvt[ct][4 * g + 2], dvt[ct][4 * g + 3]));
     }
+}
+
+// dK / dV = sum over the query parts, parts added in index order; one thread per (batch*head, key, 4 channels of dK|dV)
+__global__ __launch_bounds__(256) void flash_bwd_dkv_reduce_kernel(const Attn2Args f) {
+  const int64_t total = (int64_t)f.B * f.H * f.N * 32;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int d4 = (int)(i & 31), key = (int)((i >> 5) % f.N), bh = (int)((i >> 5) / f.N);
+  const int64_t plane = (int64_t)f.B * f.H * f.N * 128;
+  const float* p = f.dkv_part + ((int64_t)bh * f.N + key) * 128 + d4 * 4;
+  float4 a = *(const float4*)p;
+  for (int s = 1; s < f.qsplit; ++s) {
+    const float4 v = *(const float4*)(p + s * plane);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  const int b = bh / f.H, h = bh % f.H;
+  const bool is_v = d4 >= 16;
+  const int d = (d4 & 15) * 4;
+  uint16_t* dst = is_v ? f.dv + (int64_t)b * f.dv_sB + (int64_t)key * f.dv_sN + (int64_t)h * 64 + d
+                       : f.dk + (int64_t)b * f.dk_sB + (int64_t)key * f.dk_sN + (int64_t)h * 64 + d;
+  *(uint2*)dst = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
+}
+
+// query parts of the dK/dV kernel: enough workgroups for ~2 per CU, at least four 64-query tiles per part
+int dkv_qsplit(int B, int H, int Nq, int Nkv) {
+  const int64_t base = (int64_t)((Nkv + 127) / 128) * B * H;
+  const int ntiles = (Nq + 63) / 64;
+  int64_t s = (512 + base - 1) / base;
+  if (s > ntiles / 4) s = ntiles / 4;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : (int)s;
 }
 
 bool strides_ok(int64_t a, int64_t b) { return a % 8 == 0 && b % 8 == 0; }
@@ -485,12 +535,18 @@ extern "C" int gdl_flash_attn_fwd2(const void* q, int64_t q_sB, int64_t q_sN, co
   return GDL_OK;
 }
 
+extern "C" int64_t gdl_flash_attn_bwd_workspace(int B, int H, int Nq, int Nkv) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nkv <= 0) return 0;
+  const int s = dkv_qsplit(B, H, Nq, Nkv);
+  return s > 1 ? (int64_t)s * B * H * Nkv * 128 * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int gdl_flash_attn_bwd(const void* q, int64_t q_sB, int64_t q_sN, const void* k, int64_t k_sB, int64_t k_sN,
                                   const void* v, int64_t v_sB, int64_t v_sN, const void* o, int64_t o_sB, int64_t o_sN,
                                   const void* dout, int64_t do_sB, int64_t do_sN, const float* lse, float* dvec,
                                   void* dq, int64_t dq_sB, int64_t dq_sN, void* dk, int64_t dk_sB, int64_t dk_sN,
                                   void* dv, int64_t dv_sB, int64_t dv_sN, int B, int H, int Nq, int Nkv, float scale,
-                                  gdl_stream_t stream) {
+                                  float* ws, int64_t ws_bytes, gdl_stream_t stream) {
   GDL_CHECK_ARG(q && k && v && o && dout && lse && dvec && dq && dk && dv, "gdl_flash_attn_bwd: null pointer");
   GDL_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nkv > 0, "gdl_flash_attn_bwd: bad dims");
   GDL_CHECK_ARG(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)dout % 16 == 0) &&
@@ -513,7 +569,13 @@ extern "C" int gdl_flash_attn_bwd(const void* q, int64_t q_sB, int64_t q_sN, con
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(flash_bwd_dot_kernel, dim3((unsigned)(((int64_t)B * Nq + 3) / 4)), dim3(256), 0, s, f);
   hipLaunchKernelGGL(flash_bwd_dq_kernel, dim3((unsigned)((Nq + 127) / 128 * B * H)), dim3(256), 0, s, f);
-  hipLaunchKernelGGL(flash_bwd_dkv_kernel, dim3((unsigned)((Nkv + 127) / 128 * B * H)), dim3(256), 0, s, f);
+  f.qsplit = dkv_qsplit(B, H, Nq, Nkv);
+  f.dkv_part = ws;
+  GDL_CHECK_ARG(f.qsplit == 1 || (ws && ((uintptr_t)ws % 16 == 0) && ws_bytes >= gdl_flash_attn_bwd_workspace(B, H, Nq, Nkv)),
+                "gdl_flash_attn_bwd: workspace of gdl_flash_attn_bwd_workspace() bytes needed (16-byte aligned)");
+  hipLaunchKernelGGL(flash_bwd_dkv_kernel, dim3((unsigned)((Nkv + 127) / 128 * B * H), (unsigned)f.qsplit), dim3(256), 0, s, f);
+  if (f.qsplit > 1)
+    hipLaunchKernelGGL(flash_bwd_dkv_reduce_kernel, dim3((unsigned)(((int64_t)B * H * Nkv * 32 + 255) / 256)), dim3(256), 0, s, f);
   GDL_CHECK_LAUNCH("gdl_flash_attn_bwd");
   return GDL_OK;
 }

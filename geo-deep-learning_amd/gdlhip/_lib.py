@@ -107,7 +107,8 @@ SIGNATURES = {
     "gdl_flash_attn_fwd": (c_i, [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     "gdl_flash_attn_fwd2": (c_i, [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "gdl_flash_attn_bwd": (c_i, [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_p,
-                                 c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_f, c_p]),
+                                 c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p]),
+    "gdl_flash_attn_bwd_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "gdl_patchify": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "gdl_dwconv3x3": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "gdl_dofa_pack_kernel": (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_i, c_i, c_p]),

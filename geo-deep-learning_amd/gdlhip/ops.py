@@ -658,11 +658,13 @@ def attention_flash_bwd(q: Tensor, k: Tensor, v: Tensor, o: Tensor, do: Tensor, 
     if lse.shape != (B, num_heads, Nq) or lse.dtype != torch.float32 or not lse.is_contiguous():
         raise ValueError("attention_flash_bwd: lse must be contiguous f32 [B,H,Nq]")
     dvec = torch.empty_like(lse)
+    nbytes = _lib.load().gdl_flash_attn_bwd_workspace(B, num_heads, Nq, Nkv)
+    ws = torch.empty(nbytes // 4, device=q.device, dtype=torch.float32) if nbytes else None
     check(_lib.load().gdl_flash_attn_bwd(
         _p(q), q.stride(0), q.stride(1), _p(k), k.stride(0), k.stride(1), _p(v), v.stride(0), v.stride(1),
         _p(o), o.stride(0), o.stride(1), _p(do), do.stride(0), do.stride(1), _p(lse), _p(dvec),
         _p(dq), dq.stride(0), dq.stride(1), _p(dk), dk.stride(0), dk.stride(1), _p(dv), dv.stride(0), dv.stride(1),
-        B, num_heads, Nq, Nkv, float(hd) ** -0.5, _stream()), "gdl_flash_attn_bwd")
+        B, num_heads, Nq, Nkv, float(hd) ** -0.5, _p(ws), nbytes, _stream()), "gdl_flash_attn_bwd")
 
 
 def split_qkv(qkv: Tensor):

@@ -286,7 +286,9 @@ int gdl_flash_attn_fwd(const void* q, int64_t q_sB, int64_t q_sN, const void* k,
  * MiT Attention, mix_transformer.py:66-157) with the probabilities recomputed tile by tile from lse: nothing of size
  * Nq x Nkv is materialised.  q / o / dout / dq are [B,Nq,H*64] token rows, k / v / dk / dv [B,Nkv,H*64], all bf16 with
  * unit channel stride and arbitrary (16-byte aligned) batch / token strides, e.g. slices of a packed qkv tensor.
- * dvec [B,H,Nq] f32 is scratch (rowsum(dO * O)).  Deterministic (no atomics). */
+ * dvec [B,H,Nq] f32 is scratch (rowsum(dO * O)).  ws: gdl_flash_attn_bwd_workspace() bytes of 16-byte aligned
+ * scratch (0 for most shapes, then ws may be NULL): with few keys and many queries (MiT's spatial reduction) the dK / dV
+ * kernel cuts the query range into parts whose f32 partial sums are added in a fixed order.  Deterministic (no atomics). */
 int gdl_flash_attn_fwd2(const void* q, int64_t q_sB, int64_t q_sN, const void* k, int64_t k_sB, int64_t k_sN,
                         const void* v, int64_t v_sB, int64_t v_sN, void* o, int64_t o_sB, int64_t o_sN, float* lse,
                         int B, int H, int Nq, int Nkv, float scale, gdl_stream_t stream);
@@ -295,7 +297,8 @@ int gdl_flash_attn_bwd(const void* q, int64_t q_sB, int64_t q_sN, const void* k,
                        const void* dout, int64_t do_sB, int64_t do_sN, const float* lse, float* dvec,
                        void* dq, int64_t dq_sB, int64_t dq_sN, void* dk, int64_t dk_sB, int64_t dk_sN,
                        void* dv, int64_t dv_sB, int64_t dv_sN, int B, int H, int Nq, int Nkv, float scale,
-                       gdl_stream_t stream);
+                       float* ws, int64_t ws_bytes, gdl_stream_t stream);
+int64_t gdl_flash_attn_bwd_workspace(int B, int H, int Nq, int Nkv);
 
 /* ---- DOFA patch embed (dofa_v2.py:157-181) --------------------------------------------
  * im2col of conv2d(stride=P, padding=1, kernel P): in NCHW f32 [B,C,H,W] ->

@@ -239,7 +239,9 @@ def test_attention_flash(B, N, H):
     close(o, ref, dtype, "attention_flash")
 
 
-@pytest.mark.parametrize("B,Nq,Nkv,H", [(2, 70, 70, 2), (2, 300, 300, 4), (1, 1297, 1297, 8), (2, 333, 100, 4), (1, 64, 257, 3)])
+@pytest.mark.parametrize("B,Nq,Nkv,H", [(2, 70, 70, 2), (2, 300, 300, 4), (1, 1297, 1297, 8), (2, 333, 100, 4), (1, 64, 257, 3),
+                                        # few keys, many queries (MiT stage 1/2): the dK/dV kernel splits the query range
+                                        (2, 4096, 256, 1), (1, 1000, 100, 2)])
 def test_attention_flash_lse_and_fused_backward(B, Nq, Nkv, H):
     """Second-generation attention kernels: LSE output, V read row-major, and the fused backward (probabilities
     recomputed from LSE, no [Nq, Nkv] tensor) vs torch autograd; packed / strided operands; both block orders
