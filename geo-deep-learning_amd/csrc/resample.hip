@@ -140,6 +140,32 @@ __global__ __launch_bounds__(256) void bilinear_sum_kernel(SumSrc src, int nsrc,
   else V4<T>::st(out, ooff, o);
 }
 
+// Strided NHWC copy with dtype conversion (the compute-dtype cast of a channel slice, densifying a strided gradient):
+// one thread per (pixel, 4-channel vector); rows of pixels are walked per block so that no 64-bit division runs per element.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void copy_cast_kernel(const void* __restrict__ in, int W, int C, int64_t isB, int64_t isH,
+                                                        int64_t isW, void* out, int H, int64_t osB, int64_t osH, int64_t osW) {
+  const int cv = C / 4;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= W * cv) return;
+  const int x = j / cv, c = (j - x * cv) * 4;
+  const int b = blockIdx.y / H, y = blockIdx.y - b * H;
+  float v[4];
+  V4<TI>::ld(in, (int64_t)b * isB + (int64_t)y * isH + (int64_t)x * isW + c, v);
+  V4<TO>::st(out, (int64_t)b * osB + (int64_t)y * osH + (int64_t)x * osW + c, v);
+}
+// bf16 -> bf16 with 16-byte accesses
+__global__ __launch_bounds__(256) void copy8_kernel(const void* __restrict__ in, int W, int C, int64_t isB, int64_t isH,
+                                                    int64_t isW, void* out, int H, int64_t osB, int64_t osH, int64_t osW) {
+  const int cv = C / 8;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= W * cv) return;
+  const int x = j / cv, c = (j - x * cv) * 8;
+  const int b = blockIdx.y / H, y = blockIdx.y - b * H;
+  const uint4 v = *(const uint4*)((const uint16_t*)in + (int64_t)b * isB + (int64_t)y * isH + (int64_t)x * isW + c);
+  *(uint4*)((uint16_t*)out + (int64_t)b * osB + (int64_t)y * osH + (int64_t)x * osW + c) = v;
+}
+
 // Backward (gather): din[iy,ix] (+)= sum over outputs whose taps touch (iy,ix).
 // Candidate outputs: src in (i-1, i+1)  =>  dst in ((i-0.5)/ratio - 0.5, (i+1.5)/ratio - 0.5).
 template <typename TO_, typename TI_>  // TO_ = dtype of dout, TI_ = dtype of din
@@ -517,6 +543,26 @@ extern "C" int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int
   DISPATCH2(bilinear_fwd_kernel, in_dtype, out_dtype, dim3(grid_for(total)), dim3(256), 0,
             (hipStream_t)stream, in, B, Hi, Wi, C, isB, isH, isW, out, Ho, Wo, osB, osH, osW, accumulate);
   GDL_CHECK_LAUNCH("gdl_bilinear_fwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_copy_cast(const void* in, int in_dtype, int B, int H, int W, int C, int64_t isB, int64_t isH, int64_t isW,
+                             void* out, int out_dtype, int64_t osB, int64_t osH, int64_t osW, gdl_stream_t stream) {
+  GDL_CHECK_ARG(in && out && B > 0 && H > 0 && W > 0 && C > 0, "gdl_copy_cast: bad args");
+  GDL_CHECK_ARG((in_dtype == GDL_F32 || in_dtype == GDL_BF16) && (out_dtype == GDL_F32 || out_dtype == GDL_BF16), "gdl_copy_cast: bad dtype");
+  GDL_CHECK_ARG(C % 4 == 0 && isB % 4 == 0 && isH % 4 == 0 && isW % 4 == 0 && osB % 4 == 0 && osH % 4 == 0 && osW % 4 == 0 &&
+                    (uintptr_t)in % 8 == 0 && (uintptr_t)out % 8 == 0,
+                "gdl_copy_cast: C, strides and pointers must keep 4-channel alignment");
+  GDL_CHECK_ARG((int64_t)B * H <= 65535 * 1ll, "gdl_copy_cast: B * H must fit one grid dimension");
+  if (in_dtype == GDL_BF16 && out_dtype == GDL_BF16 && vec8_ok(in, out, C, isB, isH, isW, osB, osH, osW)) {
+    hipLaunchKernelGGL(copy8_kernel, dim3((unsigned)((W * (C / 8) + 255) / 256), (unsigned)(B * H)), dim3(256), 0,
+                       (hipStream_t)stream, in, W, C, isB, isH, isW, out, H, osB, osH, osW);
+  } else {
+    const dim3 grid((unsigned)((W * (C / 4) + 255) / 256), (unsigned)(B * H));
+    DISPATCH2(copy_cast_kernel, in_dtype, out_dtype, grid, dim3(256), 0, (hipStream_t)stream, in, W, C, isB, isH, isW, out, H, osB,
+              osH, osW);
+  }
+  GDL_CHECK_LAUNCH("gdl_copy_cast");
   return GDL_OK;
 }
 

@@ -93,11 +93,11 @@ class _ToCompute(Function):
     @staticmethod
     def forward(ctx, x, cd):
         ctx.in_dtype = x.dtype
-        return ops.bilinear(x, (x.shape[1], x.shape[2]), out_dtype=cd)
+        return ops.copy_cast(x, out_dtype=cd)
 
     @staticmethod
     def backward(ctx, g):
-        return ops.bilinear(g, (g.shape[1], g.shape[2]), out_dtype=ctx.in_dtype), None
+        return ops.copy_cast(g, out_dtype=ctx.in_dtype), None
 
 
 def to_compute(x: Tensor, cd: torch.dtype) -> Tensor:
@@ -106,7 +106,7 @@ def to_compute(x: Tensor, cd: torch.dtype) -> Tensor:
         return x
     if x.requires_grad and torch.is_grad_enabled():
         return _ToCompute.apply(x, cd)
-    return ops.bilinear(x, (x.shape[1], x.shape[2]), out_dtype=cd)
+    return ops.copy_cast(x, out_dtype=cd)
 
 
 def _world(group=None) -> int:
@@ -409,8 +409,7 @@ class _UpsampleAdd(Function):
     @staticmethod
     def forward(ctx, a, b):
         ctx.b_size = (b.shape[1], b.shape[2])
-        out = ops.bilinear(a, (a.shape[1], a.shape[2]), out_dtype=a.dtype,
-                           out=torch.empty(a.shape, device=a.device, dtype=a.dtype))
+        out = ops.copy_cast(a, out=torch.empty(a.shape, device=a.device, dtype=a.dtype))
         return ops.bilinear(b, (a.shape[1], a.shape[2]), out=out, accumulate=True)
 
     @staticmethod

@@ -344,6 +344,23 @@ def bilinear(x: Tensor, size: tuple[int, int], out: Tensor | None = None,
     return out
 
 
+def copy_cast(x: Tensor, out: Tensor | None = None, out_dtype: torch.dtype | None = None) -> Tensor:
+    """Strided NHWC copy with dtype conversion (f32 / bf16): dense copy of a channel slice, compute-dtype cast."""
+    _need_cuda(x)
+    x4 = _nhwc4(x, "copy_cast x")
+    B, H, W, Cc = x4.shape
+    if out is None:
+        out = torch.empty(x4.shape, device=x.device, dtype=out_dtype or x.dtype)
+    o4 = _nhwc4(out, "copy_cast out")
+    if tuple(o4.shape) != (B, H, W, Cc):
+        raise ValueError(f"copy_cast: out shape {tuple(o4.shape)} != {(B, H, W, Cc)}")
+    if B * H > 65535 or Cc % 4:        # very tall batches / odd channel counts: the identity resample handles any layout
+        return bilinear(x, (H, W), out=out)
+    check(_lib.load().gdl_copy_cast(_p(x4), dt(x4), B, H, W, Cc, x4.stride(0), x4.stride(1), x4.stride(2), _p(o4), dt(o4),
+                                    o4.stride(0), o4.stride(1), o4.stride(2), _stream()), "gdl_copy_cast")
+    return out
+
+
 def bilinear_sum(xs: list[Tensor], size: tuple[int, int]) -> Tensor:
     """sum_k bilinear(xs[k] -> size) for 1..3 dense NHWC maps with equal batch / channels / dtype, one output write."""
     _need_cuda(*xs)

@@ -46,14 +46,12 @@ def flipped_weight(weight: Tensor, cd: torch.dtype) -> Tensor:
 
 
 def _dense(g: Tensor) -> Tensor:
-    """Contiguous version of a (possibly strided, unit channel stride) gradient; copy through the
-    identity-resample kernel when needed."""
+    """Contiguous version of a (possibly strided, unit channel stride) gradient (ops.copy_cast when needed)."""
     if g.is_contiguous():
         return g
     shape = g.shape
     g4 = g if g.dim() == 4 else g.reshape(shape[0], 1, -1, shape[-1]) if g.dim() == 3 else g.unsqueeze(0).unsqueeze(0)
-    out = ops.bilinear(g4, (g4.shape[1], g4.shape[2]), out_dtype=g.dtype)
-    return out.view(shape)
+    return ops.copy_cast(g4, out_dtype=g.dtype).view(shape)
 
 
 def _to_cd(g: Tensor, cd: torch.dtype) -> Tensor:
@@ -64,7 +62,7 @@ def _to_cd(g: Tensor, cd: torch.dtype) -> Tensor:
         return ops.cast(g, cd)
     shape = g.shape
     g4 = g if g.dim() == 4 else g.reshape(shape[0], 1, -1, shape[-1])
-    return ops.bilinear(g4, (g4.shape[1], g4.shape[2]), out_dtype=cd).view(shape)
+    return ops.copy_cast(g4, out_dtype=cd).view(shape)
 
 
 def _conv_shape(weight: Tensor) -> tuple[int, int, int, int]:

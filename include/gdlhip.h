@@ -247,6 +247,10 @@ int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int Wi, int C,
                      int64_t in_sH, int64_t in_sW, void* out, int out_dtype, int Ho, int Wo,
                      int64_t out_sB, int64_t out_sH, int64_t out_sW, int accumulate,
                      gdl_stream_t stream);
+/* strided NHWC copy with dtype conversion: `x.to(dtype)` under autocast, `.contiguous()` of a channel slice
+ * (models/utils.py:50-52 inputs, torch.cat slices of upernet.py:103-109 in backward) */
+int gdl_copy_cast(const void* in, int in_dtype, int B, int H, int W, int C, int64_t in_sB, int64_t in_sH, int64_t in_sW,
+                  void* out, int out_dtype, int64_t out_sB, int64_t out_sH, int64_t out_sW, gdl_stream_t stream);
 /* out = sum_k bilinear(src_k -> Ho x Wo) for 1..3 DENSE sources [B, hs[k], ws[k], C] of one dtype, written once (dense
  * [B,Ho,Wo,C], same dtype).  segformer_mlp.py:97-125: `linear_fuse(cat([resize(_c4), resize(_c3), resize(_c2), _c1]))` is
  * evaluated per level at the level's own resolution (a 1x1 convolution commutes with the resize); this sums the upsampled

@@ -822,3 +822,21 @@ def test_conv3x3_narrow_direct_kernel(B, H, W, C, N):
     assert (outs[1] - outs[0]).abs().max().item() <= 1e-4 * ref.abs().max().item()    # same bf16 products, other K order
     yb = ops.conv_gemm(xn, wq, R=3, S=3, pad=1)                                         # plain bf16 output
     close(yb.permute(0, 3, 1, 2), F.conv2d(x, w, padding=1), dtype, "direct narrow 3x3, bf16 out")
+
+
+@pytest.mark.parametrize("dt_in,dt_out", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.float32),
+                                          (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)])
+def test_copy_cast_strided(dt_in, dt_out):
+    """Strided NHWC copy + dtype conversion: channel slices of wider buffers on both sides, 8- and 4-channel vectors."""
+    B, H, W = 2, 5, 7
+    for C, Cw in ((16, 48), (12, 20)):
+        src = rnd(B, H, W, Cw, seed=C).to(dt_in)
+        sd = src.to(DEV)
+        x = sd[..., 4:4 + C]
+        y = ops.copy_cast(x, out_dtype=dt_out)
+        assert y.is_contiguous() and y.dtype == dt_out
+        assert torch.equal(y.cpu(), src[..., 4:4 + C].to(dt_out))
+        wide = torch.zeros(B, H, W, Cw + 8, device=DEV, dtype=dt_out)
+        ops.copy_cast(x, out=wide[..., 8:8 + C])
+        assert torch.equal(wide[..., 8:8 + C].cpu(), src[..., 4:4 + C].to(dt_out))
+        assert float(wide[..., :8].abs().max()) == 0.0 and float(wide[..., 8 + C:].abs().max()) == 0.0
