@@ -421,6 +421,90 @@ __global__ __launch_bounds__(256) void bilinear_bwd8_rows_kernel(const void* __r
   V8::st(din, ioff, acc);
 }
 
+// Backward of  y = conv3x3(pad 1)(bilinear_resize(x))  WITHOUT the high-resolution data gradient.
+//   y[p] = sum_t W_t (S_t U x)[p]      U = the resize (spatial), S_t = shift by tap t with zero fill (spatial), W_t = channel mix
+// U and S_t act on pixels, W_t on channels, so they commute:  dx = sum_t W_t^T G_t  and  dW_t = sum_q G_t[q] (x) x[q]  with
+//   G_t = U^T S_t^T dy                  -- nine LOW-resolution maps per output channel.
+// Both gradients become GEMMs over the low-resolution pixels (1/16 of the MACs of the full-resolution data / weight
+// gradient for a x4 resize).  This kernel is the gather G_t[q] = sum_{p'} U[p', q] dy[p' - t] (p' and p' - t inside the
+// image), written as [B, Hi, Wi, 9 * N] with tap block 8 - t (the order of gdl_pack_dgrad's flipped taps, so that the
+// existing data-gradient operand applies as a 1x1 convolution).  One block per low-resolution row segment; the
+// vertical weights are block-uniform.  f32 accumulation, fixed order, no atomics.
+template <typename V, int VEC, int NX>
+__global__ __launch_bounds__(256) void resize_conv3x3_bwd_gather_kernel(const void* __restrict__ dy, int Ho, int Wo, int N,
+                                                                        void* g, int Hi, int Wi) {
+  const int cv = N / VEC;
+  const int nblk = gridDim.x * gridDim.y;
+  const int id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = id & 7, idx = id >> 3;      // XCD-major: neighbouring rows share an L2
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int brow = lid / gridDim.x, bx = lid - brow * gridDim.x;
+  const int j0 = bx * 256 + threadIdx.x;
+  if (j0 >= Wi * cv) return;
+  const int b = brow / Hi, iy = brow - b * Hi;
+  const int ix = j0 / cv, c = (j0 - ix * cv) * VEC;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  int oy_lo = (int)floorf(((float)iy - 0.5f) / ry - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / ry - 0.5f) + 1;
+  int ox_lo = (int)floorf(((float)ix - 0.5f) / rx - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / rx - 0.5f) + 1;
+  oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+  oy_hi = oy_hi > Ho - 1 ? Ho - 1 : oy_hi; ox_hi = ox_hi > Wo - 1 ? Wo - 1 : ox_hi;
+  // horizontal weights of the window columns ox_lo + k (zero beyond the window)
+  float wx[NX];
+#pragma unroll
+  for (int k = 0; k < NX; ++k) {
+    const int ox = ox_lo + k;
+    wx[k] = 0.f;
+    if (ox <= ox_hi) {
+      int x0, x1; float lx;
+      src_index(rx, ox, Wi, x0, x1, lx);
+      wx[k] = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+    }
+  }
+  auto wyf = [&](int oy) -> float {            // vertical weight U_y[oy, iy]; 0 outside the image / the window
+    if (oy < oy_lo || oy > oy_hi) return 0.f;
+    int y0, y1; float ly;
+    src_index(ry, oy, Hi, y0, y1, ly);
+    return (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+  };
+  float acc[9][VEC];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+  const int sy_lo = oy_lo > 0 ? oy_lo - 1 : 0, sy_hi = oy_hi < Ho - 1 ? oy_hi + 1 : Ho - 1;
+  for (int sy = sy_lo; sy <= sy_hi; ++sy) {
+    // source pixel p = (sy, sx) feeds tap (r, s) through p' = p + (r - 1, s - 1)
+    const float wr[3] = {wyf(sy - 1), wyf(sy), wyf(sy + 1)};
+    if (wr[0] == 0.f && wr[1] == 0.f && wr[2] == 0.f) continue;            // uniform over the block
+    const int64_t rowoff = (((int64_t)b * Ho + sy) * Wo) * N + c;
+#pragma unroll
+    for (int j = 0; j < NX + 2; ++j) {
+      const int sx = ox_lo - 1 + j;
+      // p'_x = sx + s - 1 = ox_lo + (j + s - 2): window column index k = j + s - 2
+      const float w0 = (j - 2 >= 0 && j - 2 < NX) ? wx[j - 2 < 0 ? 0 : (j - 2 >= NX ? NX - 1 : j - 2)] : 0.f;
+      const float w1 = (j - 1 >= 0 && j - 1 < NX) ? wx[j - 1 < 0 ? 0 : (j - 1 >= NX ? NX - 1 : j - 1)] : 0.f;
+      const float w2 = (j < NX) ? wx[j >= NX ? NX - 1 : j] : 0.f;
+      if (sx < 0 || sx >= Wo || (w0 == 0.f && w1 == 0.f && w2 == 0.f)) continue;
+      float v[VEC];
+      V::ld(dy, rowoff + (int64_t)sx * N, v);
+      const float wc[3] = {w0, w1, w2};
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        float gx[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) gx[e] = wc[s3] * v[e];
+#pragma unroll
+        for (int r3 = 0; r3 < 3; ++r3)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[r3 * 3 + s3][e] += wr[r3] * gx[e];
+      }
+    }
+  }
+  const int64_t obase = ((((int64_t)b * Hi + iy) * Wi) + ix) * (9 * (int64_t)N) + c;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) V::st(g, obase + (int64_t)(8 - t) * N, acc[t]);
+}
+
 // nn.AdaptiveAvgPool2d: bin i covers [floor(i*In/S), ceil((i+1)*In/S))
 __device__ __forceinline__ void pool_bin(int i, int in, int s, int& lo, int& hi) {
   lo = (i * in) / s;
@@ -616,6 +700,29 @@ extern "C" int gdl_bilinear_bwd(const void* dout, int dout_dtype, int B, int Ho,
   DISPATCH2(bilinear_bwd_kernel, dout_dtype, din_dtype, dim3(grid_for(total)), dim3(256), 0,
             (hipStream_t)stream, dout, B, Ho, Wo, C, osB, osH, osW, din, Hi, Wi, isB, isH, isW, accumulate);
   GDL_CHECK_LAUNCH("gdl_bilinear_bwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_resize_conv3x3_bwd_gather(const void* dy, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi, int Wi,
+                                             gdl_stream_t stream) {
+  GDL_CHECK_ARG(dy && g && B > 0 && Ho > 0 && Wo > 0 && Hi > 0 && Wi > 0, "gdl_resize_conv3x3_bwd_gather: bad args");
+  GDL_CHECK_ARG(dtype == GDL_F32 || dtype == GDL_BF16, "gdl_resize_conv3x3_bwd_gather: bad dtype");
+  const int vec = dtype == GDL_BF16 ? 8 : 4;
+  GDL_CHECK_ARG(N % vec == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)g % 16 == 0,
+                "gdl_resize_conv3x3_bwd_gather: N must be a multiple of the 16-byte vector, pointers 16-byte aligned");
+  GDL_CHECK_ARG((int64_t)B * Hi <= 65535, "gdl_resize_conv3x3_bwd_gather: B * Hi must fit one grid dimension");
+  const int nx = 2 * ((Wo + Wi - 1) / Wi) + 4;
+  GDL_CHECK_ARG(nx <= 12, "gdl_resize_conv3x3_bwd_gather: resize factors above 4 are not instantiated");
+  const dim3 grid((unsigned)((Wi * (N / vec) + 255) / 256), (unsigned)(B * Hi));
+  hipStream_t s = (hipStream_t)stream;
+#define GATHER(V, VEC, NX) hipLaunchKernelGGL((resize_conv3x3_bwd_gather_kernel<V, VEC, NX>), grid, dim3(256), 0, s, dy, Ho, Wo, N, g, Hi, Wi)
+  if (dtype == GDL_BF16) {
+    if (nx <= 8) GATHER(V8, 8, 8); else GATHER(V8, 8, 12);
+  } else {
+    if (nx <= 8) GATHER(V4<float>, 4, 8); else GATHER(V4<float>, 4, 12);
+  }
+#undef GATHER
+  GDL_CHECK_LAUNCH("gdl_resize_conv3x3_bwd_gather");
   return GDL_OK;
 }
 

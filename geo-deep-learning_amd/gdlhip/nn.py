@@ -206,15 +206,19 @@ class _ConvBNActTrain(Function):
         if has_bias and ctx.needs_input_grad[2]:
             # a bias feeding train-mode BN has an analytically zero gradient
             dbias = torch.zeros(n, device=x.device, dtype=torch.float32)
-        dx = None
-        if ctx.needs_input_grad[0]:   # (before the weight gradient: the fused x4 path consumes dy's border lines)
-            dx = ops.conv_gemm(dy, dgrad_weight(weight, x.dtype), R=r, S=s, pad=r - 1 - pad)
-            if up4:
-                dx = ops.bilinear_bwd(dx, lo)
-        dw = None
-        if ctx.needs_input_grad[1]:
-            # up4: phase weight gradients on the low-res map (31 % fewer MACs, no upsampled tensor); dy is dead afterwards
-            dw = ops.up4_conv3x3_wgrad(x_lo, dy) if up4 else ops.conv_wgrad(x, dy, R=r, S=s, pad=pad)
+        dx = dw = None
+        if up4:
+            # both gradients as GEMMs over the LOW-resolution pixels: the resize and the tap shifts act on pixels, the
+            # weights on channels, so dx = sum_t W_t^T G_t and dW_t = sum_q G_t[q] (x) x[q] with G_t = resize^T shift_t^T dy
+            # (ops.resize_conv3x3_bwd): 1/16 of the MACs of the full-resolution data gradient + phase weight gradients
+            dx, dw = ops.resize_conv3x3_bwd(x_lo, dy, dgrad_weight(weight, x.dtype) if ctx.needs_input_grad[0] else None,
+                                            want_dw=ctx.needs_input_grad[1])
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv_gemm(dy, dgrad_weight(weight, x.dtype), R=r, S=s, pad=r - 1 - pad)
+            if ctx.needs_input_grad[1]:
+                dw = ops.conv_wgrad(x, dy, R=r, S=s, pad=pad)
+        if dw is not None:
             # same strides as the channels-last parameter (for 1x1 kernels torch keeps (C,1,1,1))
             dw = dw.view(n, c, 1, 1) if r == 1 and s == 1 else dw.view(n, r, s, c).permute(0, 3, 1, 2)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None

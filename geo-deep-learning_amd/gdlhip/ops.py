@@ -344,6 +344,37 @@ def bilinear(x: Tensor, size: tuple[int, int], out: Tensor | None = None,
     return out
 
 
+def resize_conv3x3_bwd_gather(dy: Tensor, in_size: tuple[int, int]) -> Tensor:
+    """The nine low-resolution maps G_t = resize^T(shift_t^T(dy)) of conv3x3(pad 1)(bilinear resize(x)) as one dense
+    [B, Hi, Wi, 9 * N] tensor, tap block 8 - t (see gdl_resize_conv3x3_bwd_gather)."""
+    _need_cuda(dy)
+    d4 = _nhwc4(dy, "resize_conv3x3_bwd_gather dy")
+    if not d4.is_contiguous():
+        raise ValueError("resize_conv3x3_bwd_gather: dy must be dense NHWC")
+    B, Ho, Wo, N = d4.shape
+    Hi, Wi = in_size
+    g = torch.empty((B, Hi, Wi, 9 * N), device=dy.device, dtype=dy.dtype)
+    check(_lib.load().gdl_resize_conv3x3_bwd_gather(_p(d4), dt(d4), B, Ho, Wo, N, _p(g), Hi, Wi, _stream()),
+          "gdl_resize_conv3x3_bwd_gather")
+    return g
+
+
+def resize_conv3x3_bwd(x_lo: Tensor, dy: Tensor, w_dgrad: Tensor | None, want_dw: bool = True):
+    """(dx_lo, dw) of y = conv3x3(pad 1)(bilinear resize(x_lo -> dy's size)) from dy, as GEMMs over the LOW-resolution
+    pixels.  ``w_dgrad`` [C, 9 * N] (gdl_pack_dgrad operand; None = no data gradient); dw [N, 9 * C] f32."""
+    x4 = _nhwc4(x_lo, "resize_conv3x3_bwd x")
+    B, Hi, Wi, Cc = x4.shape
+    N = dy.shape[-1]
+    g = resize_conv3x3_bwd_gather(dy, (Hi, Wi))
+    dx = conv_gemm(g, w_dgrad) if w_dgrad is not None else None
+    dw = None
+    if want_dw:
+        dw = torch.empty((N, 9 * Cc), device=dy.device, dtype=torch.float32)
+        for t in range(9):
+            conv_wgrad(x4, g[..., (8 - t) * N:(9 - t) * N], R=1, S=1, dw=dw[:, t * Cc:(t + 1) * Cc])
+    return dx, dw
+
+
 def copy_cast(x: Tensor, out: Tensor | None = None, out_dtype: torch.dtype | None = None) -> Tensor:
     """Strided NHWC copy with dtype conversion (f32 / bf16): dense copy of a channel slice, compute-dtype cast."""
     _need_cuda(x)
