@@ -163,8 +163,11 @@ class _ConvBNActTrain(Function):
         cd = x.dtype
         n, c, r, s = weight.shape
         cb = None if conv_bias is None else conv_bias.detach()
-        if up4:   # conv3x3(bilinear_x4(x)) without the upsampled intermediate (ops.up4_conv3x3)
+        if up4 == 4:   # conv3x3(bilinear_x4(x)) without the upsampled intermediate (ops.up4_conv3x3)
             y = ops.up4_conv3x3(x, subpix4_weight(weight, cd), bias=cb)
+        elif up4:      # other resize factors: the upsampled map is a temporary of the forward only (backward works on x)
+            y = ops.conv_gemm(ops.bilinear(x, (up4 * x.shape[1], up4 * x.shape[2])), gemm_weight(weight, cd), R=r, S=s,
+                              pad=pad, bias=cb)
         else:
             y = ops.conv_gemm(x, gemm_weight(weight, cd), R=r, S=s, pad=pad, bias=cb)
         world = _world(sync_group) if sync_group is not False else 1
@@ -351,13 +354,18 @@ def subpix4_weight(weight: Tensor, cd: torch.dtype) -> dict:
     return cached((weight,), f"subpix4:{cd}", build)
 
 
-def conv_bn_act(x: Tensor, conv: nn.Conv2d, norm: nn.Module, *, relu: bool = True, up4: bool = False) -> Tensor:
-    """ConvModule forward on an NHWC tensor (in the compute dtype); returns NHWC.  ``up4``: the input is bilinearly
-    upsampled x4 first (MultiLevelNeck's finest level) -- fused, see ops.up4_conv3x3."""
+def conv_bn_act(x: Tensor, conv: nn.Conv2d, norm: nn.Module, *, relu: bool = True, up4: bool = False, up: int = 1) -> Tensor:
+    """ConvModule forward on an NHWC tensor (in the compute dtype); returns NHWC.  ``up`` (2 or 4; ``up4`` = 4): the input is
+    bilinearly upsampled by that factor first (MultiLevelNeck's fine levels).  Factor 4 runs as sub-pixel phase convolutions
+    on the low-resolution map (ops.up4_conv3x3); for both factors the BACKWARD runs at low resolution
+    (ops.resize_conv3x3_bwd), the upsampled map is never kept."""
     r = conv.kernel_size[0]
     pad = conv.padding[0]
-    if up4 and not (r == 3 and pad == 1 and x.shape[1] >= 2 and x.shape[2] >= 2 and FUSE_UP4):
-        x, up4 = bilinear(x, (4 * x.shape[1], 4 * x.shape[2])), False
+    up4 = 4 if up4 else (int(up) if up in (2, 4) else 0)      # from here on: the resize factor fused into the node (0 = none)
+    if up > 1 and not up4:
+        x = bilinear(x, (int(up) * x.shape[1], int(up) * x.shape[2]))
+    if up4 and not (r == 3 and pad == 1 and x.shape[1] >= 2 and x.shape[2] >= 2 and FUSE_UP4 and conv.weight.shape[0] % 8 == 0):
+        x, up4 = bilinear(x, (up4 * x.shape[1], up4 * x.shape[2])), 0
     training = norm.training
     if training:
         if isinstance(norm, nn.SyncBatchNorm):
@@ -379,9 +387,11 @@ def conv_bn_act(x: Tensor, conv: nn.Conv2d, norm: nn.Module, *, relu: bool = Tru
     scale, shift = cached((norm.weight, norm.bias, norm.running_mean, norm.running_var), "bnfold",
                           lambda: ops.bn_fold(norm.weight.detach(), norm.bias.detach(),
                                               norm.running_mean, norm.running_var, norm.eps))
-    if up4:
+    if up4 == 4:
         return ops.up4_conv3x3(x, subpix4_weight(conv.weight, cd), bias=None if conv.bias is None else conv.bias.detach(),
                                scale=scale, shift=shift, act=ACT_RELU if relu else ACT_NONE)
+    if up4:
+        x = ops.bilinear(x, (up4 * x.shape[1], up4 * x.shape[2]))
     return ops.conv_gemm(x, gemm_weight(conv.weight, cd), R=r, S=r, pad=pad,
                          bias=None if conv.bias is None else conv.bias.detach(), scale=scale,
                          shift=shift, act=ACT_RELU if relu else ACT_NONE)

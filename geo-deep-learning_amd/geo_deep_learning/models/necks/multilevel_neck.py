@@ -27,9 +27,9 @@ class ConvModule(nn.Module):
             msg = "gdlhip neck ConvModule: norm_cfg={'type': 'BN'} is required (dofa.py:58-64)"
             raise NotImplementedError(msg)
 
-    def forward_nhwc(self, x: torch.Tensor, *, up4: bool = False) -> torch.Tensor:
-        """``up4``: x is first upsampled x4 (bilinear, align_corners=False) -- fused into the convolution."""
-        return gnn.conv_bn_act(x, self.conv, self.norm, relu=self.act is not None, up4=up4)
+    def forward_nhwc(self, x: torch.Tensor, *, up4: bool = False, up: int = 1) -> torch.Tensor:
+        """``up`` (2 / 4; ``up4`` = 4): x is first upsampled by that factor (bilinear, align_corners=False) inside the node."""
+        return gnn.conv_bn_act(x, self.conv, self.norm, relu=self.act is not None, up4=up4, up=up)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = gnn.to_compute(ops.as_nhwc(x), gnn.compute_dtype())
@@ -67,6 +67,8 @@ class MultiLevelNeck(nn.Module):
         for i in range(self.num_outs):
             if self.scales[i] == 4:      # resize x4 -> 3x3 conv as ONE fused op (no [B,4H,4W,C] intermediate, 31 % fewer MACs)
                 outs.append(self.convs[i].forward_nhwc(lat[i], up4=True))
+            elif self.scales[i] == 2:    # resize x2 -> 3x3 conv: forward as is, both gradients at the low resolution
+                outs.append(self.convs[i].forward_nhwc(lat[i], up=2))
             else:
                 outs.append(self.convs[i].forward_nhwc(resize_nhwc(lat[i], self.scales[i])))
         return outs

@@ -168,6 +168,45 @@ def test_up4_conv3x3_matches_upsample_then_conv(dtype, B, H, W, C, N):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,N,up", [(2, 9, 9, 64, 256, 2), (1, 12, 7, 128, 64, 2), (3, 5, 6, 64, 64, 4), (2, 36, 36, 64, 64, 2)])
+def test_resized_conv_backward_at_low_resolution(dtype, B, H, W, C, N, up):
+    """ConvModule on a bilinearly upsampled input (MultiLevelNeck's x2 / x4 levels, multilevel_neck.py:56-67,157-158): the
+    node's data and weight gradients are GEMMs over the LOW-resolution pixels (nine gathered maps, ops.resize_conv3x3_bwd);
+    vs torch autograd of interpolate -> conv2d -> batch_norm -> relu on the CPU, every border pixel included."""
+    x, w = q(rnd(B, C, H, W), dtype), q(rnd(N, C, 3, 3, seed=1) * 0.1, dtype)
+    conv_r = torch.nn.Conv2d(C, N, 3, padding=1, bias=False)
+    bn_r = torch.nn.BatchNorm2d(N)
+    with torch.no_grad():
+        conv_r.weight.copy_(w)
+        bn_r.weight.copy_(rnd(N, seed=2).abs() + 0.5)
+        bn_r.bias.copy_(rnd(N, seed=3) * 0.1)
+    xr = x.clone().requires_grad_()
+    yr = F.relu(bn_r(conv_r(F.interpolate(xr, scale_factor=up, mode="bilinear", align_corners=False))))
+    gy = q(rnd(*yr.shape, seed=5), dtype)
+    yr.backward(gy)
+    import copy
+    conv = copy.deepcopy(conv_r).to(DEV).to(memory_format=torch.channels_last)
+    norm = copy.deepcopy(bn_r).to(DEV)
+    norm.reset_running_stats()
+    for p in list(conv.parameters()) + list(norm.parameters()):
+        p.grad = None
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype).requires_grad_()
+    y = gnn.conv_bn_act(xd, conv, norm.train(), relu=True, up=up)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(DEV, dtype))
+    close(y.permute(0, 3, 1, 2), yr, dtype, "output")
+    # bf16: conv output, dy and the nine gathered maps are stored in bf16 -- gradients are held in the L2 norm (3-4 % is
+    # what train-mode BatchNorm's backward costs in bf16 on maps this small, fused or not: test_pyramid_fuse_* prints it)
+    for got, ref, what in ((xd.grad.permute(0, 3, 1, 2), xr.grad, "dx"), (conv.weight.grad, conv_r.weight.grad, "dw"),
+                           (norm.weight.grad, bn_r.weight.grad, "dgamma"), (norm.bias.grad, bn_r.bias.grad, "dbeta")):
+        got, ref = got.float().cpu(), ref.float()
+        if dtype == torch.float32:
+            close(got, ref, dtype, what, scale=ref.abs().max().item())
+        else:
+            rel = float((got - ref).norm() / ref.norm())
+            assert rel <= 6e-2, (what, rel)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,C,N,R", [(2, 10, 12, 64, 96, 3), (1, 18, 18, 128, 256, 3), (2, 7, 5, 64, 64, 1),
                                          (3, 36, 36, 64, 128, 3),
                                          # channel tails (C not a multiple of the K chunk: MiT-B0's 32 / 160 channels)
