@@ -430,9 +430,12 @@ __global__ __launch_bounds__(256) void bilinear_bwd8_rows_kernel(const void* __r
 // image), written as [B, Hi, Wi, 9 * N] with tap block 8 - t (the order of gdl_pack_dgrad's flipped taps, so that the
 // existing data-gradient operand applies as a 1x1 convolution).  One block per low-resolution row segment; the
 // vertical weights are block-uniform.  f32 accumulation, fixed order, no atomics.
-template <typename V, int VEC, int NX>
+// WXL: the window's horizontal weights live in LDS ([NX][thread]) and the column loop is a runtime loop -- for wide windows
+// (x8 resize: NX = 20) the fully unrolled loop with register-held weights spilled.
+template <typename V, int VEC, int NX, bool WXL = false>
 __global__ __launch_bounds__(256) void resize_conv3x3_bwd_gather_kernel(const void* __restrict__ dy, int Ho, int Wo, int N,
                                                                         void* g, int Hi, int Wi) {
+  __shared__ float wxs[WXL ? NX + 4 : 1][WXL ? 256 : 1];
   const int cv = N / VEC;
   const int nblk = gridDim.x * gridDim.y;
   const int id = blockIdx.y * gridDim.x + blockIdx.x;
@@ -449,15 +452,30 @@ __global__ __launch_bounds__(256) void resize_conv3x3_bwd_gather_kernel(const vo
   oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
   oy_hi = oy_hi > Ho - 1 ? Ho - 1 : oy_hi; ox_hi = ox_hi > Wo - 1 ? Wo - 1 : ox_hi;
   // horizontal weights of the window columns ox_lo + k (zero beyond the window)
-  float wx[NX];
+  float wx[WXL ? 1 : NX];
+  if constexpr (WXL) {
+    // rows 0,1 and NX+2,NX+3 of the LDS table are zero guards: column j reads entries j, j+1, j+2 = window k = j-2, j-1, j
+    wxs[0][threadIdx.x] = 0.f; wxs[1][threadIdx.x] = 0.f; wxs[NX + 2][threadIdx.x] = 0.f; wxs[NX + 3][threadIdx.x] = 0.f;
+    for (int k = 0; k < NX; ++k) {
+      const int ox = ox_lo + k;
+      float w = 0.f;
+      if (ox <= ox_hi) {
+        int x0, x1; float lx;
+        src_index(rx, ox, Wi, x0, x1, lx);
+        w = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+      }
+      wxs[k + 2][threadIdx.x] = w;
+    }
+  } else {
 #pragma unroll
-  for (int k = 0; k < NX; ++k) {
-    const int ox = ox_lo + k;
-    wx[k] = 0.f;
-    if (ox <= ox_hi) {
-      int x0, x1; float lx;
-      src_index(rx, ox, Wi, x0, x1, lx);
-      wx[k] = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+    for (int k = 0; k < NX; ++k) {
+      const int ox = ox_lo + k;
+      wx[k] = 0.f;
+      if (ox <= ox_hi) {
+        int x0, x1; float lx;
+        src_index(rx, ox, Wi, x0, x1, lx);
+        wx[k] = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+      }
     }
   }
   auto wyf = [&](int oy) -> float {            // vertical weight U_y[oy, iy]; 0 outside the image / the window
@@ -477,14 +495,8 @@ __global__ __launch_bounds__(256) void resize_conv3x3_bwd_gather_kernel(const vo
     const float wr[3] = {wyf(sy - 1), wyf(sy), wyf(sy + 1)};
     if (wr[0] == 0.f && wr[1] == 0.f && wr[2] == 0.f) continue;            // uniform over the block
     const int64_t rowoff = (((int64_t)b * Ho + sy) * Wo) * N + c;
-#pragma unroll
-    for (int j = 0; j < NX + 2; ++j) {
-      const int sx = ox_lo - 1 + j;
-      // p'_x = sx + s - 1 = ox_lo + (j + s - 2): window column index k = j + s - 2
-      const float w0 = (j - 2 >= 0 && j - 2 < NX) ? wx[j - 2 < 0 ? 0 : (j - 2 >= NX ? NX - 1 : j - 2)] : 0.f;
-      const float w1 = (j - 1 >= 0 && j - 1 < NX) ? wx[j - 1 < 0 ? 0 : (j - 1 >= NX ? NX - 1 : j - 1)] : 0.f;
-      const float w2 = (j < NX) ? wx[j >= NX ? NX - 1 : j] : 0.f;
-      if (sx < 0 || sx >= Wo || (w0 == 0.f && w1 == 0.f && w2 == 0.f)) continue;
+    auto column = [&](int sx, float w0, float w1, float w2) {
+      if (sx < 0 || sx >= Wo || (w0 == 0.f && w1 == 0.f && w2 == 0.f)) return;
       float v[VEC];
       V::ld(dy, rowoff + (int64_t)sx * N, v);
       const float wc[3] = {w0, w1, w2};
@@ -497,6 +509,19 @@ __global__ __launch_bounds__(256) void resize_conv3x3_bwd_gather_kernel(const vo
         for (int r3 = 0; r3 < 3; ++r3)
 #pragma unroll
           for (int e = 0; e < VEC; ++e) acc[r3 * 3 + s3][e] += wr[r3] * gx[e];
+      }
+    };
+    // p'_x = sx + s - 1 = ox_lo + (j + s - 2): window column index k = j + s - 2
+    if constexpr (WXL) {
+#pragma unroll 2
+      for (int j = 0; j < NX + 2; ++j) column(ox_lo - 1 + j, wxs[j][threadIdx.x], wxs[j + 1][threadIdx.x], wxs[j + 2][threadIdx.x]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NX + 2; ++j) {
+        const float w0 = (j - 2 >= 0 && j - 2 < NX) ? wx[j - 2 < 0 ? 0 : (j - 2 >= NX ? NX - 1 : j - 2)] : 0.f;
+        const float w1 = (j - 1 >= 0 && j - 1 < NX) ? wx[j - 1 < 0 ? 0 : (j - 1 >= NX ? NX - 1 : j - 1)] : 0.f;
+        const float w2 = (j < NX) ? wx[j >= NX ? NX - 1 : j] : 0.f;
+        column(ox_lo - 1 + j, w0, w1, w2);
       }
     }
   }
@@ -712,14 +737,14 @@ extern "C" int gdl_resize_conv3x3_bwd_gather(const void* dy, int dtype, int B, i
                 "gdl_resize_conv3x3_bwd_gather: N must be a multiple of the 16-byte vector, pointers 16-byte aligned");
   GDL_CHECK_ARG((int64_t)B * Hi <= 65535, "gdl_resize_conv3x3_bwd_gather: B * Hi must fit one grid dimension");
   const int nx = 2 * ((Wo + Wi - 1) / Wi) + 4;
-  GDL_CHECK_ARG(nx <= 12, "gdl_resize_conv3x3_bwd_gather: resize factors above 4 are not instantiated");
+  GDL_CHECK_ARG(nx <= 20, "gdl_resize_conv3x3_bwd_gather: resize factors above 8 are not instantiated");
   const dim3 grid((unsigned)((Wi * (N / vec) + 255) / 256), (unsigned)(B * Hi));
   hipStream_t s = (hipStream_t)stream;
-#define GATHER(V, VEC, NX) hipLaunchKernelGGL((resize_conv3x3_bwd_gather_kernel<V, VEC, NX>), grid, dim3(256), 0, s, dy, Ho, Wo, N, g, Hi, Wi)
+#define GATHER(V, VEC, NX, WXL) hipLaunchKernelGGL((resize_conv3x3_bwd_gather_kernel<V, VEC, NX, WXL>), grid, dim3(256), 0, s, dy, Ho, Wo, N, g, Hi, Wi)
   if (dtype == GDL_BF16) {
-    if (nx <= 8) GATHER(V8, 8, 8); else GATHER(V8, 8, 12);
+    if (nx <= 8) GATHER(V8, 8, 8, false); else if (nx <= 12) GATHER(V8, 8, 12, false); else GATHER(V8, 8, 20, true);
   } else {
-    if (nx <= 8) GATHER(V4<float>, 4, 8); else GATHER(V4<float>, 4, 12);
+    if (nx <= 8) GATHER(V4<float>, 4, 8, false); else if (nx <= 12) GATHER(V4<float>, 4, 12, false); else GATHER(V4<float>, 4, 20, true);
   }
 #undef GATHER
   GDL_CHECK_LAUNCH("gdl_resize_conv3x3_bwd_gather");

@@ -227,6 +227,87 @@ class _ConvBNActTrain(Function):
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+FUSE_CONCAT_BWD = True   # A/B switch: False = keep the concat buffer and run the full-resolution data / weight gradients
+
+
+class _ConcatResizeConvBNTrain(Function):
+    """conv3x3(pad 1)(cat([l_0, bilinear(l_1 -> size), ..., bilinear(l_k -> size)])) -> BatchNorm(batch stats) -> ReLU
+    (UperNet `fpn_bottleneck` over the upsampled FPN levels, upernet.py:144-152).  Forward: the levels are resized straight
+    into the concat buffer and ONE K = 9 * sum(C_j) convolution runs on it; the buffer is a temporary.  Backward, per level:
+    the native-resolution level gets its slice of the ordinary data / weight gradient; an upsampled level gets both as GEMMs
+    over ITS OWN pixels from the nine gathered maps G_t = resize^T shift_t^T dy (ops.resize_conv3x3_bwd_gather) -- 1/4,
+    1/16, 1/64 of the MACs, no bilinear backward, and neither the concat buffer nor its gradient exists in backward."""
+
+    @staticmethod
+    def forward(ctx, weight, gamma, beta, running_mean, running_var, momentum, eps, relu, sync_group, *levels):
+        cd = levels[0].dtype
+        n = weight.shape[0]
+        B, H, W, _ = levels[0].shape
+        chans = [lv.shape[3] for lv in levels]
+        cat = torch.empty((B, H, W, sum(chans)), device=levels[0].device, dtype=cd)
+        off = 0
+        for lv, c in zip(levels, chans):
+            ops.bilinear(lv, (H, W), out=cat[..., off:off + c])
+            off += c
+        y = ops.conv_gemm(cat, gemm_weight(weight, cd), R=3, S=3, pad=1)
+        del cat
+        mean, var, world, p_local, p_share = _bn_train_stats(y, n, running_mean, running_var, momentum, sync_group)
+        out = ops.bn_apply(y, mean, var, gamma.detach(), beta.detach(), eps, relu)
+        ctx.save_for_backward(weight, y, mean, var, gamma, beta, *levels)
+        ctx.cfg = (relu, eps, sync_group, world, p_local, p_share, chans)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        weight, y, mean, var, gamma, beta, *levels = ctx.saved_tensors
+        relu, eps, sync_group, world, p_local, p_share, chans = ctx.cfg
+        n, ctot = weight.shape[0], weight.shape[1]
+        cd = y.dtype
+        dy, dgamma, dbeta = _bn_train_backward(y, gout, mean, var, gamma.detach(), beta.detach(), eps, relu, sync_group,
+                                               world, p_local, p_share)
+        H, W = dy.shape[1], dy.shape[2]
+        wd = dgrad_weight(weight, cd)                              # [sum(C_j), 9 N]: the rows of a level are contiguous
+        want_dw = ctx.needs_input_grad[0]
+        dw = torch.empty((n, 9, ctot), device=y.device, dtype=torch.float32) if want_dw else None
+        dls, off = [], 0
+        for j, (lv, c) in enumerate(zip(levels, chans)):
+            need_dx = ctx.needs_input_grad[9 + j]
+            if (lv.shape[1], lv.shape[2]) == (H, W):
+                dls.append(ops.conv_gemm(dy, wd[off:off + c], R=3, S=3, pad=1) if need_dx else None)
+                if want_dw:
+                    dw[:, :, off:off + c] = ops.conv_wgrad(lv, dy, R=3, S=3, pad=1).view(n, 9, c)
+            else:
+                dx, dwl = ops.resize_conv3x3_bwd(lv, dy, wd[off:off + c] if need_dx else None, want_dw=want_dw)
+                dls.append(dx)
+                if want_dw:
+                    dw[:, :, off:off + c] = dwl.view(n, 9, c)
+            off += c
+        if want_dw:
+            dw = dw.view(n, 3, 3, ctot).permute(0, 3, 1, 2)
+        return (dw, dgamma, dbeta, None, None, None, None, None, None, *dls)
+
+
+def concat_resize_conv_bn_act(levels: list[Tensor], conv: nn.Conv2d, norm: nn.Module, *, relu: bool = True) -> Tensor:
+    """ConvModule(3x3, pad 1, no bias) over cat([levels[0]] + [bilinear(l -> levels[0]'s size) for l in levels[1:]]) on NHWC
+    maps.  Training: see _ConcatResizeConvBNTrain; eval (and resize factors above 8): concat_upsample + conv_bn_act."""
+    size = (levels[0].shape[1], levels[0].shape[2])
+    def factor_ok(lv):
+        fy, fx = size[0] / lv.shape[1], size[1] / lv.shape[2]
+        return (lv.shape[1], lv.shape[2]) == size or (1.0 < fy <= 8.0 and 1.0 < fx <= 8.0)
+    ok = (FUSE_CONCAT_BWD and norm.training and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.bias is None
+          and conv.weight.shape[0] % 8 == 0 and all(lv.is_contiguous() and factor_ok(lv) for lv in levels)
+          and levels[0].shape[0] * max(lv.shape[1] for lv in levels) <= 65535)
+    if not ok:
+        return conv_bn_act(concat_upsample(levels, size), conv, norm, relu=relu)
+    sync_group = norm.process_group if isinstance(norm, nn.SyncBatchNorm) else False
+    momentum = 0.1 if norm.momentum is None else norm.momentum
+    out = _ConcatResizeConvBNTrain.apply(conv.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var, momentum,
+                                         norm.eps, relu, sync_group, *levels)
+    if norm.num_batches_tracked is not None:
+        norm.num_batches_tracked.add_(1)
+    return out
+
+
 FUSE_PYRAMID = True   # A/B switch: False = upsample every level into a concat buffer and run one wide 1x1 convolution
 
 

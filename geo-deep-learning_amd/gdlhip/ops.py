@@ -369,9 +369,9 @@ def resize_conv3x3_bwd(x_lo: Tensor, dy: Tensor, w_dgrad: Tensor | None, want_dw
     dx = conv_gemm(g, w_dgrad) if w_dgrad is not None else None
     dw = None
     if want_dw:
-        dw = torch.empty((N, 9 * Cc), device=dy.device, dtype=torch.float32)
-        for t in range(9):
-            conv_wgrad(x4, g[..., (8 - t) * N:(9 - t) * N], R=1, S=1, dw=dw[:, t * Cc:(t + 1) * Cc])
+        # one 1x1 weight gradient with the nine maps as 9 N "output channels": [(8 - t, n), c] -> [n, (t, c)]
+        dwp = conv_wgrad(x4, g, R=1, S=1)
+        dw = dwp.view(9, N, Cc).flip(0).permute(1, 0, 2).reshape(N, 9 * Cc)
     return dx, dw
 
 

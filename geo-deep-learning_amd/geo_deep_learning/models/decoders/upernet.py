@@ -54,7 +54,10 @@ class UperNetDecoder(nn.Module):
         fpn_outs = [self.fpn_convs[i].forward_nhwc(laterals[i]) for i in range(n - 1)]
         fpn_outs.append(laterals[-1])
         size = (fpn_outs[0].shape[1], fpn_outs[0].shape[2])
-        return self.fpn_bottleneck.forward_nhwc(gnn.concat_upsample(fpn_outs, size))
+        # 3x3 bottleneck over the concat of the upsampled levels; in training the upsampled levels' gradients are computed at
+        # their own resolution (gdlhip.nn.concat_resize_conv_bn_act)
+        return gnn.concat_resize_conv_bn_act(fpn_outs, self.fpn_bottleneck.conv, self.fpn_bottleneck.norm,
+                                             relu=self.fpn_bottleneck.act is not None)
 
     def forward(self, inputs: list[torch.Tensor]) -> torch.Tensor:
         cd = gnn.compute_dtype()

@@ -252,7 +252,7 @@ int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int Wi, int C,
  * dW_t = sum_q G_t[q] (x) x[q] where G_t = U^T S_t^T dy.  This is the gather that builds the nine maps: dy dense
  * [B,Ho,Wo,N] -> g dense [B,Hi,Wi,9*N], tap block 8 - t (= gdl_pack_dgrad's flipped tap order, so the data gradient is
  * gdl_conv_gemm(g, w_dgrad) as a 1x1 convolution with K = 9 N, and the weight gradient nine 1x1 gdl_conv_wgrad calls on
- * channel slices of g).  Resize factors up to 4.  Deterministic. */
+ * channel slices of g).  Resize factors up to 8.  Deterministic. */
 int gdl_resize_conv3x3_bwd_gather(const void* dy, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi, int Wi,
                                   gdl_stream_t stream);
 /* strided NHWC copy with dtype conversion: `x.to(dtype)` under autocast, `.contiguous()` of a channel slice

@@ -879,3 +879,57 @@ def test_copy_cast_strided(dt_in, dt_out):
         ops.copy_cast(x, out=wide[..., 8:8 + C])
         assert torch.equal(wide[..., 8:8 + C].cpu(), src[..., 4:4 + C].to(dt_out))
         assert float(wide[..., :8].abs().max()) == 0.0 and float(wide[..., 8 + C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_concat_resize_conv_backward_per_level(dtype):
+    """UperNet's fpn_bottleneck (3x3 over cat([l0, up2(l1), up4(l2), up8(l3)]), upernet.py:144-152): the training node that
+    computes the upsampled levels' data and weight gradients at their own resolution, vs torch autograd on the CPU
+    (interpolate -> cat -> conv2d -> batch_norm -> relu) and vs the build's concat path."""
+    import copy
+    from torch import nn
+    B, C, N, H, W = 2, 64, 128, 16, 24
+    sizes = [(H, W), (H // 2, W // 2), (H // 4, W // 4), (H // 8, W // 8)]
+    lv = [q(rnd(B, C, h, w, seed=20 + i), dtype) for i, (h, w) in enumerate(sizes)]
+    conv_r, bn_r = nn.Conv2d(4 * C, N, 3, padding=1, bias=False), nn.BatchNorm2d(N)
+    with torch.no_grad():
+        conv_r.weight.copy_(q(rnd(N, 4 * C, 3, 3, seed=1) * 0.05, dtype))
+        bn_r.weight.copy_(rnd(N, seed=2).abs() + 0.5)
+        bn_r.bias.copy_(rnd(N, seed=3) * 0.1)
+    ref_in = [t.clone().requires_grad_() for t in lv]
+    cat = torch.cat([ref_in[0]] + [F.interpolate(t, size=(H, W), mode="bilinear", align_corners=False) for t in ref_in[1:]], 1)
+    ref = F.relu(bn_r(conv_r(cat)))
+    gout = q(rnd(*ref.shape, seed=7), dtype)
+    ref.backward(gout)
+    outs = {}
+    for fused in (True, False):
+        gnn.FUSE_CONCAT_BWD = fused
+        try:
+            c, n = copy.deepcopy(conv_r).to(DEV).to(memory_format=torch.channels_last), copy.deepcopy(bn_r).to(DEV)
+            n.reset_running_stats()
+            for p_ in list(c.parameters()) + list(n.parameters()):
+                p_.grad = None
+            xs = [t.permute(0, 2, 3, 1).contiguous().to(DEV, dtype).requires_grad_() for t in lv]
+            y = gnn.concat_resize_conv_bn_act(xs, c, n.train(), relu=True)
+            y.backward(gout.permute(0, 2, 3, 1).contiguous().to(DEV, dtype))
+            outs[fused] = (y, xs, c, n)
+        finally:
+            gnn.FUSE_CONCAT_BWD = True
+    y, xs, c, n = outs[True]
+    _, xs_u, c_u, n_u = outs[False]
+    close(y.permute(0, 3, 1, 2), ref, dtype, "output")
+
+    def grad_ok(got, ref_, other, what):
+        got, ref_, other = got.float().cpu(), ref_.float().cpu(), other.float().cpu()
+        if dtype == torch.float32:
+            close(got, ref_, dtype, what, scale=ref_.abs().max().item())
+            return
+        rel, rel_other = float((got - ref_).norm() / ref_.norm()), float((other - ref_).norm() / ref_.norm())
+        print(f"{what}: per-level backward vs f32 reference {rel:.4f}, concat path vs reference {rel_other:.4f}")
+        assert rel <= max(2e-2, 1.5 * rel_other), (what, rel, rel_other)
+
+    for i, (x, r, xu) in enumerate(zip(xs, ref_in, xs_u)):
+        grad_ok(x.grad.permute(0, 3, 1, 2), r.grad, xu.grad.permute(0, 3, 1, 2), f"level {i} gradient")
+    grad_ok(c.weight.grad, conv_r.weight.grad, c_u.weight.grad, "3x3 weight gradient")
+    grad_ok(n.weight.grad, bn_r.weight.grad, n_u.weight.grad, "gamma gradient")
+    grad_ok(n.bias.grad, bn_r.bias.grad, n_u.bias.grad, "beta gradient")
