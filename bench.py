@@ -385,14 +385,18 @@ def main() -> None:
         dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
         name, s = dom
         achieved = s["flops"] / (s["ms"] * 1e-3) / 1e12
-        traffic, traffic_note = None, "no PMC summary committed"
+        traffic, traffic_note, pmc_extra = None, "no PMC summary committed", {}
         if PMC_TRAFFIC_FILE.is_file():
             pm = json.loads(PMC_TRAFFIC_FILE.read_text())
-            if pm.get("kernel_substring", "\0") in name:
-                traffic, traffic_note = pm["hbm_bytes_per_launch"], pm["note"]
+            for ent in pm.get("kernels", [pm]):          # one entry per implicit-GEMM kernel class (older files: one kernel)
+                if ent.get("kernel_substring", "\0") in name:
+                    traffic, traffic_note = ent["hbm_bytes_per_launch"], pm.get("note", ent.get("note", ""))
+                    pmc_extra = {k: ent[k] for k in ("fetch_bytes_per_launch", "write_bytes_per_launch", "l2_hit_rate",
+                                                     "mfma_busy_share") if k in ent}
         out["roofline"] = {
             "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
+            "pmc": pmc_extra,
             "launches": s["launches"], "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 2),
             "algorithmic_gflop_per_launch_avg": round(s["flops"] / s["launches"] / 1e9, 3),
             "share_of_step_time": round(s["ms"] * 1e-3 / res["train"], 4),
