@@ -530,6 +530,121 @@ __global__ __launch_bounds__(256) void resize_conv3x3_bwd_gather_kernel(const vo
   for (int t = 0; t < 9; ++t) V::st(g, obase + (int64_t)(8 - t) * N, acc[t]);
 }
 
+// The same gather in two separable passes (U = U_y (x) U_x and S_t = S_r (x) S_s, so U^T S_t^T = (U_y^T S_r^T) (x) (U_x^T S_s^T)):
+//   pass 1 (rows):    R_r[b, iy, ox] = sum_sy U_y[sy + r - 1, iy] dy[b, sy, ox]          three maps [3][B, Hi, Wo, N]
+//   pass 2 (columns): G_(r,s)[b, iy, ix] = sum_sx U_x[sx + s - 1, ix] R_r[b, iy, sx]     nine maps, tap block 8 - (3 r + s)
+// One load feeds 3 FMAs per channel in each pass instead of 12 per load over a (rows x columns) window: the single-pass kernel
+// is VALU-bound at resize factors of 4 and 8 (1.35 ms for the 1 GB gradient of the neck's x4 level against 0.3 ms of
+// memory time); the price is the intermediate (3 / factor of dy's size, written and read once, in dy's dtype).
+template <typename V, int VEC>
+__global__ __launch_bounds__(256) void resize_conv3x3_bwd_rows_kernel(const void* __restrict__ dy, int Ho, int Wo, int N,
+                                                                      void* r3, int Hi, int64_t plane) {
+  const int cv = N / VEC;
+  const int nblk = gridDim.x * gridDim.y;
+  const int id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = id & 7, idx = id >> 3;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int brow = lid / gridDim.x, bx = lid - brow * gridDim.x;
+  const int j0 = bx * 256 + threadIdx.x;
+  if (j0 >= Wo * cv) return;
+  const int b = brow / Hi, iy = brow - b * Hi;
+  const int ox = j0 / cv, c = (j0 - ox * cv) * VEC;
+  const float ry = (float)Hi / (float)Ho;
+  int oy_lo = (int)floorf(((float)iy - 0.5f) / ry - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / ry - 0.5f) + 1;
+  oy_lo = oy_lo < 0 ? 0 : oy_lo;
+  oy_hi = oy_hi > Ho - 1 ? Ho - 1 : oy_hi;
+  auto wyf = [&](int oy) -> float {
+    if (oy < oy_lo || oy > oy_hi) return 0.f;
+    int y0, y1; float ly;
+    src_index(ry, oy, Hi, y0, y1, ly);
+    return (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+  };
+  float acc[3][VEC];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+  const int sy_lo = oy_lo > 0 ? oy_lo - 1 : 0, sy_hi = oy_hi < Ho - 1 ? oy_hi + 1 : Ho - 1;
+  for (int sy = sy_lo; sy <= sy_hi; ++sy) {
+    const float wr[3] = {wyf(sy - 1), wyf(sy), wyf(sy + 1)};
+    if (wr[0] == 0.f && wr[1] == 0.f && wr[2] == 0.f) continue;
+    float v[VEC];
+    V::ld(dy, (((int64_t)b * Ho + sy) * Wo + ox) * N + c, v);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[t][e] += wr[t] * v[e];
+  }
+  const int64_t o = (((int64_t)b * Hi + iy) * Wo + ox) * N + c;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) V::st(r3, o + t * plane, acc[t]);
+}
+
+template <typename V, int VEC, int NX, bool WXL>
+__global__ __launch_bounds__(256) void resize_conv3x3_bwd_cols_kernel(const void* __restrict__ r3, int Wo, int N, void* g, int Hi,
+                                                                      int Wi, int64_t plane) {
+  __shared__ float wxs[WXL ? NX + 4 : 1][WXL ? 256 : 1];
+  const int cv = N / VEC;
+  const int j0 = blockIdx.x * 256 + threadIdx.x;
+  if (j0 >= Wi * cv) return;
+  const int brow = blockIdx.y;                         // = b * Hi + iy
+  const int ix = j0 / cv, c = (j0 - ix * cv) * VEC;
+  const float rx = (float)Wi / (float)Wo;
+  int ox_lo = (int)floorf(((float)ix - 0.5f) / rx - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / rx - 0.5f) + 1;
+  ox_lo = ox_lo < 0 ? 0 : ox_lo;
+  ox_hi = ox_hi > Wo - 1 ? Wo - 1 : ox_hi;
+  auto wxf = [&](int k) -> float {
+    const int ox = ox_lo + k;
+    if (ox > ox_hi) return 0.f;
+    int x0, x1; float lx;
+    src_index(rx, ox, Wi, x0, x1, lx);
+    return (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+  };
+  float wx[WXL ? 1 : NX];
+  if constexpr (WXL) {
+    wxs[0][threadIdx.x] = 0.f; wxs[1][threadIdx.x] = 0.f; wxs[NX + 2][threadIdx.x] = 0.f; wxs[NX + 3][threadIdx.x] = 0.f;
+    for (int k = 0; k < NX; ++k) wxs[k + 2][threadIdx.x] = wxf(k);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NX; ++k) wx[k] = wxf(k);
+  }
+  float acc[9][VEC];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+  const int64_t rowoff = (int64_t)brow * Wo * N + c;
+  auto column = [&](int sx, float w0, float w1, float w2) {
+    if (sx < 0 || sx >= Wo || (w0 == 0.f && w1 == 0.f && w2 == 0.f)) return;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float v[VEC];
+      V::ld(r3, rowoff + r * plane + (int64_t)sx * N, v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        acc[r * 3 + 0][e] += w0 * v[e];
+        acc[r * 3 + 1][e] += w1 * v[e];
+        acc[r * 3 + 2][e] += w2 * v[e];
+      }
+    }
+  };
+  if constexpr (WXL) {
+#pragma unroll 2
+    for (int j = 0; j < NX + 2; ++j) column(ox_lo - 1 + j, wxs[j][threadIdx.x], wxs[j + 1][threadIdx.x], wxs[j + 2][threadIdx.x]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NX + 2; ++j) {
+      const float w0 = (j - 2 >= 0 && j - 2 < NX) ? wx[j - 2 < 0 ? 0 : (j - 2 >= NX ? NX - 1 : j - 2)] : 0.f;
+      const float w1 = (j - 1 >= 0 && j - 1 < NX) ? wx[j - 1 < 0 ? 0 : (j - 1 >= NX ? NX - 1 : j - 1)] : 0.f;
+      const float w2 = (j < NX) ? wx[j >= NX ? NX - 1 : j] : 0.f;
+      column(ox_lo - 1 + j, w0, w1, w2);
+    }
+  }
+  const int64_t obase = ((int64_t)brow * Wi + ix) * (9 * (int64_t)N) + c;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) V::st(g, obase + (int64_t)(8 - t) * N, acc[t]);
+}
+
 // nn.AdaptiveAvgPool2d: bin i covers [floor(i*In/S), ceil((i+1)*In/S))
 __device__ __forceinline__ void pool_bin(int i, int in, int s, int& lo, int& hi) {
   lo = (i * in) / s;
@@ -748,6 +863,40 @@ extern "C" int gdl_resize_conv3x3_bwd_gather(const void* dy, int dtype, int B, i
   }
 #undef GATHER
   GDL_CHECK_LAUNCH("gdl_resize_conv3x3_bwd_gather");
+  return GDL_OK;
+}
+
+extern "C" int64_t gdl_resize_conv3x3_bwd_gather_workspace(int dtype, int B, int Wo, int N, int Hi) {
+  if (B <= 0 || Wo <= 0 || N <= 0 || Hi <= 0) return 0;
+  return 3ll * B * Hi * Wo * N * (dtype == GDL_BF16 ? 2 : 4);
+}
+
+// two-pass form of gdl_resize_conv3x3_bwd_gather; ws = gdl_resize_conv3x3_bwd_gather_workspace() bytes (16-byte aligned)
+extern "C" int gdl_resize_conv3x3_bwd_gather2(const void* dy, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi, int Wi,
+                                              void* ws, int64_t ws_bytes, gdl_stream_t stream) {
+  GDL_CHECK_ARG(dy && g && ws && B > 0 && Ho > 0 && Wo > 0 && Hi > 0 && Wi > 0, "gdl_resize_conv3x3_bwd_gather2: bad args");
+  GDL_CHECK_ARG(dtype == GDL_F32 || dtype == GDL_BF16, "gdl_resize_conv3x3_bwd_gather2: bad dtype");
+  const int vec = dtype == GDL_BF16 ? 8 : 4;
+  GDL_CHECK_ARG(N % vec == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)g % 16 == 0 && (uintptr_t)ws % 16 == 0,
+                "gdl_resize_conv3x3_bwd_gather2: N must be a multiple of the 16-byte vector, pointers 16-byte aligned");
+  GDL_CHECK_ARG(ws_bytes >= gdl_resize_conv3x3_bwd_gather_workspace(dtype, B, Wo, N, Hi), "gdl_resize_conv3x3_bwd_gather2: workspace too small");
+  GDL_CHECK_ARG((int64_t)B * Hi <= 65535, "gdl_resize_conv3x3_bwd_gather2: B * Hi must fit one grid dimension");
+  const int nx = 2 * ((Wo + Wi - 1) / Wi) + 4;
+  GDL_CHECK_ARG(nx <= 20, "gdl_resize_conv3x3_bwd_gather2: resize factors above 8 are not instantiated");
+  const int64_t plane = (int64_t)B * Hi * Wo * N;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid1((unsigned)((Wo * (N / vec) + 255) / 256), (unsigned)(B * Hi));
+  const dim3 grid2((unsigned)((Wi * (N / vec) + 255) / 256), (unsigned)(B * Hi));
+#define COLS(V, VEC, NX, WXL) hipLaunchKernelGGL((resize_conv3x3_bwd_cols_kernel<V, VEC, NX, WXL>), grid2, dim3(256), 0, s, ws, Wo, N, g, Hi, Wi, plane)
+  if (dtype == GDL_BF16) {
+    hipLaunchKernelGGL((resize_conv3x3_bwd_rows_kernel<V8, 8>), grid1, dim3(256), 0, s, dy, Ho, Wo, N, ws, Hi, plane);
+    if (nx <= 8) COLS(V8, 8, 8, false); else if (nx <= 12) COLS(V8, 8, 12, false); else COLS(V8, 8, 20, true);
+  } else {
+    hipLaunchKernelGGL((resize_conv3x3_bwd_rows_kernel<V4<float>, 4>), grid1, dim3(256), 0, s, dy, Ho, Wo, N, ws, Hi, plane);
+    if (nx <= 8) COLS(V4<float>, 4, 8, false); else if (nx <= 12) COLS(V4<float>, 4, 12, false); else COLS(V4<float>, 4, 20, true);
+  }
+#undef COLS
+  GDL_CHECK_LAUNCH("gdl_resize_conv3x3_bwd_gather2");
   return GDL_OK;
 }
 

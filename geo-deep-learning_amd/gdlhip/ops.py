@@ -344,6 +344,9 @@ def bilinear(x: Tensor, size: tuple[int, int], out: Tensor | None = None,
     return out
 
 
+GATHER_TWO_PASS = True    # A/B switch (tools / tests): separable two-pass gather for large resize factors
+
+
 def resize_conv3x3_bwd_gather(dy: Tensor, in_size: tuple[int, int]) -> Tensor:
     """The nine low-resolution maps G_t = resize^T(shift_t^T(dy)) of conv3x3(pad 1)(bilinear resize(x)) as one dense
     [B, Hi, Wi, 9 * N] tensor, tap block 8 - t (see gdl_resize_conv3x3_bwd_gather)."""
@@ -354,8 +357,15 @@ def resize_conv3x3_bwd_gather(dy: Tensor, in_size: tuple[int, int]) -> Tensor:
     B, Ho, Wo, N = d4.shape
     Hi, Wi = in_size
     g = torch.empty((B, Hi, Wi, 9 * N), device=dy.device, dtype=dy.dtype)
-    check(_lib.load().gdl_resize_conv3x3_bwd_gather(_p(d4), dt(d4), B, Ho, Wo, N, _p(g), Hi, Wi, _stream()),
-          "gdl_resize_conv3x3_bwd_gather")
+    lib = _lib.load()
+    if GATHER_TWO_PASS and Ho >= 2 * Hi:      # upsampling factors >= 2: the single pass is multiply-add bound
+        nbytes = lib.gdl_resize_conv3x3_bwd_gather_workspace(dt(d4), B, Wo, N, Hi)
+        ws = torch.empty(nbytes // d4.element_size(), device=dy.device, dtype=dy.dtype)
+        check(lib.gdl_resize_conv3x3_bwd_gather2(_p(d4), dt(d4), B, Ho, Wo, N, _p(g), Hi, Wi, _p(ws), nbytes, _stream()),
+              "gdl_resize_conv3x3_bwd_gather2")
+    else:
+        check(lib.gdl_resize_conv3x3_bwd_gather(_p(d4), dt(d4), B, Ho, Wo, N, _p(g), Hi, Wi, _stream()),
+              "gdl_resize_conv3x3_bwd_gather")
     return g
 
 

@@ -255,6 +255,11 @@ int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int Wi, int C,
  * channel slices of g).  Resize factors up to 8.  Deterministic. */
 int gdl_resize_conv3x3_bwd_gather(const void* dy, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi, int Wi,
                                   gdl_stream_t stream);
+/* the same result in two separable passes (rows, then columns) through a workspace of three [B,Hi,Wo,N] maps: fewer
+ * multiply-adds per loaded vector; the intermediate is rounded to dy's dtype */
+int64_t gdl_resize_conv3x3_bwd_gather_workspace(int dtype, int B, int Wo, int N, int Hi);
+int gdl_resize_conv3x3_bwd_gather2(const void* dy, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi, int Wi, void* ws,
+                                   int64_t ws_bytes, gdl_stream_t stream);
 /* strided NHWC copy with dtype conversion: `x.to(dtype)` under autocast, `.contiguous()` of a channel slice
  * (models/utils.py:50-52 inputs, torch.cat slices of upernet.py:103-109 in backward) */
 int gdl_copy_cast(const void* in, int in_dtype, int B, int H, int W, int C, int64_t in_sB, int64_t in_sH, int64_t in_sW,

@@ -933,3 +933,35 @@ def test_concat_resize_conv_backward_per_level(dtype):
     grad_ok(c.weight.grad, conv_r.weight.grad, c_u.weight.grad, "3x3 weight gradient")
     grad_ok(n.weight.grad, bn_r.weight.grad, n_u.weight.grad, "gamma gradient")
     grad_ok(n.bias.grad, bn_r.bias.grad, n_u.bias.grad, "beta gradient")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Hi,Wi,N,f", [(2, 5, 7, 64, 4), (1, 3, 4, 128, 8), (2, 9, 6, 64, 2), (1, 36, 36, 64, 4)])
+def test_resize_conv3x3_bwd_gather_two_pass(dtype, B, Hi, Wi, N, f):
+    """The nine gathered maps G_t = resize^T shift_t^T dy: the separable two-pass kernels (rows, then columns) vs the
+    single-pass kernel, and both vs the definition through torch autograd (d/dx of <dy, shift_t(interpolate(x))>)."""
+    Ho, Wo = f * Hi, f * Wi
+    dy = q(rnd(B, Ho, Wo, N, seed=3), dtype)
+    dyd = dy.to(DEV, dtype)
+    outs = {}
+    try:
+        for two in (True, False):
+            ops.GATHER_TWO_PASS = two
+            outs[two] = ops.resize_conv3x3_bwd_gather(dyd, (Hi, Wi)).float().cpu()
+    finally:
+        ops.GATHER_TWO_PASS = True
+    # definition: G_t[q, n] = d/dx[q] sum_p dy[p, n] * (shift_t(U x))[p], one channel at a time is independent -> use x = ones-probe
+    x = torch.zeros(B, N, Hi, Wi, requires_grad=True)
+    up = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False)
+    padded = F.pad(up, (1, 1, 1, 1))
+    dyn = dy.permute(0, 3, 1, 2)
+    ref = torch.empty(B, Hi, Wi, 9 * N)
+    for r in range(3):
+        for s3 in range(3):
+            (gx,) = torch.autograd.grad((padded[:, :, r:r + Ho, s3:s3 + Wo] * dyn).sum(), x, retain_graph=True)
+            t = 3 * r + s3
+            ref[..., (8 - t) * N:(9 - t) * N] = gx.permute(0, 2, 3, 1)
+    close(outs[False], ref, dtype, "single-pass gather")
+    close(outs[True], ref, dtype, "two-pass gather")
+    if dtype == torch.float32:
+        assert (outs[True] - outs[False]).abs().max().item() <= 1e-5 * ref.abs().max().item()
