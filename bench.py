@@ -400,6 +400,10 @@ def main() -> None:
             "launches": s["launches"], "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 2),
             "algorithmic_gflop_per_launch_avg": round(s["flops"] / s["launches"] / 1e9, 3),
             "share_of_step_time": round(s["ms"] * 1e-3 / res["train"], 4),
+            # the same kernel class split by reduction depth K = R*S*C of its launches (TF/s per bucket)
+            "by_k_depth": {b: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                               "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
+                           for b, v in sorted(s.get("by_k", {}).items())},
             "other_conv_gemm_variants": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                          for k, v in summ.items() if k != name},

@@ -171,16 +171,24 @@ class KernelTimer:
         e1.record()
         check(status, what)
         key = self.VARIANT[variant].format(dt="bf16" if a.dtype == BF16 else "f32")
-        self.records.append((key, fl.value, e0, e1))
+        self.records.append((key, fl.value, e0, e1, int(a.R) * int(a.S) * int(a.C)))
+
+    @staticmethod
+    def _k_bucket(k: int) -> str:
+        return "K<=1024" if k <= 1024 else ("1024<K<=4096" if k <= 4096 else "K>4096")
 
     def summary(self) -> dict:
+        """Per kernel class: launches, ms, flops, and the same split by reduction depth K = R*S*C (`by_k`): one class runs
+        12-K-step ViT linears and 100-K-step convolutions, whose achievable rates differ by a factor of two."""
         torch.cuda.synchronize()
         out: dict = {}
-        for key, flops, e0, e1 in self.records:
-            s = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0})
-            s["launches"] += 1
-            s["ms"] += e0.elapsed_time(e1)
-            s["flops"] += flops
+        for key, flops, e0, e1, kdepth in self.records:
+            ms = e0.elapsed_time(e1)
+            s = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0, "by_k": {}})
+            for d in (s, s["by_k"].setdefault(self._k_bucket(kdepth), {"launches": 0, "ms": 0.0, "flops": 0})):
+                d["launches"] += 1
+                d["ms"] += ms
+                d["flops"] += flops
         return out
 
 
