@@ -396,7 +396,7 @@ def pyramid_fuse_bn_act(levels: list[Tensor], conv: nn.Conv2d, norm: nn.Module, 
     maps, without the concat (see _PyramidFuseBNTrain).  Eval mode: the folded BN scale goes into the weights, so that every
     level's partial result is already scaled and the last GEMM's epilogue is relu(acc + shift + residual)."""
     ok = (FUSE_PYRAMID and conv.kernel_size == (1, 1) and conv.bias is None and 2 <= len(levels) <= 4
-          and all(lv.is_contiguous() for lv in levels))
+          and all(lv.is_contiguous() for lv in levels) and levels[-1].shape[0] * levels[-1].shape[1] <= 65535)
     size = (levels[-1].shape[1], levels[-1].shape[2])
     if not ok:
         return conv_bn_act(concat_upsample(levels, size), conv, norm, relu=relu)
@@ -445,7 +445,8 @@ def conv_bn_act(x: Tensor, conv: nn.Conv2d, norm: nn.Module, *, relu: bool = Tru
     up4 = 4 if up4 else (int(up) if up in (2, 4) else 0)      # from here on: the resize factor fused into the node (0 = none)
     if up > 1 and not up4:
         x = bilinear(x, (int(up) * x.shape[1], int(up) * x.shape[2]))
-    if up4 and not (r == 3 and pad == 1 and x.shape[1] >= 2 and x.shape[2] >= 2 and FUSE_UP4 and conv.weight.shape[0] % 8 == 0):
+    if up4 and not (r == 3 and pad == 1 and x.shape[1] >= 2 and x.shape[2] >= 2 and FUSE_UP4 and conv.weight.shape[0] % 8 == 0
+                    and x.shape[0] * x.shape[1] <= 65535):      # (the gather kernels put batch x rows in one grid dimension)
         x, up4 = bilinear(x, (up4 * x.shape[1], up4 * x.shape[2])), 0
     training = norm.training
     if training:
