@@ -1,0 +1,58 @@
+"""CPU checks (pure torch, f64) of the algebraic restructurings the MI355X path uses -- the GPU tests hold the KERNELS to torch
+autograd, these hold the IDENTITIES themselves, independent of any kernel:
+
+* backward of conv3x3(pad 1)(bilinear resize(x)) through nine low-resolution maps G_t = resize^T shift_t^T dy
+  (gdlhip/ops.py:resize_conv3x3_bwd; reference layer: multilevel_neck.py:56-67,157-158, upernet.py:144-152);
+* SegFormer's linear_fuse: a 1x1 convolution commutes with the bilinear resize (gdlhip/nn.py:pyramid_fuse_bn_act;
+  segformer_mlp.py:97-125).
+"""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def _gathered_maps(dy, hi, wi):
+    """G[t][b, n, q] = d/dx[b, n, q] of <dy, shift_t(resize(x))>: one map per filter tap t = 3 r + s (offset (r-1, s-1))."""
+    B, N, Ho, Wo = dy.shape
+    x = torch.zeros(B, N, hi, wi, dtype=dy.dtype, requires_grad=True)
+    up = F.pad(F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False), (1, 1, 1, 1))
+    maps = []
+    for r in range(3):
+        for s in range(3):
+            (g,) = torch.autograd.grad((up[:, :, r:r + Ho, s:s + Wo] * dy).sum(), x, retain_graph=True)
+            maps.append(g)
+    return maps
+
+
+@pytest.mark.parametrize("factor", [2, 4, 8])
+def test_resized_conv_gradients_from_nine_low_resolution_maps(factor):
+    torch.manual_seed(factor)
+    B, C, N, hi, wi = 2, 5, 7, 3, 4
+    x = torch.randn(B, C, hi, wi, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(N, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(F.interpolate(x, scale_factor=factor, mode="bilinear", align_corners=False), w, padding=1)
+    dy = torch.randn_like(y)
+    dx_ref, dw_ref = torch.autograd.grad((y * dy).sum(), (x, w))
+    G = _gathered_maps(dy, hi, wi)                                    # nine [B, N, hi, wi] maps
+    # dx = sum_t W_t^T G_t        (a GEMM over the LOW-resolution pixels with K = 9 N)
+    dx = sum(torch.einsum("nc,bnhw->bchw", w[:, :, t // 3, t % 3], G[t]) for t in range(9))
+    # dW_t = sum_q G_t[q] (x) x[q]  (a weight gradient over the low-resolution pixels)
+    dw = torch.stack([torch.einsum("bnhw,bchw->nc", G[t], x) for t in range(9)], -1).view(N, C, 3, 3)
+    assert torch.allclose(dx, dx_ref, rtol=1e-10, atol=1e-12)
+    assert torch.allclose(dw, dw_ref, rtol=1e-10, atol=1e-12)
+
+
+def test_one_by_one_convolution_commutes_with_bilinear_resize():
+    torch.manual_seed(0)
+    B, E, N = 2, 6, 5
+    sizes = [(2, 3), (4, 6), (8, 12), (16, 24)]
+    levels = [torch.randn(B, E, h, w, dtype=torch.float64) for h, w in sizes]
+    w = torch.randn(N, 4 * E, 1, 1, dtype=torch.float64)
+    cat = torch.cat([F.interpolate(l, size=sizes[-1], mode="bilinear", align_corners=False) for l in levels[:-1]] + [levels[-1]], 1)
+    ref = F.conv2d(cat, w)
+    per_level = F.conv2d(levels[-1], w[:, 3 * E:])
+    for j, l in enumerate(levels[:-1]):
+        per_level = per_level + F.interpolate(F.conv2d(l, w[:, j * E:(j + 1) * E]), size=sizes[-1], mode="bilinear",
+                                              align_corners=False)
+    assert torch.allclose(per_level, ref, rtol=1e-10, atol=1e-12)
