@@ -101,69 +101,9 @@ __global__ __launch_bounds__(256) void subpix4_weights_kernel(const float* __res
   }
 }
 
-// transpose of subpix4_weights_kernel: the gradient wrt the 3x3 weights from the gradients wrt the phase weight sets and
-// the four border-line matrices (all f32): dw[n][dy][dx][c] = sum A[py][dy][sy] A[px][dx][sx] dWc[py][px][n][sy][sx][c] + lines
-__global__ __launch_bounds__(256) void subpix4_weights_bwd_kernel(const float* __restrict__ g22, const float* __restrict__ g23,
-                                                                  const float* __restrict__ g32, const float* __restrict__ g33,
-                                                                  const float* __restrict__ lines, int N, int C,
-                                                                  float* __restrict__ dw) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)N * C) return;
-  const int n = (int)(i / C), c = (int)(i - (int64_t)n * C);
-  float acc[3][3];
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) acc[dy][dx] = 0.f;
-#pragma unroll
-  for (int py = 0; py < 4; ++py) {
-    const int R = (py == 0 || py == 3) ? 2 : 3, sy0 = py == 3 ? 1 : 0, iy = (py == 0 || py == 1) ? 0 : 1;
-#pragma unroll
-    for (int px = 0; px < 4; ++px) {
-      const int S = (px == 0 || px == 3) ? 2 : 3, sx0 = px == 3 ? 1 : 0, ix = (px == 0 || px == 1) ? 0 : 1;
-      const float* src = R == 2 ? (S == 2 ? g22 : g23) : (S == 2 ? g32 : g33);
-      const int64_t base = ((int64_t)(iy * 2 + ix) * N + n) * (R * S * C) + c;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        if (r >= R) continue;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          if (s >= S) continue;
-          const float g = src[base + (int64_t)(r * S + s) * C];
-#pragma unroll
-          for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) acc[dy][dx] += coefA(py, dy, sy0 + r) * coefA(px, dx, sx0 + s) * g;
-        }
-      }
-    }
-  }
-  const int64_t ls = (int64_t)N * 3 * C, lb = (int64_t)n * 3 * C + c;
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const float top = lines[0 * ls + lb + t * C], bot = lines[1 * ls + lb + t * C];
-    const float lef = lines[2 * ls + lb + t * C], rig = lines[3 * ls + lb + t * C];
-    acc[1][t] += top; acc[2][t] += top;
-    acc[0][t] += bot; acc[1][t] += bot;
-    acc[t][1] += lef; acc[t][2] += lef;
-    acc[t][0] += rig; acc[t][1] += rig;
-  }
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) dw[(int64_t)n * 9 * C + (dy * 3 + dx) * C + c] = acc[dy][dx];
-}
 
 }  // namespace
 
-extern "C" int gdl_subpix4_weights_bwd(const float* g22, const float* g23, const float* g32, const float* g33,
-                                       const float* lines, int N, int C, float* dw, gdl_stream_t stream) {
-  GDL_CHECK_ARG(g22 && g23 && g32 && g33 && lines && dw && N > 0 && C > 0, "gdl_subpix4_weights_bwd: bad args");
-  hipLaunchKernelGGL(subpix4_weights_bwd_kernel, dim3((unsigned)(((int64_t)N * C + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, g22, g23, g32, g33, lines, N, C, dw);
-  GDL_CHECK_LAUNCH("gdl_subpix4_weights_bwd");
-  return GDL_OK;
-}
 
 extern "C" int gdl_pad_nhwc(const void* in, int dtype, int B, int H, int W, int C, int64_t in_sB, int64_t in_sH,
                             int64_t in_sW, void* out, int pad_h, int pad_w, int zero_mode, gdl_stream_t stream) {

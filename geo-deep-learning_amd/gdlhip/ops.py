@@ -556,58 +556,6 @@ def _up4_line_views(y: Tensor):
     return [y[:, 0:1], y[:, Hh - 1:Hh], y[:, :, 0, :].unsqueeze(1), y[:, :, Ww - 1, :].unsqueeze(1)]
 
 
-def up4_conv3x3_wgrad(x: Tensor, dy: Tensor) -> Tensor:
-    """Gradient of ops.up4_conv3x3 wrt the 3x3 weights, [N, 9*C] f32, on the LOW-RES map: the four border lines through
-    their line convolutions, the rest through 16 phase weight gradients (batched per tap-count group) that the
-    transposed combination folds back onto the nine taps.  ``dy`` [B,4H,4W,N] is CONSUMED: its border lines are
-    zeroed in place (they belong to the line convolutions, not to the phase convolutions)."""
-    _need_cuda(x, dy)
-    x4 = _nhwc4(x, "up4_conv3x3_wgrad x")
-    B, H, W, Cc = x4.shape
-    N = dy.shape[-1]
-    if tuple(dy.shape) != (B, 4 * H, 4 * W, N) or not dy.is_contiguous() or dy.dtype != x4.dtype:
-        raise ValueError("up4_conv3x3_wgrad: dy must be a contiguous [B,4H,4W,N] tensor of x's dtype")
-    dev = x.device
-    dlines = torch.empty((4, N, 3 * Cc), device=dev, dtype=torch.float32)
-    # the forward writes the columns last, so the four corner pixels belong to the column convolutions: columns first,
-    # zeroed, then the rows (whose corners are zero by then)
-    lns, views = _up4_lines(x4), _up4_line_views(dy)
-    for i in (2, 3, 0, 1):
-        conv_wgrad(lns[i], views[i], R=1, S=3, dw=dlines[i])
-        views[i].zero_()
-    xp = pad_nhwc(x4, 1, 1)
-    Hp, Wp = H + 2, W + 2
-    es = dy.element_size()
-    lib = _lib.load()
-    grads = {}
-    for R in (2, 3):
-        for S in (2, 3):
-            py0, dpy = (0, 3) if R == 2 else (1, 1)
-            px0, dpx = (0, 3) if S == 2 else (1, 1)
-            dg = torch.empty((4, N, R * S * Cc), device=dev, dtype=torch.float32)
-            a = WgradArgs()
-            a.inp, a.dtype = xp.data_ptr(), dt(xp)
-            a.dy = dy.data_ptr() + (py0 * 4 * W * N + px0 * N) * es
-            a.B, a.H, a.W, a.C = B, H + R - 1, W + S - 1, Cc
-            a.in_sB, a.in_sH, a.in_sW = Hp * Wp * Cc, Wp * Cc, Cc
-            a.Ho, a.Wo, a.R, a.S, a.stride, a.pad, a.N = H, W, R, S, 1, 0, N
-            a.dy_sB, a.dy_sH, a.dy_sW = 16 * H * W * N, 16 * W * N, 4 * N
-            a.dw, a.dw_sN, a.accumulate = dg.data_ptr(), R * S * Cc, 0
-            a.nz, a.nz_inner = 4, 2
-            a.in_sZ0, a.in_sZ1 = (Wp * Cc if R == 2 else 0), (Cc if S == 2 else 0)
-            a.dy_sZ0, a.dy_sZ1 = dpy * 4 * W * N, dpx * N
-            a.dw_sZ0, a.dw_sZ1 = 2 * N * R * S * Cc, N * R * S * Cc
-            nbytes = lib.gdl_conv_wgrad_workspace(C.byref(a))
-            ws = torch.empty(max(nbytes, 4) // 4, device=dev, dtype=torch.float32)
-            a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
-            check(lib.gdl_conv_wgrad(C.byref(a), _stream()), "gdl_conv_wgrad(up4 phases)")
-            grads[(R, S)] = dg
-    dw = torch.empty((N, 9 * Cc), device=dev, dtype=torch.float32)
-    check(lib.gdl_subpix4_weights_bwd(_p(grads[(2, 2)]), _p(grads[(2, 3)]), _p(grads[(3, 2)]), _p(grads[(3, 3)]), _p(dlines),
-                                      N, Cc, _p(dw), _stream()), "gdl_subpix4_weights_bwd")
-    return dw
-
-
 # ------------------------------------------------------------------ attention (unfused + fused)
 def _attn_check(q: Tensor, k: Tensor, v: Tensor, num_heads: int):
     _need_cuda(q, k, v)

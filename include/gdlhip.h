@@ -415,9 +415,6 @@ int gdl_pad_nhwc(const void* in, int dtype, int B, int H, int W, int C, int64_t 
                  void* out, int pad_h, int pad_w, int zero_mode, gdl_stream_t stream);
 int gdl_subpix4_weights(const float* w, int N, int C, int out_dtype, void* g22, void* g23, void* g32, void* g33,
                         void* lines, gdl_stream_t stream);
-/* transpose of gdl_subpix4_weights: dw [N][9*C] f32 from the f32 gradients wrt the phase weight sets and line matrices */
-int gdl_subpix4_weights_bwd(const float* g22, const float* g23, const float* g32, const float* g33, const float* lines,
-                            int N, int C, float* dw, gdl_stream_t stream);
 
 /* ---- optimizer -------------------------------------------------------------------------
  * torch.optim.Adam step (configs/dofa_config_RGB.yaml:62-65) on one flat f32 tensor, with the
