@@ -7,6 +7,7 @@ namespace {
 
 template <typename T> struct V4;
 template <> struct V4<float> {
+  typedef float elem;
   static __device__ __forceinline__ void ld(const void* p, int64_t off, float (&o)[4]) {
     const float4 v = *(const float4*)((const float*)p + off);
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -16,6 +17,7 @@ template <> struct V4<float> {
   }
 };
 template <> struct V4<uint16_t> {
+  typedef uint16_t elem;
   static __device__ __forceinline__ void ld(const void* p, int64_t off, float (&o)[4]) {
     const uint2 v = *(const uint2*)((const uint16_t*)p + off);
     o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
@@ -28,6 +30,7 @@ template <> struct V4<uint16_t> {
 
 // 8 x bf16 = one 16-byte access: the bf16 -> bf16 resamples run 8 channels per thread (half the index math per byte)
 struct V8 {
+  typedef uint16_t elem;
   static __device__ __forceinline__ void ld(const void* p, int64_t off, float (&o)[8]) {
     const uint4 v = *(const uint4*)((const uint16_t*)p + off);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -645,6 +648,331 @@ __global__ __launch_bounds__(256) void resize_conv3x3_bwd_cols_kernel(const void
   for (int t = 0; t < 9; ++t) V::st(g, obase + (int64_t)(8 - t) * N, acc[t]);
 }
 
+// FORWARD of  y = conv3x3(pad 1)(bilinear_resize(x))  at LOW resolution (the transpose of the gather above).
+//   y = sum_t W_t (S_t U x) = sum_t S_t U (W_t x)        (U, S_t act on pixels, W_t on channels: they commute)
+// so the nine tap products z_t = W_t x are ONE 1x1 convolution over the low-resolution pixels with 9 N output channels
+// (1 / factor^2 of the MACs of the convolution on the upsampled map), and what is left is this kernel:
+//   y[b, oy, ox, n] = sum_{r,s} [0 <= oy+r-1 < Ho][0 <= ox+s-1 < Wo]  bilinear(z_(r,s))[oy + r - 1, ox + s - 1]
+// z dense [B, Hi, Wi, 9 N], tap block t = 3 r + s.  Up to three sources of different (integer) factors are summed into one
+// output (UperNet's fpn_bottleneck over its upsampled levels); the upsampled maps and the concat buffer never exist.
+// A thread owns RUN consecutive output pixels of one row x VEC channels.  For a source of factor F the run is RUN / F cells
+// (one cell = the F outputs that share a low-resolution column triple): per cell the nine taps are first combined
+// vertically into h[s][column] (54 vector loads: 3 filter rows x 2 source rows x 3 taps x 3 columns), then every output of
+// the cell takes 9 multiply-adds from h -- 54/F + 9 multiply-adds per output element instead of 36 for pixel-by-pixel
+// sampling.  f32 accumulation in a fixed order, no atomics.
+struct TapSrc { const void* p[3]; int H[3], W[3], F[3]; };
+
+template <typename V, int VEC, int RUN, int F>
+__device__ __forceinline__ void tapsum_source(float (&acc)[RUN][VEC], const void* __restrict__ z, int Hi, int Wi, int N, int b,
+                                              int oy, int Ho, int ox0, int Wo, int c) {
+  constexpr int CELLS = RUN / F;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  const int pix = 9 * N;                                           // elements per low-resolution pixel
+  const char* zb = (const char*)z + (int64_t)b * Hi * Wi * pix * (int64_t)sizeof(typename V::elem);   // this image (uniform)
+#pragma unroll 1
+  for (int cell = 0; cell < CELLS; ++cell) {
+    const int ix = ox0 / F + cell;
+    float wx[F + 2][3];                            // wx[pos][k]: weight of source column ix - 1 + k for position ix*F - 1 + pos
+#pragma unroll
+    for (int pos = 0; pos < F + 2; ++pos) {
+      const int px = ix * F - 1 + pos;
+      int x0 = -9, x1 = -9; float lx = 0.f;
+      const bool in = px >= 0 && px < Wo;
+      if (in) src_index(rx, px, Wi, x0, x1, lx);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int col = ix - 1 + k;
+        wx[pos][k] = in ? ((x0 == col ? 1.f - lx : 0.f) + (x1 == col ? lx : 0.f)) : 0.f;
+      }
+    }
+    int coff[3];                                   // out-of-image columns are clamped: their weights are zero
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int col = ix - 1 + k;
+      col = col < 0 ? 0 : (col > Wi - 1 ? Wi - 1 : col);
+      coff[k] = col * pix + c;
+    }
+    float h[3][3][VEC];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) h[s][k][e] = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {                  // filter row r reads output row oy + r - 1 of the (virtual) upsampled map
+      const int py = oy + r - 1;
+      if (py < 0 || py >= Ho) continue;            // the convolution's zero padding (uniform over the block)
+      int y0, y1; float ly;
+      src_index(ry, py, Hi, y0, y1, ly);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const float w = half ? ly : 1.f - ly;
+        if (w == 0.f) continue;                    // uniform
+        const int rowoff = (half ? y1 : y0) * Wi * pix + 3 * r * N;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            float v[VEC];
+            V::ld(zb, rowoff + coff[kx] + s * N, v);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) h[s][kx][e] += w * v[e];
+          }
+        }
+      }
+    }
+    float o[F][VEC];
+#pragma unroll
+    for (int j = 0; j < F; ++j) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[j][e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[j][e] += wx[j + s][kx] * h[s][kx][e];
+    }
+#pragma unroll
+    for (int cc = 0; cc < CELLS; ++cc) {
+      if (cell == cc) {                            // uniform: keeps the accumulator indices compile-time constants
+#pragma unroll
+        for (int j = 0; j < F; ++j)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[cc * F + j][e] += o[j][e];
+      }
+    }
+  }
+}
+
+// grid = (ceil(Wo / RUN * N / VEC / 256), B * Ho); addvec (f32 [N], may be null) is added to every output (conv bias, or
+// the folded BatchNorm shift in eval mode), then the optional ReLU.
+template <typename V, int VEC, int RUN>
+__global__ __launch_bounds__(256) void resize_conv3x3_fwd_sum_kernel(TapSrc src, int nsrc, int N, void* out, int Ho, int Wo,
+                                                                     const float* __restrict__ addvec, int relu) {
+  const int cv = N / VEC;
+  const int nblk = gridDim.x * gridDim.y;
+  const int id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = id & 7, idx = id >> 3;      // XCD-major: neighbouring rows share an L2
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int brow = lid / gridDim.x, bx = lid - brow * gridDim.x;
+  const int j0 = bx * 256 + threadIdx.x;
+  if (j0 >= (Wo / RUN) * cv) return;
+  const int b = brow / Ho, oy = brow - b * Ho;
+  const int xr = j0 / cv, c = (j0 - xr * cv) * VEC;
+  const int ox0 = xr * RUN;
+  float acc[RUN][VEC];
+#pragma unroll
+  for (int p = 0; p < RUN; ++p)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[p][e] = 0.f;
+  for (int k = 0; k < nsrc; ++k) {
+    const int F = src.F[k];
+    if constexpr (RUN >= 8) { if (F == 8) tapsum_source<V, VEC, RUN, 8>(acc, src.p[k], src.H[k], src.W[k], N, b, oy, Ho, ox0, Wo, c); }
+    if constexpr (RUN >= 4) { if (F == 4) tapsum_source<V, VEC, RUN, 4>(acc, src.p[k], src.H[k], src.W[k], N, b, oy, Ho, ox0, Wo, c); }
+    if (F == 2) tapsum_source<V, VEC, RUN, 2>(acc, src.p[k], src.H[k], src.W[k], N, b, oy, Ho, ox0, Wo, c);
+  }
+  float add[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) add[e] = addvec ? addvec[c + e] : 0.f;
+  const int64_t obase = (((int64_t)b * Ho + oy) * Wo + ox0) * N + c;
+#pragma unroll
+  for (int p = 0; p < RUN; ++p) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      acc[p][e] += add[e];
+      if (relu) acc[p][e] = fmaxf(acc[p][e], 0.f);
+    }
+    V::st(out, obase + (int64_t)p * N, acc[p]);
+  }
+}
+
+// ---- the same sum on the matrix cores (bf16, N % 64 == 0): the production form.
+// The pixel-by-pixel kernel above reads every z vector ~24 times through L1/L2 (13.5 x the output bytes: measured 1.5 ms for the
+// neck's x4 level against 0.3 ms of HBM time).  Per 4 x 4 output patch the sum is a small dense product that is THE SAME for
+// every channel:   out[p, n] = sum_k A[p, k] z[k, n],   k = (filter tap (r, s), window pixel (wy, dx)),
+// where the window is the 3 x 3 (factor 2: 4 x 4) low-resolution pixels the patch's 6 x 6 tap positions interpolate from and
+// A[p, k] = Uy[oy + r - 1, wy] * Ux[ox + s - 1, dx] (zero outside the output = the convolution's padding).  A factorises, so k
+// is laid out as a = (r, wy) outer, b = (s, dx) inner padded to 16: K = 16 * 3 WIN, five or six v_mfma_f32_16x16x32_bf16
+// steps per 16 channels.  The weights are bilinear fractions (k/4, k/8, k/16 and their pairwise products): exact in bf16.
+// A block = 4 output rows x 4 PXB columns x 64 channels of one image: it stages the low-resolution window (rows of 64
+// channels = 128 B, every (pixel, tap) one row) by LDS-DMA as it lies in memory, builds the two 1-D weight tables in LDS,
+// and each wave runs its patches: z fragments (rows = channels) through ds_read_b64_tr_b16, weight fragments (columns =
+// pixels) from the tables.  Sources are staged one after the other into the same LDS and accumulate in registers; the
+// result leaves through an LDS transpose as whole 128-byte lines.  f32 accumulation, fixed order.
+typedef __attribute__((ext_vector_type(4))) short tm_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short tm_s16x8_t;
+typedef __attribute__((address_space(3))) tm_s16x4_t* tm_lds_s16x4_ptr;
+constexpr unsigned kTmOob = 0x80000000u;
+__device__ __forceinline__ int tm_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+struct TapMArgs {
+  const uint16_t* z[3];
+  int H[3], W[3], LF[3];          // low-resolution size and log2(factor) of every source
+  int nsrc, N, Ho, Wo, B;
+  uint16_t* out;
+  const float* addvec;
+  int relu;
+};
+
+template <int PXB, int WIN>
+__device__ __forceinline__ void tapm_source(const TapMArgs& a, int k, f32x4_t (&acc)[PXB / 4][4], unsigned char* smem, int b, int oy0,
+                                            int oxb0, int c0, int tid, int lane, int wave) {
+  constexpr int COLS = 4 * PXB, NA = 3 * WIN, NKS = (NA + 1) / 2;
+  float* TYs = (float*)smem;                          // [4][12]  weight of window row wy for (patch row py, filter row r)
+  float* TXs = TYs + 64;                              // [COLS][16] the same for columns, b = s * WIN + dx, zero-padded
+  unsigned char* stage = smem + 256 + COLS * 64;
+  const int Hi = a.H[k], Wi = a.W[k], lf = a.LF[k], N = a.N;
+  const int WC = ((COLS - 4) >> lf) + WIN;            // window columns of the block
+  const int wr0 = (oy0 >> lf) - 1, wcb0 = (oxb0 >> lf) - 1;
+  const float ry = (float)Hi / (float)a.Ho, rx = (float)Wi / (float)a.Wo;
+  if (tid < 48) {
+    const int py = tid / 12, ai = tid - py * 12;
+    float w = 0.f;
+    if (ai < NA) {
+      const int r = ai / WIN, wy = ai - r * WIN, pos = oy0 + py + r - 1;
+      if (pos >= 0 && pos < a.Ho) {
+        int y0, y1; float ly;
+        src_index(ry, pos, Hi, y0, y1, ly);
+        const int row = wr0 + wy;
+        w = (y0 == row ? 1.f - ly : 0.f) + (y1 == row ? ly : 0.f);
+      }
+    }
+    TYs[tid] = w;
+  }
+  for (int i = tid; i < COLS * 16; i += 256) {
+    const int pc = i >> 4, bi = i & 15;
+    float w = 0.f;
+    if (bi < NA) {
+      const int s3 = bi / WIN, dx = bi - s3 * WIN, pos = oxb0 + pc + s3 - 1;
+      if (pos >= 0 && pos < a.Wo) {
+        int x0, x1; float lx;
+        src_index(rx, pos, Wi, x0, x1, lx);
+        const int col = ((oxb0 + (pc & ~3)) >> lf) - 1 + dx;          // the PATCH's window starts at its own first cell - 1
+        w = (x0 == col ? 1.f - lx : 0.f) + (x1 == col ? lx : 0.f);
+      }
+    }
+    TXs[i] = w;
+  }
+  // ---- stage the window: LDS row R = (wyi * WC + wci) * 9 + tap, 128 bytes = this block's 64 channels
+  {
+    const srd_t srd = make_srd(a.z[k] + (int64_t)b * Hi * Wi * 9 * N, (unsigned)((int64_t)Hi * Wi * 9 * N * 2));
+    const unsigned lds_stage = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)stage);
+    const int nrows = WIN * WC * 9, npieces = (nrows + 7) >> 3;
+    for (int piece = wave; piece < npieces; piece += 4) {
+      const int R = piece * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ tm_swz(R);
+      const int pc = R / 9, t = R - pc * 9;
+      const int wyi = pc / WC, wci = pc - wyi * WC;
+      const int row = wr0 + wyi, col = wcb0 + wci;
+      const bool ok = R < nrows && row >= 0 && row < Hi && col >= 0 && col < Wi;
+      const unsigned v = ok ? (unsigned)((((row * Wi + col) * 9 + t) * N + c0) * 2 + chunk * 16) : kTmOob;
+      dma16_buf(v, srd, 0u, lds_stage + piece * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  int lane_mfma = lane;
+  asm volatile("" : "+v"(lane_mfma));                 // keeps the fragment address arithmetic below this point (register budget)
+  const int L = lane_mfma & 15, g = lane_mfma >> 4;
+#pragma unroll
+  for (int j2 = 0; j2 < PXB / 4; ++j2) {
+    const int j = wave + 4 * j2;
+    const int wcj = (4 * j) >> lf;                                    // the patch's window start inside the block's window
+    // weight fragments (B operand: column = pixel L of the patch, k = 16 a + b)
+    float txv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) txv[e] = TXs[(4 * j + (L & 3)) * 16 + 8 * (g & 1) + e];
+    bf16x8_t wf[NKS];
+    int raddr[NKS][2];                                                // LDS byte offset of this lane's 8-byte piece for channel tile 0
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int ai = 2 * ks + (g >> 1);
+      const float ty = TYs[(L >> 2) * 12 + ai];                       // zero for ai >= NA (table padding)
+      uint32_t pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(ty * txv[2 * e], ty * txv[2 * e + 1]);
+      wf[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int bq = 8 * (g & 1) + 4 * h + (L >> 2);
+        const bool ok = ai < NA && bq < NA;
+        const int r = ai / WIN, wy = ai - r * WIN, s3 = bq / WIN, dx = bq - s3 * WIN;
+        const int R = ok ? ((wy * WC + wcj + dx) * 9 + 3 * r + s3) : 0;   // padding slots: any staged row, their weight is zero
+        // 16-byte slot = (channel >> 3) ^ swizzle(R); channel = 16 nt + 4 (L & 3): nt only flips slot bits 1-2 -> one XOR per tile
+        raddr[ks][h] = R * 128 + (((((L & 3) >> 1) ^ tm_swz(R))) << 4) + (L & 1) * 8;
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const tm_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(stage + (raddr[ks][0] ^ (nt << 5))));
+        const tm_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(stage + (raddr[ks][1] ^ (nt << 5))));
+        const tm_s16x8_t zv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        acc[j2][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zv), wf[ks], acc[j2][nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);          // one channel tile's fragment reads in flight at a time (register budget)
+    }
+  }
+}
+
+// grid = (ceil(Wo / (4 PXB)) * N / 64, B * ceil(Ho / 4)); dynamic LDS = 256 + 256 PXB + max over the sources of the window bytes
+template <int PXB>
+__global__ __launch_bounds__(256, PXB == 8 ? 3 : 4) void resize_conv3x3_fwd_sum_mfma_kernel(const TapMArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int COLS = 4 * PXB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nchunks = a.N >> 6, nprow = (a.Ho + 3) >> 2;
+  const int nblk = gridDim.x * gridDim.y;
+  const int id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = id & 7, idx = id >> 3;      // XCD-major: neighbouring patch rows share an L2
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int brow = lid / gridDim.x, bx = lid - brow * gridDim.x;
+  const int b = brow / nprow, oy0 = (brow - b * nprow) * 4;
+  const int cb = bx / nchunks, c0 = (bx - cb * nchunks) * 64, oxb0 = cb * COLS;
+  f32x4_t acc[PXB / 4][4];
+#pragma unroll
+  for (int j2 = 0; j2 < PXB / 4; ++j2)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[j2][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < a.nsrc; ++k) {
+    if (k > 0) __syncthreads();                       // the previous source's fragment reads are done: tables and window are rewritten
+    if (a.LF[k] == 1) tapm_source<PXB, 4>(a, k, acc, smem, b, oy0, oxb0, c0, tid, lane, wave);
+    else tapm_source<PXB, 3>(a, k, acc, smem, b, oy0, oxb0, c0, tid, lane, wave);
+  }
+  __syncthreads();
+  // ---- epilogue: + addvec, ReLU, bf16, through an LDS transpose ([4 rows][COLS pixels] x 128 B, 16-byte slots swizzled by pixel)
+  unsigned char* tile = smem + 256 + COLS * 64;
+  const int L = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int j2 = 0; j2 < PXB / 4; ++j2) {
+    const int pp = (L >> 2) * COLS + 4 * (wave + 4 * j2) + (L & 3);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int ch = 16 * nt + 4 * g;
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = acc[j2][nt][i] + (a.addvec ? a.addvec[c0 + ch + i] : 0.f);
+        if (a.relu) v[i] = fmaxf(v[i], 0.f);
+      }
+      *(uint2*)(tile + pp * 128 + ((((ch >> 3) ^ (pp & 7))) << 4) + (ch & 7) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 4 * COLS * 8; i += 256) {
+    const int pp = i >> 3, chunk = i & 7;
+    const int py = pp / COLS, oy = oy0 + py, ox = oxb0 + pp - py * COLS;
+    if (oy < a.Ho && ox < a.Wo) {
+      const uint4 v = *(const uint4*)(tile + pp * 128 + ((chunk ^ (pp & 7)) << 4));
+      *(uint4*)(a.out + (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.N + c0 + chunk * 8) = v;
+    }
+  }
+}
+
 // nn.AdaptiveAvgPool2d: bin i covers [floor(i*In/S), ceil((i+1)*In/S))
 __device__ __forceinline__ void pool_bin(int i, int in, int s, int& lo, int& hi) {
   lo = (i * in) / s;
@@ -741,7 +1069,79 @@ inline bool vec8_ok(const void* a, const void* b, int C, int64_t s0, int64_t s1,
          s2 % 8 == 0 && s3 % 8 == 0 && s4 % 8 == 0 && s5 % 8 == 0;
 }
 
+int g_tapsum_mfma = 1;     // A/B hook (gdl_debug_set_tapsum_mfma): 0 = the pixel-by-pixel kernel, 4 = 16-column blocks
+int g_tapsum_vec = 0;      // A/B hook (gdl_debug_set_tapsum_vec): 4 = 8-byte bf16 vectors per thread instead of 16-byte ones
+
 }  // namespace
+
+extern "C" void gdl_debug_set_tapsum_vec(int vec) { g_tapsum_vec = vec; }
+extern "C" void gdl_debug_set_tapsum_mfma(int mode) { g_tapsum_mfma = mode; }
+
+extern "C" int gdl_resize_conv3x3_fwd_sum(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N,
+                                          void* out, int Ho, int Wo, const float* addvec, int relu, gdl_stream_t stream) {
+  GDL_CHECK_ARG(zs && hs && ws && out && nsrc >= 1 && nsrc <= 3, "gdl_resize_conv3x3_fwd_sum: 1..3 sources");
+  GDL_CHECK_ARG(dtype == GDL_F32 || dtype == GDL_BF16, "gdl_resize_conv3x3_fwd_sum: bad dtype");
+  GDL_CHECK_ARG(B > 0 && Ho > 0 && Wo > 0 && N > 0, "gdl_resize_conv3x3_fwd_sum: bad sizes");
+  TapSrc s;
+  int run = 2;
+  for (int k = 0; k < 3; ++k) {
+    s.p[k] = nullptr; s.H[k] = 1; s.W[k] = 1; s.F[k] = 0;
+    if (k >= nsrc) continue;
+    GDL_CHECK_ARG(zs[k] && hs[k] > 0 && ws[k] > 0 && (uintptr_t)zs[k] % 16 == 0, "gdl_resize_conv3x3_fwd_sum: bad source %d", k);
+    const int f = Ho / hs[k];
+    GDL_CHECK_ARG((f == 2 || f == 4 || f == 8) && hs[k] * f == Ho && ws[k] * f == Wo,
+                  "gdl_resize_conv3x3_fwd_sum: source %d: the resize factor must be 2, 4 or 8 in both directions", k);
+    s.p[k] = zs[k]; s.H[k] = hs[k]; s.W[k] = ws[k]; s.F[k] = f;
+    run = f > run ? f : run;
+  }
+  GDL_CHECK_ARG(Wo % run == 0, "gdl_resize_conv3x3_fwd_sum: Wo must be a multiple of the largest factor");
+  hipStream_t st = (hipStream_t)stream;
+  bool img_ok = (uintptr_t)out % 16 == 0;
+  for (int k = 0; k < nsrc; ++k) img_ok = img_ok && (int64_t)s.H[k] * s.W[k] * 9 * N * 2 < 0x7ffffff0ll;   // 32-bit buffer offsets per image
+  if (dtype == GDL_BF16 && N % 64 == 0 && g_tapsum_mfma && img_ok && (int64_t)B * ((Ho + 3) / 4) <= 65535) {
+    // matrix-core form: one block = 4 rows x 16 or 32 columns x 64 channels; 32 columns when every window stays under 48 KiB
+    TapMArgs m;
+    int lfmin = 3;
+    for (int k = 0; k < 3; ++k) {
+      m.z[k] = (const uint16_t*)s.p[k]; m.H[k] = s.H[k]; m.W[k] = s.W[k];
+      m.LF[k] = s.F[k] == 8 ? 3 : (s.F[k] == 4 ? 2 : 1);
+      if (k < nsrc && m.LF[k] < lfmin) lfmin = m.LF[k];
+    }
+    m.nsrc = nsrc; m.N = N; m.Ho = Ho; m.Wo = Wo; m.B = B; m.out = (uint16_t*)out; m.addvec = addvec; m.relu = relu;
+    // the staging loop writes whole 1 KiB pieces (8 rows): round the window up to that
+    auto window_bytes = [&](int cols) { const int win = lfmin == 1 ? 4 : 3; return (win * (((cols - 4) >> lfmin) + win) * 9 * 128 + 1023) / 1024 * 1024; };
+    const int pxb = (window_bytes(32) <= 48 * 1024 && g_tapsum_mfma != 4) ? 8 : 4;
+    const int cols = 4 * pxb;
+    const int tile_bytes = 4 * cols * 128;
+    const size_t lds = 256 + cols * 64 + (size_t)(window_bytes(cols) > tile_bytes ? window_bytes(cols) : tile_bytes);
+    const dim3 grid((unsigned)(((Wo + cols - 1) / cols) * (N / 64)), (unsigned)(B * ((Ho + 3) / 4)));
+    if (pxb == 8) {
+      GDL_SET_MAX_LDS_ONCE(resize_conv3x3_fwd_sum_mfma_kernel<8>, 160 * 1024);
+      hipLaunchKernelGGL(resize_conv3x3_fwd_sum_mfma_kernel<8>, grid, dim3(256), lds, st, m);
+    } else {
+      GDL_SET_MAX_LDS_ONCE(resize_conv3x3_fwd_sum_mfma_kernel<4>, 160 * 1024);
+      hipLaunchKernelGGL(resize_conv3x3_fwd_sum_mfma_kernel<4>, grid, dim3(256), lds, st, m);
+    }
+    GDL_CHECK_LAUNCH("gdl_resize_conv3x3_fwd_sum");
+    return GDL_OK;
+  }
+  int vec = dtype == GDL_BF16 ? 8 : 4;
+  // 16-byte vectors with 8-pixel runs need more than 256 registers: 8-byte vectors there (and wherever N % 8 != 0)
+  if (dtype == GDL_BF16 && (g_tapsum_vec == 4 || N % 8 != 0 || (run == 8 && g_tapsum_vec != 8))) vec = 4;
+  GDL_CHECK_ARG(N % vec == 0 && (uintptr_t)out % 16 == 0, "gdl_resize_conv3x3_fwd_sum: N must be a multiple of 4, out 16-byte aligned");
+  GDL_CHECK_ARG((int64_t)B * Ho <= 65535, "gdl_resize_conv3x3_fwd_sum: B * Ho must fit one grid dimension");
+  const dim3 grid((unsigned)(((Wo / run) * (N / vec) + 255) / 256), (unsigned)(B * Ho));
+#define TAPSUM(V, VEC, RUN) hipLaunchKernelGGL((resize_conv3x3_fwd_sum_kernel<V, VEC, RUN>), grid, dim3(256), 0, st, s, nsrc, N, out, \
+                                               Ho, Wo, addvec, relu)
+#define TAPSUM_RUN(V, VEC) do { if (run == 8) TAPSUM(V, VEC, 8); else if (run == 4) TAPSUM(V, VEC, 4); else TAPSUM(V, VEC, 2); } while (0)
+  if (dtype == GDL_F32) TAPSUM_RUN(V4<float>, 4);
+  else if (vec == 8) TAPSUM_RUN(V8, 8);
+  else TAPSUM_RUN(V4<uint16_t>, 4);
+#undef TAPSUM_RUN
+#undef TAPSUM
+  GDL_CHECK_LAUNCH("gdl_resize_conv3x3_fwd_sum");
+  return GDL_OK;
+}
 
 extern "C" void gdl_debug_set_flat_resample(int on) { g_flat_resample = on; }
 

@@ -147,6 +147,27 @@ def sync_sum_pair(a: Tensor, b: Tensor, group=None) -> tuple[Tensor, Tensor]:
 
 
 FUSE_UP4 = True   # A/B switch: False = materialise the x4 upsample and run the ordinary 3x3 kernel
+FUSE_TAPSUM = True   # A/B switch: False = round-2 forward of resized-input convolutions (sub-pixel phases / concat buffer)
+
+
+def tap_weight(weight: Tensor, cd: torch.dtype, c0: int = 0, c1: int | None = None) -> Tensor:
+    """[9 N, C'] operand of the low-resolution forward of conv3x3(resize(x)) (ops.resize_conv3x3_fwd_sum): row t * N + n
+    is filter tap t = 3 r + s of output channel n over the input-channel slice c0:c1 -- the nine tap products
+    z = [W_0 x, ..., W_8 x] are then ONE 1x1 convolution with 9 N output channels."""
+    def build():
+        n, c = weight.shape[0], weight.shape[1]
+        w = conv_weight_matrix(weight).view(n, 9, c)[:, :, c0:c1].permute(1, 0, 2).reshape(9 * n, -1).contiguous()
+        return w if cd == torch.float32 else ops.cast(w, cd)
+    return cached((weight,), f"tap:{cd}:{c0}:{c1}", build)
+
+
+def slice_weight(weight: Tensor, cd: torch.dtype, c0: int, c1: int) -> Tensor:
+    """[N, 9 * (c1 - c0)] GEMM operand of a 3x3 conv parameter restricted to the input channels c0:c1 (one level of a concat)."""
+    def build():
+        n, c = weight.shape[0], weight.shape[1]
+        w = conv_weight_matrix(weight).view(n, 9, c)[:, :, c0:c1].reshape(n, -1).contiguous()
+        return w if cd == torch.float32 else ops.cast(w, cd)
+    return cached((weight,), f"slice:{cd}:{c0}:{c1}", build)
 
 
 # ------------------------------------------------------------------ conv -> BN -> ReLU
@@ -163,7 +184,13 @@ class _ConvBNActTrain(Function):
         cd = x.dtype
         n, c, r, s = weight.shape
         cb = None if conv_bias is None else conv_bias.detach()
-        if up4 == 4:   # conv3x3(bilinear_x4(x)) without the upsampled intermediate (ops.up4_conv3x3)
+        if up4 and FUSE_TAPSUM and ops.resize_conv3x3_fwd_ok((x.shape[1], x.shape[2]), (up4 * x.shape[1], up4 * x.shape[2]),
+                                                             x.shape[0]):
+            # conv3x3(resize(x)) = sum_t shift_t(resize(W_t x)): nine tap products as ONE 1x1 convolution over the
+            # LOW-resolution pixels (1 / up4^2 of the MACs), then one gather-sum pass writes the full-resolution output
+            y = ops.resize_conv3x3_fwd_sum([ops.conv_gemm(x, tap_weight(weight, cd))], (up4 * x.shape[1], up4 * x.shape[2]),
+                                           addvec=cb)
+        elif up4 == 4:   # conv3x3(bilinear_x4(x)) without the upsampled intermediate (ops.up4_conv3x3)
             y = ops.up4_conv3x3(x, subpix4_weight(weight, cd), bias=cb)
         elif up4:      # other resize factors: the upsampled map is a temporary of the forward only (backward works on x)
             y = ops.conv_gemm(ops.bilinear(x, (up4 * x.shape[1], up4 * x.shape[2])), gemm_weight(weight, cd), R=r, S=s,
@@ -244,13 +271,23 @@ class _ConcatResizeConvBNTrain(Function):
         n = weight.shape[0]
         B, H, W, _ = levels[0].shape
         chans = [lv.shape[3] for lv in levels]
-        cat = torch.empty((B, H, W, sum(chans)), device=levels[0].device, dtype=cd)
-        off = 0
-        for lv, c in zip(levels, chans):
-            ops.bilinear(lv, (H, W), out=cat[..., off:off + c])
-            off += c
-        y = ops.conv_gemm(cat, gemm_weight(weight, cd), R=3, S=3, pad=1)
-        del cat
+        if _tapsum_levels_ok(levels):
+            # per level (the convolution is linear over the concat): the native level runs the 3x3 kernel on its own
+            # channel slice; every upsampled level contributes its nine tap products, computed at ITS resolution, through
+            # one gather-sum pass whose result enters the native level's GEMM as the residual operand
+            offs = [sum(chans[:j]) for j in range(len(chans))]
+            zs = [ops.conv_gemm(lv, tap_weight(weight, cd, o, o + c)) for lv, o, c in zip(levels[1:], offs[1:], chans[1:])]
+            y = ops.conv_gemm(levels[0], slice_weight(weight, cd, 0, chans[0]), R=3, S=3, pad=1,
+                              resid=ops.resize_conv3x3_fwd_sum(zs, (H, W)))
+            del zs
+        else:
+            cat = torch.empty((B, H, W, sum(chans)), device=levels[0].device, dtype=cd)
+            off = 0
+            for lv, c in zip(levels, chans):
+                ops.bilinear(lv, (H, W), out=cat[..., off:off + c])
+                off += c
+            y = ops.conv_gemm(cat, gemm_weight(weight, cd), R=3, S=3, pad=1)
+            del cat
         mean, var, world, p_local, p_share = _bn_train_stats(y, n, running_mean, running_var, momentum, sync_group)
         out = ops.bn_apply(y, mean, var, gamma.detach(), beta.detach(), eps, relu)
         ctx.save_for_backward(weight, y, mean, var, gamma, beta, *levels)
@@ -287,6 +324,13 @@ class _ConcatResizeConvBNTrain(Function):
         return (dw, dgamma, dbeta, None, None, None, None, None, None, *dls)
 
 
+def _tapsum_levels_ok(levels) -> bool:
+    """levels[0] native, 1..3 further levels each upsampled by one integer factor of 2 / 4 / 8 (ops.resize_conv3x3_fwd_sum)."""
+    B, H, W, _ = levels[0].shape
+    return (FUSE_TAPSUM and 2 <= len(levels) <= 4
+            and all(ops.resize_conv3x3_fwd_ok((lv.shape[1], lv.shape[2]), (H, W), B) for lv in levels[1:]))
+
+
 def concat_resize_conv_bn_act(levels: list[Tensor], conv: nn.Conv2d, norm: nn.Module, *, relu: bool = True) -> Tensor:
     """ConvModule(3x3, pad 1, no bias) over cat([levels[0]] + [bilinear(l -> levels[0]'s size) for l in levels[1:]]) on NHWC
     maps.  Training: see _ConcatResizeConvBNTrain; eval (and resize factors above 8): concat_upsample + conv_bn_act."""
@@ -297,6 +341,29 @@ def concat_resize_conv_bn_act(levels: list[Tensor], conv: nn.Conv2d, norm: nn.Mo
     ok = (FUSE_CONCAT_BWD and norm.training and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.bias is None
           and conv.weight.shape[0] % 8 == 0 and all(lv.is_contiguous() and factor_ok(lv) for lv in levels)
           and levels[0].shape[0] * max(lv.shape[1] for lv in levels) <= 65535)
+    if (not norm.training and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.bias is None
+            and all(lv.is_contiguous() for lv in levels) and _tapsum_levels_ok(levels)
+            and not (torch.is_grad_enabled() and (conv.weight.requires_grad or any(lv.requires_grad for lv in levels)))):
+        # eval, per level: folded BatchNorm scale in every weight slice, epilogue relu(acc + shift + gather-sum)
+        cd = levels[0].dtype
+        chans = [lv.shape[3] for lv in levels]
+
+        def fold():
+            scale, shift = ops.bn_fold(norm.weight.detach(), norm.bias.detach(), norm.running_mean, norm.running_var, norm.eps)
+            n, c = conv.weight.shape[0], conv.weight.shape[1]
+            w = conv_weight_matrix(conv.weight).float().view(n, 9, c) * scale[:, None, None]
+            cast = (lambda t: t) if cd == torch.float32 else (lambda t: ops.cast(t, cd))
+            w0 = cast(w[:, :, :chans[0]].reshape(n, -1).contiguous())
+            taps, off = [], chans[0]
+            for cj in chans[1:]:
+                taps.append(cast(w[:, :, off:off + cj].permute(1, 0, 2).reshape(9 * n, cj).contiguous()))
+                off += cj
+            return w0, taps, shift
+        w0, taps, shift = cached((conv.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var),
+                                 f"catfold:{cd}:{chans}", fold)
+        zs = [ops.conv_gemm(lv, wt) for lv, wt in zip(levels[1:], taps)]
+        return ops.conv_gemm(levels[0], w0, R=3, S=3, pad=1, bias=shift, resid=ops.resize_conv3x3_fwd_sum(zs, size),
+                             act=ACT_RESID_RELU if relu else ACT_NONE)
     if not ok:
         return conv_bn_act(concat_upsample(levels, size), conv, norm, relu=relu)
     sync_group = norm.process_group if isinstance(norm, nn.SyncBatchNorm) else False
@@ -469,6 +536,18 @@ def conv_bn_act(x: Tensor, conv: nn.Conv2d, norm: nn.Module, *, relu: bool = Tru
     scale, shift = cached((norm.weight, norm.bias, norm.running_mean, norm.running_var), "bnfold",
                           lambda: ops.bn_fold(norm.weight.detach(), norm.bias.detach(),
                                               norm.running_mean, norm.running_var, norm.eps))
+    if up4 and FUSE_TAPSUM and ops.resize_conv3x3_fwd_ok((x.shape[1], x.shape[2]), (up4 * x.shape[1], up4 * x.shape[2]),
+                                                         x.shape[0]):
+        # eval: the BatchNorm scale is folded into the tap weights, shift (+ scale * bias) and the ReLU into the gather-sum
+        def fold():
+            n, c = conv.weight.shape[0], conv.weight.shape[1]
+            w = conv_weight_matrix(conv.weight).float().view(n, 9, c) * scale[:, None, None]
+            w = w.permute(1, 0, 2).reshape(9 * n, c).contiguous()
+            add = shift if conv.bias is None else (shift + scale * conv.bias.detach().float()).contiguous()
+            return (w if cd == torch.float32 else ops.cast(w, cd)), add
+        keyp = (conv.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var) + (() if conv.bias is None else (conv.bias,))
+        wq, add = cached(keyp, f"tapfold:{cd}", fold)
+        return ops.resize_conv3x3_fwd_sum([ops.conv_gemm(x, wq)], (up4 * x.shape[1], up4 * x.shape[2]), addvec=add, relu=relu)
     if up4 == 4:
         return ops.up4_conv3x3(x, subpix4_weight(conv.weight, cd), bias=None if conv.bias is None else conv.bias.detach(),
                                scale=scale, shift=shift, act=ACT_RELU if relu else ACT_NONE)

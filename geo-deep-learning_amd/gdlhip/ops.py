@@ -393,6 +393,38 @@ def resize_conv3x3_bwd(x_lo: Tensor, dy: Tensor, w_dgrad: Tensor | None, want_dw
     return dx, dw
 
 
+def resize_conv3x3_fwd_sum(zs: list[Tensor], size: tuple[int, int], addvec: Tensor | None = None, relu: bool = False) -> Tensor:
+    """sum_k sum_t shift_t(bilinear(zs[k][..., t*N:(t+1)*N] -> size)) (+ addvec, ReLU): the pixel side of
+    conv3x3(pad 1)(bilinear resize(x)) once the nine tap products z = [W_0 x, ..., W_8 x] exist at low resolution
+    (gdl_resize_conv3x3_fwd_sum).  zs: 1..3 dense [B, h_k, w_k, 9 N] maps of one dtype, integer factors 2 / 4 / 8."""
+    _need_cuda(*zs)
+    if not 1 <= len(zs) <= 3:
+        raise ValueError("resize_conv3x3_fwd_sum: 1..3 sources")
+    z4 = [_nhwc4(z, "resize_conv3x3_fwd_sum source") for z in zs]
+    B, N9 = z4[0].shape[0], z4[0].shape[3]
+    if N9 % 9:
+        raise ValueError("resize_conv3x3_fwd_sum: sources must have 9 * N channels")
+    N = N9 // 9
+    for z in z4:
+        if z.shape[0] != B or z.shape[3] != N9 or z.dtype != z4[0].dtype or not z.is_contiguous():
+            raise ValueError("resize_conv3x3_fwd_sum: sources must be contiguous NHWC maps with equal batch, channels and dtype")
+    out = torch.empty((B, size[0], size[1], N), device=zs[0].device, dtype=zs[0].dtype)
+    n = len(z4)
+    ptrs = (C.c_void_p * 3)(*([z.data_ptr() for z in z4] + [None] * (3 - n)))
+    hs = (C.c_int * 3)(*([z.shape[1] for z in z4] + [1] * (3 - n)))
+    ws = (C.c_int * 3)(*([z.shape[2] for z in z4] + [1] * (3 - n)))
+    check(_lib.load().gdl_resize_conv3x3_fwd_sum(ptrs, hs, ws, n, dt(z4[0]), B, N, _p(out), size[0], size[1],
+                                                 _p(_f32vec(addvec, N, "addvec")), int(relu), _stream()),
+          "gdl_resize_conv3x3_fwd_sum")
+    return out
+
+
+def resize_conv3x3_fwd_ok(lo: tuple[int, int], size: tuple[int, int], B: int) -> bool:
+    """Shapes gdl_resize_conv3x3_fwd_sum takes: one integer factor of 2, 4 or 8 in both directions, B * rows in one grid dim."""
+    f = size[0] // max(lo[0], 1)
+    return f in (2, 4, 8) and lo[0] * f == size[0] and lo[1] * f == size[1] and B * size[0] <= 65535
+
+
 def copy_cast(x: Tensor, out: Tensor | None = None, out_dtype: torch.dtype | None = None) -> Tensor:
     """Strided NHWC copy with dtype conversion (f32 / bf16): dense copy of a channel slice, compute-dtype cast."""
     _need_cuda(x)

@@ -260,6 +260,14 @@ int gdl_resize_conv3x3_bwd_gather(const void* dy, int dtype, int B, int Ho, int 
 int64_t gdl_resize_conv3x3_bwd_gather_workspace(int dtype, int B, int Wo, int N, int Hi);
 int gdl_resize_conv3x3_bwd_gather2(const void* dy, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi, int Wi, void* ws,
                                    int64_t ws_bytes, gdl_stream_t stream);
+/* FORWARD of conv3x3(pad 1)(F.interpolate(x, bilinear, factor 2/4/8)) at LOW resolution (multilevel_neck.py:157-158 levels
+ * with scale 2 and 4; upernet.py:144-152 `fpn_bottleneck` over its upsampled levels): the resize U and the tap shifts S_t act
+ * on pixels, the filter slices W_t on channels, so y = sum_t S_t U (W_t x).  The nine tap products z = [W_0 x, ..., W_8 x]
+ * are one 1x1 gdl_conv_gemm over the low-resolution pixels (dense [B,hs,ws,9*N], tap block t = 3 r + s); this call forms
+ * out[b,oy,ox,n] = addvec[n] + sum_k sum_(r,s) bilinear(zs[k]_(r,s))[oy+r-1, ox+s-1] (positions outside the output = the
+ * convolution's zero padding) for 1..3 sources of one dtype, optional ReLU, dense [B,Ho,Wo,N].  Deterministic. */
+int gdl_resize_conv3x3_fwd_sum(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N, void* out,
+                               int Ho, int Wo, const float* addvec, int relu, gdl_stream_t stream);
 /* strided NHWC copy with dtype conversion: `x.to(dtype)` under autocast, `.contiguous()` of a channel slice
  * (models/utils.py:50-52 inputs, torch.cat slices of upernet.py:103-109 in backward) */
 int gdl_copy_cast(const void* in, int in_dtype, int B, int H, int W, int C, int64_t in_sB, int64_t in_sH, int64_t in_sW,

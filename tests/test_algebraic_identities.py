@@ -3,6 +3,8 @@ autograd, these hold the IDENTITIES themselves, independent of any kernel:
 
 * backward of conv3x3(pad 1)(bilinear resize(x)) through nine low-resolution maps G_t = resize^T shift_t^T dy
   (gdlhip/ops.py:resize_conv3x3_bwd; reference layer: multilevel_neck.py:56-67,157-158, upernet.py:144-152);
+* forward of the same layers through nine low-resolution tap products: conv3x3(resize(x)) = sum_t shift_t(resize(W_t x))
+  (gdlhip/ops.py:resize_conv3x3_fwd_sum), also over a concat of upsampled levels (upernet.py:144-152);
 * SegFormer's linear_fuse: a 1x1 convolution commutes with the bilinear resize (gdlhip/nn.py:pyramid_fuse_bn_act;
   segformer_mlp.py:97-125).
 """
@@ -56,3 +58,42 @@ def test_one_by_one_convolution_commutes_with_bilinear_resize():
         per_level = per_level + F.interpolate(F.conv2d(l, w[:, j * E:(j + 1) * E]), size=sizes[-1], mode="bilinear",
                                               align_corners=False)
     assert torch.allclose(per_level, ref, rtol=1e-10, atol=1e-12)
+
+
+def tap_sum(z, size):
+    """sum_t shift_t(resize(z_t)): z [B, 9, N, h, w] tap products at low resolution -> [B, N, H, W]; shift_t reads position
+    p + (r - 1, s - 1) of the resized map, zero outside (= the convolution's zero padding).  Also the reference of the GPU test."""
+    B, _, N, _, _ = z.shape
+    H, W = size
+    out = z.new_zeros(B, N, H, W)
+    for t in range(9):
+        up = F.pad(F.interpolate(z[:, t], size=size, mode="bilinear", align_corners=False), (1, 1, 1, 1))
+        out = out + up[:, :, t // 3:t // 3 + H, t % 3:t % 3 + W]
+    return out
+
+
+@pytest.mark.parametrize("factor", [2, 4, 8])
+def test_resized_conv_forward_from_nine_low_resolution_tap_products(factor):
+    torch.manual_seed(factor)
+    B, C, N, hi, wi = 2, 5, 7, 3, 4
+    x = torch.randn(B, C, hi, wi, dtype=torch.float64)
+    w = torch.randn(N, C, 3, 3, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=factor, mode="bilinear", align_corners=False), w, padding=1)
+    z = torch.stack([torch.einsum("nc,bchw->bnhw", w[:, :, t // 3, t % 3], x) for t in range(9)], 1)   # 1x1 convs, 9 N outputs
+    assert torch.allclose(tap_sum(z, (factor * hi, factor * wi)), ref, rtol=1e-10, atol=1e-12)
+
+
+def test_conv_over_concat_of_upsampled_levels_per_level():
+    torch.manual_seed(1)
+    B, C, N = 2, 4, 6
+    sizes = [(16, 24), (8, 12), (4, 6), (2, 3)]
+    levels = [torch.randn(B, C, h, w, dtype=torch.float64) for h, w in sizes]
+    w = torch.randn(N, 4 * C, 3, 3, dtype=torch.float64)
+    cat = torch.cat([levels[0]] + [F.interpolate(l, size=sizes[0], mode="bilinear", align_corners=False) for l in levels[1:]], 1)
+    ref = F.conv2d(cat, w, padding=1)
+    got = F.conv2d(levels[0], w[:, :C], padding=1)
+    for j in (1, 2, 3):
+        wj = w[:, j * C:(j + 1) * C]
+        z = torch.stack([torch.einsum("nc,bchw->bnhw", wj[:, :, t // 3, t % 3], levels[j]) for t in range(9)], 1)
+        got = got + tap_sum(z, sizes[0])
+    assert torch.allclose(got, ref, rtol=1e-10, atol=1e-12)

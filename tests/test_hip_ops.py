@@ -965,3 +965,119 @@ def test_resize_conv3x3_bwd_gather_two_pass(dtype, B, Hi, Wi, N, f):
     close(outs[True], ref, dtype, "two-pass gather")
     if dtype == torch.float32:
         assert (outs[True] - outs[False]).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mfma", [1, 4, 0])
+@pytest.mark.parametrize("B,H,W,N,factors,vec", [(2, 16, 24, 64, (2,), 0), (1, 36, 36, 128, (4,), 0), (2, 16, 16, 64, (8,), 0),
+                                                 (2, 16, 24, 64, (2, 4, 8), 0), (1, 8, 8, 72, (4, 2), 0), (2, 12, 20, 64, (4,), 4),
+                                                 (1, 2, 2, 64, (2,), 0), (1, 18, 14, 64, (2,), 0), (1, 8, 72, 128, (4,), 0),
+                                                 (2, 32, 48, 192, (8, 4), 0), (1, 144, 144, 64, (2, 4, 8), 0)])
+def test_resize_conv3x3_fwd_sum(dtype, B, H, W, N, factors, vec, mfma):
+    """sum_k sum_t shift_t(bilinear(z_k,t)) (gdl_resize_conv3x3_fwd_sum), the pixel side of the low-resolution forward of
+    conv3x3(pad 1)(bilinear resize(x)) (multilevel_neck.py:157-158, upernet.py:144-152): vs torch's interpolate / pad / slice
+    on the CPU, every pixel including the border lines the zero padding touches; with the bias / folded-BN + ReLU epilogue.
+    mfma: 1 = the matrix-core kernel (bf16, N % 64 == 0; 32-column blocks where the window fits), 4 = its 16-column blocks,
+    0 = the pixel-by-pixel kernel (also what f32 and other channel counts run)."""
+    import ctypes
+    from gdlhip import _lib
+    if mfma != 1 and (dtype != torch.bfloat16 or N % 64 or vec):
+        pytest.skip("the matrix-core variants only exist for bf16 with N % 64 == 0")
+    lib = _lib.load()
+    lib.gdl_debug_set_tapsum_vec.argtypes = [ctypes.c_int]
+    lib.gdl_debug_set_tapsum_mfma.argtypes = [ctypes.c_int]
+    zs = [q(rnd(B, H // f, W // f, 9 * N, seed=10 + f), dtype) for f in factors]
+    ref = torch.zeros(B, N, H, W)
+    for z in zs:
+        zt = z.view(B, z.shape[1], z.shape[2], 9, N).permute(0, 3, 4, 1, 2)            # [B, 9, N, h, w]
+        for t in range(9):
+            up = F.pad(F.interpolate(zt[:, t], size=(H, W), mode="bilinear", align_corners=False), (1, 1, 1, 1))
+            ref += up[:, :, t // 3:t // 3 + H, t % 3:t % 3 + W]
+    ref = ref.permute(0, 2, 3, 1)
+    add = rnd(N, seed=5)
+    lib.gdl_debug_set_tapsum_vec(vec)
+    lib.gdl_debug_set_tapsum_mfma(0 if vec else mfma)
+    try:
+        y = ops.resize_conv3x3_fwd_sum([z.to(DEV, dtype) for z in zs], (H, W))
+        y2 = ops.resize_conv3x3_fwd_sum([z.to(DEV, dtype) for z in zs], (H, W), addvec=add.to(DEV), relu=True)
+    finally:
+        lib.gdl_debug_set_tapsum_vec(0)
+        lib.gdl_debug_set_tapsum_mfma(1)
+    close(y, ref, dtype, "tap sum")
+    for name, sl in (("top", (slice(None), 0)), ("bottom", (slice(None), -1)), ("left", (slice(None), slice(None), 0)),
+                     ("right", (slice(None), slice(None), -1))):
+        close(y[sl], ref[sl], dtype, f"tap sum {name} line", scale=ref.abs().max().item())
+    close(y2, F.relu(ref + add), dtype, "tap sum + shift + ReLU")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("up", [2, 4])
+def test_resized_conv_eval_and_train_forward_at_low_resolution(dtype, up):
+    """ConvModule(3x3, bias) on a bilinearly upsampled input (multilevel_neck.py:157-158), forward through the nine
+    low-resolution tap products: eval mode (BatchNorm folded into the tap weights / the gather-sum epilogue) and train mode
+    (batch statistics incl. the conv bias in running_mean) vs torch's interpolate -> conv2d -> batch_norm -> relu, and vs the
+    round-2 forward (gnn.FUSE_TAPSUM = False)."""
+    import copy
+    B, H, W, C, N = 2, 9, 6, 64, 128
+    x, w = q(rnd(B, C, H, W), dtype), q(rnd(N, C, 3, 3, seed=1) * 0.1, dtype)
+    conv_r, bn_r = torch.nn.Conv2d(C, N, 3, padding=1, bias=True), torch.nn.BatchNorm2d(N)
+    with torch.no_grad():
+        conv_r.weight.copy_(w)
+        conv_r.bias.copy_(rnd(N, seed=6) * 0.3)
+        bn_r.weight.copy_(rnd(N, seed=2).abs() + 0.5)
+        bn_r.bias.copy_(rnd(N, seed=3) * 0.1)
+        bn_r.running_mean.copy_(rnd(N, seed=4) * 0.2)
+        bn_r.running_var.copy_(rnd(N, seed=5).abs() + 0.5)
+    conv, norm = copy.deepcopy(conv_r).to(DEV).to(memory_format=torch.channels_last), copy.deepcopy(bn_r).to(DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    up_r = F.interpolate(x, scale_factor=up, mode="bilinear", align_corners=False)
+    with torch.no_grad():
+        ref_eval = F.relu(bn_r.eval()(conv_r(up_r)))
+        got_eval = gnn.conv_bn_act(xd, conv, norm.eval(), relu=True, up=up)
+        gnn.FUSE_TAPSUM = False
+        try:
+            old_eval = gnn.conv_bn_act(xd, conv, norm.eval(), relu=True, up=up)
+        finally:
+            gnn.FUSE_TAPSUM = True
+    scale = None if dtype == torch.float32 else 2 * ref_eval.abs().max().item()
+    close(got_eval.permute(0, 3, 1, 2), ref_eval, dtype, "eval output", scale=scale)
+    close(got_eval, old_eval, dtype, "eval output vs round-2 forward", scale=scale)
+    ref_train = F.relu(bn_r.train()(conv_r(up_r)))
+    with torch.no_grad():
+        got_train = gnn.conv_bn_act(xd, conv, norm.train(), relu=True, up=up)
+    close(got_train.permute(0, 3, 1, 2), ref_train, dtype, "train output", scale=scale)
+    close(norm.running_mean, bn_r.running_mean, dtype, "running_mean")
+    close(norm.running_var, bn_r.running_var, dtype, "running_var")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_concat_resize_conv_eval_per_level(dtype):
+    """UperNet's fpn_bottleneck in eval mode (upernet.py:144-152): native level through the 3x3 kernel on its weight slice, the
+    x2 / x4 / x8 levels through their low-resolution tap products, folded BatchNorm; vs torch (interpolate -> cat -> conv2d ->
+    batch_norm(eval) -> relu) and vs the concat-buffer path (gnn.FUSE_TAPSUM = False)."""
+    import copy
+    from torch import nn
+    B, C, N, H, W = 2, 64, 256, 16, 24
+    sizes = [(H, W), (H // 2, W // 2), (H // 4, W // 4), (H // 8, W // 8)]
+    lv = [q(rnd(B, C, h, w, seed=20 + i), dtype) for i, (h, w) in enumerate(sizes)]
+    conv_r, bn_r = nn.Conv2d(4 * C, N, 3, padding=1, bias=False), nn.BatchNorm2d(N)
+    with torch.no_grad():
+        conv_r.weight.copy_(q(rnd(N, 4 * C, 3, 3, seed=1) * 0.05, dtype))
+        bn_r.weight.copy_(rnd(N, seed=2).abs() + 0.5)
+        bn_r.bias.copy_(rnd(N, seed=3) * 0.1)
+        bn_r.running_mean.copy_(rnd(N, seed=4) * 0.2)
+        bn_r.running_var.copy_(rnd(N, seed=5).abs() + 0.5)
+        cat = torch.cat([lv[0]] + [F.interpolate(t, size=(H, W), mode="bilinear", align_corners=False) for t in lv[1:]], 1)
+        ref = F.relu(bn_r.eval()(conv_r(cat)))
+    c, n = copy.deepcopy(conv_r).to(DEV).to(memory_format=torch.channels_last), copy.deepcopy(bn_r).to(DEV).eval()
+    xs = [t.permute(0, 2, 3, 1).contiguous().to(DEV, dtype) for t in lv]
+    with torch.no_grad():
+        y = gnn.concat_resize_conv_bn_act(xs, c, n, relu=True)
+        gnn.FUSE_TAPSUM = False
+        try:
+            y_old = gnn.concat_resize_conv_bn_act(xs, c, n, relu=True)
+        finally:
+            gnn.FUSE_TAPSUM = True
+    scale = None if dtype == torch.float32 else 2 * ref.abs().max().item()
+    close(y.permute(0, 3, 1, 2), ref, dtype, "eval output", scale=scale)
+    close(y, y_old, dtype, "per-level vs concat path", scale=scale)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 3, first GPU call: the low-resolution forward of the resized-input convolutions -- parity tests, micro-benchmark, bench line
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03a
+mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_hip_ops.py -x -q -m gpu -k "resize or up4 or resized or concat or tap" 2>&1 | tail -15 > $O/pytest_ops.txt
+cat $O/pytest_ops.txt
+timeout 300 python tools/bench_tapsum.py 2>&1 | tee $O/bench_tapsum.txt
+timeout 1200 python -m pytest tests/test_hip_model.py tests/test_hip_tasks.py -x -q -m gpu 2>&1 | tail -8 > $O/pytest_model.txt
+cat $O/pytest_model.txt
+timeout 600 python bench.py --no-cpu-baseline --no-extras 2>$O/bench.err | tail -1 > $O/bench.json
+cut -c1-700 $O/bench.json
