@@ -134,14 +134,18 @@ class MiniTrainer:
     def _collect(self, name: str, value: Any, batch_size: int | None) -> None:
         """Sink of ``LightningModule.log``: batch-size weighted epoch means (on_epoch=True semantics)."""
         w = float(batch_size or 1)
-        v = float(value.detach().float().item() if isinstance(value, Tensor) else value)
         s = self._sums.setdefault(name, [0.0, 0.0])
-        s[0] += v * w
+        # tensors are accumulated on their device (no .item(): that would synchronise the stream on every step); the
+        # host read-back happens once per epoch in _epoch_means
+        v = value.detach().to(torch.float64) if isinstance(value, Tensor) else float(value)
+        s[0] = s[0] + v * w
         s[1] += w
 
     def _epoch_means(self, device: torch.device) -> dict[str, float]:
         names = sorted(self._sums)
-        vals = torch.tensor([[self._sums[n][0], self._sums[n][1]] for n in names], dtype=torch.float64, device=device)
+        vals = torch.stack([torch.stack([torch.as_tensor(self._sums[n][0], dtype=torch.float64, device=device).reshape(()),
+                                         torch.tensor(self._sums[n][1], dtype=torch.float64, device=device)])
+                            for n in names]) if names else torch.zeros((0, 2), dtype=torch.float64, device=device)
         if self.world_size > 1 and len(names):
             dist.all_reduce(vals)                        # sync_dist=True
         out = {n: (vals[i, 0] / vals[i, 1].clamp_min(1e-12)).item() for i, n in enumerate(names)}
@@ -151,6 +155,10 @@ class MiniTrainer:
     def _autocast(self, device: torch.device):
         if self.precision in ("bf16-mixed", "bf16", "16-mixed", "16") and device.type == "cuda":
             # fp16-mixed of the reference's config maps to bf16 here (BASELINE.json: bf16; no loss scaler needed)
+            if self.precision in ("16-mixed", "16") and not getattr(self, "_warned_fp16", False):
+                logger.warning("precision=%s: the HIP kernels compute in bf16 (f32 accumulation); fp16 autocast + GradScaler "
+                               "of the reference's config is replaced by bf16 autocast without loss scaling", self.precision)
+                self._warned_fp16 = True
             return torch.autocast("cuda", dtype=torch.bfloat16)
         return torch.autocast(device.type, enabled=False)
 
@@ -187,8 +195,13 @@ class MiniTrainer:
         path = Path(path)
         path.parent.mkdir(parents=True, exist_ok=True)
         hp = {k: v for k, v in getattr(model, "hparams", {}).items() if isinstance(v, (int, float, str, bool, list, tuple, type(None), dict))}
-        torch.save({"state_dict": self.state_dict_of(model), "epoch": self.current_epoch,
-                    "global_step": self.global_step, "hyper_parameters": hp, **extra}, path)
+        # the keys lightning's checkpoint migration / load_from_checkpoint look at (after_fit of the reference loads the best
+        # checkpoint with the LightningModule's load_from_checkpoint): version tag, loops-free resume state
+        ckpt = {"state_dict": self.state_dict_of(model), "epoch": self.current_epoch, "global_step": self.global_step,
+                "pytorch-lightning_version": "2.5.0", "hyper_parameters": hp,
+                "optimizer_states": [o.state_dict() for o in getattr(self, "_optimizers", [])],
+                "lr_schedulers": [c["scheduler"].state_dict() for c in getattr(self, "_sched_cfgs", [])], **extra}
+        torch.save(ckpt, path)
 
     def load_checkpoint(self, model: nn.Module, path: str | Path) -> None:
         ckpt = torch.load(path, map_location="cpu")
@@ -217,6 +230,7 @@ class MiniTrainer:
         optimizers, sched_cfgs = model.configure_optimizers()
         opt = optimizers[0]
         step_opt = self._maybe_fuse(opt, device)
+        self._optimizers, self._sched_cfgs = [step_opt], sched_cfgs       # saved with every checkpoint
         best, bad_epochs = None, 0
         for epoch in range(self.max_epochs):
             self.current_epoch = epoch
@@ -250,7 +264,7 @@ class MiniTrainer:
                     bad_epochs += 1
             if self.is_global_zero:
                 logger.info("epoch %d: %s", epoch, {k: round(v, 5) for k, v in metrics.items()})
-            if self.early_stopping_patience is not None and bad_epochs > self.early_stopping_patience:
+            if self.early_stopping_patience is not None and bad_epochs >= self.early_stopping_patience:   # Lightning: wait_count >= patience
                 break
         if self.world_size > 1:
             paths = [self.checkpoint_callback.best_model_path]
@@ -293,16 +307,8 @@ class MiniTrainer:
         model.train()
         self.training = True
         fused_clip = step_opt is not opt
-        step_opt.zero_grad(set_to_none=True)
-        for i, batch in self._batches(loader, "train"):
-            batch = model.on_before_batch_transfer(batch, 0) if hasattr(model, "on_before_batch_transfer") else batch
-            batch = _to_device(batch, device)
-            batch = model.on_after_batch_transfer(batch, 0) if hasattr(model, "on_after_batch_transfer") else batch
-            with self._autocast(device):
-                loss = model.training_step(batch, i)
-            (loss / self.accumulate_grad_batches).backward()
-            if (i + 1) % self.accumulate_grad_batches:
-                continue
+
+        def optimizer_step() -> None:
             if self.gradient_clip_val and not fused_clip:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), self.gradient_clip_val)
             step_opt.step()
@@ -311,6 +317,22 @@ class MiniTrainer:
             for cfg in sched_cfgs:
                 if cfg.get("interval") == "step" and self.global_step % int(cfg.get("frequency", 1)) == 0:
                     self._step_scheduler(cfg, {})
+
+        step_opt.zero_grad(set_to_none=True)
+        pending = False
+        for i, batch in self._batches(loader, "train"):
+            batch = model.on_before_batch_transfer(batch, 0) if hasattr(model, "on_before_batch_transfer") else batch
+            batch = _to_device(batch, device)
+            batch = model.on_after_batch_transfer(batch, 0) if hasattr(model, "on_after_batch_transfer") else batch
+            with self._autocast(device):
+                loss = model.training_step(batch, i)
+            (loss / self.accumulate_grad_batches).backward()
+            pending = True
+            if (i + 1) % self.accumulate_grad_batches == 0:
+                optimizer_step()
+                pending = False
+        if pending:              # Lightning steps on the last batch of an epoch even when the accumulation window is not full
+            optimizer_step()
         self.training = False
 
     @torch.no_grad()

@@ -210,9 +210,12 @@ class ShardedDataset:
         return self.processor.process_sample(sample)
 
     def _shards(self) -> list[str]:
+        # trn: sliced by rank (:398-401); val: wds.split_by_node does the same slice (:415); tst: every rank reads all
+        # shards (nodesplitter=None, :415).  (The reference's trn pipeline slices a second time through split_by_node --
+        # rank r then sees only every world-th shard of its own slice; that is not reproduced.)
         shard_list = sorted(self.shard_paths)
-        if self.split == "trn" and torch.distributed.is_available() and torch.distributed.is_initialized():
-            shard_list = shard_list[torch.distributed.get_rank()::torch.distributed.get_world_size()]   # :398-401
+        if self.split in ("trn", "val") and torch.distributed.is_available() and torch.distributed.is_initialized():
+            shard_list = shard_list[torch.distributed.get_rank()::torch.distributed.get_world_size()]
         return shard_list
 
     def _samples(self, epoch: int) -> Iterator[dict[str, Any]]:

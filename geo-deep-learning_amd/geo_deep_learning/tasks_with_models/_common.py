@@ -73,8 +73,14 @@ class SegmentationTaskHooks:
     def on_after_batch_transfer(self, batch: dict[str, Any], dataloader_idx: int) -> dict[str, Any]:  # noqa: ARG002
         trainer = getattr(self, "trainer", None)
         img = batch.get("image") if isinstance(batch, dict) else None
-        if trainer is not None and getattr(trainer, "training", False) and isinstance(img, Tensor) and img.is_cuda:
-            batch = self._apply_aug()(batch)
+        if trainer is not None and getattr(trainer, "training", False) and isinstance(img, Tensor):
+            if img.is_cuda:
+                batch = self._apply_aug()(batch)
+            elif not getattr(self, "_warned_no_aug", False):
+                # the augmentation pipeline is a HIP kernel (gdlhip.augment): there is no host path to fall back to
+                logger.warning("training batch is not on a GPU: the augmentation pipeline (segmentation_dofa.py:91-121) "
+                               "is skipped -- this build augments in on_after_batch_transfer on the device")
+                self._warned_no_aug = True
         return batch
 
     # ------------------------------------------------------------------ step tails

@@ -16,9 +16,11 @@ section 2) and are skipped with a log line.  Third-party classes that are absent
 
 from __future__ import annotations
 
+import copy
 import functools
 import importlib
 import logging
+import os
 import re
 import sys
 from pathlib import Path
@@ -130,8 +132,42 @@ def build(cfg: dict[str, Any]):
     return model, datamodule, MiniTrainer(**kw)
 
 
+def init_distributed() -> bool:
+    """One process per GPU under ``torchrun`` / ``torch.distributed.run``: when the launcher's environment names a world of
+    more than one rank and no process group exists yet, bind this rank to its GPU and create the default group (RCCL =
+    backend "nccl" on GPUs, "gloo" otherwise) -- what Lightning's DDP strategy does for the reference
+    (configs/dofa_config_RGB.yaml:3-13).  Returns True when this call created the group (the caller destroys it)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or dist.is_initialized() or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return False
+    if "RANK" not in os.environ:
+        msg = "WORLD_SIZE > 1 but RANK is not set: launch with torch.distributed.run (one process per GPU)"
+        raise RuntimeError(msg)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("nccl" if use_gpu else "gloo")
+    return True
+
+
 def main(args: list[str] | None = None) -> dict[str, Any]:
     """Run ``fit`` (+ the post-fit test of the best checkpoint).  Returns the trainer's metrics (for tests)."""
+    created_group = init_distributed()
+    try:
+        return _main(args)
+    finally:
+        if created_group:
+            import torch.distributed as dist
+            try:
+                dist.barrier()            # after_fit: `self.trainer.strategy.barrier()` -- the other ranks wait for rank 0's test
+            finally:
+                dist.destroy_process_group()
+
+
+def _main(args: list[str] | None = None) -> dict[str, Any]:
     args = list(sys.argv[1:] if args is None else args)
     if not args or args[0] not in ("fit", "validate", "test"):
         msg = "usage: train.py {fit|validate|test} --config <yaml> [--dotted.key=value ...]"
@@ -165,9 +201,15 @@ def main(args: list[str] | None = None) -> dict[str, Any]:
         test_loader = datamodule.test_dataloader() if datamodule is not None else None
         best = trainer.checkpoint_callback.best_model_path
         if trainer.is_global_zero and test_loader is not None and best:
-            tester = MiniTrainer(precision=trainer.precision, default_root_dir=str(trainer.default_root_dir))
+            tester = MiniTrainer(precision=trainer.precision, default_root_dir=str(trainer.default_root_dir),
+                                 limit_test_batches=trainer.limit["test"])
             tester.world_size, tester.global_rank = 1, 0
-            fresh = instantiate(cfg["model"])
+            # like load_from_checkpoint(..., weights_from_checkpoint_path=None) in after_fit (train.py:52-56): the tested
+            # weights are the best checkpoint's, not the fine-tuning start point
+            model_cfg = copy.deepcopy(cfg["model"])
+            if "weights_from_checkpoint_path" in (model_cfg.get("init_args") or {}):
+                model_cfg["init_args"]["weights_from_checkpoint_path"] = None
+            fresh = instantiate(model_cfg)
             out["test"] = tester.test(fresh, dataloaders=test_loader, ckpt_path=best)[0]
             logger.info("Test metrics of %s: %s", best, out["test"])
         elif trainer.is_global_zero and test_loader is None:

@@ -186,3 +186,67 @@ def test_minitrainer_ddp_world2_matches_single_process(tmp_path):
     assert abs(r0["val"] - tr.callback_metrics["val_loss"]) < 1e-5 and abs(r0["val"] - r1["val"]) < 1e-12
     sd = torch.load(r0["best"])["state_dict"]
     assert "model.encoder.weight" in sd and not any("module." in k for k in sd)
+
+
+def _torchrun_worker(rank, world, port, cfg_path, tmp, ret):
+    # what torch.distributed.run exports for every rank; the process group is NOT created here: train.main must do it
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as d
+    seen = {}
+    orig_fit = MiniTrainer.fit
+
+    def spy(self, *a, **kw):
+        seen.update(world=self.world_size, rank=self.global_rank, initialised=d.is_initialized())
+        return orig_fit(self, *a, **kw)
+    MiniTrainer.fit = spy
+    out = gdl_train.main(["fit", "--config", cfg_path, f"--trainer.default_root_dir={tmp}", "--trainer.max_epochs=2",
+                          "--trainer.sync_batchnorm=false", "--model.init_args.batchnorm=false"])
+    ret[rank] = {"seen": seen, "best": out["best_model_path"], "tested": "test" in out, "alive": d.is_initialized()}
+
+
+def test_train_py_under_torchrun_initialises_the_process_group(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m geo_deep_learning.train fit ...`: with only the
+    launcher's environment set, train.main creates the process group itself (gloo here, nccl = RCCL on GPUs), the trainer
+    sees world size 2, ONE checkpoint is written (by rank 0) and known to both ranks, only rank 0 runs the post-fit test,
+    and the group is destroyed again at exit."""
+    cfg_path = tmp_path / "cfg.yaml"
+    cfg_path.write_text(yaml.safe_dump(CONFIG))
+    world, port = 2, 31700 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_torchrun_worker, args=(r, world, port, str(cfg_path), str(tmp_path), ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert ret[r]["seen"] == {"world": 2, "rank": r, "initialised": True} and not ret[r]["alive"]
+    assert ret[0]["best"] == ret[1]["best"] and Path(ret[0]["best"]).is_file()
+    assert len(list((tmp_path / "checkpoints").iterdir())) == 1
+    assert ret[0]["tested"] and not ret[1]["tested"]
+    ck = torch.load(ret[0]["best"])
+    assert ck["pytorch-lightning_version"] and len(ck["optimizer_states"]) == 1 and len(ck["lr_schedulers"]) == 1
+
+
+def test_accumulation_tail_early_stopping_and_metric_sink(tmp_path):
+    """Lightning semantics MiniTrainer has to reproduce: an epoch whose batch count is not a multiple of
+    accumulate_grad_batches still steps on its last batch (estimated_stepping_batches uses ceil); EarlyStopping stops when
+    the number of epochs without improvement REACHES patience; logged tensors are reduced without a per-step host sync."""
+    acc = toy.ToyTask(3, torch.nn.CrossEntropyLoss(), optimizer=lambda p: torch.optim.SGD(p, lr=0.1))
+    tr = MiniTrainer(max_epochs=2, default_root_dir=str(tmp_path), accumulate_grad_batches=2)
+    tr.fit(acc, datamodule=toy.ToyData(train_batches=5))
+    assert tr.global_step == 6 == tr.estimated_stepping_batches            # ceil(5 / 2) * 2
+    # learning rate 0: val_loss never improves after epoch 0 -> with patience 1 training ends after epoch 1
+    bad = toy.ToyTask(3, torch.nn.CrossEntropyLoss(), optimizer=lambda p: torch.optim.SGD(p, lr=0.0), batchnorm=False)
+    tr = MiniTrainer(max_epochs=6, default_root_dir=str(tmp_path / "es"), early_stopping_patience=1)
+    tr.fit(bad, datamodule=toy.ToyData(train_batches=2))
+    assert tr.current_epoch == 1
+    # the sink keeps tensors as tensors until the epoch mean is formed
+    tr = MiniTrainer(default_root_dir=str(tmp_path))
+    tr._collect("x", torch.tensor(2.0), 3)
+    tr._collect("x", torch.tensor(4.0), 1)
+    tr._collect("y", 1.5, None)
+    assert isinstance(tr._sums["x"][0], torch.Tensor)
+    means = tr._epoch_means(torch.device("cpu"))
+    assert abs(means["x"] - 2.5) < 1e-12 and abs(means["y"] - 1.5) < 1e-12
