@@ -331,9 +331,11 @@ int launch(const KArgs& k, hipStream_t stream) {
 
 }  // namespace
 
+
 // tuning hooks (gdl_debug_*): process-global words, written only by the tools/ scripts, read with relaxed atomics
 #include <atomic>
-static std::atomic<int> g_tap_inner{1}, g_dbg{0}, g_tap_packing{1};
+static std::atomic<int> g_tap_inner{1}, g_dbg{0}, g_tap_packing{1}, g_epi_v2{1};
+extern "C" void gdl_debug_set_conv_epilogue(int v2) { g_epi_v2 = v2; }  // A/B hook: 0 = the round-2 epilogue
 extern "C" void gdl_debug_set_conv_tap_packing(int on) { g_tap_packing = on; }  // A/B hook
 extern "C" void gdl_debug_set_conv_dbg(int mode) { g_dbg = mode; }
 static std::atomic<unsigned long long*> g_probe{nullptr};
@@ -393,6 +395,7 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   // "dense" = the (b,oy,ox) -> offset map is linear in m, so no divisions are needed
   k.tap_inner = g_tap_inner;
   k.dbg = g_dbg;
+  k.epi_v2 = g_epi_v2;
   k.probe = g_probe;
   k.in_span = (unsigned)in_span;
   k.w_span = (unsigned)w_span;

@@ -18,6 +18,7 @@ struct KArgs {
   unsigned in_span, w_span;   // bytes addressed from the (z-offset) operand base: buffer num_records
   int tap_inner;              // K order: 1 = channel chunk outer / filter tap inner (default), 0 = tap outer
   int dbg;                    // tuning experiments only: 1 = no DMA after the first tile, 2 = no MFMA
+  int epi_v2;                 // A/B hook (gdl_debug_set_conv_epilogue): 0 = the round-2 epilogue (conv_epilogue_rows)
   unsigned long long* probe;  // tuning only (12288 u64): per block {shader cycles, 100 MHz ticks} of the K loop, K loop + epilogue cycles, {start, end} ticks
 };
 
@@ -265,6 +266,171 @@ __device__ __forceinline__ bool conv_epilogue_rows(const KArgs& k, f32x16_t (&ac
   return true;
 }
 
+// Round 3: the same coalesced epilogue with ALL element-wise work moved behind the transpose.  In the store layout a lane
+// always owns the same CH consecutive channels (8 for bf16 outputs, 4 for f32), so the per-channel constants are CH registers
+// loaded once per tile instead of LDS reads per accumulator group; the MFMA-layout side is a plain dump of the raw f32
+// accumulators (eight ds_write_b128 per pass, no VALU); the residual rows of pass i + 1 are requested before pass i is
+// stored (they cost one exposed memory latency per PASS before: 57 k cycles per proj tile against 36 k for its K loop).
+// Per element the arithmetic and its order are exactly conv_epilogue_rows' (x = alpha * acc + bias; x * scale + shift;
+// ReLU / GELU; * DropPath scale; + residual; ReLU) -- results are bit-identical, tests/test_hip_ops.py holds it to that.
+// Not for the training-only extras (aux_out, GELU-gradient multiply): those keep conv_epilogue_rows.
+
+template <int TM, int CH, bool RESID>
+__device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_t (&acc)[TM][2], int m0, int n0, int wm, int wn,
+                                                        int lane, int64_t out_zoff, unsigned char* lds) {
+  constexpr int NT = CH == 8 ? 4 : 8;                    // row groups per pass: a pass is 32 rows x 64 channels
+  constexpr int LPR = 64 / CH;                           // lanes per row
+  const gdl_conv_args& a = k.a;
+  const bool plain = !a.resid && !a.batch_scale;
+  const bool fast = a.dtype == GDL_BF16;
+  const int HoWo = a.Ho * a.Wo;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int srow = lane / LPR, slot = lane % LPR;        // store layout: row srow + (64 / LPR) t, channels CH * slot ..
+  // FULL tiles only (the caller checks m0 + 32 TM WARPS_M <= M and n0 + 256 <= N): no per-lane range conditions, so every
+  // load and store below is unconditional straight-line code and hipcc's waitcnt pass counts them exactly (with `continue`
+  // / exec-masked memory operations in the loop it fell back to vmcnt(0) in front of every store: the residual prefetch
+  // was serialised again)
+  const int n_l = n0 + wn * 64 + CH * slot;
+  float cb[CH], cs[CH], chh[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) { cb[e] = 0.f; cs[e] = 1.f; chh[e] = 0.f; }
+  {
+#pragma unroll
+    for (int q = 0; q < CH / 4; ++q) {
+      if (a.bias) { const float4 t = *(const float4*)(a.bias + n_l + 4 * q); cb[4 * q] = t.x; cb[4 * q + 1] = t.y; cb[4 * q + 2] = t.z; cb[4 * q + 3] = t.w; }
+      if (a.scale) { const float4 t = *(const float4*)(a.scale + n_l + 4 * q); cs[4 * q] = t.x; cs[4 * q + 1] = t.y; cs[4 * q + 2] = t.z; cs[4 * q + 3] = t.w; }
+      if (a.scale && a.shift) { const float4 t = *(const float4*)(a.shift + n_l + 4 * q); chh[4 * q] = t.x; chh[4 * q + 1] = t.y; chh[4 * q + 2] = t.z; chh[4 * q + 3] = t.w; }
+    }
+  }
+  // residual rows of one pass: NT pieces of CH channels (f32 or bf16 in memory) as f32 registers
+  // residual rows are kept RAW (as loaded: four words per row group = 4 f32, or 8 bf16 for the 8-channel layout) and
+  // converted at their use, so that nothing between the request and the use needs the data (the request is a prefetch).
+  // vmcnt counts loads and stores in ONE in-order queue: a wait for loads that were issued behind stores also waits for
+  // those stores' acknowledgements (measured: 60 k cycles per proj tile with the loads at the start of every pass).
+  // (the residual has the OUTPUT's dtype here -- f32 stream + f32 residual, bf16 map + bf16 residual -- so a row group is
+  // always one 16-byte load; other combinations keep conv_epilogue_rows)
+  constexpr int RW = 4;
+  auto load_resid_t = [&](int mp, int t, uint32_t (&rw)[NT][RW]) {
+    const int m = mp + srow + (64 / LPR) * t;
+    const int64_t ro = (int64_t)m * a.res_sW + n_l;
+    const uint4 u = CH == 8 ? *(const uint4*)((const uint16_t*)a.resid + ro) : *(const uint4*)((const float*)a.resid + ro);
+    rw[t][0] = u.x; rw[t][1] = u.y; rw[t][2] = u.z; rw[t][3] = u.w;
+  };
+  auto resid_value = [&](const uint32_t (&w)[RW], int e) -> float {
+    if constexpr (CH == 8) return __uint_as_float((e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16));
+    else return __uint_as_float(w[e]);
+  };
+  // DropPath scales, requested FIRST: these are vector loads (the compiler cannot prove the array read-only), and behind the
+  // residual prefetch in vmcnt's in-order queue the wait for them would drain the prefetch.  HoWo >= 256 (checked by the
+  // caller): the tile's 256 rows span at most two samples.
+  float rs0 = 1.f, rs1 = 1.f;
+  int rem0 = 0;                                          // row m belongs to sample b0 + 1 when m - m0 + rem0 >= HoWo
+  if (a.batch_scale) {
+    const int b0 = m0 / HoWo;
+    rem0 = m0 - b0 * HoWo;
+    rs0 = a.batch_scale[b0];
+    rs1 = b0 + 1 < a.B ? a.batch_scale[b0 + 1] : 0.f;
+  }
+  // ONE buffer: row group t of the next pass is requested right after row group t of this pass has been consumed and BEFORE
+  // its store is issued, so a wait for it never has to cover a store issued behind it
+  uint32_t rva[NT][RW];
+  if constexpr (RESID) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) load_resid_t(m0 + wm * TM * 32, t, rva);
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int mp = m0 + (wm * TM + i) * 32;              // first row of this pass (wave-uniform)
+    // ---- (1) raw accumulators, MFMA layout -> LDS (f32 rows of 256 B, 16-byte slots swizzled by row)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int sl = 8 * j + 2 * g + fhalf;
+        *(float4*)(lds + frow * 256 + ((sl ^ (frow & 7)) << 4)) =
+            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- (2) LDS -> registers in the store layout -> element-wise terms -> full row segments in global memory
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int rr = srow + (64 / LPR) * t;
+      float v[CH];
+#pragma unroll
+      for (int q = 0; q < CH / 4; ++q) {
+        const int sl = (CH / 4) * slot + q;
+        const float4 x = *(const float4*)(lds + rr * 256 + ((sl ^ (rr & 7)) << 4));
+        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+      }
+      const int m = mp + rr;
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        float x = v[e] * a.alpha + cb[e];
+        if (a.scale) x = x * cs[e] + chh[e];
+        if (a.act == GDL_ACT_RELU) x = fmaxf(x, 0.f);
+        v[e] = x;
+      }
+      if (a.act == GDL_ACT_GELU) {
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+          const float4 x4 = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+          const float4 y4 = fast ? gelu4_fast(x4) : gelu4(x4);
+          v[4 * q] = y4.x; v[4 * q + 1] = y4.y; v[4 * q + 2] = y4.z; v[4 * q + 3] = y4.w;
+        }
+      }
+      if (!plain) {
+        if (a.batch_scale) {
+          const float rs = rem0 + (wm * TM + i) * 32 + rr >= HoWo ? rs1 : rs0;
+#pragma unroll
+          for (int e = 0; e < CH; ++e) v[e] *= rs;
+        }
+        if constexpr (RESID) {
+#pragma unroll
+          for (int e = 0; e < CH; ++e) {
+            float x = v[e] + resid_value(rva[t], e);
+            if (a.act == GDL_ACT_RESID_RELU) x = fmaxf(x, 0.f);
+            v[e] = x;
+          }
+          if (i + 1 < TM) load_resid_t(mp + 32, t, rva);
+        }
+      }
+      const int64_t off = (int64_t)m * a.out_sW + out_zoff + n_l;
+      if constexpr (CH == 8) {
+        *(uint4*)((uint16_t*)a.out + off) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                        pack_bf16x2(v[6], v[7]));
+      } else {
+        *(float4*)((float*)a.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int TM>
+__device__ __forceinline__ bool conv_epilogue_rows2(const KArgs& k, f32x16_t (&acc)[TM][2], int m0, int n0, int wm, int wn, int lane,
+                                                   int64_t out_zoff, unsigned char* lds) {
+  const gdl_conv_args& a = k.a;
+  const bool out_bf16 = a.out_dtype == GDL_BF16;
+  const int HoWo = a.Ho * a.Wo;
+  const bool vec_ok = ((uintptr_t)a.out % 16 == 0) && (a.out_sW % 8 == 0) && (out_zoff % 8 == 0) && (a.N % 16 == 0);
+  const bool res_ok = !a.resid || (((uintptr_t)a.resid % 16 == 0) && (a.res_sW % 8 == 0) && (a.resid_dtype == a.out_dtype));
+  const bool vecs_ok = ((uintptr_t)a.bias % 16 == 0) && ((uintptr_t)a.scale % 16 == 0) && ((uintptr_t)a.shift % 16 == 0);
+  if (!k.epi_v2 || a.aux_out || a.act == GDL_ACT_MUL_GELU_GRAD ||
+      !(k.out_dense && k.res_dense && vec_ok && res_ok && vecs_ok && (!a.batch_scale || HoWo >= 256)))
+    return false;
+  // full tiles only (see the implementation); WARPS_M = 2 for every tile that carries this epilogue
+  if (m0 + 2 * TM * 32 > k.M || n0 + 256 > a.N) return false;
+  if (a.resid) {
+    if (out_bf16) conv_epilogue_rows2_impl<TM, 8, true>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
+    else conv_epilogue_rows2_impl<TM, 4, true>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
+  } else {
+    if (out_bf16) conv_epilogue_rows2_impl<TM, 8, false>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
+    else conv_epilogue_rows2_impl<TM, 4, false>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
+  }
+  return true;
+}
+
 // ---- epilogue.  Call with the accumulators of MFMAs that ran with SWAPPED operands (D = W_tile x X_tile^T).
 // `lds_wave` / `lds_consts`: 8 KiB + 768 B of LDS private to this wave and free to overwrite (the caller has passed a
 // workgroup barrier after the last fragment read of the K loop), or nullptr.  With it, and for pixel-dense outputs, the tile leaves
@@ -282,6 +448,7 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& k, f32x16_t (&acc)[TM
   const int frow = lane & 31, fhalf = lane >> 5;
   const int HoWo = a.Ho * a.Wo;
   if constexpr (TN == 2) {
+    if (lds_wave && conv_epilogue_rows2<TM>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds_wave)) return;
     if (lds_wave && conv_epilogue_rows<TM, EXTRA>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds_wave, lds_consts)) return;
   }
   // ---- epilogue.  The MFMAs ran with swapped operands (D = W_tile x X_tile^T), so a lane owns ONE output row

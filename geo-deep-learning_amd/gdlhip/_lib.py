@@ -177,6 +177,9 @@ def load() -> C.CDLL:
     if os.environ.get("GDL_CONV_SF") is not None:      # tuning hook: 0 disables the 3x3 shared-staging kernel
         lib.gdl_debug_set_conv_sf.argtypes = [C.c_int]
         lib.gdl_debug_set_conv_sf(int(os.environ["GDL_CONV_SF"]))
+    if os.environ.get("GDL_CONV_EPILOGUE") is not None:   # tuning hook: 0 = the round-2 epilogue of the 256^2 tiles
+        lib.gdl_debug_set_conv_epilogue.argtypes = [C.c_int]
+        lib.gdl_debug_set_conv_epilogue(int(os.environ["GDL_CONV_EPILOGUE"]))
     if os.environ.get("GDL_WGRAD_MODE") is not None:   # tuning hook: kernel-selection bits of gdl_debug_force_wgrad_small
         lib.gdl_debug_force_wgrad_small.argtypes = [C.c_int]
         lib.gdl_debug_force_wgrad_small(int(os.environ["GDL_WGRAD_MODE"]))

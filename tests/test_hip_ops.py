@@ -1081,3 +1081,54 @@ def test_concat_resize_conv_eval_per_level(dtype):
     scale = None if dtype == torch.float32 else 2 * ref.abs().max().item()
     close(y.permute(0, 3, 1, 2), ref, dtype, "eval output", scale=scale)
     close(y, y_old, dtype, "per-level vs concat path", scale=scale)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_epilogue_v2_bit_identical_to_round2_epilogue(dtype):
+    """The round-3 epilogue of the 256^2 tiles (element-wise terms behind the LDS transpose, per-lane channel constants,
+    residual rows requested one pass ahead) performs the same operations in the same order per element as the round-2
+    one: every combination the models use must come out bit-identical (gdl_debug_set_conv_epilogue switches).  Linear
+    layers with M tail and a sample boundary inside a pass, a 3x3 convolution through the shared-staging kernel."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
+    lib.gdl_debug_set_conv_epilogue.argtypes = [ctypes.c_int]
+    B, T, K, N = 3, 1297, 128, 512
+    xd = q(rnd(B, T, K), dtype).to(DEV, dtype).view(B, 1, T, K)
+    wd = (q(rnd(N, K, seed=1), dtype) * 0.1).to(DEV, dtype)
+    bias, scale, shift = rnd(N, seed=2).to(DEV), rnd(N, seed=3).to(DEV), rnd(N, seed=4).to(DEV)
+    bs = torch.tensor([0.0, 1.25, 0.5], device=DEV)
+    resid = rnd(B, T, N, seed=5)
+    xc = q(rnd(2, 19, 23, 64, seed=7), dtype).to(DEV, dtype)
+    wc = (q(rnd(256, 9 * 64, seed=8), dtype) * 0.05).to(DEV, dtype)
+    rc = rnd(2, 19, 23, 256, seed=9)
+    cases = []
+    for odt in DTYPES:
+        cases.append((f"plain bias {odt}", lambda odt=odt: ops.conv_gemm(xd, wd, bias=bias, out_dtype=odt)))
+        cases.append((f"gelu {odt}", lambda odt=odt: ops.conv_gemm(xd, wd, bias=bias, act=ops.ACT_GELU, out_dtype=odt)))
+        cases.append((f"folded BN + relu {odt}", lambda odt=odt: ops.conv_gemm(xd, wd, scale=scale, shift=shift, act=ops.ACT_RELU, out_dtype=odt)))
+        for rdt in DTYPES:
+            r1 = q(resid, rdt).to(DEV, rdt).view(B, 1, T, N)
+            cases.append((f"LayerScale + DropPath + residual {odt} {rdt}",
+                          lambda odt=odt, r1=r1: ops.conv_gemm(xd, wd, bias=bias, scale=scale, batch_scale=bs, resid=r1, out_dtype=odt)))
+            cases.append((f"residual then relu {odt} {rdt}",
+                          lambda odt=odt, r1=r1: ops.conv_gemm(xd, wd, bias=bias, resid=r1, act=ops.ACT_RESID_RELU, out_dtype=odt)))
+            r2 = q(rc, rdt).to(DEV, rdt)
+            cases.append((f"3x3 + residual {odt} {rdt}",
+                          lambda odt=odt, r2=r2: ops.conv_gemm(xc, wc, R=3, S=3, pad=1, resid=r2, out_dtype=odt)))
+    lib.gdl_debug_force_conv_variant(3)
+    try:
+        for name, fn in cases:
+            if name.startswith("3x3"):
+                lib.gdl_debug_force_conv_variant(4)
+            outs = []
+            for v2 in (1, 0):
+                lib.gdl_debug_set_conv_epilogue(v2)
+                outs.append(fn())
+            lib.gdl_debug_force_conv_variant(3)
+            assert torch.isfinite(outs[0].float()).all(), name
+            assert torch.equal(outs[0], outs[1]), f"{name}: max dev {(outs[0].float() - outs[1].float()).abs().max().item():.3e}"
+    finally:
+        lib.gdl_debug_set_conv_epilogue(1)
+        lib.gdl_debug_force_conv_variant(-1)

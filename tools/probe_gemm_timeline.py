@@ -16,6 +16,7 @@ lib = _lib.load()
 lib.gdl_debug_set_conv_probe.argtypes = [ctypes.c_void_p]
 lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
 lib.gdl_debug_set_conv_dbg.argtypes = [ctypes.c_int]
+lib.gdl_debug_set_conv_epilogue.argtypes = [ctypes.c_int]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 bf = torch.bfloat16
 M = B * 1297
@@ -87,6 +88,19 @@ def run(name, m, k, n, kind, odt, variant, dbg):
 
 
 FULL = len(sys.argv) > 2 and sys.argv[2] == "full"
+if len(sys.argv) > 2 and sys.argv[2] == "epilogue_parts":   # round-3 epilogue: as is / without its global stores (10) / without residual loads (11)
+    for shp in (SHAPES[0], SHAPES[1]):
+        for dbg in (0, 10, 11, 0, 10, 11):
+            run(*shp, 3, dbg)
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "epilogue":      # round-3 epilogue (1) against the round-2 one (0), 256^2 ping-pong tiles
+    for shp in SHAPES:
+        for v2 in (0, 1, 0, 1):
+            lib.gdl_debug_set_conv_epilogue(v2)
+            print(f"epilogue v{2 if v2 else 1}: ", end="")
+            run(*shp, 3, 0)
+    lib.gdl_debug_set_conv_epilogue(1)
+    sys.exit(0)
 for shp in ([] if len(sys.argv) > 2 and sys.argv[2] in ("convs", "phases") else SHAPES):
     for variant in (3, 1):
         for dbg in ((0, 1, 2) if FULL else (0,)):
