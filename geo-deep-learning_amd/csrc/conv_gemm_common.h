@@ -286,7 +286,7 @@ __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_
   const int HoWo = a.Ho * a.Wo;
   const int frow = lane & 31, fhalf = lane >> 5;
   const int srow = lane / LPR, slot = lane % LPR;        // store layout: row srow + (64 / LPR) t, channels CH * slot ..
-  // FULL tiles only (the caller checks m0 + 32 TM WARPS_M <= M and n0 + 256 <= N): no per-lane range conditions, so every
+  // FULL wave tiles only (the caller checks the wave's rows and channels against M and N): no per-lane range conditions, so every
   // load and store below is unconditional straight-line code and hipcc's waitcnt pass counts them exactly (with `continue`
   // / exec-masked memory operations in the loop it fell back to vmcnt(0) in front of every store: the residual prefetch
   // was serialised again)
@@ -322,7 +322,7 @@ __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_
   };
   // DropPath scales, requested FIRST: these are vector loads (the compiler cannot prove the array read-only), and behind the
   // residual prefetch in vmcnt's in-order queue the wait for them would drain the prefetch.  HoWo >= 256 (checked by the
-  // caller): the tile's 256 rows span at most two samples.
+  // caller): the tile's (at most 256) rows span at most two samples.
   float rs0 = 1.f, rs1 = 1.f;
   int rem0 = 0;                                          // row m belongs to sample b0 + 1 when m - m0 + rem0 >= HoWo
   if (a.batch_scale) {
@@ -419,8 +419,9 @@ __device__ __forceinline__ bool conv_epilogue_rows2(const KArgs& k, f32x16_t (&a
   if (!k.epi_v2 || a.aux_out || a.act == GDL_ACT_MUL_GELU_GRAD ||
       !(k.out_dense && k.res_dense && vec_ok && res_ok && vecs_ok && (!a.batch_scale || HoWo >= 256)))
     return false;
-  // full tiles only (see the implementation); WARPS_M = 2 for every tile that carries this epilogue
-  if (m0 + 2 * TM * 32 > k.M || n0 + 256 > a.N) return false;
+  // full WAVE tiles only (see the implementation): the wave's TM x 32 rows and 64 channels are all in range.  The decision
+  // is per wave -- both epilogues only touch wave-private LDS
+  if (m0 + (wm + 1) * TM * 32 > k.M || n0 + (wn + 1) * 64 > a.N) return false;
   if (a.resid) {
     if (out_bf16) conv_epilogue_rows2_impl<TM, 8, true>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
     else conv_epilogue_rows2_impl<TM, 4, true>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);

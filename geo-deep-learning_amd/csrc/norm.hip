@@ -383,6 +383,17 @@ extern "C" int gdl_bn_stats(const void* x, int dtype, int64_t P, int C, int64_t 
   return GDL_OK;
 }
 
+// final reduction of per-block partial sums [nsplit][2][C] written by another kernel (gdl_resize_conv3x3_fwd_sum_bn): the
+// second half of gdl_bn_stats
+extern "C" int gdl_bn_stats_finalize(const float* ws, int nsplit, int C, int64_t P, float* mean, float* var, float* running_mean,
+                                     float* running_var, float momentum, gdl_stream_t stream) {
+  GDL_CHECK_ARG(ws && mean && var && nsplit > 0 && C > 0 && P > 0, "gdl_bn_stats_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_stats_final, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, ws, nsplit, C, P, mean, var, running_mean,
+                     running_var, momentum);
+  GDL_CHECK_LAUNCH("gdl_bn_stats_finalize");
+  return GDL_OK;
+}
+
 extern "C" int gdl_bn_apply(const void* x, void* y, int dtype, int64_t P, int C, int64_t x_sP, int64_t y_sP,
                             const float* mean, const float* var, const float* gamma, const float* beta,
                             float eps, int relu, gdl_stream_t stream) {

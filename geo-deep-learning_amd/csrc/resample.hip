@@ -814,18 +814,16 @@ struct TapMArgs {
   uint16_t* out;
   const float* addvec;
   int relu;
+  int nslots, slot_off[3];        // version 2: byte offsets of the window slots (two for one source, else one per source)
 };
 
-template <int PXB, int WIN>
-__device__ __forceinline__ void tapm_source(const TapMArgs& a, int k, f32x4_t (&acc)[PXB / 4][4], unsigned char* smem, int b, int oy0,
-                                            int oxb0, int c0, int tid, int lane, int wave) {
-  constexpr int COLS = 4 * PXB, NA = 3 * WIN, NKS = (NA + 1) / 2;
-  float* TYs = (float*)smem;                          // [4][12]  weight of window row wy for (patch row py, filter row r)
-  float* TXs = TYs + 64;                              // [COLS][16] the same for columns, b = s * WIN + dx, zero-padded
-  unsigned char* stage = smem + 256 + COLS * 64;
-  const int Hi = a.H[k], Wi = a.W[k], lf = a.LF[k], N = a.N;
-  const int WC = ((COLS - 4) >> lf) + WIN;            // window columns of the block
-  const int wr0 = (oy0 >> lf) - 1, wcb0 = (oxb0 >> lf) - 1;
+// the two 1-D weight tables of source k for the block at (oy0, oxb0): TYs [4][12] (+ padding to 64 floats), TXs [COLS][16]
+template <int PXB, int LF>
+__device__ __forceinline__ void tapm_tables(const TapMArgs& a, int k, float* TYs, float* TXs, int oy0, int oxb0, int tid) {
+  constexpr int WIN = LF == 1 ? 4 : 3, lf = LF;
+  constexpr int COLS = 4 * PXB, NA = 3 * WIN;
+  const int Hi = a.H[k], Wi = a.W[k];
+  const int wr0 = (oy0 >> lf) - 1;
   const float ry = (float)Hi / (float)a.Ho, rx = (float)Wi / (float)a.Wo;
   if (tid < 48) {
     const int py = tid / 12, ai = tid - py * 12;
@@ -855,24 +853,38 @@ __device__ __forceinline__ void tapm_source(const TapMArgs& a, int k, f32x4_t (&
     }
     TXs[i] = w;
   }
-  // ---- stage the window: LDS row R = (wyi * WC + wci) * 9 + tap, 128 bytes = this block's 64 channels
-  {
-    const srd_t srd = make_srd(a.z[k] + (int64_t)b * Hi * Wi * 9 * N, (unsigned)((int64_t)Hi * Wi * 9 * N * 2));
-    const unsigned lds_stage = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)stage);
-    const int nrows = WIN * WC * 9, npieces = (nrows + 7) >> 3;
-    for (int piece = wave; piece < npieces; piece += 4) {
-      const int R = piece * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ tm_swz(R);
-      const int pc = R / 9, t = R - pc * 9;
-      const int wyi = pc / WC, wci = pc - wyi * WC;
-      const int row = wr0 + wyi, col = wcb0 + wci;
-      const bool ok = R < nrows && row >= 0 && row < Hi && col >= 0 && col < Wi;
-      const unsigned v = ok ? (unsigned)((((row * Wi + col) * 9 + t) * N + c0) * 2 + chunk * 16) : kTmOob;
-      dma16_buf(v, srd, 0u, lds_stage + piece * 1024);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// stage the window of source k, channels c0 .. c0 + 63: LDS row R = (wyi * WC + wci) * 9 + tap, 128 bytes; no wait
+template <int PXB, int LF>
+__device__ __forceinline__ void tapm_issue(const TapMArgs& a, int k, unsigned lds_stage, int b, int oy0, int oxb0, int c0, int lane,
+                                           int wave) {
+  constexpr int WIN = LF == 1 ? 4 : 3, lf = LF;
+  constexpr int COLS = 4 * PXB;
+  const int Hi = a.H[k], Wi = a.W[k], N = a.N;
+  constexpr int WC = ((COLS - 4) >> lf) + WIN;        // window columns of the block (compile-time: the divisions below are cheap)
+  const int wr0 = (oy0 >> lf) - 1, wcb0 = (oxb0 >> lf) - 1;
+  const srd_t srd = make_srd(a.z[k] + (int64_t)b * Hi * Wi * 9 * N, (unsigned)((int64_t)Hi * Wi * 9 * N * 2));
+  constexpr int nrows = WIN * WC * 9, npieces = (nrows + 7) >> 3;
+  for (int piece = wave; piece < npieces; piece += 4) {
+    const int R = piece * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ tm_swz(R);
+    const int pc = R / 9, t = R - pc * 9;
+    const int wyi = pc / WC, wci = pc - wyi * WC;
+    const int row = wr0 + wyi, col = wcb0 + wci;
+    const bool ok = R < nrows && row >= 0 && row < Hi && col >= 0 && col < Wi;
+    const unsigned v = ok ? (unsigned)((((row * Wi + col) * 9 + t) * N + c0) * 2 + chunk * 16) : kTmOob;
+    dma16_buf(v, srd, 0u, lds_stage + piece * 1024);
   }
-  __syncthreads();
+}
+
+// the wave's patches of source k from a staged window: acc[j2][nt] += z-fragments x weight-fragments
+template <int PXB, int LF>
+__device__ __forceinline__ void tapm_mfma(const TapMArgs& a, int k, f32x4_t (&acc)[PXB / 4][4], const float* TYs, const float* TXs,
+                                          const unsigned char* stage, int lane, int wave) {
+  constexpr int WIN = LF == 1 ? 4 : 3, lf = LF;
+  constexpr int COLS = 4 * PXB, NA = 3 * WIN, NKS = (NA + 1) / 2;
+  constexpr int WC = ((COLS - 4) >> lf) + WIN;
   int lane_mfma = lane;
   asm volatile("" : "+v"(lane_mfma));                 // keeps the fragment address arithmetic below this point (register budget)
   const int L = lane_mfma & 15, g = lane_mfma >> 4;
@@ -918,34 +930,10 @@ __device__ __forceinline__ void tapm_source(const TapMArgs& a, int k, f32x4_t (&
   }
 }
 
-// grid = (ceil(Wo / (4 PXB)) * N / 64, B * ceil(Ho / 4)); dynamic LDS = 256 + 256 PXB + max over the sources of the window bytes
+// accumulators -> (+ addvec, ReLU) -> bf16 -> LDS tile [4 rows][COLS pixels] x 128 B, 16-byte slots swizzled by pixel
 template <int PXB>
-__global__ __launch_bounds__(256, PXB == 8 ? 3 : 4) void resize_conv3x3_fwd_sum_mfma_kernel(const TapMArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void tapm_to_tile(const TapMArgs& a, f32x4_t (&acc)[PXB / 4][4], unsigned char* tile, int c0, int lane, int wave) {
   constexpr int COLS = 4 * PXB;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nchunks = a.N >> 6, nprow = (a.Ho + 3) >> 2;
-  const int nblk = gridDim.x * gridDim.y;
-  const int id = blockIdx.y * gridDim.x + blockIdx.x;
-  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = id & 7, idx = id >> 3;      // XCD-major: neighbouring patch rows share an L2
-  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const int brow = lid / gridDim.x, bx = lid - brow * gridDim.x;
-  const int b = brow / nprow, oy0 = (brow - b * nprow) * 4;
-  const int cb = bx / nchunks, c0 = (bx - cb * nchunks) * 64, oxb0 = cb * COLS;
-  f32x4_t acc[PXB / 4][4];
-#pragma unroll
-  for (int j2 = 0; j2 < PXB / 4; ++j2)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[j2][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < a.nsrc; ++k) {
-    if (k > 0) __syncthreads();                       // the previous source's fragment reads are done: tables and window are rewritten
-    if (a.LF[k] == 1) tapm_source<PXB, 4>(a, k, acc, smem, b, oy0, oxb0, c0, tid, lane, wave);
-    else tapm_source<PXB, 3>(a, k, acc, smem, b, oy0, oxb0, c0, tid, lane, wave);
-  }
-  __syncthreads();
-  // ---- epilogue: + addvec, ReLU, bf16, through an LDS transpose ([4 rows][COLS pixels] x 128 B, 16-byte slots swizzled by pixel)
-  unsigned char* tile = smem + 256 + COLS * 64;
   const int L = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int j2 = 0; j2 < PXB / 4; ++j2) {
@@ -962,6 +950,47 @@ __global__ __launch_bounds__(256, PXB == 8 ? 3 : 4) void resize_conv3x3_fwd_sum_
       *(uint2*)(tile + pp * 128 + ((((ch >> 3) ^ (pp & 7))) << 4) + (ch & 7) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
     }
   }
+}
+
+// grid = (ceil(Wo / (4 PXB)) * N / 64, B * ceil(Ho / 4)); dynamic LDS = 256 + 256 PXB + max over the sources of the window bytes
+template <int PXB>
+__global__ __launch_bounds__(256, PXB == 8 ? 3 : 4) void resize_conv3x3_fwd_sum_mfma_kernel(const TapMArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int COLS = 4 * PXB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nchunks = a.N >> 6, nprow = (a.Ho + 3) >> 2;
+  const int nblk = gridDim.x * gridDim.y;
+  const int id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = id & 7, idx = id >> 3;      // XCD-major: neighbouring patch rows share an L2
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int brow = lid / gridDim.x, bx = lid - brow * gridDim.x;
+  const int b = brow / nprow, oy0 = (brow - b * nprow) * 4;
+  const int cb = bx / nchunks, c0 = (bx - cb * nchunks) * 64, oxb0 = cb * COLS;
+  float* TYs = (float*)smem;
+  float* TXs = TYs + 64;
+  unsigned char* stage = smem + 256 + COLS * 64;
+  const unsigned lds_stage = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)stage);
+  f32x4_t acc[PXB / 4][4];
+#pragma unroll
+  for (int j2 = 0; j2 < PXB / 4; ++j2)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[j2][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < a.nsrc; ++k) {
+    if (k > 0) __syncthreads();                       // the previous source's fragment reads are done: tables and window are rewritten
+    if (a.LF[k] == 1) { tapm_tables<PXB, 1>(a, k, TYs, TXs, oy0, oxb0, tid); tapm_issue<PXB, 1>(a, k, lds_stage, b, oy0, oxb0, c0, lane, wave); }
+    else if (a.LF[k] == 2) { tapm_tables<PXB, 2>(a, k, TYs, TXs, oy0, oxb0, tid); tapm_issue<PXB, 2>(a, k, lds_stage, b, oy0, oxb0, c0, lane, wave); }
+    else { tapm_tables<PXB, 3>(a, k, TYs, TXs, oy0, oxb0, tid); tapm_issue<PXB, 3>(a, k, lds_stage, b, oy0, oxb0, c0, lane, wave); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (a.LF[k] == 1) tapm_mfma<PXB, 1>(a, k, acc, TYs, TXs, stage, lane, wave);
+    else if (a.LF[k] == 2) tapm_mfma<PXB, 2>(a, k, acc, TYs, TXs, stage, lane, wave);
+    else tapm_mfma<PXB, 3>(a, k, acc, TYs, TXs, stage, lane, wave);
+  }
+  __syncthreads();
+  // ---- epilogue through an LDS transpose (the window's memory is free now)
+  unsigned char* tile = stage;
+  tapm_to_tile<PXB>(a, acc, tile, c0, lane, wave);
   __syncthreads();
   for (int i = tid; i < 4 * COLS * 8; i += 256) {
     const int pp = i >> 3, chunk = i & 7;
@@ -969,6 +998,215 @@ __global__ __launch_bounds__(256, PXB == 8 ? 3 : 4) void resize_conv3x3_fwd_sum_
     if (oy < a.Ho && ox < a.Wo) {
       const uint4 v = *(const uint4*)(tile + pp * 128 + ((chunk ^ (pp & 7)) << 4));
       *(uint4*)(a.out + (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.N + c0 + chunk * 8) = v;
+    }
+  }
+}
+
+// ---- version 2: one block owns its 4 x 4 PXB output pixels for ALL channels and walks the 64-channel chunks (and, per chunk,
+// the sources) through LDS window slots: the window of step i + 1 is in flight while step i runs on the matrix cores.
+// Everything that does not depend on the channel is computed ONCE per block and kept in registers: the weight fragments
+// and fragment addresses of the wave's patches, and the per-lane DMA offsets (the chunk enters as the buffer instruction's
+// scalar offset).  PMC of version 1 on the neck's x4 level: 1400 VALU instructions per wave and 64-channel block -- runtime
+// divisions in the DMA addressing, the table and fragment set-up -- against 40 MFMAs: VALU-bound at 2.2 TB/s.
+// With `stats` the per-channel sum and sum of squares of the (bf16-rounded) outputs of the block are written as one partial
+// row each ([block][2][N] f32, the layout bn_stats_final reduces): train-mode BatchNorm needs no statistics pass.
+// grid = (ceil(Wo / (4 PXB)), B * ceil(Ho / 4)); dynamic LDS = NSRC * (256 + 256 PXB) tables + 512 PXB tile bytes + the window
+// slots: one source -> two slots used alternately; several sources -> one slot per source (step (chunk, k) reads slot k while
+// the next step's window lands in another one)
+template <int PXB, int NSRC>
+__global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum_mfma2_kernel(const TapMArgs a, float* stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int COLS = 4 * PXB, TBL = 256 + COLS * 64, NPW = PXB / 4;
+  constexpr int MAXP = PXB == 8 ? 9 : 12;                 // DMA pieces per wave and window (factor 2 needs 4 x 16 blocks)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nchunks = a.N >> 6, nprow = (a.Ho + 3) >> 2;
+  const int nblk = gridDim.x * gridDim.y;
+  const int id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = id & 7, idx = id >> 3;      // XCD-major: neighbouring patch rows share an L2
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int brow = lid / gridDim.x, cb = lid - brow * gridDim.x;
+  const int b = brow / nprow, oy0 = (brow - b * nprow) * 4;
+  const int oxb0 = cb * COLS;
+  unsigned char* tile = smem + NSRC * TBL;
+  unsigned char* ring = tile + 4 * COLS * 128;
+  const unsigned lds_ring = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ring);
+#pragma unroll
+  for (int k = 0; k < NSRC; ++k) {
+    float* TYs = (float*)(smem + k * TBL);
+    if (a.LF[k] == 1) tapm_tables<PXB, 1>(a, k, TYs, TYs + 64, oy0, oxb0, tid);
+    else if (a.LF[k] == 2) tapm_tables<PXB, 2>(a, k, TYs, TYs + 64, oy0, oxb0, tid);
+    else tapm_tables<PXB, 3>(a, k, TYs, TYs + 64, oy0, oxb0, tid);
+  }
+  __syncthreads();
+  // ---- channel-independent state of every source
+  const int L = lane & 15, g = lane >> 4;
+  bf16x8_t wf[NSRC][NPW][6];                              // weight fragments (B operand: column = pixel L of the patch)
+  int raddr[NSRC][NPW][6][2];                             // LDS byte offsets of the z fragment pieces, channel tile 0
+  unsigned doff[NSRC][MAXP];                              // DMA source offsets of this lane's pieces (channel 0)
+  srd_t srd[NSRC];
+#pragma unroll
+  for (int k = 0; k < NSRC; ++k) {
+    const int lf = a.LF[k], Hi = a.H[k], Wi = a.W[k];
+    const bool w4 = lf == 1;
+    const int win = w4 ? 4 : 3, na = 3 * win;
+    const int WC = ((COLS - 4) >> lf) + win;
+    const float* TYs = (const float*)(smem + k * TBL);
+    const float* TXs = TYs + 64;
+#pragma unroll
+    for (int j2 = 0; j2 < NPW; ++j2) {
+      const int j = wave + 4 * j2;
+      const int wcj = (4 * j) >> lf;
+      float txv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) txv[e] = TXs[(4 * j + (L & 3)) * 16 + 8 * (g & 1) + e];
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        const int ai = 2 * ks + (g >> 1);
+        const float ty = TYs[(L >> 2) * 12 + ai];         // zero for ai >= na (table padding)
+        uint32_t pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(ty * txv[2 * e], ty * txv[2 * e + 1]);
+        wf[k][j2][ks] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int bq = 8 * (g & 1) + 4 * h + (L >> 2);
+          const bool ok = ai < na && bq < na;
+          const int r = w4 ? ai >> 2 : ai / 3, wy = ai - r * win, s3 = w4 ? bq >> 2 : bq / 3, dx = bq - s3 * win;
+          const int R = ok ? ((wy * WC + wcj + dx) * 9 + 3 * r + s3) : 0;
+          raddr[k][j2][ks][h] = R * 128 + (((((L & 3) >> 1) ^ tm_swz(R))) << 4) + (L & 1) * 8;
+        }
+      }
+    }
+    const int wr0 = (oy0 >> lf) - 1, wcb0 = (oxb0 >> lf) - 1;
+    const int nrows = win * WC * 9;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int piece = wave + 4 * i;
+      const int R = piece * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ tm_swz(R);
+      const int pc = R / 9, t = R - pc * 9;
+      const int wyi = pc / WC, wci = pc - wyi * WC;
+      const int row = wr0 + wyi, col = wcb0 + wci;
+      const bool ok = R < nrows && row >= 0 && row < Hi && col >= 0 && col < Wi;
+      doff[k][i] = ok ? (unsigned)((((row * Wi + col) * 9 + t) * a.N) * 2 + chunk * 16) : kTmOob;
+    }
+    srd[k] = make_srd(a.z[k] + (int64_t)b * Hi * Wi * 9 * a.N, (unsigned)((int64_t)Hi * Wi * 9 * a.N * 2));
+  }
+  auto issue = [&](int it) {
+    const int c = it / NSRC, k = it - c * NSRC;
+    const unsigned dst = lds_ring + a.slot_off[it % a.nslots];
+#pragma unroll
+    for (int kk = 0; kk < NSRC; ++kk) {
+      if (kk != k) continue;                               // (static source index for the register arrays)
+      const int lf = a.LF[kk], win = lf == 1 ? 4 : 3;
+      const int npieces = (win * (((COLS - 4) >> lf) + win) * 9 + 7) >> 3;
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) {
+        if (wave + 4 * i < npieces) dma16_buf(doff[kk][i], srd[kk], (unsigned)(c * 128), dst + (wave + 4 * i) * 1024);
+      }
+    }
+  };
+  f32x4_t acc[NPW][4];
+#pragma unroll
+  for (int j2 = 0; j2 < NPW; ++j2)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[j2][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nit = nchunks * NSRC;
+  const bool full = oy0 + 4 <= a.Ho && oxb0 + COLS <= a.Wo;
+  issue(0);
+  for (int it = 0; it < nit; ++it) {
+    const int c = it / NSRC, k = it - c * NSRC;
+    // this wave's pieces of step `it` have landed.  They were issued BEFORE the previous step's output stores, and vmcnt
+    // retires in order: inside the image (every thread stores exactly PXB / 2 pieces per chunk) the wait leaves those stores
+    // in flight instead of exposing their acknowledgement
+    if (full && it > 0 && (it - 1) % NSRC == NSRC - 1) {
+      if (stats && wave < 2) {                             // (waves 0 and 1 also wrote one statistics row each)
+        if constexpr (PXB == 8) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      } else {
+        if constexpr (PXB == 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                                      // ... everyone's; nobody reads the other slot or the tile any more
+    if (it + 1 < nit) issue(it + 1);
+    const unsigned char* stage = ring + a.slot_off[it % a.nslots];
+#pragma unroll
+    for (int kk = 0; kk < NSRC; ++kk) {
+      if (kk != k) continue;
+      const int nks = a.LF[kk] == 1 ? 6 : 5;
+#pragma unroll
+      for (int j2 = 0; j2 < NPW; ++j2) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+          for (int ks = 0; ks < 6; ++ks) {
+            if (ks < nks) {
+              const tm_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(stage + (raddr[kk][j2][ks][0] ^ (nt << 5))));
+              const tm_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(stage + (raddr[kk][j2][ks][1] ^ (nt << 5))));
+              const tm_s16x8_t zv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+              acc[j2][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zv), wf[kk][j2][ks], acc[j2][nt], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (k != NSRC - 1) continue;
+    // ---- the chunk is complete: transpose through the tile, store whole 128-byte lines, optional statistics
+    const int c0 = c * 64;
+    tapm_to_tile<PXB>(a, acc, tile, c0, lane, wave);
+#pragma unroll
+    for (int j2 = 0; j2 < NPW; ++j2)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[j2][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < (4 * COLS * 8) / 256; ++u) {
+      const int i = tid + 256 * u;
+      const int pp = i >> 3, chunk = i & 7;                // chunk = tid & 7 for every u: a thread always owns the same 8 channels
+      const int py = pp / COLS, oy = oy0 + py, ox = oxb0 + pp - py * COLS;
+      if (full || (oy < a.Ho && ox < a.Wo)) {               // `full` is uniform: then every thread stores, and the wait above counts on it
+        const uint4 v = *(const uint4*)(tile + pp * 128 + ((chunk ^ (pp & 7)) << 4));
+        *(uint4*)(a.out + (((int64_t)b * a.Ho + oy) * a.Wo + ox) * a.N + c0 + chunk * 8) = v;
+        if (stats) {
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(w[e] << 16), hi = __uint_as_float(w[e] & 0xffff0000u);
+            s1[2 * e] += lo; s2[2 * e] += lo * lo;
+            s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
+          }
+        }
+      }
+    }
+    if (stats) {
+      // lanes with equal (lane & 7) own the same channels: fold lane bits 3, 4, 5, then the four waves through the (by then
+      // idle) tile memory, in a fixed order
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+      }
+      __syncthreads();                                    // every thread has read its pixels from the tile
+      float* red = (float*)tile;                          // [wave][sum | sum of squares][64 channels]
+      if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[(wave * 2) * 64 + lane * 8 + e] = s1[e]; red[(wave * 2 + 1) * 64 + lane * 8 + e] = s2[e]; }
+      }
+      __syncthreads();
+      if (tid < 128) {
+        const int which = tid >> 6, ch = tid & 63;
+        const float t = ((red[(0 * 2 + which) * 64 + ch] + red[(1 * 2 + which) * 64 + ch]) + red[(2 * 2 + which) * 64 + ch]) +
+                        red[(3 * 2 + which) * 64 + ch];
+        stats[((int64_t)lid * 2 + which) * a.N + c0 + ch] = t;
+      }
     }
   }
 }
@@ -1069,7 +1307,8 @@ inline bool vec8_ok(const void* a, const void* b, int C, int64_t s0, int64_t s1,
          s2 % 8 == 0 && s3 % 8 == 0 && s4 % 8 == 0 && s5 % 8 == 0;
 }
 
-int g_tapsum_mfma = 1;     // A/B hook (gdl_debug_set_tapsum_mfma): 0 = the pixel-by-pixel kernel, 4 = 16-column blocks
+int g_tapsum_mfma = 1;     // A/B hook (gdl_debug_set_tapsum_mfma): 0 = the pixel-by-pixel kernel; 1 = MFMA, version chosen by shape;
+                           // 5 = version 2 (4 x 16 pixel blocks, all channels, pipelined); 2 / 4 = version 1 (32- / 16-column blocks x 64 channels)
 int g_tapsum_vec = 0;      // A/B hook (gdl_debug_set_tapsum_vec): 4 = 8-byte bf16 vectors per thread instead of 16-byte ones
 
 }  // namespace
@@ -1077,8 +1316,9 @@ int g_tapsum_vec = 0;      // A/B hook (gdl_debug_set_tapsum_vec): 4 = 8-byte bf
 extern "C" void gdl_debug_set_tapsum_vec(int vec) { g_tapsum_vec = vec; }
 extern "C" void gdl_debug_set_tapsum_mfma(int mode) { g_tapsum_mfma = mode; }
 
-extern "C" int gdl_resize_conv3x3_fwd_sum(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N,
-                                          void* out, int Ho, int Wo, const float* addvec, int relu, gdl_stream_t stream) {
+// shared launcher; stats != nullptr: per-block partial sums of the outputs ([rows][2][N] f32, rows = gdl_resize_conv3x3_fwd_sum_bn_rows)
+static int tapsum_launch(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N, void* out, int Ho, int Wo,
+                         const float* addvec, int relu, float* stats, hipStream_t st) {
   GDL_CHECK_ARG(zs && hs && ws && out && nsrc >= 1 && nsrc <= 3, "gdl_resize_conv3x3_fwd_sum: 1..3 sources");
   GDL_CHECK_ARG(dtype == GDL_F32 || dtype == GDL_BF16, "gdl_resize_conv3x3_fwd_sum: bad dtype");
   GDL_CHECK_ARG(B > 0 && Ho > 0 && Wo > 0 && N > 0, "gdl_resize_conv3x3_fwd_sum: bad sizes");
@@ -1095,11 +1335,11 @@ extern "C" int gdl_resize_conv3x3_fwd_sum(const void* const* zs, const int* hs, 
     run = f > run ? f : run;
   }
   GDL_CHECK_ARG(Wo % run == 0, "gdl_resize_conv3x3_fwd_sum: Wo must be a multiple of the largest factor");
-  hipStream_t st = (hipStream_t)stream;
   bool img_ok = (uintptr_t)out % 16 == 0;
   for (int k = 0; k < nsrc; ++k) img_ok = img_ok && (int64_t)s.H[k] * s.W[k] * 9 * N * 2 < 0x7ffffff0ll;   // 32-bit buffer offsets per image
-  if (dtype == GDL_BF16 && N % 64 == 0 && g_tapsum_mfma && img_ok && (int64_t)B * ((Ho + 3) / 4) <= 65535) {
-    // matrix-core form: one block = 4 rows x 16 or 32 columns x 64 channels; 32 columns when every window stays under 48 KiB
+  const bool mfma_ok = dtype == GDL_BF16 && N % 64 == 0 && img_ok && (int64_t)B * ((Ho + 3) / 4) <= 65535;
+  GDL_CHECK_ARG(!stats || mfma_ok, "gdl_resize_conv3x3_fwd_sum_bn: needs bf16, N %% 64 == 0, 16-byte aligned output");
+  if (mfma_ok && (g_tapsum_mfma || stats)) {
     TapMArgs m;
     int lfmin = 3;
     for (int k = 0; k < 3; ++k) {
@@ -1108,8 +1348,36 @@ extern "C" int gdl_resize_conv3x3_fwd_sum(const void* const* zs, const int* hs, 
       if (k < nsrc && m.LF[k] < lfmin) lfmin = m.LF[k];
     }
     m.nsrc = nsrc; m.N = N; m.Ho = Ho; m.Wo = Wo; m.B = B; m.out = (uint16_t*)out; m.addvec = addvec; m.relu = relu;
-    // the staging loop writes whole 1 KiB pieces (8 rows): round the window up to that
-    auto window_bytes = [&](int cols) { const int win = lfmin == 1 ? 4 : 3; return (win * (((cols - 4) >> lfmin) + win) * 9 * 128 + 1023) / 1024 * 1024; };
+    m.nslots = 0; m.slot_off[0] = m.slot_off[1] = m.slot_off[2] = 0;
+    // the staging loop writes whole 1 KiB pieces (8 rows): round a window up to that
+    auto window_bytes_lf = [&](int cols, int lf) { const int win = lf == 1 ? 4 : 3; return (win * (((cols - 4) >> lf) + win) * 9 * 128 + 1023) / 1024 * 1024; };
+    // version 2 (all channels of a 4 x 16 pixel block per workgroup, windows double-buffered) where three blocks fit a CU: ONE
+    // source of factor 4 or 8 (measured on the neck's x4 level: 442 us against 768; with the 46 KiB windows of a factor-2
+    // source, or three sources, one block per CU remains and version 1 is the faster one: 284 vs 315 us, 693 vs 1148 us);
+    // always for the statistics variant
+    const bool v2_pays = nsrc == 1 && lfmin >= 2;
+    if ((g_tapsum_mfma == 1 && v2_pays) || g_tapsum_mfma == 5 || stats) {
+      const int pxb = 4, cols = 4 * pxb;   // (4 x 32 blocks: the cached fragments of two patches per wave do not fit the register budget)
+      int ring = 0;
+      m.nslots = nsrc == 1 ? 2 : nsrc;
+      for (int j = 0; j < m.nslots; ++j) { m.slot_off[j] = ring; ring += window_bytes_lf(cols, m.LF[nsrc == 1 ? 0 : j]); }
+      const size_t lds = (size_t)nsrc * (256 + cols * 64) + 4 * cols * 128 + ring;
+      GDL_CHECK_ARG(lds <= 160 * 1024 || !stats, "gdl_resize_conv3x3_fwd_sum_bn: LDS budget exceeded");
+      const dim3 grid((unsigned)((Wo + cols - 1) / cols), (unsigned)(B * ((Ho + 3) / 4)));
+      if (lds > 160 * 1024) {
+        // (does not happen for 1..3 sources of factors 2 / 4 / 8; version 1 below would take over)
+      } else
+#define TAPM2(PXB_, NSRC_) do { GDL_SET_MAX_LDS_ONCE((resize_conv3x3_fwd_sum_mfma2_kernel<PXB_, NSRC_>), 160 * 1024);                 \
+    hipLaunchKernelGGL((resize_conv3x3_fwd_sum_mfma2_kernel<PXB_, NSRC_>), grid, dim3(256), lds, st, m, stats); } while (0)
+      if (nsrc == 1) TAPM2(4, 1); else if (nsrc == 2) TAPM2(4, 2); else TAPM2(4, 3);
+#undef TAPM2
+      if (lds <= 160 * 1024) {
+        GDL_CHECK_LAUNCH("gdl_resize_conv3x3_fwd_sum");
+        return GDL_OK;
+      }
+    }
+    // version 1: one block = 4 rows x 16 or 32 columns x 64 channels; 32 columns when every window stays under 48 KiB
+    auto window_bytes = [&](int cols) { return window_bytes_lf(cols, lfmin); };
     const int pxb = (window_bytes(32) <= 48 * 1024 && g_tapsum_mfma != 4) ? 8 : 4;
     const int cols = 4 * pxb;
     const int tile_bytes = 4 * cols * 128;
@@ -1141,6 +1409,28 @@ extern "C" int gdl_resize_conv3x3_fwd_sum(const void* const* zs, const int* hs, 
 #undef TAPSUM
   GDL_CHECK_LAUNCH("gdl_resize_conv3x3_fwd_sum");
   return GDL_OK;
+}
+
+extern "C" int gdl_resize_conv3x3_fwd_sum(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N,
+                                          void* out, int Ho, int Wo, const float* addvec, int relu, gdl_stream_t stream) {
+  return tapsum_launch(zs, hs, ws, nsrc, dtype, B, N, out, Ho, Wo, addvec, relu, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int64_t gdl_resize_conv3x3_fwd_sum_bn_rows(int B, int Ho, int Wo) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0) return 0;
+  return (int64_t)B * ((Ho + 3) / 4) * ((Wo + 15) / 16);
+}
+
+extern "C" int gdl_resize_conv3x3_fwd_sum_bn(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N,
+                                             void* out, int Ho, int Wo, const float* addvec, float* workspace, int64_t ws_bytes,
+                                             float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                                             gdl_stream_t stream) {
+  GDL_CHECK_ARG(workspace && mean && var, "gdl_resize_conv3x3_fwd_sum_bn: null pointer");
+  const int64_t rows = gdl_resize_conv3x3_fwd_sum_bn_rows(B, Ho, Wo);
+  GDL_CHECK_ARG(ws_bytes >= rows * 2 * N * (int64_t)sizeof(float), "gdl_resize_conv3x3_fwd_sum_bn: workspace too small");
+  const int st = tapsum_launch(zs, hs, ws, nsrc, dtype, B, N, out, Ho, Wo, addvec, 0, workspace, (hipStream_t)stream);
+  if (st != GDL_OK) return st;
+  return gdl_bn_stats_finalize(workspace, (int)rows, N, (int64_t)B * Ho * Wo, mean, var, running_mean, running_var, momentum, stream);
 }
 
 extern "C" void gdl_debug_set_flat_resample(int on) { g_flat_resample = on; }

@@ -148,6 +148,7 @@ def sync_sum_pair(a: Tensor, b: Tensor, group=None) -> tuple[Tensor, Tensor]:
 
 FUSE_UP4 = True   # A/B switch: False = materialise the x4 upsample and run the ordinary 3x3 kernel
 FUSE_TAPSUM = True   # A/B switch: False = round-2 forward of resized-input convolutions (sub-pixel phases / concat buffer)
+FUSE_TAPSUM_STATS = True   # A/B switch: False = separate BatchNorm statistics pass over the gather-sum's output
 
 
 def tap_weight(weight: Tensor, cd: torch.dtype, c0: int = 0, c1: int | None = None) -> Tensor:
@@ -184,12 +185,22 @@ class _ConvBNActTrain(Function):
         cd = x.dtype
         n, c, r, s = weight.shape
         cb = None if conv_bias is None else conv_bias.detach()
+        stats_done = None
         if up4 and FUSE_TAPSUM and ops.resize_conv3x3_fwd_ok((x.shape[1], x.shape[2]), (up4 * x.shape[1], up4 * x.shape[2]),
                                                              x.shape[0]):
             # conv3x3(resize(x)) = sum_t shift_t(resize(W_t x)): nine tap products as ONE 1x1 convolution over the
             # LOW-resolution pixels (1 / up4^2 of the MACs), then one gather-sum pass writes the full-resolution output
-            y = ops.resize_conv3x3_fwd_sum([ops.conv_gemm(x, tap_weight(weight, cd))], (up4 * x.shape[1], up4 * x.shape[2]),
-                                           addvec=cb)
+            z, size = ops.conv_gemm(x, tap_weight(weight, cd)), (up4 * x.shape[1], up4 * x.shape[2])
+            if FUSE_TAPSUM_STATS and ops.resize_conv3x3_fwd_bn_ok(cd, n):
+                # ... and the batch statistics of the output come out of the same pass (per-block partial sums)
+                world = _world(sync_group) if sync_group is not False else 1
+                own = world == 1
+                y, mean, var = ops.resize_conv3x3_fwd_sum_bn([z], size, addvec=cb, running_mean=running_mean if own else None,
+                                                             running_var=running_var if own else None, momentum=momentum)
+                stats_done = (mean, var)
+            else:
+                y = ops.resize_conv3x3_fwd_sum([z], size, addvec=cb)
+            del z
         elif up4 == 4:   # conv3x3(bilinear_x4(x)) without the upsampled intermediate (ops.up4_conv3x3)
             y = ops.up4_conv3x3(x, subpix4_weight(weight, cd), bias=cb)
         elif up4:      # other resize factors: the upsampled map is a temporary of the forward only (backward works on x)
@@ -200,13 +211,13 @@ class _ConvBNActTrain(Function):
         world = _world(sync_group) if sync_group is not False else 1
         p_local, p_share = y.numel() // n, None
         if world > 1:
-            mean, var = ops.bn_stats(y)
+            mean, var = stats_done if stats_done is not None else ops.bn_stats(y)
             mean, var, total = sync_batch_stats(mean, var, sync_group or None, count=p_local)
             if running_mean is not None:
                 update_running_stats(running_mean, running_var, mean, var, momentum, total)
             p_share = p_local / total          # this rank's share of the global pixel count (device scalar)
         else:
-            mean, var = ops.bn_stats(y, running_mean, running_var, momentum)
+            mean, var = stats_done if stats_done is not None else ops.bn_stats(y, running_mean, running_var, momentum)
             if running_mean is not None:     # written through raw pointers: invalidate the eval-mode fold cache
                 mark_updated(running_mean)
                 mark_updated(running_var)

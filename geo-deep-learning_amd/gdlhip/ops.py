@@ -419,6 +419,39 @@ def resize_conv3x3_fwd_sum(zs: list[Tensor], size: tuple[int, int], addvec: Tens
     return out
 
 
+def resize_conv3x3_fwd_sum_bn(zs: list[Tensor], size: tuple[int, int], addvec: Tensor | None = None,
+                              running_mean: Tensor | None = None, running_var: Tensor | None = None, momentum: float = 0.1):
+    """resize_conv3x3_fwd_sum + the train-mode BatchNorm statistics of its result in the same pass
+    (gdl_resize_conv3x3_fwd_sum_bn): returns (out, mean, biased var); updates the running buffers when given.  bf16, N % 64 == 0."""
+    _need_cuda(*zs)
+    z4 = [_nhwc4(z, "resize_conv3x3_fwd_sum_bn source") for z in zs]
+    B, N9 = z4[0].shape[0], z4[0].shape[3]
+    N = N9 // 9
+    for z in z4:
+        if z.shape[0] != B or z.shape[3] != N9 or z.dtype != z4[0].dtype or not z.is_contiguous():
+            raise ValueError("resize_conv3x3_fwd_sum_bn: sources must be contiguous NHWC maps with equal batch, channels and dtype")
+    out = torch.empty((B, size[0], size[1], N), device=zs[0].device, dtype=zs[0].dtype)
+    mean = torch.empty(N, device=out.device, dtype=torch.float32)
+    var = torch.empty_like(mean)
+    lib = _lib.load()
+    rows = lib.gdl_resize_conv3x3_fwd_sum_bn_rows(B, size[0], size[1])
+    wsp = torch.empty(rows * 2 * N, device=out.device, dtype=torch.float32)
+    n = len(z4)
+    ptrs = (C.c_void_p * 3)(*([z.data_ptr() for z in z4] + [None] * (3 - n)))
+    hs = (C.c_int * 3)(*([z.shape[1] for z in z4] + [1] * (3 - n)))
+    ws = (C.c_int * 3)(*([z.shape[2] for z in z4] + [1] * (3 - n)))
+    check(lib.gdl_resize_conv3x3_fwd_sum_bn(ptrs, hs, ws, n, dt(z4[0]), B, N, _p(out), size[0], size[1],
+                                            _p(_f32vec(addvec, N, "addvec")), _p(wsp), wsp.numel() * 4, _p(mean), _p(var),
+                                            _p(running_mean), _p(running_var), momentum, _stream()),
+          "gdl_resize_conv3x3_fwd_sum_bn")
+    return out, mean, var
+
+
+def resize_conv3x3_fwd_bn_ok(z_dtype: torch.dtype, N: int) -> bool:
+    """The statistics variant runs on the matrix-core kernel only: bf16 and N % 64 == 0."""
+    return z_dtype == torch.bfloat16 and N % 64 == 0
+
+
 def resize_conv3x3_fwd_ok(lo: tuple[int, int], size: tuple[int, int], B: int) -> bool:
     """Shapes gdl_resize_conv3x3_fwd_sum takes: one integer factor of 2, 4 or 8 in both directions, B * rows in one grid dim."""
     f = size[0] // max(lo[0], 1)

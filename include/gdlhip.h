@@ -268,6 +268,18 @@ int gdl_resize_conv3x3_bwd_gather2(const void* dy, int dtype, int B, int Ho, int
  * convolution's zero padding) for 1..3 sources of one dtype, optional ReLU, dense [B,Ho,Wo,N].  Deterministic. */
 int gdl_resize_conv3x3_fwd_sum(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N, void* out,
                                int Ho, int Wo, const float* addvec, int relu, gdl_stream_t stream);
+/* the same with the train-mode BatchNorm statistics of the result as a side output (models/utils.py:10-52, ConvModule = conv ->
+ * BatchNorm -> ReLU): per-channel mean / biased variance of `out` (and the running-stat update of nn.BatchNorm2d when the
+ * running buffers are given) from per-block partial sums -- no separate pass over the output.  bf16, N % 64 == 0.
+ * workspace: gdl_resize_conv3x3_fwd_sum_bn_rows(B, Ho, Wo) * 2 * N floats. */
+int64_t gdl_resize_conv3x3_fwd_sum_bn_rows(int B, int Ho, int Wo);
+int gdl_resize_conv3x3_fwd_sum_bn(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N, void* out,
+                                  int Ho, int Wo, const float* addvec, float* workspace, int64_t ws_bytes, float* mean, float* var,
+                                  float* running_mean, float* running_var, float momentum, gdl_stream_t stream);
+/* final reduction of [nsplit][2][C] partial sums (sum, sum of squares over P pixels in total) into mean / biased variance
+ * (+ running statistics): the second half of gdl_bn_stats, for producers that emit the partials themselves */
+int gdl_bn_stats_finalize(const float* partials, int nsplit, int C, int64_t P, float* mean, float* var, float* running_mean,
+                          float* running_var, float momentum, gdl_stream_t stream);
 /* strided NHWC copy with dtype conversion: `x.to(dtype)` under autocast, `.contiguous()` of a channel slice
  * (models/utils.py:50-52 inputs, torch.cat slices of upernet.py:103-109 in backward) */
 int gdl_copy_cast(const void* in, int in_dtype, int B, int H, int W, int C, int64_t in_sB, int64_t in_sH, int64_t in_sW,

@@ -968,7 +968,7 @@ def test_resize_conv3x3_bwd_gather_two_pass(dtype, B, Hi, Wi, N, f):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("mfma", [1, 4, 0])
+@pytest.mark.parametrize("mfma", [1, 5, 2, 4, 0])
 @pytest.mark.parametrize("B,H,W,N,factors,vec", [(2, 16, 24, 64, (2,), 0), (1, 36, 36, 128, (4,), 0), (2, 16, 16, 64, (8,), 0),
                                                  (2, 16, 24, 64, (2, 4, 8), 0), (1, 8, 8, 72, (4, 2), 0), (2, 12, 20, 64, (4,), 4),
                                                  (1, 2, 2, 64, (2,), 0), (1, 18, 14, 64, (2,), 0), (1, 8, 72, 128, (4,), 0),
@@ -977,8 +977,9 @@ def test_resize_conv3x3_fwd_sum(dtype, B, H, W, N, factors, vec, mfma):
     """sum_k sum_t shift_t(bilinear(z_k,t)) (gdl_resize_conv3x3_fwd_sum), the pixel side of the low-resolution forward of
     conv3x3(pad 1)(bilinear resize(x)) (multilevel_neck.py:157-158, upernet.py:144-152): vs torch's interpolate / pad / slice
     on the CPU, every pixel including the border lines the zero padding touches; with the bias / folded-BN + ReLU epilogue.
-    mfma: 1 = the matrix-core kernel (bf16, N % 64 == 0; 32-column blocks where the window fits), 4 = its 16-column blocks,
-    0 = the pixel-by-pixel kernel (also what f32 and other channel counts run)."""
+    mfma: 1 = the matrix-core kernels with the production choice of version, 5 = version 2 (bf16, N % 64 == 0: all channels of
+    a 4 x 16 pixel block per workgroup, pipelined windows, channel-independent state in registers), 2 / 4 = version 1 (32- / 16-column blocks x 64 channels), 0 = the pixel-by-pixel kernel
+    (also what f32 and other channel counts run)."""
     import ctypes
     from gdlhip import _lib
     if mfma != 1 and (dtype != torch.bfloat16 or N % 64 or vec):
@@ -1132,3 +1133,23 @@ def test_conv_epilogue_v2_bit_identical_to_round2_epilogue(dtype):
     finally:
         lib.gdl_debug_set_conv_epilogue(1)
         lib.gdl_debug_force_conv_variant(-1)
+
+
+@pytest.mark.parametrize("B,H,W,N,factors", [(2, 16, 24, 64, (2,)), (1, 36, 36, 128, (4,)), (2, 18, 14, 192, (2,)), (2, 32, 48, 64, (8, 4))])
+def test_resize_conv3x3_fwd_sum_with_batchnorm_statistics(B, H, W, N, factors):
+    """gdl_resize_conv3x3_fwd_sum_bn: the gather-sum with train-mode BatchNorm statistics as a side output -- same output
+    bits as the plain call, mean / biased variance / running statistics equal to nn.BatchNorm2d's on that (bf16) output."""
+    dtype = torch.bfloat16
+    zs = [q(rnd(B, H // f, W // f, 9 * N, seed=10 + f), dtype).to(DEV, dtype) for f in factors]
+    add = rnd(N, seed=5).to(DEV)
+    y0 = ops.resize_conv3x3_fwd_sum(zs, (H, W), addvec=add)
+    rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    y, mean, var = ops.resize_conv3x3_fwd_sum_bn(zs, (H, W), addvec=add, running_mean=rm, running_var=rv, momentum=0.1)
+    assert torch.equal(y, y0)
+    bn = torch.nn.BatchNorm2d(N).train()
+    bn(y.float().cpu().permute(0, 3, 1, 2))
+    yf = y.float().cpu().reshape(-1, N)
+    close(mean, yf.mean(0), torch.float32, "mean", scale=yf.abs().max().item())
+    close(var, yf.var(0, unbiased=False), torch.float32, "var")
+    close(rm, bn.running_mean, torch.float32, "running_mean", scale=yf.abs().max().item())
+    close(rv, bn.running_var, torch.float32, "running_var")

@@ -58,7 +58,7 @@ with torch.no_grad():
             res.append(timeit(lambda: ops.resize_conv3x3_fwd_sum([z], size)))
         lib.gdl_debug_set_tapsum_vec(0)
         ref = ops.resize_conv3x3_fwd_sum([z], size)
-        for mode in (1, 4):
+        for mode in (5, 2, 4):
             lib.gdl_debug_set_tapsum_mfma(mode)
             res.append(timeit(lambda: ops.resize_conv3x3_fwd_sum([z], size)))
             dev = (ops.resize_conv3x3_fwd_sum([z], size).float() - ref.float()).abs().max().item() / ref.float().abs().max().item()
@@ -70,8 +70,8 @@ with torch.no_grad():
         gnn.FUSE_TAPSUM = True
         out_b = B * size[0] * size[1] * 768 * 2
         print(f"neck x{up} 768->768 @36^2 -> {size[0]}^2: tap GEMM {t_gemm:6.0f} us ({2 * B * 1296 * 768 * 6912 / t_gemm / 1e6:5.0f} TF/s), "
-              f"gather-sum vec8 {res[0]:6.0f} us / vec4 {res[1]:6.0f} us / MFMA 32-col {res[2]:6.0f} us (dev {res[3]:.1e}) / MFMA 16-col {res[4]:6.0f} us "
-              f"(dev {res[5]:.1e}) ({(out_b + z.numel() * 2) / min(res[0], res[1], res[2], res[4]) / 1e3:5.0f} GB/s), "
+              f"gather-sum vec8 {res[0]:6.0f} us / vec4 {res[1]:6.0f} us / MFMA v2 {res[2]:6.0f} us (dev {res[3]:.1e}) / v1 32-col {res[4]:6.0f} us (dev {res[5]:.1e}) / v1 16-col {res[6]:6.0f} us "
+              f"({(out_b + z.numel() * 2) / min(res[0], res[1], res[2], res[4], res[6]) / 1e3:5.0f} GB/s), "
               f"node (eval) new {new:6.0f} us vs round-2 {old:6.0f} us", flush=True)
 
     conv, norm = conv_module(1024, 256, False)
@@ -84,8 +84,10 @@ with torch.no_grad():
         lib.gdl_debug_set_tapsum_vec(vec)
         res.append(timeit(lambda: ops.resize_conv3x3_fwd_sum(zs, (144, 144))))
     lib.gdl_debug_set_tapsum_vec(0)
+    for mode in (5, 2):
+        lib.gdl_debug_set_tapsum_mfma(mode)
+        res.append(timeit(lambda: ops.resize_conv3x3_fwd_sum(zs, (144, 144))))
     lib.gdl_debug_set_tapsum_mfma(1)
-    res.append(timeit(lambda: ops.resize_conv3x3_fwd_sum(zs, (144, 144))))
     w0 = gnn.slice_weight(conv.weight, bf, 0, 256)
     r = ops.resize_conv3x3_fwd_sum(zs, (144, 144))
     t0 = timeit(lambda: ops.conv_gemm(lv[0], w0, R=3, S=3, pad=1, resid=r))
@@ -94,5 +96,5 @@ with torch.no_grad():
     old = timeit(lambda: gnn.concat_resize_conv_bn_act(lv, conv, norm, relu=True))
     gnn.FUSE_TAPSUM = True
     print(f"fpn_bottleneck 4x256 -> 256 @144^2: tap GEMMs {t_gemm[0]:5.0f} + {t_gemm[1]:5.0f} + {t_gemm[2]:5.0f} us, gather-sum (3 sources) "
-          f"vec8 {res[0]:6.0f} us / vec4 {res[1]:6.0f} us / MFMA {res[2]:6.0f} us, native 3x3 + residual {t0:6.0f} us, node (eval) new {new:6.0f} us vs "
+          f"vec8 {res[0]:6.0f} us / vec4 {res[1]:6.0f} us / MFMA v2 {res[2]:6.0f} us / v1 {res[3]:6.0f} us, native 3x3 + residual {t0:6.0f} us, node (eval) new {new:6.0f} us vs "
           f"round-2 {old:6.0f} us", flush=True)
