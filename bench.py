@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--model", default="dofa", choices=["dofa", "segformer", "unetpp"],
                     help="dofa = DOFA-base+UperNet (headline, configs[1]); segformer = SegFormer-B2 (configs[2], all parameters trainable); "
                          "unetpp = UNet++/ResNet18 (configs[0], the reference's CPU smoke case)")
+    ap.add_argument("--no-input-stage", action="store_true", help="skip the PCIe-inclusive leg (host tiles through DeviceInputStage)")
     ap.add_argument("--with-input-stage", action="store_true",
                     help="also time the train step fed by host uint8 tiles through DeviceInputStage (PCIe-inclusive; "
                          "reported beside `value`, never as `value`)")
@@ -315,17 +316,41 @@ def main() -> None:
         res["infer"] = timed(infer_step, args.steps, args.warmup, world, device)
 
     ddp_info = None
-    if dist_on:
+    if dist_on and "train" in res:
+        from gdlhip import nn as gnn
         # the exchange step on its own: one all-reduce of the trainable gradients' bytes (what DDP's buckets move per step)
         nparam = sum(p.numel() for p in task.parameters() if p.requires_grad)
         buf = torch.zeros(nparam, device=device)
         dt_c = timed(lambda: dist.all_reduce(buf), 5, 2, world, device)
-        ddp_info = {"backend": "nccl (RCCL)", "ranks": dist.get_world_size(), "grad_bytes": nparam * 4,
-                    "grad_allreduce_ms_alone": round(1e3 * dt_c / 5, 3)}
         del buf
+        # SyncBatchNorm messages of one step, and what the gradient exchange costs INSIDE the step: the same step with DDP's
+        # all-reduce switched off (no_sync: gradients stay local) against the normal one -- the difference is the part of
+        # the communication that backward does not hide
+        gnn.SYNC_MESSAGES[:] = [0, 0]
+        train_step()
+        sync_msgs = list(gnn.SYNC_MESSAGES)
+        ddp_mod = task.model
+        def step_no_sync():
+            with ddp_mod.no_sync():
+                train_step()
+        k_ab = max(3, min(args.steps, 5))
+        dt_ns = timed(step_no_sync, k_ab, 1, world, device)
+        dt_s = timed(train_step, k_ab, 1, world, device)
+        try:
+            log = ddp_mod._get_ddp_logging_data()
+            sizes = [x for x in str(log.get("bucket_sizes", "")).replace(",", " ").split() if x]
+            buckets = {"count": len(sizes) or None, "bucket_sizes": sizes[:16], "bucket_cap_bytes": log.get("bucket_cap_bytes")}
+        except Exception:  # noqa: BLE001  (private torch API)
+            buckets = {"count": None, "bucket_cap_bytes": None}
+        ddp_info = {"backend": "nccl (RCCL)", "ranks": dist.get_world_size(),
+                    "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                    "grad_bytes": nparam * 4, "grad_allreduce_ms_alone": round(1e3 * dt_c / 5, 3),
+                    "syncbn_messages_per_step": {"forward": sync_msgs[0], "backward": sync_msgs[1]},
+                    "step_ms_with_grad_sync": round(1e3 * dt_s / k_ab, 3), "step_ms_no_sync": round(1e3 * dt_ns / k_ab, 3),
+                    "exposed_grad_comm_ms": round(1e3 * (dt_s - dt_ns) / k_ab, 3), "buckets": buckets}
 
     pcie = None
-    if args.with_input_stage and "train" in res:
+    if not args.no_input_stage and "train" in res:
         # host batches exactly as the dataset workers hand them over: raw uint8 tiles + int64 masks + sensor stats
         from geo_deep_learning.datamodules.device_input import DeviceInputStage
         g = torch.Generator(device="cpu").manual_seed(7 + rank)
@@ -342,7 +367,8 @@ def main() -> None:
         dt = timed(staged_train, args.steps, args.warmup, world, device)
         pcie = {"train_tiles_per_s": round(args.batch * world * args.steps / dt, 3),
                 "h2d_bytes_per_tile": stage.bytes_h2d // (n_total * args.batch),
-                "note": "host uint8 tiles -> pinned ring -> copy stream (2 batches ahead) -> normalise kernel -> step"}
+                "note": "host uint8 tiles + int64 masks (shipped as uint8) -> pinned ring -> copy stream (2 batches ahead) -> "
+                        "normalise kernel -> step; `value` stays the HBM-resident rate"}
 
     if rank != 0:
         if dist_on:
@@ -399,6 +425,8 @@ def main() -> None:
             "pmc": pmc_extra,
             "launches": s["launches"], "avg_launch_us": round(1e3 * s["ms"] / s["launches"], 2),
             "algorithmic_gflop_per_launch_avg": round(s["flops"] / s["launches"] / 1e9, 3),
+            # operands read once + result written once at their dtypes: compare with `traffic` (counted HBM bytes per launch)
+            "algorithmic_bytes_per_launch_avg": int(s["bytes"] / s["launches"]),
             "share_of_step_time": round(s["ms"] * 1e-3 / res["train"], 4),
             # the same kernel class split by reduction depth K = R*S*C of its launches (TF/s per bucket)
             "by_k_depth": {b: {"launches": v["launches"], "ms": round(v["ms"], 3),

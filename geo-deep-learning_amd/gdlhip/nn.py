@@ -123,6 +123,7 @@ def sync_batch_stats(mean: Tensor, var: Tensor, group=None, count: int | None = 
     n = float(count if count is not None else 1)
     packed = torch.cat([mean * n, (var + mean * mean) * n, mean.new_full((1,), n)])
     dist.all_reduce(packed, group=group)
+    SYNC_MESSAGES[0] += 1
     c = mean.numel()
     total = packed[2 * c]
     gmean = (packed[:c] / total).contiguous()
@@ -143,6 +144,7 @@ def sync_sum_pair(a: Tensor, b: Tensor, group=None) -> tuple[Tensor, Tensor]:
     """all-reduce(SUM) of the two BN-backward reductions in one message (SyncBatchNorm backward)."""
     packed = torch.stack([a, b])
     dist.all_reduce(packed, group=group)
+    SYNC_MESSAGES[1] += 1
     return packed[0].contiguous(), packed[1].contiguous()
 
 
@@ -172,6 +174,54 @@ def slice_weight(weight: Tensor, cd: torch.dtype, c0: int, c1: int) -> Tensor:
 
 
 # ------------------------------------------------------------------ conv -> BN -> ReLU
+# messages of the SyncBatchNorm exchange since the last reset: [forward all-reduces, backward all-reduces]
+SYNC_MESSAGES = [0, 0]
+
+
+def _cba_conv(x, weight, cb, pad, up4, sync_group, running_mean, running_var, momentum):
+    """conv(+bias) of a training ConvModule on NHWC x (the resize of an `up4` member fused in) -> (y, (mean, var) | None):
+    the batch statistics come with y when the producing kernel emits them (gather-sum of the low-resolution forward)."""
+    cd = x.dtype
+    n, c, r, s = weight.shape
+    if up4 and FUSE_TAPSUM and ops.resize_conv3x3_fwd_ok((x.shape[1], x.shape[2]), (up4 * x.shape[1], up4 * x.shape[2]), x.shape[0]):
+        # conv3x3(resize(x)) = sum_t shift_t(resize(W_t x)): nine tap products as ONE 1x1 convolution over the
+        # LOW-resolution pixels (1 / up4^2 of the MACs), then one gather-sum pass writes the full-resolution output
+        z, size = ops.conv_gemm(x, tap_weight(weight, cd)), (up4 * x.shape[1], up4 * x.shape[2])
+        if FUSE_TAPSUM_STATS and ops.resize_conv3x3_fwd_bn_ok(cd, n):
+            # ... and the batch statistics of the output come out of the same pass (per-block partial sums)
+            own = (_world(sync_group) if sync_group is not False else 1) == 1
+            y, mean, var = ops.resize_conv3x3_fwd_sum_bn([z], size, addvec=cb, running_mean=running_mean if own else None,
+                                                         running_var=running_var if own else None, momentum=momentum)
+            return y, (mean, var)
+        return ops.resize_conv3x3_fwd_sum([z], size, addvec=cb), None
+    if up4 == 4:   # conv3x3(bilinear_x4(x)) without the upsampled intermediate (ops.up4_conv3x3)
+        return ops.up4_conv3x3(x, subpix4_weight(weight, cd), bias=cb), None
+    if up4:        # other resize factors: the upsampled map is a temporary of the forward only (backward works on x)
+        return ops.conv_gemm(ops.bilinear(x, (up4 * x.shape[1], up4 * x.shape[2])), gemm_weight(weight, cd), R=r, S=s, pad=pad,
+                             bias=cb), None
+    return ops.conv_gemm(x, gemm_weight(weight, cd), R=r, S=s, pad=pad, bias=cb), None
+
+
+def _cba_grads(x, weight, dy, pad, up4, need_dx, need_dw):
+    """(dx, dw) of the conv of a training ConvModule from the gradient dy of its output (BatchNorm backward already applied)."""
+    n, c, r, s = weight.shape
+    dx = dw = None
+    if up4:
+        # both gradients as GEMMs over the LOW-resolution pixels: the resize and the tap shifts act on pixels, the
+        # weights on channels, so dx = sum_t W_t^T G_t and dW_t = sum_q G_t[q] (x) x[q] with G_t = resize^T shift_t^T dy
+        # (ops.resize_conv3x3_bwd): 1/16 of the MACs of the full-resolution data gradient + phase weight gradients
+        dx, dw = ops.resize_conv3x3_bwd(x, dy, dgrad_weight(weight, x.dtype) if need_dx else None, want_dw=need_dw)
+    else:
+        if need_dx:
+            dx = ops.conv_gemm(dy, dgrad_weight(weight, x.dtype), R=r, S=s, pad=r - 1 - pad)
+        if need_dw:
+            dw = ops.conv_wgrad(x, dy, R=r, S=s, pad=pad)
+    if dw is not None:
+        # same strides as the channels-last parameter (for 1x1 kernels torch keeps (C,1,1,1))
+        dw = dw.view(n, c, 1, 1) if r == 1 and s == 1 else dw.view(n, r, s, c).permute(0, 3, 1, 2)
+    return dx, dw
+
+
 class _ConvBNActTrain(Function):
     """Training-mode ConvModule: conv(+bias) -> BatchNorm(batch stats) -> ReLU.
 
@@ -182,32 +232,9 @@ class _ConvBNActTrain(Function):
     @staticmethod
     def forward(ctx, x, weight, conv_bias, gamma, beta, running_mean, running_var, momentum, eps,
                 pad, relu, sync_group, up4=False):
-        cd = x.dtype
-        n, c, r, s = weight.shape
+        n = weight.shape[0]
         cb = None if conv_bias is None else conv_bias.detach()
-        stats_done = None
-        if up4 and FUSE_TAPSUM and ops.resize_conv3x3_fwd_ok((x.shape[1], x.shape[2]), (up4 * x.shape[1], up4 * x.shape[2]),
-                                                             x.shape[0]):
-            # conv3x3(resize(x)) = sum_t shift_t(resize(W_t x)): nine tap products as ONE 1x1 convolution over the
-            # LOW-resolution pixels (1 / up4^2 of the MACs), then one gather-sum pass writes the full-resolution output
-            z, size = ops.conv_gemm(x, tap_weight(weight, cd)), (up4 * x.shape[1], up4 * x.shape[2])
-            if FUSE_TAPSUM_STATS and ops.resize_conv3x3_fwd_bn_ok(cd, n):
-                # ... and the batch statistics of the output come out of the same pass (per-block partial sums)
-                world = _world(sync_group) if sync_group is not False else 1
-                own = world == 1
-                y, mean, var = ops.resize_conv3x3_fwd_sum_bn([z], size, addvec=cb, running_mean=running_mean if own else None,
-                                                             running_var=running_var if own else None, momentum=momentum)
-                stats_done = (mean, var)
-            else:
-                y = ops.resize_conv3x3_fwd_sum([z], size, addvec=cb)
-            del z
-        elif up4 == 4:   # conv3x3(bilinear_x4(x)) without the upsampled intermediate (ops.up4_conv3x3)
-            y = ops.up4_conv3x3(x, subpix4_weight(weight, cd), bias=cb)
-        elif up4:      # other resize factors: the upsampled map is a temporary of the forward only (backward works on x)
-            y = ops.conv_gemm(ops.bilinear(x, (up4 * x.shape[1], up4 * x.shape[2])), gemm_weight(weight, cd), R=r, S=s,
-                              pad=pad, bias=cb)
-        else:
-            y = ops.conv_gemm(x, gemm_weight(weight, cd), R=r, S=s, pad=pad, bias=cb)
+        y, stats_done = _cba_conv(x, weight, cb, pad, up4, sync_group, running_mean, running_var, momentum)
         world = _world(sync_group) if sync_group is not False else 1
         p_local, p_share = y.numel() // n, None
         if world > 1:
@@ -230,9 +257,7 @@ class _ConvBNActTrain(Function):
     def backward(ctx, gout):
         x, weight, y, mean, var, gamma, beta = ctx.saved_tensors
         pad, relu, eps, has_bias, sync_group, world, p_local, p_share, up4 = ctx.cfg
-        n, c, r, s = weight.shape
-        lo = (x.shape[1], x.shape[2])
-        x_lo = x
+        n = weight.shape[0]
         if gout.dtype != y.dtype:
             gout = to_compute(gout, y.dtype)
         g, b = gamma.detach(), beta.detach()
@@ -247,22 +272,109 @@ class _ConvBNActTrain(Function):
         if has_bias and ctx.needs_input_grad[2]:
             # a bias feeding train-mode BN has an analytically zero gradient
             dbias = torch.zeros(n, device=x.device, dtype=torch.float32)
-        dx = dw = None
-        if up4:
-            # both gradients as GEMMs over the LOW-resolution pixels: the resize and the tap shifts act on pixels, the
-            # weights on channels, so dx = sum_t W_t^T G_t and dW_t = sum_q G_t[q] (x) x[q] with G_t = resize^T shift_t^T dy
-            # (ops.resize_conv3x3_bwd): 1/16 of the MACs of the full-resolution data gradient + phase weight gradients
-            dx, dw = ops.resize_conv3x3_bwd(x_lo, dy, dgrad_weight(weight, x.dtype) if ctx.needs_input_grad[0] else None,
-                                            want_dw=ctx.needs_input_grad[1])
-        else:
-            if ctx.needs_input_grad[0]:
-                dx = ops.conv_gemm(dy, dgrad_weight(weight, x.dtype), R=r, S=s, pad=r - 1 - pad)
-            if ctx.needs_input_grad[1]:
-                dw = ops.conv_wgrad(x, dy, R=r, S=s, pad=pad)
-        if dw is not None:
-            # same strides as the channels-last parameter (for 1x1 kernels torch keeps (C,1,1,1))
-            dw = dw.view(n, c, 1, 1) if r == 1 and s == 1 else dw.view(n, r, s, c).permute(0, 3, 1, 2)
+        dx, dw = _cba_grads(x, weight, dy, pad, up4, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+class _ConvBNActGroupTrain(Function):
+    """K independent training ConvModules (conv -> SyncBatchNorm(batch stats) -> ReLU on K different inputs) as ONE autograd
+    node, so that their statistics cross the ranks in ONE all-reduce forward (all members' [count * mean, count * E[x^2],
+    count]) and ONE backward (all members' [sum dy, sum dy * xhat]) instead of K each: the four lateral / four 3x3
+    convolutions of MultiLevelNeck (multilevel_neck.py:141-160), UperNet's laterals + PPM branches + auxiliary head
+    convolution (upernet.py:103-127) and its three fpn_convs (:137-141) are siblings -- 21 + 21 latency-bound messages per
+    step become 6 + 6.  Per member the arithmetic is _ConvBNActTrain's; autograd runs this node's backward once all K
+    output gradients exist.  flat = K x (x, weight, conv_bias, gamma, beta, running_mean, running_var)."""
+
+    @staticmethod
+    def forward(ctx, metas, sync_group, *flat):
+        k = len(metas)
+        mem = [flat[7 * i:7 * i + 7] for i in range(k)]
+        ys, locals_, counts = [], [], []
+        for (x, weight, conv_bias, gamma, beta, rm, rv), (momentum, eps, pad, relu, up4) in zip(mem, metas):
+            cb = None if conv_bias is None else conv_bias.detach()
+            y, stats_done = _cba_conv(x, weight, cb, pad, up4, sync_group, rm, rv, momentum)
+            ys.append(y)
+            locals_.append(stats_done if stats_done is not None else ops.bn_stats(y))
+            counts.append(y.numel() // weight.shape[0])
+        # one message: per member [n * mean, n * E[x^2], n]  (count-weighted merge, see sync_batch_stats)
+        packed = torch.cat([t for (mean, var), n in zip(locals_, counts)
+                            for t in (mean * float(n), (var + mean * mean) * float(n), mean.new_full((1,), float(n)))])
+        dist.all_reduce(packed, group=sync_group or None)
+        SYNC_MESSAGES[0] += 1
+        outs, saved, cfg, off = [], [], [], 0
+        for (x, weight, conv_bias, gamma, beta, rm, rv), (momentum, eps, pad, relu, up4), y, n in zip(mem, metas, ys, counts):
+            c = weight.shape[0]
+            total = packed[off + 2 * c]
+            gmean = (packed[off:off + c] / total).contiguous()
+            gvar = (packed[off + c:off + 2 * c] / total - gmean * gmean).clamp_min_(0).contiguous()
+            off += 2 * c + 1
+            if rm is not None:
+                update_running_stats(rm, rv, gmean, gvar, momentum, total)
+            outs.append(ops.bn_apply(y, gmean, gvar, gamma.detach(), beta.detach(), eps, relu))
+            saved += [x, weight, y, gmean, gvar, gamma, beta]
+            cfg.append((pad, relu, eps, conv_bias is not None, n, n / total, up4))
+        ctx.save_for_backward(*saved)
+        ctx.cfg, ctx.sync_group = cfg, sync_group
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        k = len(ctx.cfg)
+        mem = [ctx.saved_tensors[7 * i:7 * i + 7] for i in range(k)]
+        sums = []
+        gs = []
+        for (x, weight, y, mean, var, gamma, beta), (pad, relu, eps, has_bias, p_local, p_share, up4), gout in zip(mem, ctx.cfg, gouts):
+            if gout.dtype != y.dtype:
+                gout = to_compute(gout, y.dtype)
+            gs.append(gout)
+            sums.append(ops.bn_bwd_reduce(y, gout, mean, var, gamma.detach(), beta.detach(), eps, relu))
+        packed = torch.cat([t for pair in sums for t in pair])
+        dist.all_reduce(packed, group=ctx.sync_group or None)
+        SYNC_MESSAGES[1] += 1
+        grads, off = [], 0
+        for i, ((x, weight, y, mean, var, gamma, beta), (pad, relu, eps, has_bias, p_local, p_share, up4), gout, (dgamma, dbeta)) in \
+                enumerate(zip(mem, ctx.cfg, gs, sums)):
+            c = weight.shape[0]
+            sg, sb = packed[off:off + c] * p_share, packed[off + c:off + 2 * c] * p_share
+            off += 2 * c
+            dy = ops.bn_bwd_dx(y, gout, mean, var, gamma.detach(), beta.detach(), eps, relu, sg.contiguous(), sb.contiguous(),
+                               p_local, out=y)
+            need = ctx.needs_input_grad[2 + 7 * i:2 + 7 * i + 7]
+            dx, dw = _cba_grads(x, weight, dy, pad, up4, need[0], need[1])
+            dbias = torch.zeros(c, device=x.device, dtype=torch.float32) if has_bias and need[2] else None
+            grads += [dx, dw, dbias, dgamma, dbeta, None, None]
+        return (None, None, *grads)
+
+
+def conv_bn_act_group(items: list[dict]) -> list[Tensor]:
+    """[conv_bn_act(**item) for item in items] for INDEPENDENT ConvModules (item: x, conv, norm, relu, up).  Under
+    SyncBatchNorm training with more than one rank the members share one statistics message per direction
+    (_ConvBNActGroupTrain); otherwise they simply run one after the other."""
+    norms = [it["norm"] for it in items]
+    grouped = (GROUP_SYNC_BN and len(items) > 1 and all(isinstance(nm, nn.SyncBatchNorm) and nm.training for nm in norms)
+               and len({id(nm.process_group) for nm in norms}) == 1 and _world(norms[0].process_group) > 1)
+    if grouped:
+        for it in items:      # members the single-module path would have re-routed (odd shapes) keep that path
+            conv, x, up = it["conv"], it["x"], int(it.get("up", 1))
+            if up > 1 and not (conv.kernel_size[0] == 3 and conv.padding[0] == 1 and x.shape[1] >= 2 and x.shape[2] >= 2
+                               and FUSE_UP4 and conv.weight.shape[0] % 8 == 0 and x.shape[0] * x.shape[1] <= 65535 and up in (2, 4)):
+                grouped = False
+    if not grouped:
+        return [conv_bn_act(it["x"], it["conv"], it["norm"], relu=it.get("relu", True), up=it.get("up", 1)) for it in items]
+    metas, flat = [], []
+    for it in items:
+        conv, norm = it["conv"], it["norm"]
+        momentum = 0.1 if norm.momentum is None else norm.momentum
+        metas.append((momentum, norm.eps, conv.padding[0], it.get("relu", True), int(it.get("up", 1)) if it.get("up", 1) > 1 else 0))
+        flat += [it["x"], conv.weight, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var]
+    outs = _ConvBNActGroupTrain.apply(tuple(metas), norms[0].process_group, *flat)
+    for norm in norms:
+        if norm.num_batches_tracked is not None:
+            norm.num_batches_tracked.add_(1)
+    return list(outs)
+
+
+GROUP_SYNC_BN = True   # A/B switch: False = one statistics exchange per ConvModule (round 2)
 
 
 FUSE_CONCAT_BWD = True   # A/B switch: False = keep the concat buffer and run the full-resolution data / weight gradients

@@ -171,7 +171,14 @@ class KernelTimer:
         e1.record()
         check(status, what)
         key = self.VARIANT[variant].format(dt="bf16" if a.dtype == BF16 else "f32")
-        self.records.append((key, fl.value, e0, e1, int(a.R) * int(a.S) * int(a.C)))
+        # algorithmic bytes of the launch: every operand read once, the result written once, at their dtypes
+        es, oes = (2 if a.dtype == BF16 else 4), (2 if a.out_dtype == BF16 else 4)
+        nz = int(a.nz)
+        nbytes = nz * (int(a.B) * int(a.H) * int(a.W) * int(a.C) * es + int(a.N) * int(a.R) * int(a.S) * int(a.C) * es
+                       + int(a.B) * int(a.Ho) * int(a.Wo) * int(a.N) * oes)
+        if a.resid:
+            nbytes += nz * int(a.B) * int(a.Ho) * int(a.Wo) * int(a.N) * (2 if a.resid_dtype == BF16 else 4)
+        self.records.append((key, fl.value, e0, e1, int(a.R) * int(a.S) * int(a.C), nbytes))
 
     @staticmethod
     def _k_bucket(k: int) -> str:
@@ -182,13 +189,14 @@ class KernelTimer:
         12-K-step ViT linears and 100-K-step convolutions, whose achievable rates differ by a factor of two."""
         torch.cuda.synchronize()
         out: dict = {}
-        for key, flops, e0, e1, kdepth in self.records:
+        for key, flops, e0, e1, kdepth, nbytes in self.records:
             ms = e0.elapsed_time(e1)
-            s = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0, "by_k": {}})
-            for d in (s, s["by_k"].setdefault(self._k_bucket(kdepth), {"launches": 0, "ms": 0.0, "flops": 0})):
+            s = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0, "by_k": {}})
+            for d in (s, s["by_k"].setdefault(self._k_bucket(kdepth), {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0})):
                 d["launches"] += 1
                 d["ms"] += ms
                 d["flops"] += flops
+                d["bytes"] += nbytes
         return out
 
 

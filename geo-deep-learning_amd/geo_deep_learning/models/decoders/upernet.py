@@ -46,12 +46,19 @@ class UperNetDecoder(nn.Module):
         return self.bottleneck.forward_nhwc(cat)
 
     def forward_nhwc(self, inputs: list[torch.Tensor]) -> torch.Tensor:
-        laterals = [conv.forward_nhwc(inputs[i]) for i, conv in enumerate(self.lateral_convs)]
-        laterals.append(self.psp_forward_nhwc(inputs[-1]))
+        # lateral 1x1 convolutions and the PPM branches are independent: one group (one SyncBatchNorm message per direction)
+        lat_items = [dict(x=inputs[i], conv=m.conv, norm=m.norm) for i, m in enumerate(self.lateral_convs)]
+        ppm_items = self.psp_modules.items_nhwc(inputs[-1])
+        res = gnn.conv_bn_act_group(lat_items + ppm_items)
+        laterals = res[:len(lat_items)]
+        x = inputs[-1]
+        cat = gnn.concat_upsample([x, *res[len(lat_items):]], (x.shape[1], x.shape[2]))      # upernet.py:103-109
+        laterals.append(self.bottleneck.forward_nhwc(cat))
         n = len(laterals)
         for i in range(n - 1, 0, -1):  # top-down: lat[i-1] += up(lat[i])
             laterals[i - 1] = gnn.upsample_add(laterals[i - 1], laterals[i])
-        fpn_outs = [self.fpn_convs[i].forward_nhwc(laterals[i]) for i in range(n - 1)]
+        fpn_outs = gnn.conv_bn_act_group([dict(x=laterals[i], conv=self.fpn_convs[i].conv, norm=self.fpn_convs[i].norm)
+                                          for i in range(n - 1)])
         fpn_outs.append(laterals[-1])
         size = (fpn_outs[0].shape[1], fpn_outs[0].shape[2])
         # 3x3 bottleneck over the concat of the upsampled levels; in training the upsampled levels' gradients are computed at

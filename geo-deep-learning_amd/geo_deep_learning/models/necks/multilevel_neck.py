@@ -60,18 +60,22 @@ class MultiLevelNeck(nn.Module):
              for co in out_channels])
 
     def forward_nhwc(self, inputs: list[torch.Tensor]) -> list[torch.Tensor]:
-        lat = [conv.forward_nhwc(inputs[i]) for i, conv in enumerate(self.lateral_convs)]
+        # the lateral convolutions are independent of each other, and so are the 3x3 convolutions: each set runs as one group,
+        # so that under SyncBatchNorm their statistics travel in ONE message per direction (gnn.conv_bn_act_group)
+        lat = gnn.conv_bn_act_group([dict(x=inputs[i], conv=m.conv, norm=m.norm, relu=m.act is not None)
+                                     for i, m in enumerate(self.lateral_convs)])
         if len(lat) == 1:
             lat = [lat[0] for _ in range(self.num_outs)]
-        outs = []
+        items = []
         for i in range(self.num_outs):
-            if self.scales[i] == 4:      # resize x4 -> 3x3 conv as ONE fused op (no [B,4H,4W,C] intermediate, 31 % fewer MACs)
-                outs.append(self.convs[i].forward_nhwc(lat[i], up4=True))
-            elif self.scales[i] == 2:    # resize x2 -> 3x3 conv: forward as is, both gradients at the low resolution
-                outs.append(self.convs[i].forward_nhwc(lat[i], up=2))
+            m = self.convs[i]
+            if self.scales[i] in (2, 4):
+                # resize x4 / x2 -> 3x3 conv as ONE fused op: forward through the nine low-resolution tap products (no
+                # [B,4H,4W,C] intermediate, 1/16 resp. 1/4 of the MACs), both gradients at the low resolution
+                items.append(dict(x=lat[i], conv=m.conv, norm=m.norm, relu=m.act is not None, up=int(self.scales[i])))
             else:
-                outs.append(self.convs[i].forward_nhwc(resize_nhwc(lat[i], self.scales[i])))
-        return outs
+                items.append(dict(x=resize_nhwc(lat[i], self.scales[i]), conv=m.conv, norm=m.norm, relu=m.act is not None))
+        return gnn.conv_bn_act_group(items)
 
     def forward(self, inputs: list[torch.Tensor]) -> tuple[torch.Tensor, ...]:
         if len(inputs) != len(self.in_channels):

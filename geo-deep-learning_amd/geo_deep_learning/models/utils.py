@@ -61,14 +61,19 @@ class PPM(nn.ModuleList):
             self.append(nn.Sequential(nn.AdaptiveAvgPool2d(pool_scale),
                                       ConvModule(self.in_channels, self.channels, 1, inplace=True)))
 
-    def forward_nhwc_lowres(self, x: torch.Tensor) -> list[torch.Tensor]:
-        """Per-scale [B,s,s,channels] outputs BEFORE the upsample (the caller fuses upsample+concat)."""
-        outs = []
+    def items_nhwc(self, x: torch.Tensor) -> list[dict]:
+        """Per scale: the pooled map and the ConvModule that follows it, as members for gnn.conv_bn_act_group (the branches
+        are independent of each other and of UperNet's lateral convolutions)."""
+        items = []
         for ppm in self:
             pooled = gnn.adaptive_avgpool(x, int(ppm[0].output_size if isinstance(ppm[0].output_size, int)
                                                  else ppm[0].output_size[0]))
-            outs.append(ppm[1].forward_nhwc(pooled))
-        return outs
+            items.append(dict(x=pooled, conv=ppm[1].conv, norm=ppm[1].norm))
+        return items
+
+    def forward_nhwc_lowres(self, x: torch.Tensor) -> list[torch.Tensor]:
+        """Per-scale [B,s,s,channels] outputs BEFORE the upsample (the caller fuses upsample+concat)."""
+        return gnn.conv_bn_act_group(self.items_nhwc(x))
 
     def forward(self, x: torch.Tensor) -> list[torch.Tensor]:
         xn = gnn.to_compute(ops.as_nhwc(x), gnn.compute_dtype())

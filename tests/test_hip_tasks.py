@@ -458,7 +458,7 @@ def _ddp_gpu_worker(rank, world, port, ret):
         loss = crit(r.out, y) + 0.4 * crit(r.aux, y)
         loss.backward()
         torch.cuda.synchronize()
-        ret[rank] = {"loss": loss.item(),
+        ret[rank] = {"loss": loss.item(), "msgs": list(gnn.SYNC_MESSAGES),
                      "grads": {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None},
                      "bufs": {n: b.detach().cpu() for n, b in m.named_buffers() if n.endswith(("running_mean", "running_var"))}}
     finally:
@@ -500,6 +500,10 @@ def test_ddp_syncbn_world2_on_one_gpu_matches_full_batch_oracle():
     (0.5 * (halves[0] + halves[1])).backward()
     r0, r1 = ret[0], ret[1]
     assert abs(r0["loss"] - halves[0].item()) < 1e-5 and abs(r1["loss"] - halves[1].item()) < 1e-5
+    # sibling ConvModules share one statistics message per direction (gnn.conv_bn_act_group): 21 BatchNorm layers, 7 messages
+    # forward (neck laterals | neck 3x3 | decoder laterals + PPM branches | PSP bottleneck | fpn_convs | fpn_bottleneck | aux
+    # head) and 7 backward
+    assert r0["msgs"] == r1["msgs"] == [7, 7], r0["msgs"]
     refp = dict(ref.named_parameters())
     n = 0
     for name, g0 in r0["grads"].items():

@@ -67,6 +67,7 @@ def test_device_input_stage_matches_reference(stats, kind):
     n = 0
     for i, b in enumerate(stage):
         assert b["image"].is_cuda and b["image"].dtype == torch.float32 and b["mask"].is_cuda
+        assert b["mask"].dtype == torch.int64            # crossed the link as uint8 (class indices), widened on the device
         assert not b["wavelengths"].is_cuda
         want = torch.roll(ref, i, dims=2)
         got = b["image"].cpu()
@@ -75,7 +76,13 @@ def test_device_input_stage_matches_reference(stats, kind):
         n += 1
     assert n == 7
     raw_bytes = batches[0]["image"].numel() * batches[0]["image"].element_size()
-    assert stage.bytes_h2d < 7 * (raw_bytes + 2 * 24 * 24 * 8 + 4096)     # raw tiles, not f32, crossed PCIe
+    assert stage.bytes_h2d < 7 * (raw_bytes + 2 * 24 * 24 * 1 + 4096)     # raw tiles, not f32, and byte masks crossed PCIe
+    # a mask that does not fit a byte (e.g. an ignore index of 300) is shipped as it is
+    wide = dict(batches[0])
+    wide["mask"] = batches[0]["mask"].clone()
+    wide["mask"].view(-1)[0] = 300
+    (b,) = list(DeviceInputStage([wide], "cuda", depth=1))
+    assert b["mask"].dtype == torch.int64 and int(b["mask"].view(-1)[0]) == 300
 
 
 @pytest.mark.gpu

@@ -13,6 +13,8 @@ import json
 import sys
 
 root = sys.argv[1]
+# steps the traced command ran (tools/pmc_bench_traffic.sh: --warmup 1 --steps 1 = 2 training steps)
+STEPS_TRACED = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob(f"{root}/pass_*/*/*counter_collection.csv"):
     with open(path) as f:
@@ -52,7 +54,7 @@ for prof_name, bench_name in NAMES:
     write = sum(r[4] * r[2] for r in sel) / n
     hr = sum(r[5] * r[2] for r in sel) / n
     mf = sum(r[6] * r[2] for r in sel) / n
-    entries.append({"kernel_substring": bench_name, "launches_per_train_step": n, "hbm_bytes_per_launch": round(fetch + write),
+    entries.append({"kernel_substring": bench_name, "launches_per_train_step": n // STEPS_TRACED, "launches_traced": n, "hbm_bytes_per_launch": round(fetch + write),
                     "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write), "l2_hit_rate": round(hr, 4),
                     "mfma_busy_share": round(mf, 4)})
 with open(f"{root}/pmc_dominant_kernel_traffic.json", "w") as f:
