@@ -7,6 +7,7 @@ reference's ``loss.backward()`` / DDP hooks keep working unchanged.
 
 from __future__ import annotations
 
+import logging
 import weakref
 
 import torch
@@ -18,6 +19,18 @@ from . import ops
 from .ops import ACT_GELU, ACT_NONE, ACT_RELU, ACT_RESID_RELU  # noqa: F401
 
 
+_log = logging.getLogger(__name__)
+_WARNED_FP16 = False
+_WARNED_FALLBACK: set = set()
+
+
+def warn_unfused(what: str, why: str) -> None:
+    """One log line per (path, reason) when a grid-limit / shape guard sends a fused node down its unfused path."""
+    if (what, why) not in _WARNED_FALLBACK:
+        _WARNED_FALLBACK.add((what, why))
+        _log.warning("gdlhip: %s runs UNFUSED (%s): correct, but several times slower", what, why)
+
+
 # ------------------------------------------------------------------ precision policy
 def compute_dtype() -> torch.dtype:
     """bf16 MFMA path under ``torch.autocast('cuda', bfloat16/float16)``, exact-f32 MFMA otherwise.
@@ -26,6 +39,12 @@ def compute_dtype() -> torch.dtype:
     (configs/dofa_config_RGB.yaml:12); the kernels accumulate in f32 either way.
     """
     if torch.is_autocast_enabled("cuda"):
+        global _WARNED_FP16
+        if not _WARNED_FP16 and torch.get_autocast_dtype("cuda") == torch.float16:
+            # the reference's `precision: 16-mixed` (configs/dofa_config_RGB.yaml:12): there is no fp16 kernel set here
+            _log.warning("gdlhip: fp16 autocast is computed in bf16 (f32 accumulation) by the HIP kernels; no loss scaling is "
+                         "needed or applied")
+            _WARNED_FP16 = True
         return torch.bfloat16
     return torch.float32
 
@@ -488,6 +507,9 @@ def concat_resize_conv_bn_act(levels: list[Tensor], conv: nn.Conv2d, norm: nn.Mo
         return ops.conv_gemm(levels[0], w0, R=3, S=3, pad=1, bias=shift, resid=ops.resize_conv3x3_fwd_sum(zs, size),
                              act=ACT_RESID_RELU if relu else ACT_NONE)
     if not ok:
+        if FUSE_CONCAT_BWD and norm.training:
+            warn_unfused("3x3 ConvModule over a concat of resized levels", f"levels {[tuple(lv.shape) for lv in levels]}: needs "
+                         "contiguous levels, resize factors <= 8, N % 8 == 0 and batch * rows <= 65535")
         return conv_bn_act(concat_upsample(levels, size), conv, norm, relu=relu)
     sync_group = norm.process_group if isinstance(norm, nn.SyncBatchNorm) else False
     momentum = 0.1 if norm.momentum is None else norm.momentum
@@ -589,6 +611,9 @@ def pyramid_fuse_bn_act(levels: list[Tensor], conv: nn.Conv2d, norm: nn.Module, 
           and all(lv.is_contiguous() for lv in levels) and levels[-1].shape[0] * levels[-1].shape[1] <= 65535)
     size = (levels[-1].shape[1], levels[-1].shape[2])
     if not ok:
+        if FUSE_PYRAMID:
+            warn_unfused("1x1 ConvModule over a concat of resized levels", f"levels {[tuple(lv.shape) for lv in levels]}: needs 2..4 "
+                         "contiguous levels, no bias and batch * rows <= 65535")
         return conv_bn_act(concat_upsample(levels, size), conv, norm, relu=relu)
     if norm.training:
         sync_group = norm.process_group if isinstance(norm, nn.SyncBatchNorm) else False
@@ -637,6 +662,9 @@ def conv_bn_act(x: Tensor, conv: nn.Conv2d, norm: nn.Module, *, relu: bool = Tru
         x = bilinear(x, (int(up) * x.shape[1], int(up) * x.shape[2]))
     if up4 and not (r == 3 and pad == 1 and x.shape[1] >= 2 and x.shape[2] >= 2 and FUSE_UP4 and conv.weight.shape[0] % 8 == 0
                     and x.shape[0] * x.shape[1] <= 65535):      # (the gather kernels put batch x rows in one grid dimension)
+        if FUSE_UP4:
+            warn_unfused(f"ConvModule on a x{up4} resized input", f"input {tuple(x.shape)}, {conv.weight.shape[0]} output channels: "
+                         "needs a 3x3 / pad 1 filter, N % 8 == 0 and batch * rows <= 65535")
         x, up4 = bilinear(x, (up4 * x.shape[1], up4 * x.shape[2])), 0
     training = norm.training
     if training:
@@ -870,17 +898,21 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = max_grad_norm
         self._acc = None
+        self._tables: dict = {}      # param group index -> (address signature, device chunk table)
+        self.table_builds = 0        # how often a chunk table was (re)built: 1 per group in steady state
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        todo = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
+        todo = [(gi, g, p) for gi, g in enumerate(self.param_groups) for p in g["params"] if p.grad is not None]
         if not todo:
             return loss
-        dev = todo[0][1].device
-        # one chunk table per hyper-parameter set (lr, betas, eps, wd, step) -> one launch each
+        dev = todo[0][2].device
+        # one chunk table per (param group, step count) -> one launch each.  A table only holds addresses and sizes: it is
+        # rebuilt (535 rows for DOFA-base + one H2D copy) only when a parameter, gradient or state buffer moved -- with
+        # gradient_as_bucket_view / set_to_none=False and a caching allocator that is the first step only
         buckets: dict = {}
-        for group, p in todo:
+        for gi, group, p in todo:
             st = self.state[p]
             if not st:
                 st["step"] = 0
@@ -890,14 +922,21 @@ class FusedAdam(torch.optim.Optimizer):
             if p.grad.stride() != p.stride():
                 p.grad = _restride(p.grad, p)
             _flat(p), _flat(p.grad)  # layout check (dense storage)
-            key = (group["lr"], *group["betas"], group["eps"], group["weight_decay"], st["step"])
-            rows = buckets.setdefault(key, [])
-            n, pp, gp = p.numel(), p.data_ptr(), p.grad.data_ptr()
-            mp, vp = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-            for off in range(0, n, self.CHUNK):
-                rows.append((pp + 4 * off, gp + 4 * off, mp + 4 * off, vp + 4 * off, min(self.CHUNK, n - off)))
+            sig = buckets.setdefault((gi, st["step"]), [])
+            sig.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()))
             mark_updated(p)
-        tables = {k: torch.tensor(v, dtype=torch.int64).to(dev, non_blocking=True) for k, v in buckets.items()}
+        tables = {}
+        for key, sig in buckets.items():
+            sig = tuple(sig)
+            hit = self._tables.get(key[0])
+            if hit is None or hit[0] != sig:
+                rows = [(pp + 4 * off, gp + 4 * off, mp + 4 * off, vp + 4 * off, min(self.CHUNK, n - off))
+                        for pp, gp, mp, vp, n in sig for off in range(0, n, self.CHUNK)]
+                hit = (sig, torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True))
+                if len(buckets) == len({k[0] for k in buckets}):      # (one step count per group: the usual case -> cacheable)
+                    self._tables[key[0]] = hit
+                self.table_builds += 1
+            tables[key] = hit[1]
         clip = None
         if self.max_grad_norm is not None:
             if self._acc is None:
@@ -907,8 +946,9 @@ class FusedAdam(torch.optim.Optimizer):
                 ops.multi_sumsq(t, self._acc[0:1])
             ops.clip_coef(self._acc[0:1], float(self.max_grad_norm), self._acc[1:2])
             clip = self._acc[1:2]
-        for (lr, b1, b2, eps, wd, step), t in tables.items():
-            ops.multi_adam(t, lr, b1, b2, eps, wd, step, clip)
+        for (gi, step), t in tables.items():
+            group = self.param_groups[gi]
+            ops.multi_adam(t, group["lr"], *group["betas"], group["eps"], group["weight_decay"], step, clip)
         return loss
 
     CHUNK = 65536

@@ -477,7 +477,7 @@ def copy_cast(x: Tensor, out: Tensor | None = None, out_dtype: torch.dtype | Non
     if tuple(o4.shape) != (B, H, W, Cc):
         raise ValueError(f"copy_cast: out shape {tuple(o4.shape)} != {(B, H, W, Cc)}")
     if B * H > 65535 or Cc % 4:        # very tall batches / odd channel counts: the identity resample handles any layout
-        return bilinear(x, (H, W), out=out)
+        return bilinear(x, (H, W), out=out)      # (same HBM-bound copy through the flat-index kernel: no slow path to warn about)
     check(_lib.load().gdl_copy_cast(_p(x4), dt(x4), B, H, W, Cc, x4.stride(0), x4.stride(1), x4.stride(2), _p(o4), dt(o4),
                                     o4.stride(0), o4.stride(1), o4.stride(2), _stream()), "gdl_copy_cast")
     return out

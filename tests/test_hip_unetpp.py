@@ -193,3 +193,46 @@ def test_unetpp_train_bf16_descends():
         opt.step()
         losses.append(loss.item())
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+
+
+def test_unetpp_512_bf16_eval_and_train_step_match_oracle():
+    """configs[0] at the BENCHMARKED shape and dtype: UNet++ / ResNet18 on 512 x 512 RGB under bf16 autocast -- eval logits
+    and one training step (loss, every parameter gradient in the relative L2 norm, BatchNorm running statistics) against
+    the f32 oracle on the CPU.  The 512^2 / 256^2 decoder stages run the direct narrow 3x3 kernel and the tap-packed
+    256 x 64 tiles that smaller test images never reach."""
+    ora, m = _build("resnet18", 21)
+    batch = synthetic_batch(2, 3, 512, 5, 21)
+    x, yt = batch["image"].to(DEV), batch["mask"].to(DEV)
+    ora.eval(); m.eval()
+    with torch.no_grad():
+        yo = ora(batch["image"])
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            yb = m(x)
+    sc = yo.abs().max().item()
+    assert (yb.float().cpu() - yo).abs().max().item() < 0.06 * sc
+    top2 = yo.topk(2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 0.06 * sc
+    assert (gnn.predict_mask(yb.float()).cpu() == yo.argmax(1))[decided].all()
+    ora.train(); m.train()
+    lo = dice_loss_multiclass(ora(batch["image"]), batch["mask"].squeeze(1).long())
+    lo.backward()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = gnn.DiceLoss()(m(x), yt)
+    loss.backward()
+    assert abs(loss.item() - lo.item()) < 2e-2 * abs(lo.item())
+    ref = dict(ora.named_parameters())
+    rels = []
+    for n, p in m.named_parameters():
+        g, r = p.grad.float().cpu(), ref[n].grad
+        assert torch.isfinite(g).all(), n
+        if r.norm().item() > 1e-6:
+            rels.append((float((g - r).norm() / r.norm()), n))
+    rels.sort()
+    med, worst = rels[len(rels) // 2][0], rels[-1]
+    print(f"UNet++ 512^2 bf16 train step: gradient relative L2 median {med:.3f}, 90 % {rels[int(0.9 * len(rels))][0]:.3f}, worst {worst}")
+    # bf16 activations + ReLU-mask flips in a 11-block dense decoder: bounds as for the DOFA bf16 task test
+    assert med < 0.08 and rels[int(0.9 * len(rels))][0] < 0.3
+    rb = dict(ora.named_buffers())
+    for n, b in m.named_buffers():
+        if n.endswith("running_mean"):
+            assert torch.allclose(b.cpu(), rb[n], atol=2e-2, rtol=5e-2), n

@@ -132,3 +132,53 @@ def test_smp_state_dict_key_list_is_exact():
     for k, (cin, cout) in plan.items():
         assert b[k].conv1[0].weight.shape[:2] == (cout, cin), (k, tuple(b[k].conv1[0].weight.shape))
         assert b[k].conv2[0].weight.shape[:2] == (cout, cout), k
+
+
+def test_dense_skip_decoder_matches_the_published_recurrence():
+    """The UNet++ decoder topology pinned by an independent construction: the nested dense skip
+    pathways of Zhou et al. 2018, X[i, j] = H([X[i, 0], ..., X[i, j-1], Up(X[i+1, j-1])]) with X[i, 0] = encoder feature of
+    stride 2^(i+1), written here as a functional loop over (j, i) that never touches oracle/unetpp.py's decoder code -- only
+    its weights, looked up under smp's key names.  smp names node X[i, j] `x_{4-i-j}_{3-i}`, concatenates the upsampled
+    deeper node first and the same-level nodes in descending j, and appends one skip-less block `x_0_4` that brings
+    X[0, 4] to full resolution.  A wrong topology or key mapping cannot pass: the channel counts of the 22 convolutions
+    only line up for this wiring, and the outputs must agree to 1e-5."""
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    m = UnetPlusPlus("resnet18", 3, 5).eval()
+    with torch.no_grad():
+        for name, t in m.state_dict().items():      # random weights AND random BatchNorm statistics
+            if name.endswith("running_var"):
+                t.copy_(torch.rand_like(t) + 0.5)
+            elif name.endswith(("running_mean", "bias")):
+                t.copy_(torch.randn_like(t) * 0.1)
+            elif name.endswith("weight") and t.dim() == 1:
+                t.copy_(torch.rand_like(t) + 0.5)
+    sd = m.state_dict()
+    x = torch.randn(2, 3, 64, 96)
+    with torch.no_grad():
+        e = m.encoder(x)                             # [x, e1 (1/2), e2 (1/4), e3 (1/8), e4 (1/16), e5 (1/32)]
+
+        def conv_bn_relu(t, prefix):
+            t = F.conv2d(t, sd[f"{prefix}.0.weight"], padding=1)
+            t = F.batch_norm(t, sd[f"{prefix}.1.running_mean"], sd[f"{prefix}.1.running_var"], sd[f"{prefix}.1.weight"],
+                             sd[f"{prefix}.1.bias"], training=False, eps=1e-5)
+            return F.relu(t)
+
+        def H(t, node):                              # smp DecoderBlock after the concat: two Conv2dReLU
+            return conv_bn_relu(conv_bn_relu(t, f"decoder.blocks.{node}.conv1"), f"decoder.blocks.{node}.conv2")
+
+        def up(t):
+            return F.interpolate(t, scale_factor=2.0, mode="nearest")
+
+        X = {(i, 0): e[i + 1] for i in range(5)}
+        for j in range(1, 5):
+            for i in range(0, 5 - j):
+                cat = torch.cat([up(X[i + 1, j - 1])] + [X[i, jj] for jj in range(j - 1, -1, -1)], dim=1)
+                X[i, j] = H(cat, f"x_{4 - i - j}_{3 - i}")
+        out = H(up(X[0, 4]), "x_0_4")
+        ref = m.decoder(e)
+        assert out.shape == ref.shape == (2, 16, 64, 96)
+        assert (out - ref).abs().max().item() <= 1e-5 * max(ref.abs().max().item(), 1.0)
+        # and through the head, against the whole model
+        logits = F.conv2d(out, sd["segmentation_head.0.weight"], sd["segmentation_head.0.bias"], padding=1)
+        assert torch.allclose(logits, m(x), atol=1e-5)
