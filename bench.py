@@ -111,9 +111,9 @@ def timed(fn, steps: int, warmup: int, world: int, device) -> float:
     return dt
 
 
-def build_task(model: str, device, dist_on: bool, local: int):
+def build_task(model: str, device, dist_on: bool, local: int, capturable: bool = False):
     from gdlhip.nn import DiceLoss, FusedAdam
-    opt = lambda params: FusedAdam(params, lr=6e-5, max_grad_norm=1.0)  # noqa: E731
+    opt = lambda params: FusedAdam(params, lr=6e-5, max_grad_norm=1.0, capturable=capturable)  # noqa: E731
     if model == "unetpp":
         from tasks_with_models.segmentation_unetplus import SegmentationUnetPlus
         task = SegmentationUnetPlus(encoder="resnet18", image_size=(512, 512), in_channels=3, num_classes=5,
@@ -153,9 +153,124 @@ def make_steps(task, optimizer, get_batch, use_bf16: bool):
     return train_step, infer_step
 
 
-def side_measurement(model: str, batch_size: int, steps: int, warmup: int, device, use_bf16: bool) -> dict:
-    """Train + inference tiles/s of another model / batch size, measured like the headline (N = 1)."""
-    task, optimizer = build_task(model, device, False, 0)
+class OpAccounting:
+    """Roofline accounting of one step at the level of the C-ABI wrappers (gdlhip.ops): every top-level op call is bracketed
+    by HIP events on the launch stream and charged its ALGORITHMIC bytes -- each tensor argument read once, each result
+    written once, at its dtype; intermediates inside a fused op are not charged, weights and optimizer state are -- and,
+    for the matrix ops, its algorithmic flops.  bound = max(bytes / 8 TB/s, flops / 2.5 PF/s); the fraction of a step is
+    sum of the ops' bounds / measured step time.  An op called from inside another op of gdlhip.ops is charged to the outer
+    call only (its tensors are the outer op's intermediates)."""
+
+    OUT_KW = ("out", "dw", "din", "aux_out", "dq", "dk", "dv")
+    SKIP = {"dt", "as_nhwc", "as_nchw", "image_f32", "split_qkv", "flash_ok", "resize_conv3x3_fwd_ok", "resize_conv3x3_fwd_bn_ok",
+            "check", "KernelTimer"}
+
+    def __init__(self) -> None:
+        self.records: list = []
+        self._saved: dict = {}
+        self._depth = 0
+
+    @staticmethod
+    def _nbytes(obj) -> int:
+        if isinstance(obj, torch.Tensor):
+            return obj.numel() * obj.element_size() if obj.is_cuda else 0
+        if isinstance(obj, (list, tuple)):
+            return sum(OpAccounting._nbytes(o) for o in obj)
+        if isinstance(obj, dict):
+            return sum(OpAccounting._nbytes(o) for o in obj.values())
+        return 0
+
+    @staticmethod
+    def _flops(name: str, a: tuple, k: dict, ret) -> int:
+        try:
+            if name in ("conv_gemm", "linear"):
+                x, w = a[0], a[1]
+                m = (ret.numel() // w.shape[0]) if isinstance(ret, torch.Tensor) else 0
+                return 2 * m * w.shape[0] * w.shape[1]
+            if name == "conv_wgrad":
+                x, dy = a[0], a[1]
+                return 2 * (dy.numel() // dy.shape[-1]) * dy.shape[-1] * k.get("R", 1) * k.get("S", 1) * x.shape[-1]
+            if name in ("attention", "attention_flash", "attention_unfused", "attention_flash_v1"):
+                q, kk = a[0], a[1]
+                return 4 * q.shape[0] * q.shape[1] * kk.shape[1] * q.shape[2]
+            if name in ("attention_flash_bwd", "attention_bwd"):
+                q, kk = a[0], a[1]
+                return 10 * q.shape[0] * q.shape[1] * kk.shape[1] * q.shape[2]
+            if name == "resize_conv3x3_bwd":      # two GEMMs over the low-resolution pixels (K = 9 N): data and weight gradient
+                x_lo, dy, wd = a[0], a[1], a[2]
+                px = x_lo.numel() // x_lo.shape[-1]
+                g = 2 * px * x_lo.shape[-1] * 9 * dy.shape[-1]
+                return g * ((wd is not None) + bool(k.get("want_dw", True)))
+        except Exception:  # noqa: BLE001
+            return 0
+        return 0
+
+    def __enter__(self):
+        import types
+        from gdlhip import ops
+        for name, fn in list(vars(ops).items()):
+            if isinstance(fn, types.FunctionType) and fn.__module__ == ops.__name__ and not name.startswith("_") and name not in self.SKIP:
+                self._saved[name] = fn
+                setattr(ops, name, self._wrap(name, fn))
+        return self
+
+    def _wrap(self, name, fn):
+        def wrapper(*a, **k):
+            if self._depth:                                  # an op called from inside another op (module globals are patched
+                return fn(*a, **k)                           # too): charged to the outer call only
+            self._depth += 1
+            try:
+                return charged(*a, **k)
+            finally:
+                self._depth -= 1
+
+        def charged(*a, **k):
+            reads = self._nbytes([v for v in a]) + self._nbytes({kk: v for kk, v in k.items() if kk not in self.OUT_KW})
+            if name in ("multi_adam", "multi_sumsq"):        # chunk table rows [p, g, m, v, n]: 28 resp. 4 bytes per parameter
+                reads = int(a[0][:, 4].sum().item()) * (28 if name == "multi_adam" else 4)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ret = fn(*a, **k)
+            e1.record()
+            writes = self._nbytes(ret) if ret is not None else self._nbytes({kk: v for kk, v in k.items() if kk in self.OUT_KW})
+            self.records.append((name, reads + writes, self._flops(name, a, k, ret), e0, e1))
+            return ret
+        return wrapper
+
+    def __exit__(self, *exc):
+        from gdlhip import ops
+        for name, fn in self._saved.items():
+            setattr(ops, name, fn)
+        return False
+
+    def summary(self, step_ms: float, top: int = 3) -> dict:
+        torch.cuda.synchronize()
+        per: dict = {}
+        for name, nbytes, flops, e0, e1 in self.records:
+            d = per.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0, "flops": 0})
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += nbytes
+            d["flops"] += flops
+        bound = lambda d: max(d["bytes"] / (PEAK_HBM_GBS * 1e9), d["flops"] / (PEAK_BF16_TFLOPS * 1e12)) * 1e3  # noqa: E731
+        tot_b, tot_f = sum(d["bytes"] for d in per.values()), sum(d["flops"] for d in per.values())
+        sum_bounds = sum(bound(d) for d in per.values())
+        ranked = sorted(per.items(), key=lambda kv: -kv[1]["ms"])[:top]
+        return {"algorithmic_gbytes_per_step": round(tot_b / 1e9, 3), "algorithmic_tflop_per_step": round(tot_f / 1e12, 3),
+                "bound_ms": round(sum_bounds, 3), "bound_kind": "sum over ops of max(bytes / 8 TB/s, flops / 2.5 PF/s)",
+                "whole_step_bound_ms": round(max(tot_b / (PEAK_HBM_GBS * 1e9), tot_f / (PEAK_BF16_TFLOPS * 1e12)) * 1e3, 3),
+                "frac_of_bound": round(sum_bounds / step_ms, 4), "ops_ms_under_accounting": round(sum(d["ms"] for d in per.values()), 3),
+                "top_ops": [{"op": n, "calls": d["calls"], "ms": round(d["ms"], 3), "gbytes": round(d["bytes"] / 1e9, 3),
+                             "tflop": round(d["flops"] / 1e12, 3), "bound": "hbm" if d["bytes"] / (PEAK_HBM_GBS * 1e9) >= d["flops"] / (PEAK_BF16_TFLOPS * 1e12) else "mfma",
+                             "frac_of_own_bound": round(bound(d) / max(d["ms"], 1e-9), 4)} for n, d in ranked]}
+
+
+def side_measurement(model: str, batch_size: int, steps: int, warmup: int, device, use_bf16: bool, roofline: bool = False,
+                     graphs: bool = False) -> dict:
+    """Train + inference tiles/s of another model / batch size, measured like the headline (N = 1).  graphs: also with the
+    whole step replayed from a hipGraph (gdlhip.graphs) -- at small batches the eager step is bound by the host issuing
+    several hundred launches, not by the GPU."""
+    task, optimizer = build_task(model, device, False, 0, capturable=graphs)
     batch = synthetic_batch(batch_size, device, 43)
     train_step, infer_step = make_steps(task, optimizer, lambda: batch, use_bf16)
     dt_t = timed(train_step, steps, warmup, 1, device)
@@ -166,6 +281,26 @@ def side_measurement(model: str, batch_size: int, steps: int, warmup: int, devic
            "train_ms_per_step": round(1e3 * dt_t / steps, 3), "inference_ms_per_step": round(1e3 * dt_i / steps, 3),
            "model_flops_utilisation": {"train": round(MODEL_GF[model]["train"] * 1e-3 * n / dt_t / peak, 4),
                                        "infer": round(MODEL_GF[model]["infer"] * 1e-3 * n / dt_i / peak, 4)}}
+    if graphs:
+        from gdlhip.graphs import GraphedEvalStep, GraphedTrainStep
+        try:
+            gt = GraphedTrainStep(task, optimizer, batch, autocast_dtype=torch.bfloat16 if use_bf16 else None)
+            dt_g = timed(lambda: gt(), steps, warmup, 1, device)
+            task.eval()
+            ge = GraphedEvalStep(lambda b: task.validation_step(b, 0), batch, autocast_dtype=torch.bfloat16 if use_bf16 else None)
+            dt_ge = timed(lambda: ge(), steps, warmup, 1, device)
+            out["hipgraph"] = {"train_tiles_per_s": round(n / dt_g, 2), "train_ms_per_step": round(1e3 * dt_g / steps, 3),
+                               "inference_tiles_per_s": round(n / dt_ge, 2), "inference_ms_per_step": round(1e3 * dt_ge / steps, 3),
+                               "note": "forward + loss + backward + clip + Adam (resp. forward + argmax) captured once, replayed per step"}
+            del gt, ge
+        except Exception as exc:  # noqa: BLE001  (report, do not lose the eager numbers)
+            out["hipgraph"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    if roofline:
+        # these models are HBM- / launch-bound, not MFMA-bound: a FLOP utilisation says little; one accounted step each
+        for key, fn, ms in (("train", train_step, 1e3 * dt_t / steps), ("infer", infer_step, 1e3 * dt_i / steps)):
+            with OpAccounting() as acct:
+                fn()
+            out.setdefault("roofline", {})[key] = acct.summary(ms)
     del task, optimizer, batch
     torch.cuda.empty_cache()
     return out
@@ -315,6 +450,17 @@ def main() -> None:
     if args.mode in ("both", "infer"):
         res["infer"] = timed(infer_step, args.steps, args.warmup, world, device)
 
+    step_roofline = None
+    if not args.no_extras and world == 1:
+        # op-level accounting of the headline steps (see OpAccounting): what the whole step looks like against the HBM / MFMA
+        # bounds of its ops, beside the dominant-kernel roofline below
+        step_roofline = {}
+        for key, fn in (("train", train_step), ("infer", infer_step)):
+            if key in res:
+                with OpAccounting() as acct:
+                    fn()
+                step_roofline[key] = acct.summary(1e3 * res[key] / args.steps, top=5)
+
     ddp_info = None
     if dist_on and "train" in res:
         from gdlhip import nn as gnn
@@ -436,6 +582,8 @@ def main() -> None:
                                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                          for k, v in summ.items() if k != name},
         }
+    if step_roofline:
+        out["step_roofline"] = step_roofline
     if pcie is not None:
         out["pcie_inclusive"] = pcie
     if ddp_info is not None:
@@ -444,8 +592,9 @@ def main() -> None:
         del task, optimizer
         torch.cuda.empty_cache()
         out["hbm_kernels"] = hbm_kernels(device, args.batch)
-        out["by_batch"] = {"4": side_measurement("dofa", 4, max(args.steps, 10), args.warmup, device, True)}
-        out["other_models"] = {m: side_measurement(m, args.batch, args.steps, args.warmup, device, True)
+        out["by_batch"] = {str(bsz): side_measurement("dofa", bsz, max(args.steps, 10), args.warmup, device, True, graphs=True)
+                           for bsz in (2, 4, 8)}      # 4 = the per-GPU batch of the reference's own config
+        out["other_models"] = {m: side_measurement(m, args.batch, args.steps, args.warmup, device, True, roofline=True)
                                for m in ("segformer", "unetpp")}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()

@@ -47,7 +47,56 @@ __global__ __launch_bounds__(256) void multi_adam_kernel(const int64_t* __restri
   }
 }
 
+// hipGraph-capturable form: the step count and the hyper-parameters live in DEVICE memory, so that a captured optimizer step
+// replays with the right bias corrections and a learning rate the host may rewrite between replays.
+// state = {step, lr, beta1, beta2, eps, weight_decay, bc1, bc2} (f32)
+__global__ void adam_tick_kernel(float* __restrict__ st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float step = st[0] + 1.f;
+    st[0] = step;
+    st[6] = 1.f - powf(st[2], step);
+    st[7] = 1.f - powf(st[3], step);
+  }
+}
+
+__global__ __launch_bounds__(256) void multi_adam_dev_kernel(const int64_t* __restrict__ table, const float* __restrict__ st,
+                                                             const float* __restrict__ clip_coef) {
+  const int64_t* row = table + (int64_t)blockIdx.x * ROW;
+  float* p = (float*)row[0];
+  const float* g = (const float*)row[1];
+  float* m = (float*)row[2];
+  float* v = (float*)row[3];
+  const int n = (int)row[4];
+  const float lr = st[1], b1 = st[2], b2 = st[3], eps = st[4], wd = st[5], bc1 = st[6], bc2 = st[7];
+  const float cc = clip_coef ? clip_coef[0] : 1.f;
+  const float step = lr / bc1, rs = 1.f / sqrtf(bc2);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float gi = g[i] * cc;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = pi - step * mi / (sqrtf(vi) * rs + eps);
+  }
+}
+
 }  // namespace
+
+extern "C" int gdl_adam_tick(float* state, gdl_stream_t stream) {
+  GDL_CHECK_ARG(state, "gdl_adam_tick: null state");
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
+  GDL_CHECK_LAUNCH("gdl_adam_tick");
+  return GDL_OK;
+}
+
+extern "C" int gdl_multi_adam_dev(const int64_t* table, int nchunks, const float* state, const float* clip_coef, gdl_stream_t stream) {
+  GDL_CHECK_ARG(table && state && nchunks >= 0, "gdl_multi_adam_dev: bad args");
+  if (nchunks == 0) return GDL_OK;
+  hipLaunchKernelGGL(multi_adam_dev_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, table, state, clip_coef);
+  GDL_CHECK_LAUNCH("gdl_multi_adam_dev");
+  return GDL_OK;
+}
 
 extern "C" int gdl_multi_sumsq(const int64_t* table, int nchunks, float* acc, gdl_stream_t stream) {
   GDL_CHECK_ARG(table && acc && nchunks >= 0, "gdl_multi_sumsq: bad args");

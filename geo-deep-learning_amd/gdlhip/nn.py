@@ -894,9 +894,14 @@ class FusedAdam(torch.optim.Optimizer):
     ``gradient_clip_val``) done by HIP kernels.  Reference: configs/dofa_config_RGB.yaml:11,62-65."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, max_grad_norm: float | None = None) -> None:
+                 weight_decay: float = 0.0, max_grad_norm: float | None = None, capturable: bool = False) -> None:
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = max_grad_norm
+        # capturable (torch.optim.Adam(capturable=True)): step count, bias corrections and hyper-parameters live in device
+        # memory, so that a hipGraph-captured step (gdlhip.graphs) replays correctly; chunk tables come from pinned memory
+        self.capturable = capturable
+        self._dev_state: dict = {}    # param group index -> f32[8] {step, lr, b1, b2, eps, wd, bc1, bc2}
+        self._table_bufs: dict = {}   # param group index -> (pinned, device) chunk-table buffers, allocated once
         self._acc = None
         self._tables: dict = {}      # param group index -> (address signature, device chunk table)
         self.table_builds = 0        # how often a chunk table was (re)built: 1 per group in steady state
@@ -932,7 +937,19 @@ class FusedAdam(torch.optim.Optimizer):
             if hit is None or hit[0] != sig:
                 rows = [(pp + 4 * off, gp + 4 * off, mp + 4 * off, vp + 4 * off, min(self.CHUNK, n - off))
                         for pp, gp, mp, vp, n in sig for off in range(0, n, self.CHUNK)]
-                hit = (sig, torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True))
+                host = torch.tensor(rows, dtype=torch.int64)
+                if self.capturable:
+                    # under stream capture nothing may be allocated (pinned or device): both buffers exist since the first
+                    # table of this group; the captured H2D copy re-reads the pinned one at every replay
+                    bufs = self._table_bufs.get(key[0])
+                    if bufs is None or bufs[0].shape != host.shape:
+                        bufs = (torch.empty(host.shape, dtype=torch.int64).pin_memory(), torch.empty(host.shape, dtype=torch.int64, device=dev))
+                        self._table_bufs[key[0]] = bufs
+                    bufs[0].copy_(host)
+                    bufs[1].copy_(bufs[0], non_blocking=True)
+                    hit = (sig, bufs[1])
+                else:
+                    hit = (sig, host.to(dev, non_blocking=True))
                 if len(buckets) == len({k[0] for k in buckets}):      # (one step count per group: the usual case -> cacheable)
                     self._tables[key[0]] = hit
                 self.table_builds += 1
@@ -948,8 +965,29 @@ class FusedAdam(torch.optim.Optimizer):
             clip = self._acc[1:2]
         for (gi, step), t in tables.items():
             group = self.param_groups[gi]
-            ops.multi_adam(t, group["lr"], *group["betas"], group["eps"], group["weight_decay"], step, clip)
+            if self.capturable:
+                ops.adam_tick(self.device_state(gi, dev))
+                ops.multi_adam_dev(t, self._dev_state[gi], clip)
+            else:
+                ops.multi_adam(t, group["lr"], *group["betas"], group["eps"], group["weight_decay"], step, clip)
         return loss
+
+    def device_state(self, gi: int, dev=None) -> Tensor:
+        """The device-side {step, lr, b1, b2, eps, wd, bc1, bc2} of param group gi (capturable mode), created from the group's
+        current hyper-parameters on first use.  A scheduler's new learning rate reaches a captured step through sync_lr()."""
+        st = self._dev_state.get(gi)
+        if st is None:
+            g = self.param_groups[gi]
+            steps = {self.state[p]["step"] - 1 for p in g["params"] if p in self.state and self.state[p]}
+            step0 = float(steps.pop()) if len(steps) == 1 else 0.0
+            st = torch.tensor([step0, g["lr"], *g["betas"], g["eps"], g["weight_decay"], 0.0, 0.0], dtype=torch.float32).to(dev)
+            self._dev_state[gi] = st
+        return st
+
+    def sync_lr(self) -> None:
+        """Write the param groups' current learning rates into the device state (call between graph replays after a scheduler step)."""
+        for gi, st in self._dev_state.items():
+            st[1:2].fill_(float(self.param_groups[gi]["lr"]))
 
     CHUNK = 65536
 

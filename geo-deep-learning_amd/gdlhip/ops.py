@@ -1436,6 +1436,15 @@ def multi_adam(table: Tensor, lr: float, b1: float, b2: float, eps: float, wd: f
                                      _stream()), "gdl_multi_adam")
 
 
+def adam_tick(state: Tensor) -> None:
+    """state[0] += 1 and the two bias corrections refreshed, on the device (capturable Adam, see gdl_adam_tick)."""
+    check(_lib.load().gdl_adam_tick(_p(state), _stream()), "gdl_adam_tick")
+
+
+def multi_adam_dev(table: Tensor, state: Tensor, clip: Tensor | None) -> None:
+    check(_lib.load().gdl_multi_adam_dev(_p(table), table.shape[0], _p(state), _p(clip), _stream()), "gdl_multi_adam_dev")
+
+
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, b1: float, b2: float,
               eps: float, wd: float, step: int, clip: Tensor | None) -> None:
     bc1, bc2 = 1.0 - b1**step, 1.0 - b2**step

@@ -47,7 +47,8 @@ except ImportError:
             self.hparams.update(kw)
 
         def log(self, name: str, value: Any, batch_size: int | None = None, **_kw: Any) -> None:
-            self.logged[name] = value
+            # detached: a logged loss must not keep its autograd graph (and the AccumulateGrad nodes of every parameter) alive
+            self.logged[name] = value.detach() if isinstance(value, Tensor) else value
             sink = getattr(self.trainer, "_collect", None)
             if sink is not None:
                 sink(name, value, batch_size)

@@ -449,6 +449,11 @@ int gdl_multi_sumsq(const int64_t* table, int nchunks, float* out_accum, gdl_str
 int gdl_multi_adam(const int64_t* table, int nchunks, float lr, float beta1, float beta2, float eps,
                    float weight_decay, float bc1, float bc2, const float* clip_coef,
                    gdl_stream_t stream);
+/* capturable form (hipGraph replay of a whole training step, torch.optim.Adam(capturable=True)): step count and
+ * hyper-parameters in DEVICE memory -- state = {step, lr, beta1, beta2, eps, weight_decay, bc1, bc2} f32; gdl_adam_tick
+ * advances the step and refreshes the two bias corrections, gdl_multi_adam_dev reads everything from `state` */
+int gdl_adam_tick(float* state, gdl_stream_t stream);
+int gdl_multi_adam_dev(const int64_t* table, int nchunks, const float* state, const float* clip_coef, gdl_stream_t stream);
 int gdl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, float bc1, float bc2,
                   const float* clip_coef, gdl_stream_t stream);

@@ -519,3 +519,66 @@ def test_ddp_syncbn_world2_on_one_gpu_matches_full_batch_oracle():
     for name, b0 in r0["bufs"].items():
         assert torch.equal(b0, r1["bufs"][name]), name
         assert torch.allclose(b0, rb[name], atol=2e-5, rtol=1e-4), name
+
+
+def test_graphed_train_step_matches_eager():
+    """gdlhip.graphs.GraphedTrainStep (hipGraph capture of forward + Dice loss + backward + clipping + Adam) against the same
+    steps run eagerly: identical losses step by step and identical parameters afterwards (stochastic layers switched off so
+    that both sides are deterministic), the captured optimizer keeps counting steps (bias corrections) and follows a
+    learning rate written between replays; then, with DropPath / Dropout2d back on, replays draw fresh masks."""
+    from gdlhip.graphs import GraphedEvalStep, GraphedTrainStep
+
+    def make(capturable):
+        _, task = _dofa_task(freeze=("encoder",))
+        task.trainer = _Trainer(True)
+        for blk in task.model.encoder.blocks:
+            blk.drop_prob = 0.0
+        task.model.aux_head.dropout_ratio = 0.0
+        params = [p for p in task.parameters() if p.requires_grad]
+        return task, gnn.FusedAdam(params, lr=1e-3, max_grad_norm=1.0, capturable=capturable)
+
+    batches = [_to_dev(synthetic_batch(2, 3, 112, 5, 30 + i)) for i in range(5)]
+    for b in batches:
+        b["mask"] = b["mask"].long()
+    te, oe = make(False)
+    tg, og = make(True)
+    graphed = GraphedTrainStep(tg, og, batches[0], autocast_dtype=None, warmup=2)
+    # the two warm-up steps were real optimizer steps on batches[0] (the capture pass only records): bring the eager twin
+    # to the same state
+    te.train()
+    for _ in range(2):
+        oe.zero_grad(set_to_none=True)
+        te.training_step(batches[0], 0).backward()
+        oe.step()
+    for i, b in enumerate(batches):
+        if i == 3:      # a scheduler lowers the learning rate between two steps
+            for opt in (oe, og):
+                opt.param_groups[0]["lr"] = 2e-4
+            og.sync_lr()
+        oe.zero_grad(set_to_none=True)
+        le = te.training_step(b, 0)
+        le.backward()
+        oe.step()
+        lg = graphed(b)
+        # (the gradient-norm reduction uses float atomics: its summation order differs from run to run in the last bits)
+        assert abs(le.item() - lg.item()) <= 3e-5 * max(1.0, abs(le.item())), (i, le.item(), lg.item())
+    pe = dict(te.named_parameters())
+    for n, p in tg.named_parameters():
+        if p.requires_grad:
+            # Adam normalises: an element whose gradient is at round-off level may step by +-lr on either side
+            d = (p - pe[n]).abs()
+            assert d.max().item() <= 8e-3 and (d > 1e-4).float().mean().item() < 2e-2, (n, d.max().item())
+    assert float(og.device_state(0)[0]) == 7.0                     # 2 warm-up steps + 5 replays
+    # eval step from a graph: same logits as eager
+    te.eval(); tg.eval()
+    ev = GraphedEvalStep(lambda b_: tg(b_["image"], b_["wavelengths"]).out, batches[1], autocast_dtype=None)
+    with torch.no_grad():
+        want = tg(batches[2]["image"], batches[2]["wavelengths"]).out
+    assert torch.equal(ev(batches[2]), want)
+    # stochastic layers on: every replay draws new DropPath / Dropout2d masks (graph-safe Philox offsets)
+    _, ts = _dofa_task(freeze=("encoder",))
+    ts.trainer = _Trainer(True)
+    osx = gnn.FusedAdam([p for p in ts.parameters() if p.requires_grad], lr=0.0, capturable=True)
+    gs = GraphedTrainStep(ts, osx, batches[0], autocast_dtype=None, warmup=1)
+    losses = {round(gs(batches[0]).item(), 7) for _ in range(6)}
+    assert len(losses) > 1, losses                                 # lr = 0: the only thing that changes is the Dropout2d draw
