@@ -1211,6 +1211,154 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
   }
 }
 
+// ---- the BACKWARD gather on the matrix cores (bf16, N % 64 == 0, factors 2 and 4): G_t = U^T S_t^T dy as ONE pass.
+// For a low-resolution pixel q the nine maps are a small dense product that is the same for every channel:
+//   G[q, t, n] = sum_p W[p, t] dy[p, n],   p = the (2F + 2)^2 output pixels whose tap positions interpolate from q,
+//   W[p, (r, s)] = Uy[py + r - 1, qy] Ux[px + s - 1, qx]   (zero when the position lies outside the output),
+// k = 16 * (row of the window) + (column of the window): three (factor 2) or five (factor 4) v_mfma_f32_16x16x32_bf16 steps per
+// 16 channels, nine of the sixteen output columns used.  The two-pass kernels above move dy once and an intermediate of 3 / F
+// of its size twice (0.93 ms for the neck's x4 level); here dy is staged once per 64 channels into LDS by DMA, the weights are
+// products of two small tables, and -- as in the forward kernel (version 2) -- a block walks all channel chunks with the next
+// window in flight and everything channel-independent in registers.  One block = four neighbouring pixels of one
+// low-resolution row (one per wave).  Output layout = the two-pass kernels': [B, Hi, Wi, 9 N], tap block 8 - t.
+struct GatherMArgs {
+  const uint16_t* dy;
+  uint16_t* g;
+  int B, Ho, Wo, N, Hi, Wi;
+};
+
+template <int LF>
+__global__ __launch_bounds__(256, 2) void resize_conv3x3_bwd_gather_mfma_kernel(const GatherMArgs a) {
+  constexpr int F = 1 << LF, WINB = 2 * F + 2, NKS = WINB / 2, QB = 4;
+  constexpr int WCOLS = F * (QB - 1) + WINB;                         // window columns of the block
+  constexpr int NROWS = WINB * WCOLS, NPIECES = (NROWS + 7) / 8, MAXP = (NPIECES + 3) / 4;
+  constexpr int SLOT = NPIECES * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* TYb = (float*)smem;                                         // [3][16]      weight of window row for filter row r
+  float* TXb = TYb + 48;                                             // [QB][3][16]  the same for columns, per pixel of the block
+  unsigned char* tile = smem + 1024;                                 // [QB * 9 rows][128 B]
+  unsigned char* ring = tile + 5 * 1024;
+  const unsigned lds_ring = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ring);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = gridDim.x * gridDim.y;
+  const int id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = id & 7, idx = id >> 3;      // XCD-major: neighbouring rows share an L2
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int brow = lid / gridDim.x, cb = lid - brow * gridDim.x;
+  const int b = brow / a.Hi, qy = brow - b * a.Hi;
+  const int qxb0 = cb * QB;
+  const int py0 = F * qy - (F / 2 + 1), pxb0 = F * qxb0 - (F / 2 + 1);
+  const float ry = (float)a.Hi / (float)a.Ho, rx = (float)a.Wi / (float)a.Wo;
+  if (tid < 48) {
+    const int r = tid >> 4, wl = tid & 15;
+    float w = 0.f;
+    const int pos = py0 + wl + r - 1;
+    if (wl < WINB && pos >= 0 && pos < a.Ho && py0 + wl >= 0 && py0 + wl < a.Ho) {
+      int y0, y1; float ly;
+      src_index(ry, pos, a.Hi, y0, y1, ly);
+      w = (y0 == qy ? 1.f - ly : 0.f) + (y1 == qy ? ly : 0.f);
+    }
+    TYb[tid] = w;
+  }
+  if (tid >= 64 && tid < 64 + QB * 48) {
+    const int i = tid - 64, j = i / 48, r3 = (i - j * 48) >> 4, wl = i & 15;
+    const int qx = qxb0 + j, px = pxb0 + F * j + wl, pos = px + r3 - 1;
+    float w = 0.f;
+    if (wl < WINB && qx < a.Wi && pos >= 0 && pos < a.Wo && px >= 0 && px < a.Wo) {
+      int x0, x1; float lx;
+      src_index(rx, pos, a.Wi, x0, x1, lx);
+      w = (x0 == qx ? 1.f - lx : 0.f) + (x1 == qx ? lx : 0.f);
+    }
+    TXb[i] = w;
+  }
+  __syncthreads();
+  // ---- channel-independent state: weight fragments (B operand: column = tap), fragment addresses, DMA offsets
+  const int L = lane & 15, g = lane >> 4;
+  const int j = wave;                                                // this wave's pixel of the block
+  bf16x8_t wf[NKS];
+  int raddr[NKS][2];
+  {
+    const int r = L / 3, s3 = L - 3 * r;
+    float txv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) txv[e] = L < 9 ? TXb[(j * 3 + s3) * 16 + 8 * (g & 1) + e] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int pyl = 2 * ks + (g >> 1);
+      const float ty = L < 9 ? TYb[r * 16 + pyl] : 0.f;
+      uint32_t pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(ty * txv[2 * e], ty * txv[2 * e + 1]);
+      wf[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pxl = 8 * (g & 1) + 4 * h + (L >> 2);
+        const bool ok = pyl < WINB && pxl < WINB;
+        const int R = ok ? pyl * WCOLS + F * j + pxl : 0;            // padding slots: any staged row, their weight is zero
+        raddr[ks][h] = R * 128 + (((((L & 3) >> 1) ^ tm_swz(R))) << 4) + (L & 1) * 8;
+      }
+    }
+  }
+  unsigned doff[MAXP];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int R = (wave + 4 * i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ tm_swz(R);
+    const int wy = R / WCOLS, wc = R - wy * WCOLS;
+    const int py = py0 + wy, px = pxb0 + wc;
+    const bool ok = R < NROWS && py >= 0 && py < a.Ho && px >= 0 && px < a.Wo;
+    doff[i] = ok ? (unsigned)(((py * a.Wo + px) * a.N) * 2 + chunk * 16) : kTmOob;
+  }
+  const srd_t srd = make_srd(a.dy + (int64_t)b * a.Ho * a.Wo * a.N, (unsigned)((int64_t)a.Ho * a.Wo * a.N * 2));
+  auto issue = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      if (wave + 4 * i < NPIECES) dma16_buf(doff[i], srd, (unsigned)(c * 128), lds_ring + (c & 1) * SLOT + (wave + 4 * i) * 1024);
+    }
+  };
+  const int nchunks = a.N >> 6;
+  issue(0);
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                 // chunk c landed; nobody reads the other slot or the tile
+    if (c + 1 < nchunks) issue(c + 1);
+    const unsigned char* stage = ring + (c & 1) * SLOT;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const tm_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(stage + (raddr[ks][0] ^ (nt << 5))));
+        const tm_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(stage + (raddr[ks][1] ^ (nt << 5))));
+        const tm_s16x8_t zv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zv), wf[ks], acc[nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // D[n][t]: lane = (tap L, channels 4 g ..): tile row = pixel * 9 + (8 - tap)
+    if (L < 9) {
+      const int row = j * 9 + (8 - L);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int ch = 16 * nt + 4 * g;
+        *(uint2*)(tile + row * 128 + ((((ch >> 3) ^ (row & 7))) << 4) + (ch & 7) * 2) =
+            make_uint2(pack_bf16x2(acc[nt][0], acc[nt][1]), pack_bf16x2(acc[nt][2], acc[nt][3]));
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < QB * 9 * 8; i += 256) {
+      const int row = i >> 3, chunk = i & 7;
+      const int jq = row / 9, tb = row - jq * 9, qx = qxb0 + jq;
+      if (qx < a.Wi) {
+        const uint4 v = *(const uint4*)(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+        *(uint4*)(a.g + ((((int64_t)b * a.Hi + qy) * a.Wi + qx) * 9 + tb) * a.N + c * 64 + chunk * 8) = v;
+      }
+    }
+  }
+}
+
 // nn.AdaptiveAvgPool2d: bin i covers [floor(i*In/S), ceil((i+1)*In/S))
 __device__ __forceinline__ void pool_bin(int i, int in, int s, int& lo, int& hi) {
   lo = (i * in) / s;
@@ -1307,6 +1455,7 @@ inline bool vec8_ok(const void* a, const void* b, int C, int64_t s0, int64_t s1,
          s2 % 8 == 0 && s3 % 8 == 0 && s4 % 8 == 0 && s5 % 8 == 0;
 }
 
+int g_gather_mfma = 1;     // A/B hook (gdl_debug_set_gather_mfma): 0 = the two-pass / single-pass VALU gathers of the backward
 int g_tapsum_mfma = 1;     // A/B hook (gdl_debug_set_tapsum_mfma): 0 = the pixel-by-pixel kernel; 1 = MFMA, version chosen by shape;
                            // 5 = version 2 (4 x 16 pixel blocks, all channels, pipelined); 2 / 4 = version 1 (32- / 16-column blocks x 64 channels)
 int g_tapsum_vec = 0;      // A/B hook (gdl_debug_set_tapsum_vec): 4 = 8-byte bf16 vectors per thread instead of 16-byte ones
@@ -1315,6 +1464,37 @@ int g_tapsum_vec = 0;      // A/B hook (gdl_debug_set_tapsum_vec): 4 = 8-byte bf
 
 extern "C" void gdl_debug_set_tapsum_vec(int vec) { g_tapsum_vec = vec; }
 extern "C" void gdl_debug_set_tapsum_mfma(int mode) { g_tapsum_mfma = mode; }
+extern "C" void gdl_debug_set_gather_mfma(int on) { g_gather_mfma = on; }
+
+// matrix-core form of the backward gather; returns false when the shape does not qualify (the caller runs the VALU kernels)
+static bool gather_mfma_ok(int dtype, int B, int Ho, int Wo, int N, int Hi, int Wi) {
+  if (!g_gather_mfma || dtype != GDL_BF16 || N % 64 != 0 || Hi <= 0 || Wi <= 0) return false;
+  const int f = Ho / Hi;
+  if (!((f == 2 || f == 4) && Hi * f == Ho && Wi * f == Wo)) return false;
+  return (int64_t)B * Hi <= 65535 && (int64_t)Ho * Wo * N * 2 < 0x7ffffff0ll;
+}
+extern "C" int gdl_resize_conv3x3_bwd_gather_one_pass(int dtype, int B, int Ho, int Wo, int N, int Hi, int Wi) {
+  return gather_mfma_ok(dtype, B, Ho, Wo, N, Hi, Wi) ? 1 : 0;
+}
+
+static bool gather_mfma_launch(const void* dy, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi, int Wi, hipStream_t s) {
+  if (!gather_mfma_ok(dtype, B, Ho, Wo, N, Hi, Wi) || (uintptr_t)dy % 16 || (uintptr_t)g % 16) return false;
+  const int f = Ho / Hi;
+  GatherMArgs a = {(const uint16_t*)dy, (uint16_t*)g, B, Ho, Wo, N, Hi, Wi};
+  const dim3 grid((unsigned)((Wi + 3) / 4), (unsigned)(B * Hi));
+  if (f == 2) {
+    constexpr int pieces = (6 * (2 * 3 + 6) + 7) / 8;
+    const size_t lds = 6 * 1024 + 2 * pieces * 1024;
+    GDL_SET_MAX_LDS_ONCE(resize_conv3x3_bwd_gather_mfma_kernel<1>, 160 * 1024);
+    hipLaunchKernelGGL(resize_conv3x3_bwd_gather_mfma_kernel<1>, grid, dim3(256), lds, s, a);
+  } else {
+    constexpr int pieces = (10 * (4 * 3 + 10) + 7) / 8;
+    const size_t lds = 6 * 1024 + 2 * pieces * 1024;
+    GDL_SET_MAX_LDS_ONCE(resize_conv3x3_bwd_gather_mfma_kernel<2>, 160 * 1024);
+    hipLaunchKernelGGL(resize_conv3x3_bwd_gather_mfma_kernel<2>, grid, dim3(256), lds, s, a);
+  }
+  return true;
+}
 
 // shared launcher; stats != nullptr: per-block partial sums of the outputs ([rows][2][N] f32, rows = gdl_resize_conv3x3_fwd_sum_bn_rows)
 static int tapsum_launch(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N, void* out, int Ho, int Wo,
@@ -1545,6 +1725,10 @@ extern "C" int gdl_resize_conv3x3_bwd_gather(const void* dy, int dtype, int B, i
   GDL_CHECK_ARG(nx <= 20, "gdl_resize_conv3x3_bwd_gather: resize factors above 8 are not instantiated");
   const dim3 grid((unsigned)((Wi * (N / vec) + 255) / 256), (unsigned)(B * Hi));
   hipStream_t s = (hipStream_t)stream;
+  if (gather_mfma_launch(dy, dtype, B, Ho, Wo, N, g, Hi, Wi, s)) {
+    GDL_CHECK_LAUNCH("gdl_resize_conv3x3_bwd_gather");
+    return GDL_OK;
+  }
 #define GATHER(V, VEC, NX, WXL) hipLaunchKernelGGL((resize_conv3x3_bwd_gather_kernel<V, VEC, NX, WXL>), grid, dim3(256), 0, s, dy, Ho, Wo, N, g, Hi, Wi)
   if (dtype == GDL_BF16) {
     if (nx <= 8) GATHER(V8, 8, 8, false); else if (nx <= 12) GATHER(V8, 8, 12, false); else GATHER(V8, 8, 20, true);
@@ -1575,6 +1759,10 @@ extern "C" int gdl_resize_conv3x3_bwd_gather2(const void* dy, int dtype, int B, 
   GDL_CHECK_ARG(nx <= 20, "gdl_resize_conv3x3_bwd_gather2: resize factors above 8 are not instantiated");
   const int64_t plane = (int64_t)B * Hi * Wo * N;
   hipStream_t s = (hipStream_t)stream;
+  if (gather_mfma_launch(dy, dtype, B, Ho, Wo, N, g, Hi, Wi, s)) {      // one pass on the matrix cores: the workspace stays unused
+    GDL_CHECK_LAUNCH("gdl_resize_conv3x3_bwd_gather2");
+    return GDL_OK;
+  }
   const dim3 grid1((unsigned)((Wo * (N / vec) + 255) / 256), (unsigned)(B * Hi));
   const dim3 grid2((unsigned)((Wi * (N / vec) + 255) / 256), (unsigned)(B * Hi));
 #define COLS(V, VEC, NX, WXL) hipLaunchKernelGGL((resize_conv3x3_bwd_cols_kernel<V, VEC, NX, WXL>), grid2, dim3(256), 0, s, ws, Wo, N, g, Hi, Wi, plane)

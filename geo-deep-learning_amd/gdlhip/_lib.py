@@ -96,6 +96,7 @@ SIGNATURES = {
     "gdl_bilinear_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_i, c_i, c_i,
                                c_l, c_l, c_l, c_i, c_p]),
     "gdl_resize_conv3x3_bwd_gather": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
+    "gdl_resize_conv3x3_bwd_gather_one_pass": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "gdl_resize_conv3x3_bwd_gather_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "gdl_resize_conv3x3_bwd_gather2": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_l, c_p]),
     "gdl_resize_conv3x3_fwd_sum": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p]),
@@ -185,6 +186,9 @@ def load() -> C.CDLL:
     if os.environ.get("GDL_CONV_EPILOGUE") is not None:   # tuning hook: 0 = the round-2 epilogue of the 256^2 tiles
         lib.gdl_debug_set_conv_epilogue.argtypes = [C.c_int]
         lib.gdl_debug_set_conv_epilogue(int(os.environ["GDL_CONV_EPILOGUE"]))
+    if os.environ.get("GDL_GATHER_MFMA") is not None:     # tuning hook: 0 = the VALU gathers of the low-resolution backward
+        lib.gdl_debug_set_gather_mfma.argtypes = [C.c_int]
+        lib.gdl_debug_set_gather_mfma(int(os.environ["GDL_GATHER_MFMA"]))
     if os.environ.get("GDL_WGRAD_MODE") is not None:   # tuning hook: kernel-selection bits of gdl_debug_force_wgrad_small
         lib.gdl_debug_force_wgrad_small.argtypes = [C.c_int]
         lib.gdl_debug_force_wgrad_small(int(os.environ["GDL_WGRAD_MODE"]))

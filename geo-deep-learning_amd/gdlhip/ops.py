@@ -374,7 +374,8 @@ def resize_conv3x3_bwd_gather(dy: Tensor, in_size: tuple[int, int]) -> Tensor:
     Hi, Wi = in_size
     g = torch.empty((B, Hi, Wi, 9 * N), device=dy.device, dtype=dy.dtype)
     lib = _lib.load()
-    if GATHER_TWO_PASS and Ho >= 2 * Hi:      # upsampling factors >= 2: the single pass is multiply-add bound
+    one_pass = lib.gdl_resize_conv3x3_bwd_gather_one_pass(dt(d4), B, Ho, Wo, N, Hi, Wi)     # matrix-core form (bf16, x2 / x4)
+    if GATHER_TWO_PASS and Ho >= 2 * Hi and not one_pass:      # upsampling factors >= 2: the single VALU pass is multiply-add bound
         nbytes = lib.gdl_resize_conv3x3_bwd_gather_workspace(dt(d4), B, Wo, N, Hi)
         ws = torch.empty(nbytes // d4.element_size(), device=dy.device, dtype=dy.dtype)
         check(lib.gdl_resize_conv3x3_bwd_gather2(_p(d4), dt(d4), B, Ho, Wo, N, _p(g), Hi, Wi, _p(ws), nbytes, _stream()),

@@ -255,6 +255,9 @@ int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int Wi, int C,
  * channel slices of g).  Resize factors up to 8.  Deterministic. */
 int gdl_resize_conv3x3_bwd_gather(const void* dy, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi, int Wi,
                                   gdl_stream_t stream);
+/* 1 when gdl_resize_conv3x3_bwd_gather runs its one-pass matrix-core form for this shape (bf16, N % 64 == 0, factor 2 or 4:
+ * dy read once, no intermediate) -- the caller then skips the two-pass entry and its workspace */
+int gdl_resize_conv3x3_bwd_gather_one_pass(int dtype, int B, int Ho, int Wo, int N, int Hi, int Wi);
 /* the same result in two separable passes (rows, then columns) through a workspace of three [B,Hi,Wo,N] maps: fewer
  * multiply-adds per loaded vector; the intermediate is rounded to dy's dtype */
 int64_t gdl_resize_conv3x3_bwd_gather_workspace(int dtype, int B, int Wo, int N, int Hi);

@@ -951,20 +951,32 @@ def test_concat_resize_conv_backward_per_level(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,Hi,Wi,N,f", [(2, 5, 7, 64, 4), (1, 3, 4, 128, 8), (2, 9, 6, 64, 2), (1, 36, 36, 64, 4)])
+@pytest.mark.parametrize("B,Hi,Wi,N,f", [(2, 5, 7, 64, 4), (1, 3, 4, 128, 8), (2, 9, 6, 64, 2), (1, 36, 36, 64, 4), (1, 6, 10, 192, 2),
+                                         (2, 1, 1, 64, 4), (1, 2, 13, 128, 4), (1, 72, 72, 64, 2)])
 def test_resize_conv3x3_bwd_gather_two_pass(dtype, B, Hi, Wi, N, f):
-    """The nine gathered maps G_t = resize^T shift_t^T dy: the separable two-pass kernels (rows, then columns) vs the
-    single-pass kernel, and both vs the definition through torch autograd (d/dx of <dy, shift_t(interpolate(x))>)."""
+    """The nine gathered maps G_t = resize^T shift_t^T dy: the one-pass matrix-core kernel (bf16, factors 2 and 4), the separable
+    two-pass kernels (rows, then columns) and the single-pass VALU kernel, all vs the definition through torch autograd (d/dx of
+    <dy, shift_t(interpolate(x))>)."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_set_gather_mfma.argtypes = [ctypes.c_int]
     Ho, Wo = f * Hi, f * Wi
     dy = q(rnd(B, Ho, Wo, N, seed=3), dtype)
     dyd = dy.to(DEV, dtype)
     outs = {}
     try:
+        one_pass = lib.gdl_resize_conv3x3_bwd_gather_one_pass(ops.dt(dyd), B, Ho, Wo, N, Hi, Wi)
+        assert bool(one_pass) == (dtype == torch.bfloat16 and f in (2, 4))
+        if one_pass:
+            outs["mfma"] = ops.resize_conv3x3_bwd_gather(dyd, (Hi, Wi)).float().cpu()
+        lib.gdl_debug_set_gather_mfma(0)
         for two in (True, False):
             ops.GATHER_TWO_PASS = two
             outs[two] = ops.resize_conv3x3_bwd_gather(dyd, (Hi, Wi)).float().cpu()
     finally:
         ops.GATHER_TWO_PASS = True
+        lib.gdl_debug_set_gather_mfma(1)
     # definition: G_t[q, n] = d/dx[q] sum_p dy[p, n] * (shift_t(U x))[p], one channel at a time is independent -> use x = ones-probe
     x = torch.zeros(B, N, Hi, Wi, requires_grad=True)
     up = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False)
@@ -978,6 +990,9 @@ def test_resize_conv3x3_bwd_gather_two_pass(dtype, B, Hi, Wi, N, f):
             ref[..., (8 - t) * N:(9 - t) * N] = gx.permute(0, 2, 3, 1)
     close(outs[False], ref, dtype, "single-pass gather")
     close(outs[True], ref, dtype, "two-pass gather")
+    if "mfma" in outs:
+        close(outs["mfma"], ref, dtype, "one-pass matrix-core gather")
+        print(f"max |error|: one-pass {(outs['mfma'] - ref).abs().max().item():.3e}, two-pass {(outs[True] - ref).abs().max().item():.3e}")
     if dtype == torch.float32:
         assert (outs[True] - outs[False]).abs().max().item() <= 1e-5 * ref.abs().max().item()
 

@@ -216,23 +216,41 @@ def test_unetpp_512_bf16_eval_and_train_step_match_oracle():
     ora.train(); m.train()
     lo = dice_loss_multiclass(ora(batch["image"]), batch["mask"].squeeze(1).long())
     lo.backward()
+    ref = {n: p.grad.clone() for n, p in ora.named_parameters()}
+    rb = {n: b.clone() for n, b in ora.named_buffers()}
+    # second reference: the SAME oracle under torch's own bf16 autocast on the CPU.  This network at a random initialisation
+    # is ill-conditioned in bf16 whoever computes it: the Dice gradient is nearly constant over the pixels of a class, every
+    # train-mode BatchNorm backward subtracts that common part (dy - mean(dy) - xhat mean(dy xhat)), and the bf16 rounding of
+    # dy before the subtraction is of the size of what remains -- torch's CPU bf16 step is 52 % (median, relative L2) away
+    # from its own f32 step, growing from 2 % at the head to 50 % at the encoder.  The build is held to the f32 oracle where
+    # that is meaningful (head, loss, statistics; the f32 build at this shape is within 1 % in test_unetpp_train_step...)
+    # and to "not further from f32 than torch's bf16" everywhere else.
+    ora.zero_grad(set_to_none=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        y16 = ora(batch["image"])
+    dice_loss_multiclass(y16.float(), batch["mask"].squeeze(1).long()).backward()
+    ref16 = {n: p.grad.float() for n, p in ora.named_parameters()}
     with torch.autocast("cuda", dtype=torch.bfloat16):
         loss = gnn.DiceLoss()(m(x), yt)
     loss.backward()
     assert abs(loss.item() - lo.item()) < 2e-2 * abs(lo.item())
-    ref = dict(ora.named_parameters())
-    rels = []
+    rels, rels16 = [], []
     for n, p in m.named_parameters():
-        g, r = p.grad.float().cpu(), ref[n].grad
+        g, r = p.grad.float().cpu(), ref[n]
         assert torch.isfinite(g).all(), n
         if r.norm().item() > 1e-6:
             rels.append((float((g - r).norm() / r.norm()), n))
-    rels.sort()
-    med, worst = rels[len(rels) // 2][0], rels[-1]
-    print(f"UNet++ 512^2 bf16 train step: gradient relative L2 median {med:.3f}, 90 % {rels[int(0.9 * len(rels))][0]:.3f}, worst {worst}")
-    # bf16 activations + ReLU-mask flips in a 11-block dense decoder: bounds as for the DOFA bf16 task test
-    assert med < 0.08 and rels[int(0.9 * len(rels))][0] < 0.3
-    rb = dict(ora.named_buffers())
+            rels16.append((float((ref16[n] - r).norm() / r.norm()), n))
+    by_name, by_name16 = {n: e for e, n in rels}, {n: e for e, n in rels16}
+    rels.sort(); rels16.sort()
+    med, p90, worst = rels[len(rels) // 2][0], rels[int(0.9 * len(rels))][0], rels[-1]
+    med16, p9016 = rels16[len(rels16) // 2][0], rels16[int(0.9 * len(rels16))][0]
+    print(f"UNet++ 512^2 bf16 train step: gradient relative L2 vs the f32 oracle: median {med:.3f}, 90 % {p90:.3f}, worst {worst}; "
+          f"torch CPU bf16 autocast vs the same: median {med16:.3f}, 90 % {p9016:.3f}; head {by_name['segmentation_head.0.weight']:.4f} "
+          f"(torch bf16 {by_name16['segmentation_head.0.weight']:.4f})")
+    assert med <= 1.15 * med16 + 0.01 and p90 <= 1.15 * p9016 + 0.01, (med, med16, p90, p9016)
+    for n in ("segmentation_head.0.weight", "segmentation_head.0.bias", "decoder.blocks.x_0_4.conv2.1.weight"):
+        assert by_name[n] <= max(0.08, 1.5 * by_name16[n]), (n, by_name[n], by_name16[n])
     for n, b in m.named_buffers():
         if n.endswith("running_mean"):
             assert torch.allclose(b.cpu(), rb[n], atol=2e-2, rtol=5e-2), n
