@@ -1,11 +1,13 @@
 // Multi-tensor optimizer kernels: ONE launch covers every parameter tensor of the step.
-// The host passes a device table of chunks; row = {param, grad, exp_avg, exp_avg_sq, count} with the
-// pointers already offset to the chunk (<= 65536 elements each), all f32, dense.
+// The host passes a device table of chunks; row = {param, grad, exp_avg, exp_avg_sq, count, shadow} with the
+// pointers already offset to the chunk (<= 65536 elements each), all f32, dense.  shadow (0 = none) = a bf16 copy of the
+// parameter in the same element order (the GEMM operand the next forward reads): the update writes it too, so the step has
+// no per-parameter cast launches (28 per DOFA + UperNet step).
 #include "gdl_common.h"
 
 namespace {
 
-constexpr int ROW = 5;
+constexpr int ROW = 6;
 
 __global__ __launch_bounds__(256) void multi_sumsq_kernel(const int64_t* __restrict__ table, float* __restrict__ acc) {
   __shared__ float red[4];
@@ -34,6 +36,7 @@ __global__ __launch_bounds__(256) void multi_adam_kernel(const int64_t* __restri
   float* m = (float*)row[2];
   float* v = (float*)row[3];
   const int n = (int)row[4];
+  uint16_t* sh = (uint16_t*)row[5];
   const float cc = clip_coef ? clip_coef[0] : 1.f;
   const float step = lr / bc1, rs = 1.f / sqrtf(bc2);
   for (int i = threadIdx.x; i < n; i += 256) {
@@ -43,7 +46,9 @@ __global__ __launch_bounds__(256) void multi_adam_kernel(const int64_t* __restri
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
-    p[i] = pi - step * mi / (sqrtf(vi) * rs + eps);
+    const float pn = pi - step * mi / (sqrtf(vi) * rs + eps);
+    p[i] = pn;
+    if (sh) sh[i] = f32_to_bf16(pn);
   }
 }
 
@@ -67,6 +72,7 @@ __global__ __launch_bounds__(256) void multi_adam_dev_kernel(const int64_t* __re
   float* m = (float*)row[2];
   float* v = (float*)row[3];
   const int n = (int)row[4];
+  uint16_t* sh = (uint16_t*)row[5];
   const float lr = st[1], b1 = st[2], b2 = st[3], eps = st[4], wd = st[5], bc1 = st[6], bc2 = st[7];
   const float cc = clip_coef ? clip_coef[0] : 1.f;
   const float step = lr / bc1, rs = 1.f / sqrtf(bc2);
@@ -77,7 +83,9 @@ __global__ __launch_bounds__(256) void multi_adam_dev_kernel(const int64_t* __re
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
-    p[i] = pi - step * mi / (sqrtf(vi) * rs + eps);
+    const float pn = pi - step * mi / (sqrtf(vi) * rs + eps);
+    p[i] = pn;
+    if (sh) sh[i] = f32_to_bf16(pn);
   }
 }
 

@@ -14,6 +14,7 @@ import torch
 from torch import Tensor, nn
 from torch.autograd import Function
 
+from . import nn as gnn
 from . import ops
 from .nn import (_world, cached, mark_updated, conv_weight_matrix, sync_batch_stats, sync_sum_pair, to_compute,
                  update_running_stats)
@@ -174,8 +175,7 @@ def conv_bn(x: Tensor, weight: Tensor, norm: nn.Module, *, stride: int = 1, pad:
         momentum = 0.1 if norm.momentum is None else norm.momentum
         y = _ConvBNTrain.apply(x, weight, norm.weight, norm.bias, norm.running_mean, norm.running_var, momentum,
                                norm.eps, stride, pad, relu and resid is None, sync_group)
-        if norm.num_batches_tracked is not None:
-            norm.num_batches_tracked.add_(1)
+        gnn.bump(norm.num_batches_tracked)
         if resid is not None:
             y = add_relu(y, resid) if relu else y + resid
         return y

@@ -20,6 +20,8 @@ from typing import Any
 import torch
 from torch import Tensor
 
+from . import nn as gnn
+
 
 def _clone_static(batch: dict[str, Any]) -> dict[str, Any]:
     return {k: (v.clone() if isinstance(v, Tensor) and v.is_cuda else v) for k, v in batch.items()}
@@ -64,6 +66,9 @@ class GraphedTrainStep:
         optimizer.zero_grad(set_to_none=True)           # gradients are (re)allocated from the graph's private pool
         with torch.cuda.graph(self.graph):
             self.loss = self._eager(zero=False)
+        self._rewritten = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
+        self._rewritten += [b for m in task.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training
+                            for b in (m.running_mean, m.running_var) if b is not None]
 
     def _eager(self, zero: bool = True) -> Tensor:
         if zero:
@@ -78,6 +83,8 @@ class GraphedTrainStep:
         if batch is not None and batch is not self.static:
             _copy_into(self.static, batch)
         self.graph.replay()
+        for t in self._rewritten:       # the replay rewrote these through raw pointers: eager code must not trust operands
+            gnn.mark_updated(t)         # cached from their earlier values (eval-time BatchNorm folds, packed weights)
         return self.loss
 
 

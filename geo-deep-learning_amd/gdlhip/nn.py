@@ -7,6 +7,9 @@ reference's ``loss.backward()`` / DDP hooks keep working unchanged.
 
 from __future__ import annotations
 
+import contextlib
+import os
+
 import logging
 import weakref
 
@@ -32,6 +35,66 @@ def warn_unfused(what: str, why: str) -> None:
 
 
 # ------------------------------------------------------------------ precision policy
+# A/B switch (tools): GDL_LAUNCH_FUSION=0 restores one launch per DropPath draw / BatchNorm counter / parameter cast
+LAUNCH_FUSION = os.environ.get("GDL_LAUNCH_FUSION", "1") != "0"
+_COUNTER_BATCH: list | None = None
+
+
+@contextlib.contextmanager
+def counter_batch():
+    """Inside this context the ``num_batches_tracked += 1`` of every train-mode BatchNorm (nn.BatchNorm2d.forward) is collected
+    and applied by ONE multi-tensor launch at exit instead of one launch per layer (21 in DOFA + UperNet, 62 in UNet++); the
+    model forwards wrap themselves in it.  Outside of it ``bump`` increments at once."""
+    global _COUNTER_BATCH
+    if _COUNTER_BATCH is not None or not LAUNCH_FUSION:      # nested: the outermost context applies
+        yield
+        return
+    _COUNTER_BATCH = []
+    try:
+        yield
+    finally:
+        pending, _COUNTER_BATCH = _COUNTER_BATCH, None
+        if pending:
+            torch._foreach_add_(pending, 1)
+
+
+def bump(counter: Tensor | None) -> None:
+    if counter is None:
+        return
+    if _COUNTER_BATCH is None:
+        counter.add_(1)
+    else:
+        _COUNTER_BATCH.append(counter)
+
+
+_KEEP_CACHE: dict = {}
+
+
+def drop_path_scales(probs: list[float], batch: int, device) -> list[tuple[Tensor | None, Tensor | None]]:
+    """The per-sample DropPath scales (mask / keep, timm ``drop_path`` with scale_by_keep) of a whole encoder pass, two draws per
+    block (attention branch, MLP branch), from ONE Bernoulli launch and ONE division instead of two launches per draw (46 per
+    DOFA-base step; at the reference's batch of 4 these sub-5-us launches are 2 % of the step).  ``probs[i]`` = block i's drop
+    probability; blocks with probability 0 get (None, None).  Rows of one [2 n, B] tensor, dense."""
+    live = [i for i, p_ in enumerate(probs) if p_ > 0.0]
+    out: list[tuple[Tensor | None, Tensor | None]] = [(None, None)] * len(probs)
+    if not live:
+        return out
+    if not LAUNCH_FUSION:
+        for i in live:
+            out[i] = tuple((torch.empty(batch, device=device, dtype=torch.float32).bernoulli_(1.0 - probs[i]) / (1.0 - probs[i]))
+                           for _ in (0, 1))
+        return out
+    key = (str(device), tuple(probs[i] for i in live))
+    keep = _KEEP_CACHE.get(key)
+    if keep is None:
+        keep = torch.tensor([1.0 - probs[i] for i in live for _ in (0, 1)], dtype=torch.float32, device=device).view(-1, 1)
+        _KEEP_CACHE[key] = keep
+    scales = torch.bernoulli(keep.expand(-1, batch)) / keep
+    for j, i in enumerate(live):
+        out[i] = (scales[2 * j], scales[2 * j + 1])
+    return out
+
+
 def compute_dtype() -> torch.dtype:
     """bf16 MFMA path under ``torch.autocast('cuda', bfloat16/float16)``, exact-f32 MFMA otherwise.
 
@@ -98,6 +161,31 @@ def gemm_weight(weight: Tensor, cd: torch.dtype) -> Tensor:
         w = w if w.is_contiguous() else w.contiguous()
         return w if cd == torch.float32 else ops.cast(w, cd)
     return cached((weight,), f"gemm:{cd}", build)
+
+
+def gemm_weight_shadow(weight: Tensor):
+    """(cache key, bf16 tensor) of ``gemm_weight(weight, bf16)`` when that operand exists and is a plain cast of the parameter's
+    dense storage (same element order) -- then the fused optimizer rewrites it together with the parameter
+    (gdl_multi_adam's `shadow` column) and ``refresh_shadow`` revalidates the cache entry; None otherwise."""
+    key = (f"gemm:{torch.bfloat16}", id(weight))
+    hit = _CACHE.get(key)
+    if hit is None or hit[2][0]() is not weight:
+        return None
+    val = hit[1]
+    if val.dtype != torch.bfloat16 or val.numel() != weight.numel() or not val.is_contiguous() or weight.dtype != torch.float32:
+        return None
+    if weight.dim() == 2:
+        same_order = weight.is_contiguous()
+    else:
+        same_order = weight.dim() == 4 and weight.permute(0, 2, 3, 1).is_contiguous()
+    return (key, val) if same_order else None
+
+
+def refresh_shadow(key, val: Tensor, weight: Tensor) -> None:
+    """After the optimizer rewrote ``weight`` AND its bf16 shadow ``val``: the cache entry is current again."""
+    hit = _CACHE.get(key)
+    if hit is not None and hit[1] is val and hit[2][0]() is weight:
+        _CACHE[key] = ((((weight._version, _RAW_WRITES.get(id(weight), 0), weight.data_ptr())),), val, hit[2])
 
 
 def dgrad_weight(weight: Tensor, cd: torch.dtype) -> Tensor:
@@ -388,8 +476,7 @@ def conv_bn_act_group(items: list[dict]) -> list[Tensor]:
         flat += [it["x"], conv.weight, conv.bias, norm.weight, norm.bias, norm.running_mean, norm.running_var]
     outs = _ConvBNActGroupTrain.apply(tuple(metas), norms[0].process_group, *flat)
     for norm in norms:
-        if norm.num_batches_tracked is not None:
-            norm.num_batches_tracked.add_(1)
+        bump(norm.num_batches_tracked)
     return list(outs)
 
 
@@ -515,8 +602,7 @@ def concat_resize_conv_bn_act(levels: list[Tensor], conv: nn.Conv2d, norm: nn.Mo
     momentum = 0.1 if norm.momentum is None else norm.momentum
     out = _ConcatResizeConvBNTrain.apply(conv.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var, momentum,
                                          norm.eps, relu, sync_group, *levels)
-    if norm.num_batches_tracked is not None:
-        norm.num_batches_tracked.add_(1)
+    bump(norm.num_batches_tracked)
     return out
 
 
@@ -620,8 +706,7 @@ def pyramid_fuse_bn_act(levels: list[Tensor], conv: nn.Conv2d, norm: nn.Module, 
         momentum = 0.1 if norm.momentum is None else norm.momentum
         out = _PyramidFuseBNTrain.apply(conv.weight, norm.weight, norm.bias, norm.running_mean, norm.running_var,
                                         momentum, norm.eps, relu, sync_group, *levels)
-        if norm.num_batches_tracked is not None:
-            norm.num_batches_tracked.add_(1)
+        bump(norm.num_batches_tracked)
         return out
     if torch.is_grad_enabled() and (conv.weight.requires_grad or any(lv.requires_grad for lv in levels)):
         msg = ("gdlhip: autograd through eval-mode BatchNorm is not implemented; call under "
@@ -676,8 +761,7 @@ def conv_bn_act(x: Tensor, conv: nn.Conv2d, norm: nn.Module, *, relu: bool = Tru
         out = _ConvBNActTrain.apply(x, conv.weight, conv.bias, norm.weight, norm.bias,
                                     norm.running_mean, norm.running_var, momentum, norm.eps, pad,
                                     relu, sync_group, up4)
-        if norm.num_batches_tracked is not None:
-            norm.num_batches_tracked.add_(1)
+        bump(norm.num_batches_tracked)
         return out
     if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
         msg = ("gdlhip: autograd through eval-mode BatchNorm is not implemented; call under "
@@ -905,6 +989,9 @@ class FusedAdam(torch.optim.Optimizer):
         self._acc = None
         self._tables: dict = {}      # param group index -> (address signature, device chunk table)
         self.table_builds = 0        # how often a chunk table was (re)built: 1 per group in steady state
+        # bf16 GEMM operands of the parameters (gemm_weight cache) are rewritten by the update kernel itself
+        self.shadows = LAUNCH_FUSION
+        self._shadowed: list = []
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -917,6 +1004,7 @@ class FusedAdam(torch.optim.Optimizer):
         # rebuilt (535 rows for DOFA-base + one H2D copy) only when a parameter, gradient or state buffer moved -- with
         # gradient_as_bucket_view / set_to_none=False and a caching allocator that is the first step only
         buckets: dict = {}
+        shadowed: list = []
         for gi, group, p in todo:
             st = self.state[p]
             if not st:
@@ -928,15 +1016,19 @@ class FusedAdam(torch.optim.Optimizer):
                 p.grad = _restride(p.grad, p)
             _flat(p), _flat(p.grad)  # layout check (dense storage)
             sig = buckets.setdefault((gi, st["step"]), [])
-            sig.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()))
+            sh = gemm_weight_shadow(p) if self.shadows else None
+            if sh is not None:
+                shadowed.append((sh[0], sh[1], p))     # the tensor is held: the table's address stays valid
+            sig.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                        0 if sh is None else sh[1].data_ptr()))
             mark_updated(p)
         tables = {}
         for key, sig in buckets.items():
             sig = tuple(sig)
             hit = self._tables.get(key[0])
             if hit is None or hit[0] != sig:
-                rows = [(pp + 4 * off, gp + 4 * off, mp + 4 * off, vp + 4 * off, min(self.CHUNK, n - off))
-                        for pp, gp, mp, vp, n in sig for off in range(0, n, self.CHUNK)]
+                rows = [(pp + 4 * off, gp + 4 * off, mp + 4 * off, vp + 4 * off, min(self.CHUNK, n - off), sp + 2 * off if sp else 0)
+                        for pp, gp, mp, vp, n, sp in sig for off in range(0, n, self.CHUNK)]
                 host = torch.tensor(rows, dtype=torch.int64)
                 if self.capturable:
                     # under stream capture nothing may be allocated (pinned or device): both buffers exist since the first
@@ -970,6 +1062,9 @@ class FusedAdam(torch.optim.Optimizer):
                 ops.multi_adam_dev(t, self._dev_state[gi], clip)
             else:
                 ops.multi_adam(t, group["lr"], *group["betas"], group["eps"], group["weight_decay"], step, clip)
+        self._shadowed = shadowed
+        for key, val, p in shadowed:      # the kernels above rewrote the bf16 GEMM operands too
+            refresh_shadow(key, val, p)
         return loss
 
     def device_state(self, gi: int, dev=None) -> Tensor:

@@ -235,12 +235,17 @@ class Block(nn.Module):
             mask = torch.empty(batch, device=device, dtype=torch.float32).bernoulli_(keep)
         return (mask.to(device=device, dtype=torch.float32) / keep).contiguous()
 
-    def forward(self, x: Tensor, masks: tuple[Tensor, Tensor] | None = None) -> Tensor:
-        """x: f32 [B, N, D] token stream.  ``masks`` pins the two DropPath draws (tests).
+    def forward(self, x: Tensor, masks: tuple[Tensor, Tensor] | None = None,
+                scales: tuple[Tensor | None, Tensor | None] | None = None) -> Tensor:
+        """x: f32 [B, N, D] token stream.  ``masks`` pins the two DropPath draws (tests); ``scales`` = the two per-sample
+        scales already drawn for this block (gdlhip.nn.drop_path_scales: one launch for the whole encoder).
         One autograd node per block (gdlhip.tnn._VitBlock): forward and backward are HIP kernels."""
         b = x.shape[0]
-        s1 = self._drop_scale(b, x.device, None if masks is None else masks[0])
-        s2 = self._drop_scale(b, x.device, None if masks is None else masks[1])
+        if scales is not None and masks is None:
+            s1, s2 = scales
+        else:
+            s1 = self._drop_scale(b, x.device, None if masks is None else masks[0])
+            s2 = self._drop_scale(b, x.device, None if masks is None else masks[1])
         at, m = self.attn, self.mlp
         prm = (self.norm1.weight, self.norm1.bias, at.qkv.weight, at.qkv.bias, at.proj.weight, at.proj.bias,
                self.ls1.gamma, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
@@ -458,8 +463,11 @@ class DOFAv2(nn.Module):
         cols = ops.patchify(ops.image_f32(x, "DOFAv2"), k, 1, gh, gw, wq.shape[1], cd)
         # cls token rows (no pos-embed: dofa_v2.py:447-452), then patch GEMM + bias + pos_embed[1:]
         tok = tnn.dofa_tokens(cols.view(b, n, -1), wq, bias, self.cls_token, self.pos_embed)
+        scales = None
+        if self.training and drop_masks is None:      # every DropPath draw of the pass in one launch
+            scales = gnn.drop_path_scales([blk.drop_prob for blk in self.blocks], b, tok.device)
         for i, blk in enumerate(self.blocks):
-            tok = blk(tok, None if drop_masks is None else drop_masks[i])
+            tok = blk(tok, None if drop_masks is None else drop_masks[i], None if scales is None else scales[i])
             yield i, tok
 
     def forward_features_nhwc(self, x: Tensor, wavelengths: Tensor, drop_masks=None) -> list[Tensor]:

@@ -117,11 +117,15 @@ class Block(nn.Module):
             prm += [at.sr.weight, at.sr.bias, at.norm.weight, at.norm.bias]
         return tuple(prm)
 
-    def forward(self, x: Tensor, h: int, w: int, masks=None) -> Tensor:
-        """x: f32 token stream [B, N, C]; ``masks`` pins the two DropPath draws (tests)."""
+    def forward(self, x: Tensor, h: int, w: int, masks=None, scales=None) -> Tensor:
+        """x: f32 token stream [B, N, C]; ``masks`` pins the two DropPath draws (tests); ``scales`` = the two per-sample
+        scales already drawn for this block (gdlhip.nn.drop_path_scales: one launch for the whole encoder)."""
         b = x.shape[0]
-        s1 = _drop_scale(self.drop_prob, self.training, b, x.device, None if masks is None else masks[0])
-        s2 = _drop_scale(self.drop_prob, self.training, b, x.device, None if masks is None else masks[1])
+        if scales is not None and masks is None:
+            s1, s2 = scales
+        else:
+            s1 = _drop_scale(self.drop_prob, self.training, b, x.device, None if masks is None else masks[0])
+            s2 = _drop_scale(self.drop_prob, self.training, b, x.device, None if masks is None else masks[1])
         at = self.attn
         eps_sr = at.norm.eps if at.sr_ratio > 1 else 0.0
         return tnn.mit_block(x, s1, s2, h, w, at.num_heads, at.sr_ratio, self.norm1.eps, eps_sr, gnn.compute_dtype(),
@@ -214,10 +218,14 @@ class MixVisionTransformer(nn.Module):
         cd = gnn.compute_dtype()
         b = x.shape[0]
         outs, bi = [], 0
+        scales = None
+        if self.training and drop_masks is None:      # every DropPath draw of the pass in one launch
+            blocks = [blk for i in range(4) for blk in getattr(self, f"block{i + 1}")]
+            scales = gnn.drop_path_scales([blk.drop_prob for blk in blocks], b, x.device)
         for i in range(4):
             tok, h, w = self._embed(i)(x)
             for blk in getattr(self, f"block{i + 1}"):
-                tok = blk(tok, h, w, None if drop_masks is None else drop_masks[bi])
+                tok = blk(tok, h, w, None if drop_masks is None else drop_masks[bi], None if scales is None else scales[bi])
                 bi += 1
             x = tnn.layernorm(tok, getattr(self, f"norm{i + 1}"), cd).view(b, h, w, -1)
             outs.append(x)

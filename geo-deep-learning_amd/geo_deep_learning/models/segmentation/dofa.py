@@ -48,8 +48,9 @@ class DOFASegmentationModel(BaseSegmentationModel):
                 aux_drop_mask: torch.Tensor | None = None) -> SegmentationOutput:
         """dofa.py:83-107.  ``drop_masks`` / ``aux_drop_mask`` pin the stochastic draws (tests)."""
         image_size = x.shape[2:]
-        feats = self.neck.forward_nhwc(self.encoder.forward_features_nhwc(x, wavelengths, drop_masks))
-        dec = self.decoder.forward_nhwc(feats)
-        out = self.head.forward_logits(dec, image_size)
-        aux = self.aux_head.forward_logits(feats[-1], image_size, aux_drop_mask)
+        with gnn.counter_batch():       # the BatchNorm step counters of the pass advance in one launch
+            feats = self.neck.forward_nhwc(self.encoder.forward_features_nhwc(x, wavelengths, drop_masks))
+            dec = self.decoder.forward_nhwc(feats)
+            out = self.head.forward_logits(dec, image_size)
+            aux = self.aux_head.forward_logits(feats[-1], image_size, aux_drop_mask)
         return self.output_struct(out=out, aux=aux)

@@ -6,6 +6,7 @@ import torch
 
 from geo_deep_learning.models.decoders.segformer_mlp import Decoder
 from geo_deep_learning.models.encoders.mix_transformer import DynamicMixTransformer, get_encoder
+from gdlhip import nn as gnn
 
 from .base import BaseSegmentationModel
 
@@ -26,5 +27,6 @@ class SegFormerSegmentationModel(BaseSegmentationModel):
         self.decoder = Decoder(encoder=encoder, num_classes=num_classes)
 
     def forward(self, img: torch.Tensor, drop_masks=None, dec_drop_mask: torch.Tensor | None = None) -> torch.Tensor:
-        feats = self.encoder.forward_nhwc(img, drop_masks)
-        return self.decoder.forward_logits(feats, img.shape[2:], dec_drop_mask)
+        with gnn.counter_batch():       # the BatchNorm step counters of the pass advance in one launch
+            feats = self.encoder.forward_nhwc(img, drop_masks)
+            return self.decoder.forward_logits(feats, img.shape[2:], dec_drop_mask)

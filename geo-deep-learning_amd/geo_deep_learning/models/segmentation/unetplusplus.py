@@ -176,5 +176,6 @@ class UnetPlusPlus(nn.Module):
         if x.shape[2] % 32 or x.shape[3] % 32:
             msg = f"Wrong input shape height={x.shape[2]}, width={x.shape[3]}: must be divisible by 32"   # smp's check
             raise RuntimeError(msg)
-        dec = self.decoder.forward_nhwc(self.encoder.forward_nhwc(x))
-        return cnn.logits_nchw(cnn.conv_bias(dec, self.segmentation_head[0]))
+        with gnn.counter_batch():       # the BatchNorm step counters of the pass advance in one launch
+            dec = self.decoder.forward_nhwc(self.encoder.forward_nhwc(x))
+            return cnn.logits_nchw(cnn.conv_bias(dec, self.segmentation_head[0]))

@@ -446,8 +446,10 @@ int gdl_sumsq(const float* x, int64_t n, float* out_accum, gdl_stream_t stream);
 /* coef = min(1, max_norm / (sqrt(sumsq) + 1e-6))  (torch.nn.utils.clip_grad_norm_) */
 int gdl_clip_coef(const float* sumsq, float max_norm, float* coef, gdl_stream_t stream);
 /* Multi-tensor forms: ONE launch for all parameter tensors.  `table` is a DEVICE array of
- * nchunks rows {param*, grad*, exp_avg*, exp_avg_sq*, count} (int64 each; pointers already offset
- * to the chunk, count <= 65536; all f32 dense).  step-wide bias corrections bc1/bc2. */
+ * nchunks rows {param*, grad*, exp_avg*, exp_avg_sq*, count, shadow*} (int64 each; pointers already offset
+ * to the chunk, count <= 65536; all f32 dense; shadow = 0 or a bf16 copy of the parameter in the same element order, which
+ * the update rewrites with the new values -- the compute-dtype GEMM operand of the next forward, so that no per-parameter
+ * cast runs between steps).  step-wide bias corrections bc1/bc2. */
 int gdl_multi_sumsq(const int64_t* table, int nchunks, float* out_accum, gdl_stream_t stream);
 int gdl_multi_adam(const int64_t* table, int nchunks, float lr, float beta1, float beta2, float eps,
                    float weight_decay, float bc1, float bc2, const float* clip_coef,

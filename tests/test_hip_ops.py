@@ -600,6 +600,56 @@ def test_adam_and_clip():
         assert (m.detach().cpu() - r.detach()).abs().max().item() < 4e-6
 
 
+def test_adam_rewrites_the_bf16_gemm_operands(monkeypatch):
+    """The optimizer's update kernel also rewrites the bf16 GEMM operand of each parameter (gnn.gemm_weight's cache entry), so
+    the next forward finds it current: bit-identical to a fresh cast of the new parameter, no cast launch, and a parameter
+    whose operand is NOT a plain cast (stored NCHW: the operand is a repack) keeps the rebuild-on-use path."""
+    torch.manual_seed(1)
+    lin = torch.randn(96, 200, device=DEV).requires_grad_(True)                                        # nn.Linear weight
+    cl = torch.randn(64, 32, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    nchw = torch.randn(64, 32, 3, 3, device=DEV).requires_grad_(True)
+    params = [lin, cl, nchw]
+    opt = gnn.FusedAdam(params, lr=1e-2)
+    first = [gnn.gemm_weight(p, torch.bfloat16) for p in params]      # what a forward under bf16 autocast creates
+    casts = []
+    real_cast = ops.cast
+    monkeypatch.setattr(ops, "cast", lambda *a, **k: (casts.append(1), real_cast(*a, **k))[1])
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    for step in range(3):
+        for p in params:
+            p.grad.copy_(torch.randn_like(p))
+        opt.step()
+        casts.clear()
+        now = [gnn.gemm_weight(p, torch.bfloat16) for p in params]
+        assert len(casts) == 1, casts                                  # only the NCHW-stored parameter is re-cast
+        assert now[0] is first[0] and now[1] is first[1] and now[2] is not first[2]
+        assert torch.equal(now[0], lin.detach().to(torch.bfloat16))
+        assert torch.equal(now[1], cl.detach().permute(0, 2, 3, 1).reshape(64, -1).to(torch.bfloat16))
+        assert torch.equal(now[2], nchw.detach().permute(0, 2, 3, 1).reshape(64, -1).to(torch.bfloat16))
+    assert opt.table_builds == 1
+    # a parameter rewritten by someone else (load_state_dict, manual copy_) invalidates the operand as before
+    with torch.no_grad():
+        lin.mul_(2.0)
+    assert torch.equal(gnn.gemm_weight(lin, torch.bfloat16), lin.detach().to(torch.bfloat16))
+
+
+def test_drop_path_scales_one_launch_per_pass():
+    """gnn.drop_path_scales: all DropPath draws of an encoder pass at once -- rows are mask / keep with the block's own keep
+    probability (timm drop_path, scale_by_keep), None for blocks that never drop."""
+    torch.manual_seed(0)
+    probs = [0.0, 0.05, 0.5]
+    out = gnn.drop_path_scales(probs, 20000, torch.device(DEV))
+    assert out[0] == (None, None)
+    for p_, pair in zip(probs[1:], out[1:]):
+        for t in pair:
+            assert t.shape == (20000,) and t.is_contiguous() and t.dtype == torch.float32
+            vals = t.unique().cpu()
+            assert torch.allclose(vals, torch.tensor([0.0, 1.0 / (1.0 - p_)]))
+            assert abs((t > 0).float().mean().item() - (1.0 - p_)) < 0.02
+    assert not torch.equal(out[2][0], out[2][1])
+
+
 def test_patch_embed_pieces():
     B, C, H, P, D = 2, 3, 56, 14, 64
     img = rnd(B, C, H, H)

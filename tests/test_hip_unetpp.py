@@ -176,6 +176,8 @@ def test_unetpp_train_step_matches_oracle():
     for n, b in m.named_buffers():
         if n.endswith(("running_mean", "running_var")):
             assert torch.allclose(b.cpu(), rb[n], atol=1e-4, rtol=1e-4), n
+        if n.endswith("num_batches_tracked"):      # advanced by ONE multi-tensor launch at the end of the forward (gnn.counter_batch)
+            assert int(b) == int(rb[n]) == 1, n
 
 
 def test_unetpp_train_bf16_descends():

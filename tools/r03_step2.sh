@@ -1,10 +1,12 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03b
-mkdir -p $O
-cd $R
-timeout 900 python -m pytest tests/test_hip_ops.py -x -q -m gpu -k "resize or up4 or resized or concat or tap" 2>&1 | tail -15 > $O/pytest_ops.txt
-cat $O/pytest_ops.txt
-timeout 300 python tools/bench_tapsum.py 2>&1 | tee $O/bench_tapsum.txt
-timeout 600 python bench.py --no-cpu-baseline --no-extras 2>$O/bench.err | tail -1 > $O/bench.json
-cut -c1-900 $O/bench.json
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r03aa}; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests/test_hip_ops.py tests/test_hip_unetpp.py tests/test_hip_tasks.py -m gpu -x -q -k "adam or drop_path or unetpp_train or graphed or task or ddp" 2>&1 | tail -8 | cut -c1-300 > $O/pytest.txt
+cat $O/pytest.txt
+for b in 32 4; do
+timeout 600 python bench.py --batch $b --no-cpu-baseline --no-extras --no-kernel-timer --no-input-stage 2>/dev/null | tail -1 > $O/bench_b$b.json
+python - <<PY
+import json
+d=json.loads(open("$O/bench_b$b.json").read())
+print("batch $b: train %.1f tiles/s (%.2f ms), inference %.1f tiles/s (%.2f ms)" % (d["value"], d["ms_per_step"], d["inference_tiles_per_s"], d["inference_ms_per_step"]))
+PY
+done
