@@ -254,6 +254,140 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, round 3
+// Same tiles, operands and arithmetic as flash_fwd2_kernel (bit-identical results with defer = 0), but a wave owns ONE
+// 32-query tile and four waves share a SIMD (<= 128 registers).  Why: at head dim 64 the softmax costs more VALU cycles
+// (max, scale, exp2, row sum, bf16 pack: ~230 issue slots per 32 x 64 scores, exp2 at quarter rate) than its two GEMMs cost
+// matrix cycles (16 MFMAs), and the chip holds ~1.7 GHz under this load -- the kernel is VALU-bound, and what was missing
+// with two 64-query waves per SIMD was overlap: each wave runs S -> softmax -> PV as one dependent chain behind a per-tile
+// barrier, so the matrix pipe idled while both waves did softmax and the VALU idled while both waited for MFMAs or LDS
+// (PMC, round 2: MFMA busy 28 %, VALU busy 54 %).  Four shorter chains per SIMD interleave: 278 -> 240 us at batch 32
+// (N = 1297, 12 heads), 60 -> 47 us at batch 4.  Costs: every K / V fragment read from the LDS feeds one MFMA instead of
+// two (LDS read traffic doubles, still < 50 % of the LDS rate here) and blocks of 128 queries stage K / V twice as often.
+// Tried and measured, not kept: staggering the two query tiles of a 64-query wave (S0 S1 | softmax0 | PV0 | softmax1 |
+// PV1, fragments held in registers: 278 -> 268 us); v_pk_fma_f32 / v_pk_add_f32 for the exponent arguments and row sums
+// (20 % fewer VALU instructions, no time: packed f32 issues at half rate); eight-wave blocks of 256 queries (244 us).
+// `defer` > 0: the running maximum is only raised (and O rescaled) when some row's tile maximum exceeds it by more than
+// `defer` in the exp2 domain -- P stays below 2^defer; with the usual slowly growing maxima most tiles skip the rescale.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void flash_fwd3_kernel(const Attn2Args f, const float defer) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];   // stage s: K at 2s, V at 2s+1
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int blk, bh;
+  decode_block((f.Nq + 32 * NW - 1) / (32 * NW), f.B * f.H, blk, bh);
+  const int b = bh / f.H, h = bh % f.H;
+  const int q0 = blk * (32 * NW) + wave * 32;
+  const bool active = q0 < f.Nq;                                   // wave-uniform; idle waves still stage and sync
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const uint16_t* qbase = f.q + (int64_t)b * f.q_sB + (int64_t)h * 64;
+  const srd_t srd_k = make_srd(f.k + (int64_t)b * f.k_sB + (int64_t)h * 64, (unsigned)(((int64_t)f.N - 1) * f.k_sN * 2 + 128));
+  const srd_t srd_v = make_srd(f.v + (int64_t)b * f.v_sB + (int64_t)h * 64, (unsigned)(((int64_t)f.N - 1) * f.v_sN * 2 + 128));
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+
+  bf16x8_t qf[4];   // B operand of S^T: lane (query frow, half) holds channels 16kk + 8 half ..
+  {
+    const int q = q0 + frow;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < f.Nq) v = *(const uint4*)(qbase + (int64_t)q * f.q_sN + kk * 16 + fhalf * 8);
+      qf[kk] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+  auto issue = [&](int stage, int kv0) {   // 8 + 8 pieces per tile pair, dealt round-robin to the NW waves
+#pragma unroll
+    for (int i = 0; i < (8 + NW - 1) / NW; ++i) {
+      const int p = wave + NW * i;
+      if (p < 8) {
+        stage_piece(srd_k, f.k_sN * 2, kv0, f.N, p, lds_base + (2 * stage) * TILE_BYTES, lane);
+        stage_piece(srd_v, f.v_sN * 2, kv0, f.N, p, lds_base + (2 * stage + 1) * TILE_BYTES, lane);
+      }
+    }
+  };
+  f32x16_t ot[2] = {zero16(), zero16()};   // O^T accumulators [channel tile]: rows = channels, column = query
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sl2 = f.scale_log2e;
+  const int ntiles = (f.N + 63) / 64;
+  issue(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles) issue((t + 1) & 1, (t + 1) * 64);
+    if (!active) continue;
+    const unsigned char* sk = smem + (2 * (t & 1)) * TILE_BYTES;
+    const unsigned char* sv = sk + TILE_BYTES;
+    // ---- S^T[key, query] = K . Q^T for two key row tiles
+    f32x16_t st[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) st[kt] = MFMA(row_frag(sk, kt, kk, lane), qf[kk], st[kt]);
+    // ---- online softmax per query (lane + partner lane^32 hold its 64 scores of this tile)
+    if (t == ntiles - 1) {   // only the last tile can hold keys >= N
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+          st[kt][r] = key < f.N ? st[kt][r] : -INFINITY;
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float m_new = fmaxf(m_run, mx);
+    if (defer > 0.f && __all((m_new - m_run) * sl2 <= defer)) m_new = m_run;   // (-inf start: never deferred)
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
+    m_run = m_new;
+    const float mc = m_new * sl2;
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], sl2, -mc));
+        st[kt][r] = p;
+        lsum += p;
+      }
+    l_run = l_run * alpha + lsum;
+    if (!__all(alpha == 1.f)) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[ct][r] *= alpha;
+    }
+    // ---- O^T[ch, query] += V^T . P^T : A = transposed V fragments, B = the probabilities in registers
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const bf16x8_t pb = acc_as_b(st[kt], sl);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) ot[ct] = MFMA(col_frag(sv, ct, kt, sl, lane), pb, ot[ct]);
+      }
+  }
+  if (!active) return;
+  const float l = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l;
+  const int q = q0 + frow;
+  if (q >= f.Nq) return;
+  if (f.lse && fhalf == 0)
+    f.lse[(int64_t)bh * f.Nq + q] = (m_run * sl2 + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+  uint16_t* orow = f.out + (int64_t)b * f.o_sB + (int64_t)q * f.o_sN + (int64_t)h * 64;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = ct * 32 + 8 * g + 4 * fhalf;
+      *(uint2*)(orow + d) = make_uint2(pack_bf16x2(ot[ct][4 * g] * inv, ot[ct][4 * g + 1] * inv),
+                                       pack_bf16x2(ot[ct][4 * g + 2] * inv, ot[ct][4 * g + 3] * inv));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward, part 0
 // dvec[b,h,q] = sum_d dO[q,d] * O[q,d]: one wave per (b, q) row, lane = channel within a head
 __global__ __launch_bounds__(256) void flash_bwd_dot_kernel(const Attn2Args f) {
@@ -508,7 +642,12 @@ int dkv_qsplit(int B, int H, int Nq, int Nkv) {
 
 bool strides_ok(int64_t a, int64_t b) { return a % 8 == 0 && b % 8 == 0; }
 
+int g_flash_fwd = 3;          // A/B hook (gdl_debug_set_flash_fwd): 2 = the round-2 kernel (64-query waves), 3 = 32-query waves
+float g_flash_defer = 6.f;    // deferred running maximum (see flash_fwd3_kernel); 0 = exact online softmax, bit-identical to 2
+
 }  // namespace
+
+extern "C" void gdl_debug_set_flash_fwd(int version, float defer) { g_flash_fwd = version; g_flash_defer = defer; }
 
 extern "C" int gdl_flash_attn_fwd2(const void* q, int64_t q_sB, int64_t q_sN, const void* k, int64_t k_sB, int64_t k_sN,
                                    const void* v, int64_t v_sB, int64_t v_sN, void* o, int64_t o_sB, int64_t o_sN,
@@ -529,7 +668,10 @@ extern "C" int gdl_flash_attn_fwd2(const void* q, int64_t q_sB, int64_t q_sN, co
   // less-padded 3-wave blocks at N = 1297), fewer only when the whole query range is shorter than that
   const int nw = Nq > 128 ? 4 : 2;
   const unsigned grid = (unsigned)((Nq + 64 * nw - 1) / (64 * nw) * B * H);
-  if (nw == 4) hipLaunchKernelGGL(flash_fwd2_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, f);
+  if (g_flash_fwd >= 3) {      // 32-query waves, four per SIMD
+    if (Nq > 64) hipLaunchKernelGGL(flash_fwd3_kernel<4>, dim3((unsigned)((Nq + 127) / 128 * B * H)), dim3(256), 0, (hipStream_t)stream, f, g_flash_defer);
+    else hipLaunchKernelGGL(flash_fwd3_kernel<2>, dim3((unsigned)((Nq + 63) / 64 * B * H)), dim3(128), 0, (hipStream_t)stream, f, g_flash_defer);
+  } else if (nw == 4) hipLaunchKernelGGL(flash_fwd2_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, f);
   else hipLaunchKernelGGL(flash_fwd2_kernel<2>, dim3(grid), dim3(128), 0, (hipStream_t)stream, f);
   GDL_CHECK_LAUNCH("gdl_flash_attn_fwd2");
   return GDL_OK;

@@ -314,6 +314,43 @@ def test_attention_flash_lse_and_fused_backward(B, Nq, Nkv, H):
     close(dkv, dkv2, dtype, "fused vs materialised dkv")
 
 
+@pytest.mark.parametrize("B,Nq,Nkv,H", [(2, 70, 70, 2), (1, 1297, 1297, 4), (2, 333, 100, 4), (1, 64, 257, 3), (2, 4096, 256, 1), (1, 33, 65, 1)])
+def test_attention_flash_forward_kernels_agree(B, Nq, Nkv, H):
+    """The round-3 forward (32-query waves, four per SIMD) against the round-2 kernel (64-query waves): with the exact online
+    softmax (defer 0) outputs and LSE are BIT-IDENTICAL (same MFMAs in the same order, same f32 arithmetic); with the deferred
+    running maximum (the default: the maximum is only raised when a tile exceeds it by more than 2^6) they agree to bf16
+    rounding, also when one late key dominates a row (forces the rescale branch after many deferred tiles)."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_set_flash_fwd.argtypes = [ctypes.c_int, ctypes.c_float]
+    dtype, hd = torch.bfloat16, 64
+    D = H * hd
+    qh = rnd(B, Nq, D) * 1.2
+    kvh = rnd(B, Nkv, 2 * D, seed=1) * 1.2
+    qh[0, Nq // 2, :hd] = 4.0
+    kvh[0, Nkv - 3, :hd] = 4.0            # a late key aligned with that query: score 128 after many small tiles
+    qd, kvd = q(qh, dtype).to(DEV, dtype), q(kvh, dtype).to(DEV, dtype)
+    outs = {}
+    try:
+        for tag, ver, defer in (("r2", 2, 0.0), ("r3 exact", 3, 0.0), ("r3 deferred", 3, 6.0)):
+            lib.gdl_debug_set_flash_fwd(ver, defer)
+            outs[tag] = ops.attention_flash(qd, kvd[..., :D], kvd[..., D:], H, return_lse=True)
+    finally:
+        lib.gdl_debug_set_flash_fwd(3, 6.0)
+    assert torch.equal(outs["r3 exact"][0], outs["r2"][0]) and torch.equal(outs["r3 exact"][1], outs["r2"][1])
+
+    def heads(t, n):
+        return t.float().cpu().reshape(B, n, H, hd).transpose(1, 2)
+    sc = heads(qd, Nq) @ heads(kvd[..., :D], Nkv).transpose(-1, -2) * hd ** -0.5
+    ref = (sc.softmax(-1) @ heads(kvd[..., D:], Nkv)).transpose(1, 2).reshape(B, Nq, D)
+    close(outs["r3 deferred"][0], ref, dtype, "deferred-maximum forward")
+    close(outs["r3 deferred"][1], torch.logsumexp(sc, -1), torch.float32, "deferred-maximum lse", scale=max(1.0, sc.abs().max().item()) * 20)
+    err2 = (outs["r2"][0].float().cpu() - ref).abs().max().item()
+    err3 = (outs["r3 deferred"][0].float().cpu() - ref).abs().max().item()
+    assert err3 <= 2.0 * err2 + 1e-3, (err2, err3)
+
+
 def test_attention_flash_spike():
     """one dominant key late in the sequence forces the online-softmax rescale branch."""
     B, N, H, hd = 1, 300, 1, 64
