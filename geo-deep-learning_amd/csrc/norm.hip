@@ -266,6 +266,72 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const void* __restrict__ x
   }
 }
 
+// bf16, dense rows, C % 8 == 0 and C / 8 a divisor of the block size: the same sums with 16-BYTE loads -- thread t owns the
+// eight channels 8 (t % G) of pixel row t / G (G = C / 8 lanes cover one pixel), so a block reads whole contiguous pixel rows
+// and a lane's channels never change; four row groups in flight.  The 8-byte / 256-channel mapping above reached 3.4 TB/s on
+// the decoder's maps (2 x 1 GB for the neck x4 level); this one 5.0-5.9 TB/s (tools/bench_bn.py).  The element-wise passes
+// (apply, dx) gain nothing from the same mapping -- they are bound by their writes at ~5.0 TB/s either way (measured, not kept).
+__device__ __forceinline__ void unpack8(const uint4& v, float (&o)[8]) {
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+  o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+template <int TPB>
+__global__ __launch_bounds__(TPB) void bn_bwd_partial8(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t P,
+                                                       int C, const float* __restrict__ mean, const float* __restrict__ var,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                       int relu, float* __restrict__ ws) {
+  __shared__ float red[2][TPB][9];          // [sum | sum * xhat][thread][channel] (+1: bank spread)
+  const int G = C >> 3, R = TPB / G;        // lanes per pixel, pixel rows per block step
+  const int t = threadIdx.x, g = t % G, prow = t / G;
+  const int nsplit = gridDim.x;
+  const int64_t per = (P + nsplit - 1) / nsplit;
+  const int64_t p0 = per * blockIdx.x, p1 = p0 + per < P ? p0 + per : P;
+  float s[8], q[8], sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = 8 * g + j;
+    s[j] = 0.f; q[j] = 0.f;
+    mu[j] = mean[c]; rs[j] = rsqrtf(var[c] + eps);
+    sc[j] = gamma[c]; sh[j] = beta[c];
+  }
+  auto add = [&](const uint4& xv, const uint4& gv) {
+    float v[8], d[8];
+    unpack8(xv, v); unpack8(gv, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (v[j] - mu[j]) * rs[j];
+      const float gg = (relu && !(xh * sc[j] + sh[j] > 0.f)) ? 0.f : d[j];
+      s[j] += gg; q[j] += gg * xh;
+    }
+  };
+  if (prow < R) {
+    int64_t p = p0 + prow;
+    for (; p + 3 * R < p1; p += 4 * R) {
+      uint4 xv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = *(const uint4*)(x + (p + (int64_t)u * R) * C + 8 * g);
+        gv[u] = *(const uint4*)(dy + (p + (int64_t)u * R) * C + 8 * g);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) add(xv[u], gv[u]);
+    }
+    for (; p < p1; p += R) add(*(const uint4*)(x + p * C + 8 * g), *(const uint4*)(dy + p * C + 8 * g));
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[0][t][j] = s[j]; red[1][t][j] = q[j]; }
+  __syncthreads();
+  for (int c = t; c < C; c += TPB) {
+    float ss = 0.f, qq = 0.f;
+    for (int r = 0; r < R; ++r) { ss += red[0][r * G + (c >> 3)][c & 7]; qq += red[1][r * G + (c >> 3)][c & 7]; }
+    ws[((int64_t)blockIdx.x * 2 + 0) * C + c] = ss;
+    ws[((int64_t)blockIdx.x * 2 + 1) * C + c] = qq;
+  }
+}
+
 __global__ void bn_bwd_final(const float* __restrict__ ws, int nsplit, int C, float* __restrict__ dgamma,
                              float* __restrict__ dbeta) {
   __shared__ double ps[64][4], pq[64][4];
@@ -331,6 +397,8 @@ int bn_ew_splits(int64_t P, int C) {
   return (int)n;
 }
 
+int g_bn_wide = 1;     // A/B hook (gdl_debug_set_bn_wide): 0 = the 8-byte / 256-channel mapping for every shape
+
 int bn_nsplit(int64_t P, int C) {
   // ~2048 blocks in total (8 per CU): these reductions are HBM-bound and need many waves in flight
   const int cg = (C + 255) / 256;
@@ -341,6 +409,8 @@ int bn_nsplit(int64_t P, int C) {
 }
 
 }  // namespace
+
+extern "C" void gdl_debug_set_bn_wide(int on) { g_bn_wide = on; }
 
 extern "C" int gdl_layernorm_fwd(const float* x, int64_t x_stride, const float* gamma,
                                  const float* beta, void* y, int y_dtype, int64_t rows, int D, float eps,
@@ -419,9 +489,17 @@ extern "C" int gdl_bn_bwd_reduce(const void* x, const void* dy, int dtype, int64
   GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && dy_sP % 4 == 0, "gdl_bn_bwd_reduce: C/strides % 4");
   GDL_CHECK_ARG(ws_bytes >= gdl_bn_stats_workspace(P, C), "gdl_bn_bwd_reduce: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  const int nsplit = bn_nsplit(P, C);
+  int nsplit = bn_nsplit(P, C);
   dim3 grid((C + 255) / 256, nsplit);
-  if (dtype == GDL_BF16)
+  const int G = C / 8;
+  const bool wide = g_bn_wide && dtype == GDL_BF16 && C % 8 == 0 && x_sP == C && dy_sP == C && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 &&
+                    (256 % G == 0 || 192 % G == 0) && P >= 4096;
+  if (wide) {     // one block = whole pixel rows; as many blocks as the workspace has rows (<= 2048, ~8 per CU)
+    if (256 % G == 0)
+      hipLaunchKernelGGL(bn_bwd_partial8<256>, dim3(nsplit), dim3(256), 0, s, (const uint16_t*)x, (const uint16_t*)dy, P, C, mean, var, gamma, beta, eps, relu, ws);
+    else
+      hipLaunchKernelGGL(bn_bwd_partial8<192>, dim3(nsplit), dim3(192), 0, s, (const uint16_t*)x, (const uint16_t*)dy, P, C, mean, var, gamma, beta, eps, relu, ws);
+  } else if (dtype == GDL_BF16)
     hipLaunchKernelGGL(bn_bwd_partial<uint16_t>, grid, dim3(256), 0, s, x, dy, P, C, x_sP, dy_sP, mean, var, gamma, beta, eps, relu, ws);
   else
     hipLaunchKernelGGL(bn_bwd_partial<float>, grid, dim3(256), 0, s, x, dy, P, C, x_sP, dy_sP, mean, var, gamma, beta, eps, relu, ws);

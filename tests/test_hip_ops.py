@@ -376,7 +376,9 @@ def test_layernorm(out_dtype, D):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,W,C", [(2, 9, 7, 64), (2, 1, 1, 256), (3, 24, 24, 128), (2, 31, 9, 32), (1, 17, 23, 320)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 7, 64), (2, 1, 1, 256), (3, 24, 24, 128), (2, 31, 9, 32), (1, 17, 23, 320),
+                                     # >= 4096 pixels: the backward sums take the 16-byte-load kernel when C / 8 divides 256 or 192
+                                     (4, 36, 36, 768), (2, 64, 64, 256), (2, 48, 48, 96), (1, 80, 80, 40), (1, 67, 67, 64)])
 def test_batchnorm_train(dtype, B, H, W, C):
     x = q(rnd(B, H, W, C) * 2 + 0.5, dtype)
     g, b = rnd(C, seed=1), rnd(C, seed=2)

@@ -46,10 +46,28 @@ def logged(x, w, **kw):
     return out
 
 
+orig_w = ops.conv_wgrad
+wrows = collections.OrderedDict()
+
+
+def logged_w(x, dy, **kw):
+    x4 = x if x.dim() == 4 else x.reshape(1, 1, -1, x.shape[-1])
+    d4 = dy if dy.dim() == 4 else dy.reshape(1, 1, -1, dy.shape[-1])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = orig_w(x, dy, **kw)
+    e1.record()
+    key = (*x4.shape, d4.shape[-1], kw.get("R", 1), kw.get("S", 1), kw.get("stride", 1), d4.shape[0] * d4.shape[1] * d4.shape[2])
+    wrows.setdefault(key, []).append((e0, e1))
+    return out
+
+
 ops.conv_gemm = logged
+ops.conv_wgrad = logged_w
 train_step()
 torch.cuda.synchronize()
 ops.conv_gemm = orig
+ops.conv_wgrad = orig_w
 lib = ops._lib.load()
 print(f"{model}, batch {B}: conv_gemm calls of one training step")
 print(f"{'calls':>5} {'B':>3} {'H':>4} {'W':>6} {'C':>5} {'N':>5} RxS/s/p   {'M':>8} {'us/call':>8} {'TF/s':>7}  in->out")
@@ -61,3 +79,12 @@ for k, evs in rows.items():
     fl = 2.0 * M * N * R * S * Cc
     print(f"{len(evs):5d} {Bq:3d} {H:4d} {W:6d} {Cc:5d} {N:5d} {R}x{S}/{stride}/{pad} {M:10d} {us:8.1f} {fl / us / 1e6:7.1f}  {idt}->{odt} {res}")
 print(f"total {tot / 1e3:.2f} ms in conv_gemm (HIP events around single calls: includes launch gaps)")
+print(f"{model}, batch {B}: conv_wgrad calls of one training step (pixels are the reduction dimension)")
+print(f"{'calls':>5} {'B':>3} {'H':>4} {'W':>6} {'C':>5} {'N':>5} RxS/s  {'pixels':>8} {'us/call':>8} {'TF/s':>7}")
+tot = 0.0
+for k, evs in wrows.items():
+    Bq, H, W, Cc, N, R, S, stride, M = k
+    us = sum(a.elapsed_time(b) for a, b in evs) / len(evs) * 1e3
+    tot += us * len(evs)
+    print(f"{len(evs):5d} {Bq:3d} {H:4d} {W:6d} {Cc:5d} {N:5d} {R}x{S}/{stride} {M:10d} {us:8.1f} {2.0 * M * N * R * S * Cc / us / 1e6:7.1f}")
+print(f"total {tot / 1e3:.2f} ms in conv_wgrad (incl. split-K reductions)")
