@@ -464,7 +464,8 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   // the training-only epilogue (aux_out / GELU-grad) does not fit the 256^2 tile's register budget
   const bool extra = a.aux_out != nullptr || a.act == GDL_ACT_MUL_GELU_GRAD;
   const bool ctail = a.C % (a.dtype == GDL_BF16 ? 64 : 32) != 0;   // only the small tiles zero-fill a channel tail
-  if (!extra && !ctail && a.N % 256 == 0 && (t256 >= 512 || (t256 >= 256 && ksteps >= 32)))
+  // (tools/bench_conv_variants.py, batch 32: ViT proj / neck 1x1 768 -> 768 with 486-489 tiles: 256^2 92 / 59 us vs 128^2 101 / 67 us)
+  if (!extra && !ctail && a.N % 256 == 0 && (t256 >= 480 || (t256 >= 256 && ksteps >= 32)))
     return (g_sf_enabled && conv3x3_sf_applicable(a)) ? 4 : 3;   // ping-pong 256^2 (4: 3x3 with shared staging)
   if (t128 >= 256 && a.N >= 128) return 1;
   // narrow outputs (N <= 64: UNet++ decoder, ResNet layer1, MiT stage 1): a 256 (m) x 64 (n) tile, four waves of

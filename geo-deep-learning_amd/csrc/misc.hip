@@ -311,8 +311,8 @@ __global__ __launch_bounds__(256) void head_1x1_bwd_w_partial(const void* __rest
   float accb[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) { accb[k] = 0.f; acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.f; }
-  for (int64_t p = p0 + wv; p < p1; p += 4) {
-    float v[4] = {0, 0, 0, 0};
+  auto load = [&](int64_t p, float (&v)[4]) {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
     if (c < C) {
       if constexpr (sizeof(T) == 4) {
         const float4 t = *(const float4*)((const float*)feat + p * f_sP + c);
@@ -328,6 +328,8 @@ __global__ __launch_bounds__(256) void head_1x1_bwd_w_partial(const void* __rest
         for (int j = 0; j < 4; ++j) v[j] *= cs[j];
       }
     }
+  };
+  auto add = [&](int64_t p, const float (&v)[4]) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const float g = dlog[p * K + k];
@@ -335,6 +337,19 @@ __global__ __launch_bounds__(256) void head_1x1_bwd_w_partial(const void* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[k][j] += g * v[j];
     }
+  };
+  int64_t p = p0 + wv;
+  for (; p + 12 < p1; p += 16) {      // four pixel rows in flight per wave (one at a time ran at 2 TB/s), same summation order
+    float v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load(p + 4 * u, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) add(p + 4 * u, v[u]);
+  }
+  for (; p < p1; p += 4) {
+    float v[4];
+    load(p, v);
+    add(p, v);
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -555,8 +570,7 @@ __global__ __launch_bounds__(256) void dice_final_kernel(const float* __restrict
   const int t = threadIdx.x, v = t & 63, grp = t >> 6;   // 4 groups of 64 value slots (3K <= 48)
   static_assert(3 * K <= 64, "dice_final_kernel: at most 21 classes");
   double s = 0;
-  if (v < 3 * K)
-    for (int i = grp; i < nblk; i += 4) s += ws[(int64_t)i * 3 * K + v];
+  if (v < 3 * K) s = ordered_sum8<double>(grp, nblk, 4, [&](int i) { return ws[(int64_t)i * 3 * K + v]; });   // same order, 8 loads in flight
   part[grp][v] = s;
   __syncthreads();
   if (t < 3 * K) {

@@ -313,6 +313,66 @@ __global__ __launch_bounds__(256) void bilinear_bwd8_kernel(const void* __restri
   }
 }
 
+// Large upsampling factors (UperNet's pyramid pooling: 1x1 .. 6x6 maps resized to 18 x 18, factors 3 .. 18): an input pixel
+// gathers from up to (2 f + 2)^2 output pixels, and the flat kernel above walks that window with ONE thread per 8 channels --
+// 324 dependent 16-byte loads for the 1x1 branch, 1024 threads on the whole chip: 112 us at batch 4, 162 us at batch 32.
+// Here a block owns one input pixel: 32 lanes cover 256 channels, the 8 lane groups split the window rows, LDS adds the
+// eight partial sums in a fixed order.
+__global__ __launch_bounds__(256) void bilinear_bwd8_window_kernel(const void* __restrict__ dout, int Ho, int Wo, int C,
+                                                                   int64_t osB, int64_t osH, int64_t osW, void* din, int Hi,
+                                                                   int Wi, int64_t isB, int64_t isH, int64_t isW, int accumulate) {
+  __shared__ float red[8][32][8];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cl) * 8;
+  int t = blockIdx.y;
+  const int ix = t % Wi; t /= Wi;
+  const int iy = t % Hi;
+  const int b = t / Hi;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  int oy_lo = (int)floorf(((float)iy - 0.5f) / ry - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / ry - 0.5f) + 1;
+  int ox_lo = (int)floorf(((float)ix - 0.5f) / rx - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / rx - 0.5f) + 1;
+  oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+  oy_hi = oy_hi > Ho - 1 ? Ho - 1 : oy_hi; ox_hi = ox_hi > Wo - 1 ? Wo - 1 : ox_hi;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (c < C) {
+    for (int oy = oy_lo + sl; oy <= oy_hi; oy += 8) {
+      int y0, y1; float ly;
+      src_index(ry, oy, Hi, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float lx;
+        src_index(rx, ox, Wi, x0, x1, lx);
+        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx == 0.f) continue;
+        float g[8];
+        V8::ld(dout, (int64_t)b * osB + (int64_t)oy * osH + (int64_t)ox * osW + c, g);
+        const float w = wy * wx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += w * g[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[sl][cl][j] = acc[j];
+  __syncthreads();
+  if (sl != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += red[k][cl][j];
+  const int64_t ioff = (int64_t)b * isB + (int64_t)iy * isH + (int64_t)ix * isW + c;
+  if (accumulate) {
+    float o[8];
+    V8::ld(din, ioff, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += o[j];
+  }
+  V8::st(din, ioff, acc);
+}
+
 // ---- row-structured versions of the two 8-channel kernels: blockIdx.y = (batch, row), so the row decomposition and the
 // vertical source index are per-block scalars and a thread divides once (the flat kernels above spend ~100 VALU
 // instructions of index arithmetic per 16 bytes and ran at 2.3 TB/s; DOFA's resamples are 5.6 % of the train step).
@@ -1395,6 +1455,46 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const void* __restrict
   }
 }
 
+// Large bins (pyramid pooling of an 18 x 18 map into 1 .. 3 bins per side: 36 .. 324 pixels each): the kernel above sums a bin
+// with one thread per 4 channels -- 35 us whatever the batch.  Here 32 lanes cover 128 channels and the block's 8 lane groups
+// split the bin's rows; LDS adds the partial sums in a fixed order.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void avgpool_fwd_split_kernel(const void* __restrict__ in, int Hi, int Wi, int C, int64_t isB,
+                                                                int64_t isH, int64_t isW, void* out, int S) {
+  __shared__ float red[8][32][4];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cl) * 4;
+  int t = blockIdx.y;
+  const int ox = t % S; t /= S;
+  const int oy = t % S;
+  const int b = t / S;
+  int y0, y1, x0, x1;
+  pool_bin(oy, Hi, S, y0, y1);
+  pool_bin(ox, Wi, S, x0, x1);
+  float acc[4] = {0, 0, 0, 0};
+  if (c < C) {
+    for (int y = y0 + sl; y < y1; y += 8)
+      for (int x = x0; x < x1; ++x) {
+        float v[4];
+        V4<TI>::ld(in, (int64_t)b * isB + y * isH + x * isW + c, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j];
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[sl][cl][j] = acc[j];
+  __syncthreads();
+  if (sl != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += red[k][cl][j];
+  const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] *= inv;
+  V4<TO>::st(out, (((int64_t)b * S + oy) * S + ox) * C + c, acc);
+}
+
 template <typename TO_, typename TI_>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const void* __restrict__ dout, int B, int S, int C,
                                                           void* din, int Hi, int Wi, int64_t isB,
@@ -1699,6 +1799,9 @@ extern "C" int gdl_bilinear_bwd(const void* dout, int dout_dtype, int B, int Ho,
                                         Wo, C, osB, osH, osW, din, Hi, Wi, isB, isH, isW, accumulate)
     if ((int64_t)B * Hi <= 65535 && nx <= 20 && !g_flat_resample) {
       if (nx <= 8) BWD_ROWS(8); else if (nx <= 12) BWD_ROWS(12); else BWD_ROWS(20);
+    } else if (nx > 20 && (int64_t)B * Hi * Wi <= 65535 && !g_flat_resample) {
+      hipLaunchKernelGGL(bilinear_bwd8_window_kernel, dim3((unsigned)((C / 8 + 31) / 32), (unsigned)(B * Hi * Wi)), dim3(256), 0,
+                         (hipStream_t)stream, dout, Ho, Wo, C, osB, osH, osW, din, Hi, Wi, isB, isH, isW, accumulate);
     } else
 #undef BWD_ROWS
     hipLaunchKernelGGL(bilinear_bwd8_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, dout, B, Ho, Wo,
@@ -1784,6 +1887,12 @@ extern "C" int gdl_adaptive_avgpool_fwd(const void* in, int dtype, int B, int Hi
   GDL_CHECK_ARG(in && out && So > 0, "gdl_adaptive_avgpool_fwd: bad args");
   GDL_CHECK_ARG(C % 4 == 0 && isB % 4 == 0 && isH % 4 == 0 && isW % 4 == 0, "gdl_adaptive_avgpool_fwd: C/strides % 4");
   const int64_t total = (int64_t)B * So * So * (C / 4);
+  if ((Hi / So) * (Wi / So) >= 32 && (int64_t)B * So * So <= 65535 && !g_flat_resample) {      // large bins: rows split over 8 lane groups
+    const dim3 grid((unsigned)((C / 4 + 31) / 32), (unsigned)(B * So * So));
+    DISPATCH2(avgpool_fwd_split_kernel, dtype, out_dtype, grid, dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, isB, isH, isW, out, So);
+    GDL_CHECK_LAUNCH("gdl_adaptive_avgpool_fwd");
+    return GDL_OK;
+  }
   DISPATCH2(avgpool_fwd_kernel, dtype, out_dtype, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
             B, Hi, Wi, C, isB, isH, isW, out, So);
   GDL_CHECK_LAUNCH("gdl_adaptive_avgpool_fwd");

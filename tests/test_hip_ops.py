@@ -415,7 +415,9 @@ def test_bn_fold_matches_eval_bn():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("hi,ho", [(9, 36), (18, 36), (36, 18), (9, 32), (5, 5), (1, 6), (36, 128)])
+@pytest.mark.parametrize("hi,ho", [(9, 36), (18, 36), (36, 18), (9, 32), (5, 5), (1, 6), (36, 128),
+                                   # pyramid pooling branches (factors 18 / 9 / 6): the backward takes the window-parallel kernel
+                                   (1, 18), (2, 18), (3, 18), (2, 37)])
 def test_bilinear(dtype, hi, ho):
     B, C = 2, 64
     x = q(rnd(B, hi, hi, C), dtype)

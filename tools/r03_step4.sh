@@ -1,14 +1,13 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03l
-mkdir -p $O
-cd $R
-timeout 900 python -m pytest tests/test_hip_ops.py -x -q -m gpu -k "resize or up4 or resized or concat or tap or epilogue or batchnorm" 2>&1 | tail -15 > $O/pytest_ops.txt
-cat $O/pytest_ops.txt
-timeout 300 python tools/bench_tapsum.py 2>&1 | grep -v amdgpu.ids | tee $O/bench_tapsum.txt
-timeout 600 python bench.py --no-cpu-baseline --no-extras --no-kernel-timer 2>$O/bench.err | tail -1 > $O/bench.json
-python - <<'PY'
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r03ag}; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests/test_hip_ops.py tests/test_hip_model.py -m gpu -x -q -k "bilinear or avgpool or dice or head or model or psp or upernet" 2>&1 | tail -5 | cut -c1-300 > $O/pytest.txt
+cat $O/pytest.txt
+for b in 32 4; do
+timeout 600 python bench.py --batch $b --no-cpu-baseline --no-extras --no-kernel-timer --no-input-stage 2>/dev/null | tail -1 > $O/bench_b$b.json
+python - <<PY
 import json
-d=json.loads(open('gpurun_out/r03l/bench.json').read())
-print(d['value'], d['ms_per_step'], d['inference_tiles_per_s'], d['inference_ms_per_step'])
+d=json.loads(open("$O/bench_b$b.json").read())
+print("batch $b: train %.1f tiles/s (%.2f ms), inference %.1f tiles/s (%.2f ms)" % (d["value"], d["ms_per_step"], d["inference_tiles_per_s"], d["inference_ms_per_step"]))
 PY
+done
+bash tools/r03_profile_b4.sh $1 4 | tail -62 > $O/prof_b4_summary.txt
