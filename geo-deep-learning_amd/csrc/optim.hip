@@ -55,12 +55,15 @@ __global__ __launch_bounds__(256) void multi_adam_kernel(const int64_t* __restri
 // hipGraph-capturable form: the step count and the hyper-parameters live in DEVICE memory, so that a captured optimizer step
 // replays with the right bias corrections and a learning rate the host may rewrite between replays.
 // state = {step, lr, beta1, beta2, eps, weight_decay, bc1, bc2} (f32)
-__global__ void adam_tick_kernel(float* __restrict__ st) {
+__global__ void adam_tick_kernel(float* __restrict__ st, double b1, double b2) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const float step = st[0] + 1.f;
     st[0] = step;
-    st[6] = 1.f - powf(st[2], step);
-    st[7] = 1.f - powf(st[3], step);
+    // in double from the optimizer's own (double) betas, like the host form's `1 - beta ** step`: the f32 results are the
+    // same bits, so a captured step and an eager step update identically (an f32 powf differs in the last bit, 1e-7 of a
+    // parameter after one step -- which a random-init network with train-mode BatchNorm amplifies to O(lr) within two steps)
+    st[6] = (float)(1.0 - pow(b1, (double)step));
+    st[7] = (float)(1.0 - pow(b2, (double)step));
   }
 }
 
@@ -91,9 +94,9 @@ __global__ __launch_bounds__(256) void multi_adam_dev_kernel(const int64_t* __re
 
 }  // namespace
 
-extern "C" int gdl_adam_tick(float* state, gdl_stream_t stream) {
+extern "C" int gdl_adam_tick(float* state, double beta1, double beta2, gdl_stream_t stream) {
   GDL_CHECK_ARG(state, "gdl_adam_tick: null state");
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, beta1, beta2);
   GDL_CHECK_LAUNCH("gdl_adam_tick");
   return GDL_OK;
 }

@@ -153,7 +153,7 @@ SIGNATURES = {
     "gdl_clip_coef": (c_i, [c_p, c_f, c_p, c_p]),
     "gdl_multi_sumsq": (c_i, [c_p, c_i, c_p, c_p]),
     "gdl_multi_adam": (c_i, [c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
-    "gdl_adam_tick": (c_i, [c_p, c_p]),
+    "gdl_adam_tick": (c_i, [c_p, C.c_double, C.c_double, c_p]),
     "gdl_multi_adam_dev": (c_i, [c_p, c_i, c_p, c_p, c_p]),
     "gdl_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
 }

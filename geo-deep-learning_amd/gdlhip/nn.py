@@ -1035,10 +1035,17 @@ class FusedAdam(torch.optim.Optimizer):
                     # table of this group; the captured H2D copy re-reads the pinned one at every replay
                     bufs = self._table_bufs.get(key[0])
                     if bufs is None or bufs[0].shape != host.shape:
-                        bufs = (torch.empty(host.shape, dtype=torch.int64).pin_memory(), torch.empty(host.shape, dtype=torch.int64, device=dev))
+                        bufs = (torch.empty(host.shape, dtype=torch.int64).pin_memory(), torch.empty(host.shape, dtype=torch.int64, device=dev),
+                                torch.cuda.Event())
                         self._table_bufs[key[0]] = bufs
+                    elif not torch.cuda.is_current_stream_capturing():
+                        # the previous table's asynchronous H2D copy reads this pinned buffer: the host must not overwrite it
+                        # before that copy ran (eager steps with set_to_none gradients rebuild the table every step)
+                        bufs[2].synchronize()
                     bufs[0].copy_(host)
                     bufs[1].copy_(bufs[0], non_blocking=True)
+                    if not torch.cuda.is_current_stream_capturing():
+                        bufs[2].record()
                     hit = (sig, bufs[1])
                 else:
                     hit = (sig, host.to(dev, non_blocking=True))
@@ -1058,7 +1065,7 @@ class FusedAdam(torch.optim.Optimizer):
         for (gi, step), t in tables.items():
             group = self.param_groups[gi]
             if self.capturable:
-                ops.adam_tick(self.device_state(gi, dev))
+                ops.adam_tick(self.device_state(gi, dev), *group["betas"])
                 ops.multi_adam_dev(t, self._dev_state[gi], clip)
             else:
                 ops.multi_adam(t, group["lr"], *group["betas"], group["eps"], group["weight_decay"], step, clip)

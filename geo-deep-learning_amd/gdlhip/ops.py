@@ -1437,9 +1437,9 @@ def multi_adam(table: Tensor, lr: float, b1: float, b2: float, eps: float, wd: f
                                      _stream()), "gdl_multi_adam")
 
 
-def adam_tick(state: Tensor) -> None:
+def adam_tick(state: Tensor, b1: float, b2: float) -> None:
     """state[0] += 1 and the two bias corrections refreshed, on the device (capturable Adam, see gdl_adam_tick)."""
-    check(_lib.load().gdl_adam_tick(_p(state), _stream()), "gdl_adam_tick")
+    check(_lib.load().gdl_adam_tick(_p(state), float(b1), float(b2), _stream()), "gdl_adam_tick")
 
 
 def multi_adam_dev(table: Tensor, state: Tensor, clip: Tensor | None) -> None:

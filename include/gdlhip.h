@@ -457,7 +457,7 @@ int gdl_multi_adam(const int64_t* table, int nchunks, float lr, float beta1, flo
 /* capturable form (hipGraph replay of a whole training step, torch.optim.Adam(capturable=True)): step count and
  * hyper-parameters in DEVICE memory -- state = {step, lr, beta1, beta2, eps, weight_decay, bc1, bc2} f32; gdl_adam_tick
  * advances the step and refreshes the two bias corrections, gdl_multi_adam_dev reads everything from `state` */
-int gdl_adam_tick(float* state, gdl_stream_t stream);
+int gdl_adam_tick(float* state, double beta1, double beta2, gdl_stream_t stream);   /* betas in double: bc = 1 - beta^step as the host computes it */
 int gdl_multi_adam_dev(const int64_t* table, int nchunks, const float* state, const float* clip_coef, gdl_stream_t stream);
 int gdl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, float bc1, float bc2,

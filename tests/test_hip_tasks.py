@@ -96,19 +96,18 @@ def _dofa_task(freeze=("encoder",), num_classes=5, img=112, seed=7, **task_kw):
     return ref, task.to(DEV)
 
 
+def _replay_drop_path(blocks, b):
+    """The DropPath draws of one encoder pass as the model makes them: ONE Bernoulli launch over [2 x live blocks, batch]
+    (gdlhip.nn.drop_path_scales) -- replayed from the current generator state and turned back into 0/1 masks for the oracle."""
+    scales = gnn.drop_path_scales([blk.drop_prob for blk in blocks], b, torch.device(DEV))
+    return [tuple(torch.ones(b) if s is None else (s > 0).float().cpu() for s in pair) for pair in scales]
+
+
 def _replay_dofa_draws(model, b, seed):
     """The device-RNG draws of one training forward, in the order the model makes them (two DropPath masks per block
     with a non-zero rate, then the aux head's Dropout2d channel mask)."""
     torch.manual_seed(seed)
-    masks = []
-    for blk in model.encoder.blocks:
-        pair = []
-        for _ in range(2):
-            if blk.drop_prob > 0:
-                pair.append(torch.empty(b, device=DEV, dtype=torch.float32).bernoulli_(1.0 - blk.drop_prob).cpu())
-            else:
-                pair.append(torch.ones(b))
-        masks.append(tuple(pair))
+    masks = _replay_drop_path(list(model.encoder.blocks), b)
     aux = torch.empty((b, model.aux_head.channels), device=DEV, dtype=torch.float32).bernoulli_(0.9).cpu()
     return masks, aux
 
@@ -190,16 +189,8 @@ def test_dofa_task_binary_head_and_raw_tile_rejected():
 # ------------------------------------------------------------------------------------------------ SegFormer
 def _replay_mit_draws(model, b, seed):
     torch.manual_seed(seed)
-    masks = []
-    for stage in (model.encoder.block1, model.encoder.block2, model.encoder.block3, model.encoder.block4):
-        for blk in stage:
-            pair = []
-            for _ in range(2):
-                if blk.drop_prob > 0:
-                    pair.append(torch.empty(b, device=DEV, dtype=torch.float32).bernoulli_(1.0 - blk.drop_prob).cpu())
-                else:
-                    pair.append(torch.ones(b))
-            masks.append(tuple(pair))
+    enc = model.encoder
+    masks = _replay_drop_path([blk for stage in (enc.block1, enc.block2, enc.block3, enc.block4) for blk in stage], b)
     dec = model.decoder
     dmask = torch.empty((b, dec.linear_pred.in_channels), device=DEV, dtype=torch.float32).bernoulli_(1.0 - dec.dropout_ratio).cpu()
     return masks, dmask
