@@ -332,6 +332,46 @@ __global__ __launch_bounds__(TPB) void bn_bwd_partial8(const uint16_t* __restric
   }
 }
 
+// forward statistics with the same mapping (sum and sum of squares of x)
+template <int TPB>
+__global__ __launch_bounds__(TPB) void bn_stats_partial8(const uint16_t* __restrict__ x, int64_t P, int C, float* __restrict__ ws) {
+  __shared__ float red[2][TPB][9];
+  const int G = C >> 3, R = TPB / G;
+  const int t = threadIdx.x, g = t % G, prow = t / G;
+  const int nsplit = gridDim.x;
+  const int64_t per = (P + nsplit - 1) / nsplit;
+  const int64_t p0 = per * blockIdx.x, p1 = p0 + per < P ? p0 + per : P;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  auto add = [&](const uint4& xv) {
+    float v[8];
+    unpack8(xv, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+  };
+  if (prow < R) {
+    int64_t p = p0 + prow;
+    for (; p + 7 * R < p1; p += 8 * R) {
+      uint4 xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = *(const uint4*)(x + (p + (int64_t)u * R) * C + 8 * g);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) add(xv[u]);
+    }
+    for (; p < p1; p += R) add(*(const uint4*)(x + p * C + 8 * g));
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[0][t][j] = s[j]; red[1][t][j] = q[j]; }
+  __syncthreads();
+  for (int c = t; c < C; c += TPB) {
+    float ss = 0.f, qq = 0.f;
+    for (int r = 0; r < R; ++r) { ss += red[0][r * G + (c >> 3)][c & 7]; qq += red[1][r * G + (c >> 3)][c & 7]; }
+    ws[((int64_t)blockIdx.x * 2 + 0) * C + c] = ss;
+    ws[((int64_t)blockIdx.x * 2 + 1) * C + c] = qq;
+  }
+}
+
 __global__ void bn_bwd_final(const float* __restrict__ ws, int nsplit, int C, float* __restrict__ dgamma,
                              float* __restrict__ dbeta) {
   __shared__ double ps[64][4], pq[64][4];
@@ -446,7 +486,11 @@ extern "C" int gdl_bn_stats(const void* x, int dtype, int64_t P, int C, int64_t 
   hipStream_t s = (hipStream_t)stream;
   const int nsplit = bn_nsplit(P, C);
   dim3 grid((C + 255) / 256, nsplit);
-  if (dtype == GDL_BF16) hipLaunchKernelGGL(bn_stats_partial<uint16_t>, grid, dim3(256), 0, s, x, P, C, x_sP, ws);
+  const int G = C / 8;
+  if (g_bn_wide && dtype == GDL_BF16 && C % 8 == 0 && x_sP == C && (uintptr_t)x % 16 == 0 && (256 % G == 0 || 192 % G == 0) && P >= 4096) {
+    if (256 % G == 0) hipLaunchKernelGGL(bn_stats_partial8<256>, dim3(nsplit), dim3(256), 0, s, (const uint16_t*)x, P, C, ws);
+    else hipLaunchKernelGGL(bn_stats_partial8<192>, dim3(nsplit), dim3(192), 0, s, (const uint16_t*)x, P, C, ws);
+  } else if (dtype == GDL_BF16) hipLaunchKernelGGL(bn_stats_partial<uint16_t>, grid, dim3(256), 0, s, x, P, C, x_sP, ws);
   else hipLaunchKernelGGL(bn_stats_partial<float>, grid, dim3(256), 0, s, x, P, C, x_sP, ws);
   hipLaunchKernelGGL(bn_stats_final, dim3((C + 3) / 4), dim3(256), 0, s, ws, nsplit, C, P, mean, var, running_mean, running_var, momentum);
   GDL_CHECK_LAUNCH("gdl_bn_stats");

@@ -1034,19 +1034,30 @@ class FusedAdam(torch.optim.Optimizer):
                     # under stream capture nothing may be allocated (pinned or device): both buffers exist since the first
                     # table of this group; the captured H2D copy re-reads the pinned one at every replay
                     bufs = self._table_bufs.get(key[0])
-                    if bufs is None or bufs[0].shape != host.shape:
-                        bufs = (torch.empty(host.shape, dtype=torch.int64).pin_memory(), torch.empty(host.shape, dtype=torch.int64, device=dev),
-                                torch.cuda.Event())
+                    if bufs is None or bufs["dev"].shape != host.shape:
+                        pin = lambda: torch.empty(host.shape, dtype=torch.int64).pin_memory()      # noqa: E731
+                        bufs = {"eager": [pin(), pin()], "events": [None, None], "capture": pin(), "i": 0,
+                                "dev": torch.empty(host.shape, dtype=torch.int64, device=dev)}
                         self._table_bufs[key[0]] = bufs
-                    elif not torch.cuda.is_current_stream_capturing():
-                        # the previous table's asynchronous H2D copy reads this pinned buffer: the host must not overwrite it
-                        # before that copy ran (eager steps with set_to_none gradients rebuild the table every step)
-                        bufs[2].synchronize()
-                    bufs[0].copy_(host)
-                    bufs[1].copy_(bufs[0], non_blocking=True)
-                    if not torch.cuda.is_current_stream_capturing():
-                        bufs[2].record()
-                    hit = (sig, bufs[1])
+                    if torch.cuda.is_current_stream_capturing():
+                        # the captured H2D copy re-reads this pinned buffer at every replay: eager rebuilds never touch it
+                        src = bufs["capture"]
+                        src.copy_(host)
+                        bufs["dev"].copy_(src, non_blocking=True)
+                    else:
+                        # eager steps with set_to_none gradients rebuild the table every step; its asynchronous H2D copy reads
+                        # the pinned buffer later, so the host alternates between two and only waits for the copy issued two
+                        # rebuilds ago (long done) instead of overwriting a buffer whose copy has not run yet
+                        i = bufs["i"] = bufs["i"] ^ 1
+                        if bufs["events"][i] is not None:
+                            bufs["events"][i].synchronize()
+                        src = bufs["eager"][i]
+                        src.copy_(host)
+                        bufs["dev"].copy_(src, non_blocking=True)
+                        ev = bufs["events"][i] or torch.cuda.Event()
+                        ev.record()
+                        bufs["events"][i] = ev
+                    hit = (sig, bufs["dev"])
                 else:
                     hit = (sig, host.to(dev, non_blocking=True))
                 if len(buckets) == len({k[0] for k in buckets}):      # (one step count per group: the usual case -> cacheable)
