@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const void* __restrict__ x
 // eight channels 8 (t % G) of pixel row t / G (G = C / 8 lanes cover one pixel), so a block reads whole contiguous pixel rows
 // and a lane's channels never change; four row groups in flight.  The 8-byte / 256-channel mapping above reached 3.4 TB/s on
 // the decoder's maps (2 x 1 GB for the neck x4 level); this one 5.0-5.9 TB/s (tools/bench_bn.py).  The element-wise passes
-// (apply, dx) gain nothing from the same mapping -- they are bound by their writes at ~5.0 TB/s either way (measured, not kept).
+// (apply, dx) gain nothing from the same mapping -- they are bound by their writes at ~5.0 TB/s either way -- and neither do the
+// forward statistics, whose 8-byte kernel already keeps four loads in flight (4.4-5.5 TB/s both ways; measured, not kept).
 __device__ __forceinline__ void unpack8(const uint4& v, float (&o)[8]) {
   o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
   o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
@@ -320,46 +321,6 @@ __global__ __launch_bounds__(TPB) void bn_bwd_partial8(const uint16_t* __restric
       for (int u = 0; u < 4; ++u) add(xv[u], gv[u]);
     }
     for (; p < p1; p += R) add(*(const uint4*)(x + p * C + 8 * g), *(const uint4*)(dy + p * C + 8 * g));
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { red[0][t][j] = s[j]; red[1][t][j] = q[j]; }
-  __syncthreads();
-  for (int c = t; c < C; c += TPB) {
-    float ss = 0.f, qq = 0.f;
-    for (int r = 0; r < R; ++r) { ss += red[0][r * G + (c >> 3)][c & 7]; qq += red[1][r * G + (c >> 3)][c & 7]; }
-    ws[((int64_t)blockIdx.x * 2 + 0) * C + c] = ss;
-    ws[((int64_t)blockIdx.x * 2 + 1) * C + c] = qq;
-  }
-}
-
-// forward statistics with the same mapping (sum and sum of squares of x)
-template <int TPB>
-__global__ __launch_bounds__(TPB) void bn_stats_partial8(const uint16_t* __restrict__ x, int64_t P, int C, float* __restrict__ ws) {
-  __shared__ float red[2][TPB][9];
-  const int G = C >> 3, R = TPB / G;
-  const int t = threadIdx.x, g = t % G, prow = t / G;
-  const int nsplit = gridDim.x;
-  const int64_t per = (P + nsplit - 1) / nsplit;
-  const int64_t p0 = per * blockIdx.x, p1 = p0 + per < P ? p0 + per : P;
-  float s[8], q[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-  auto add = [&](const uint4& xv) {
-    float v[8];
-    unpack8(xv, v);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
-  };
-  if (prow < R) {
-    int64_t p = p0 + prow;
-    for (; p + 7 * R < p1; p += 8 * R) {
-      uint4 xv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) xv[u] = *(const uint4*)(x + (p + (int64_t)u * R) * C + 8 * g);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) add(xv[u]);
-    }
-    for (; p < p1; p += R) add(*(const uint4*)(x + p * C + 8 * g));
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) { red[0][t][j] = s[j]; red[1][t][j] = q[j]; }
@@ -486,11 +447,7 @@ extern "C" int gdl_bn_stats(const void* x, int dtype, int64_t P, int C, int64_t 
   hipStream_t s = (hipStream_t)stream;
   const int nsplit = bn_nsplit(P, C);
   dim3 grid((C + 255) / 256, nsplit);
-  const int G = C / 8;
-  if (g_bn_wide && dtype == GDL_BF16 && C % 8 == 0 && x_sP == C && (uintptr_t)x % 16 == 0 && (256 % G == 0 || 192 % G == 0) && P >= 4096) {
-    if (256 % G == 0) hipLaunchKernelGGL(bn_stats_partial8<256>, dim3(nsplit), dim3(256), 0, s, (const uint16_t*)x, P, C, ws);
-    else hipLaunchKernelGGL(bn_stats_partial8<192>, dim3(nsplit), dim3(192), 0, s, (const uint16_t*)x, P, C, ws);
-  } else if (dtype == GDL_BF16) hipLaunchKernelGGL(bn_stats_partial<uint16_t>, grid, dim3(256), 0, s, x, P, C, x_sP, ws);
+  if (dtype == GDL_BF16) hipLaunchKernelGGL(bn_stats_partial<uint16_t>, grid, dim3(256), 0, s, x, P, C, x_sP, ws);
   else hipLaunchKernelGGL(bn_stats_partial<float>, grid, dim3(256), 0, s, x, P, C, x_sP, ws);
   hipLaunchKernelGGL(bn_stats_final, dim3((C + 3) / 4), dim3(256), 0, s, ws, nsplit, C, P, mean, var, running_mean, running_var, momentum);
   GDL_CHECK_LAUNCH("gdl_bn_stats");

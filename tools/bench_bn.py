@@ -42,9 +42,6 @@ for name, hw, c in (("neck x4", 144, 768), ("neck x2", 72, 768), ("fpn 144", 144
     mean, var = ops.bn_stats(x, rm, rv, 0.1)
     nbytes = x.numel() * 2
     t_stats = timeit(lambda: ops.bn_stats(x, rm, rv, 0.1))
-    lib.gdl_debug_set_bn_wide(0)
-    t_stats_r2 = timeit(lambda: ops.bn_stats(x, rm, rv, 0.1))
-    lib.gdl_debug_set_bn_wide(1)
     t_apply = timeit(lambda: ops.bn_apply(x, mean, var, g, b, 1e-5, True))
     res = {}
     for wide in (1, 0):
@@ -54,6 +51,6 @@ for name, hw, c in (("neck x4", 144, 768), ("neck x2", 72, 768), ("fpn 144", 144
     dg, db = res[1][1]
     dev = max(((res[1][1][i] - res[0][1][i]).abs().max() / res[0][1][i].abs().max()).item() for i in (0, 1))
     t_dx = timeit(lambda: ops.bn_bwd_dx(x, dy, mean, var, g, b, 1e-5, True, dg, db, B * hw * hw))
-    print(f"{name:8s} [{B},{hw},{hw},{c}] {nbytes / 1e6:6.0f} MB: stats 16-byte {t_stats:6.0f} us ({nbytes / t_stats / 1e3:5.0f} GB/s) vs round 2 {t_stats_r2:6.0f} us | apply {t_apply:6.0f} us "
+    print(f"{name:8s} [{B},{hw},{hw},{c}] {nbytes / 1e6:6.0f} MB: stats {t_stats:6.0f} us ({nbytes / t_stats / 1e3:5.0f} GB/s) | apply {t_apply:6.0f} us "
           f"({2 * nbytes / t_apply / 1e3:5.0f} GB/s) | bwd sums 16-byte {res[1][0]:6.0f} us ({2 * nbytes / res[1][0] / 1e3:5.0f} GB/s) vs round 2 "
           f"{res[0][0]:6.0f} us ({2 * nbytes / res[0][0] / 1e3:5.0f} GB/s), rel diff {dev:.1e} | bwd dx {t_dx:6.0f} us ({3 * nbytes / t_dx / 1e3:5.0f} GB/s)", flush=True)
