@@ -182,6 +182,8 @@ def test_conv_tile_selection(lib):
         fl = C.c_int64()
         v = lib.gdl_conv_gemm_plan(C.byref(_conv_args(*a, **k)), C.byref(fl))
         return v, fl.value
+    assert plan(32, 1, 1297, 768, 768, 1)[0] == 3            # ViT proj: 163 x 3 = 489 tiles still take the 256^2 tile (round 3)
+    assert plan(4, 1, 1297, 768, 768, 1)[0] in (0, 1)        # the same layer at the reference's batch of 4: small tiles
     v, fl = plan(32, 144, 144, 768, 768, 3)                  # DOFA neck conv
     assert v == 4 and fl == 2 * 32 * 144 * 144 * 768 * 9 * 768
     assert plan(32, 144, 144, 768, 256, 1)[0] == 3           # lateral 1x1: 256^2 ping-pong
@@ -232,3 +234,47 @@ def test_dynamic_segformer_mirror_has_the_reference_state_dict():
         assert any(k.startswith("encoder.dynamic_patch_embed1.channel_attention.") for k in ms)
     with pytest.raises(ValueError):                       # no CPU fallback: the stem needs the device library
         SegFormerSegmentationModel("mit_b0", 3, None, None, 5, use_dynamic_encoder=True)(torch.zeros(1, 4, 32, 32))
+
+
+def test_counter_batch_defers_batchnorm_counters_to_one_update():
+    """gnn.counter_batch (host logic, CPU): inside the context `bump` only collects the BatchNorm step counters and the exit
+    applies them all at once -- also when the body raises -- while outside of it (and in a nested context) the increment is
+    what nn.BatchNorm2d.forward does: immediate, once."""
+    import torch
+    from gdlhip import nn as gnn
+    counters = [torch.zeros((), dtype=torch.long) for _ in range(5)]
+    gnn.bump(counters[0])
+    assert int(counters[0]) == 1                       # outside: at once
+    gnn.bump(None)                                     # track_running_stats=False modules have no counter
+    with gnn.counter_batch():
+        for c in counters:
+            gnn.bump(c)
+        with gnn.counter_batch():                      # nested: the outermost context applies
+            gnn.bump(counters[1])
+        assert [int(c) for c in counters] == [1, 0, 0, 0, 0]
+    assert [int(c) for c in counters] == [2, 2, 1, 1, 1]
+    try:
+        with gnn.counter_batch():
+            gnn.bump(counters[4])
+            raise RuntimeError("forward failed after this layer ran")
+    except RuntimeError:
+        pass
+    assert int(counters[4]) == 2 and gnn._COUNTER_BATCH is None
+
+
+def test_drop_path_scales_semantics_on_cpu():
+    """gnn.drop_path_scales (pure torch, runs on the CPU too): timm's drop_path with scale_by_keep -- a kept sample is scaled
+    by 1 / keep, a dropped one by 0 -- drawn for every block of an encoder pass at once; blocks that never drop get None."""
+    import torch
+    from gdlhip import nn as gnn
+    torch.manual_seed(0)
+    probs = [0.0, 0.1, 0.0, 0.3]
+    out = gnn.drop_path_scales(probs, 50000, torch.device("cpu"))
+    assert out[0] == (None, None) and out[2] == (None, None)
+    for p_, pair in ((0.1, out[1]), (0.3, out[3])):
+        for t in pair:
+            vals = sorted(t.unique().tolist())
+            assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.0 / (1.0 - p_)) < 1e-6
+            assert abs(float((t > 0).float().mean()) - (1.0 - p_)) < 0.01
+            assert abs(float(t.mean()) - 1.0) < 0.02          # unbiased: E[scale] = 1
+    assert gnn.drop_path_scales([0.0, 0.0], 4, torch.device("cpu")) == [(None, None), (None, None)]
