@@ -42,22 +42,45 @@ def mark_flat(weight: Tensor) -> None:
     weight._gdl_flat = True
 
 
+def mark_groups(weight: Tensor, groups: int) -> None:
+    """A grouped convolution's parameter ([N, C / groups, R, S], torchvision ResNeXt ``conv2``).  The kernels see it as the
+    block-diagonal DENSE filter [N, R*S, C] (zeros between groups): forward, data gradient and weight gradient are then the
+    ordinary implicit-GEMM calls and the parameter's gradient is the block diagonal of the dense one.  Correct and
+    deterministic, at groups x the multiply-adds of the grouped form on these layers (the encoder the reference's shipped
+    UNet++ config names, resnext101_32x8d, is a boundary requirement, not the benchmarked configuration)."""
+    weight._gdl_groups = int(groups)
+
+
+def _groups(weight: Tensor) -> int:
+    return getattr(weight, "_gdl_groups", 1)
+
+
 def _is_flat(weight: Tensor) -> bool:
     return weight.dim() == 2 or getattr(weight, "_gdl_flat", False)
 
 
 def _wshape(weight: Tensor) -> tuple[int, int, int, int]:
+    """(N, C, R, S) of the DENSE filter the kernels run (C = all input channels, also for a grouped parameter)."""
     if _is_flat(weight):
         return weight.shape[0], weight[0].numel(), 1, 1
-    return tuple(weight.shape)
+    n, c, r, s = weight.shape
+    return n, c * _groups(weight), r, s
 
 
 def _matrix3(weight: Tensor) -> Tensor:
-    """f32 [N, R*S, C] view/copy of a conv parameter ([N,C,R,S]), a 2-D [N,K] matrix or a flat stem (taps = 1)."""
+    """f32 [N, R*S, C] view/copy of a conv parameter ([N,C,R,S]), a 2-D [N,K] matrix or a flat stem (taps = 1); a grouped
+    parameter becomes its block-diagonal dense filter."""
     if _is_flat(weight):
         return weight.detach().reshape(weight.shape[0], 1, -1)
     n, c, r, s = weight.shape
-    return conv_weight_matrix(weight).view(n, r * s, c)
+    m = conv_weight_matrix(weight).view(n, r * s, c)
+    g = _groups(weight)
+    if g == 1:
+        return m
+    dense = torch.zeros((g, n // g, r * s, g, c), device=weight.device, dtype=m.dtype)
+    idx = torch.arange(g, device=weight.device)
+    dense[idx, :, :, idx, :] = m.view(g, n // g, r * s, c)          # group i: outputs i*N/g.., inputs i*c..
+    return dense.view(n, r * s, g * c)
 
 
 def padded_operands(weight: Tensor, cd: torch.dtype, cpad: int, npad: int) -> tuple[Tensor, Tensor]:
@@ -96,6 +119,11 @@ def _param_grad(dw: Tensor, weight: Tensor, cpad: int) -> Tensor:
     d = dw.view(-1, r * s, cpad)[:n, :, :c]
     if _is_flat(weight):
         return d.reshape(weight.shape)
+    g = _groups(weight)
+    if g > 1:      # the parameter's gradient = the block diagonal of the dense filter's
+        idx = torch.arange(g, device=dw.device)
+        d = d.reshape(g, n // g, r * s, g, c // g)[idx, :, :, idx, :].reshape(n, r * s, c // g)
+        c = c // g
     if r == 1 and s == 1:
         return d.reshape(n, c, 1, 1)
     return d.reshape(n, r, s, c).permute(0, 3, 1, 2)

@@ -1,11 +1,13 @@
-"""UNet++ with a ResNet BasicBlock encoder on MI355X: drop-in for the ``smp.UnetPlusPlus`` instance the reference
+"""UNet++ with a ResNet (BasicBlock or Bottleneck / ResNeXt) encoder on MI355X: drop-in for the ``smp.UnetPlusPlus`` instance the reference
 builds at tasks_with_models/segmentation_unetplus.py:126-131 (same constructor keywords, same state-dict keys as
 segmentation-models-pytorch 0.5.0 / torchvision, so its checkpoints load).
 
 Everything runs NHWC in the compute dtype on the implicit-GEMM MFMA kernel:
 * stem 7x7/2 on the raw bands = strided patchify + GEMM + BN + ReLU, then the 3x3/2 max-pool kernel;
 * BasicBlock = conv3x3-BN-ReLU, conv3x3-BN, (+ 1x1/s downsample-BN), residual add + ReLU (one kernel in
-  training; folded into the second conv's epilogue in eval);
+  training; folded into the second conv's epilogue in eval); Bottleneck = 1x1, (grouped) 3x3 with the stride, 1x1 to
+  4 x planes, same tail -- resnet50 / 101, resnext50_32x4d and resnext101_32x8d, the encoder of the reference's shipped
+  config (configs/unetplus_config_RGB.yaml:37);
 * DecoderBlock = nearest x2 of the input written straight into the dense-skip concat buffer, then two
   conv3x3-BN-ReLU; the 32- and 16-channel stages run at their true width (channel-tail kernels, gdlhip.cnn);
 * head = 3x3 conv to ``classes`` -> NCHW f32 logits.
@@ -21,6 +23,17 @@ from gdlhip import cnn, ops
 from gdlhip import nn as gnn
 
 RESNET_LAYERS = {"resnet18": [2, 2, 2, 2], "resnet34": [3, 4, 6, 3]}
+# torchvision's Bottleneck ResNets / ResNeXts: (layers, groups, width_per_group).  resnext101_32x8d is the encoder of the
+# reference's shipped config (configs/unetplus_config_RGB.yaml:37).
+BOTTLENECK_SPECS = {"resnet50": ([3, 4, 6, 3], 1, 64), "resnet101": ([3, 4, 23, 3], 1, 64),
+                    "resnext50_32x4d": ([3, 4, 6, 3], 32, 4), "resnext101_32x8d": ([3, 4, 23, 3], 32, 8)}
+
+
+def _cl_conv_g(cin: int, cout: int, k: int, *, padding: int, groups: int) -> nn.Conv2d:
+    """Grouped Conv2d(bias=False) parameter container, stored channels-last like _cl_conv ([N, R, S, C / groups] in memory)."""
+    conv = nn.Conv2d(cin, cout, k, padding=padding, groups=groups, bias=False)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    return conv
 
 
 class BasicBlock(nn.Module):
@@ -48,17 +61,60 @@ class BasicBlock(nn.Module):
         return cnn.conv_bn(out, self.conv2.weight, self.bn2, pad=1, resid=identity)
 
 
+class Bottleneck(nn.Module):
+    """torchvision models/resnet.py Bottleneck (v1.5: stride on the 3x3), parameter names conv1..3 / bn1..3 /
+    downsample.{0,1}; ``groups`` > 1 = ResNeXt's grouped 3x3 (gdlhip.cnn.mark_groups: run as a block-diagonal dense filter)."""
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1, groups: int = 1, base_width: int = 64) -> None:
+        super().__init__()
+        width = int(planes * (base_width / 64.0)) * groups
+        self.stride, self.groups = stride, groups
+        self.conv1 = _cl_conv(inplanes, width, 1, padding=0, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = _cl_conv_g(width, width, 3, padding=1, groups=groups)
+        self.conv2.stride = (stride, stride)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = _cl_conv(width, planes * 4, 1, padding=0, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = None
+        if stride != 1 or inplanes != planes * 4:
+            ds = _cl_conv(inplanes, planes * 4, 1, padding=0, bias=False)
+            ds.stride = (stride, stride)
+            self.downsample = nn.Sequential(ds, nn.BatchNorm2d(planes * 4))
+
+    def forward_nhwc(self, x: Tensor) -> Tensor:
+        identity = x
+        if self.downsample is not None:
+            identity = cnn.conv_bn(x, self.downsample[0].weight, self.downsample[1], stride=self.stride, relu=False)
+        cnn.mark_groups(self.conv2.weight, self.groups)      # (the mark lives on the Parameter object)
+        out = cnn.conv_bn(x, self.conv1.weight, self.bn1)
+        out = cnn.conv_bn(out, self.conv2.weight, self.bn2, stride=self.stride, pad=1)
+        return cnn.conv_bn(out, self.conv3.weight, self.bn3, resid=identity)
+
+
 class ResNetEncoder(nn.Module):
     """smp encoders/resnet.py ResNetEncoder (depth 5): features at strides 1, 2, 4, 8, 16, 32."""
 
     def __init__(self, name: str = "resnet18", in_channels: int = 3) -> None:
         super().__init__()
-        if name not in RESNET_LAYERS:
-            msg = f"gdlhip UnetPlusPlus: encoder {name!r} is not built (BasicBlock ResNets: {sorted(RESNET_LAYERS)})"
+        if name not in RESNET_LAYERS and name not in BOTTLENECK_SPECS:
+            msg = (f"gdlhip UnetPlusPlus: encoder {name!r} is not built (BasicBlock ResNets {sorted(RESNET_LAYERS)}, "
+                   f"Bottleneck ResNets / ResNeXts {sorted(BOTTLENECK_SPECS)})")
             raise NotImplementedError(msg)
         self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)     # standard OIHW layout: consumed flat
         self.bn1 = nn.BatchNorm2d(64)
         inplanes = 64
+        if name in BOTTLENECK_SPECS:
+            layers, groups, base_width = BOTTLENECK_SPECS[name]
+            for i, (planes, blocks) in enumerate(zip([64, 128, 256, 512], layers)):
+                layer = []
+                for j in range(blocks):
+                    layer.append(Bottleneck(inplanes, planes, (1 if i == 0 else 2) if j == 0 else 1, groups, base_width))
+                    inplanes = planes * 4
+                setattr(self, f"layer{i + 1}", nn.Sequential(*layer))
+            self.out_channels = (in_channels, 64, 256, 512, 1024, 2048)
+            return
         for i, (planes, blocks) in enumerate(zip([64, 128, 256, 512], RESNET_LAYERS[name])):
             layer = []
             for j in range(blocks):
@@ -160,17 +216,32 @@ class UnetPlusPlus(nn.Module):
                  decoder_channels=(256, 128, 64, 32, 16), in_channels: int = 3, classes: int = 1,
                  activation=None, aux_params=None, **kwargs: object) -> None:
         super().__init__()
-        if encoder_weights is not None:
-            msg = ("pretrained encoder weights are downloaded by smp in the reference; this build has no network: "
-                   "pass encoder_weights=None and load a checkpoint with load_state_dict")
-            raise RuntimeError(msg)
         if encoder_depth != 5 or activation is not None or aux_params is not None or kwargs:
             msg = "gdlhip UnetPlusPlus implements the reference's configuration (depth 5, no activation / aux head)"
             raise NotImplementedError(msg)
         self.encoder = ResNetEncoder(encoder_name, in_channels)
+        if encoder_weights is not None:
+            self._load_cached_encoder_weights(encoder_name, encoder_weights, in_channels)
         self.decoder = UnetPlusPlusDecoder(self.encoder.out_channels, tuple(decoder_channels))
         self.segmentation_head = nn.Sequential(_cl_conv(decoder_channels[-1], classes, 3, padding=1, bias=True),
                                                nn.Identity(), nn.Identity())
+
+    def _load_cached_encoder_weights(self, name: str, weights: str, in_channels: int) -> None:
+        """``encoder_weights="imagenet"`` (configs/unetplus_config_RGB.yaml:39): smp downloads torchvision's checkpoint into the
+        torch-hub cache; this build never downloads -- it reads ``<hub>/checkpoints/<name>-*.pth`` when a previous (networked)
+        run or the operator put it there, and says where it looked otherwise."""
+        import glob
+        import os
+        pattern = os.path.join(torch.hub.get_dir(), "checkpoints", f"{name}-*.pth")
+        found = sorted(glob.glob(pattern))
+        if weights != "imagenet" or not found or in_channels != 3:
+            msg = (f"encoder_weights={weights!r}: the reference lets smp download torchvision's {name} checkpoint; this build has no "
+                   f"network and found {'no file' if not found else 'a file but in_channels != 3'} at {pattern}. Pass encoder_weights=None "
+                   "and load a checkpoint with load_state_dict, or place the torchvision checkpoint there")
+            raise RuntimeError(msg)
+        sd = torch.load(found[-1], map_location="cpu", weights_only=True)
+        sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
+        self.encoder.load_state_dict(sd, strict=True)
 
     def forward(self, x: Tensor) -> Tensor:
         if x.shape[2] % 32 or x.shape[3] % 32:

@@ -9,7 +9,9 @@ path (tests/test_notebooks_00quickstart.py:98-118) asserts nothing numeric.  Thi
 algorithms:
 
 * torchvision ``models/resnet.py``: ``BasicBlock`` (conv3x3-BN-ReLU, conv3x3-BN, + identity / 1x1-stride-s
-  downsample, ReLU), ``ResNet._make_layer``, stem conv 7x7/2 + BN + ReLU + max-pool 3x3/2 (pad 1);
+  downsample, ReLU), ``Bottleneck`` (1x1, grouped 3x3 carrying the stride, 1x1 to 4 x planes; resnet50 / 101,
+  resnext50_32x4d, resnext101_32x8d -- the encoder the reference's shipped config names), ``ResNet._make_layer``, stem
+  conv 7x7/2 + BN + ReLU + max-pool 3x3/2 (pad 1);
 * smp ``encoders/resnet.py`` ``ResNetEncoder.forward`` feature list (identity, stem, layer1..4; ``fc`` removed);
 * smp ``decoders/unetplusplus/decoder.py``: ``DecoderBlock`` (nearest x2, concat skip, 2 x Conv2dReLU) and the
   dense grid ``x_{depth}_{layer}``; ``base/modules.py`` ``Conv2dReLU`` = Conv2d(bias=False) + BatchNorm2d + ReLU;
@@ -27,6 +29,10 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 RESNET_LAYERS = {"resnet18": [2, 2, 2, 2], "resnet34": [3, 4, 6, 3]}
+# torchvision models/resnet.py constructors with Bottleneck blocks: (layers, groups, width_per_group).  The reference's SHIPPED
+# UNet++ config names resnext101_32x8d (configs/unetplus_config_RGB.yaml:37).
+BOTTLENECK_SPECS = {"resnet50": ([3, 4, 6, 3], 1, 64), "resnet101": ([3, 4, 23, 3], 1, 64),
+                    "resnext50_32x4d": ([3, 4, 6, 3], 32, 4), "resnext101_32x8d": ([3, 4, 23, 3], 32, 8)}
 
 
 class BasicBlock(nn.Module):
@@ -47,12 +53,48 @@ class BasicBlock(nn.Module):
         return F.relu(out + identity)
 
 
+class Bottleneck(nn.Module):
+    """torchvision models/resnet.py Bottleneck (v1.5: the stride sits on the 3x3 convolution), expansion 4;
+    ``width = int(planes * base_width / 64) * groups`` and the 3x3 convolution is grouped (ResNeXt)."""
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1, groups: int = 1, base_width: int = 64) -> None:
+        super().__init__()
+        width = int(planes * (base_width / 64.0)) * groups
+        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, groups=groups, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = None
+        if stride != 1 or inplanes != planes * 4:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+
+    def forward(self, x: Tensor) -> Tensor:
+        identity = x if self.downsample is None else self.downsample(x)
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = F.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return F.relu(out + identity)
+
+
 class ResNetEncoder(nn.Module):
     def __init__(self, name: str = "resnet18", in_channels: int = 3) -> None:
         super().__init__()
         self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         inplanes = 64
+        if name in BOTTLENECK_SPECS:
+            layers, groups, base_width = BOTTLENECK_SPECS[name]
+            for i, (planes, blocks) in enumerate(zip([64, 128, 256, 512], layers)):
+                layer = []
+                for j in range(blocks):
+                    layer.append(Bottleneck(inplanes, planes, (1 if i == 0 else 2) if j == 0 else 1, groups, base_width))
+                    inplanes = planes * 4
+                setattr(self, f"layer{i + 1}", nn.Sequential(*layer))
+            self.out_channels = (in_channels, 64, 256, 512, 1024, 2048)
+            return
         for i, (planes, blocks) in enumerate(zip([64, 128, 256, 512], RESNET_LAYERS[name])):
             layer = []
             for j in range(blocks):

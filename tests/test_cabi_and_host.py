@@ -278,3 +278,31 @@ def test_drop_path_scales_semantics_on_cpu():
             assert abs(float((t > 0).float().mean()) - (1.0 - p_)) < 0.01
             assert abs(float(t.mean()) - 1.0) < 0.02          # unbiased: E[scale] = 1
     assert gnn.drop_path_scales([0.0, 0.0], 4, torch.device("cpu")) == [(None, None), (None, None)]
+
+
+def test_unetpp_bottleneck_mirror_keys_and_cached_imagenet_weights(tmp_path, monkeypatch):
+    """The UNet++ mirror accepts the encoder of the reference's shipped config (resnext101_32x8d,
+    configs/unetplus_config_RGB.yaml:37-39): same state-dict keys and shapes as the oracle (= torchvision / smp names), and
+    ``encoder_weights="imagenet"`` reads torchvision's checkpoint from the torch-hub cache (never downloads): strict load
+    with ``fc.*`` dropped, a clear error that names the path when the file is not there."""
+    import torch
+    from geo_deep_learning.models.segmentation.unetplusplus import UnetPlusPlus
+    from oracle.unetpp import ResNetEncoder as OracleEncoder
+    from oracle.unetpp import UnetPlusPlus as OracleUnetPlusPlus
+    for name in ("resnext50_32x4d", "resnet50"):
+        ora, m = OracleUnetPlusPlus(name, 3, 2), UnetPlusPlus(name, encoder_weights=None, classes=2)
+        want = {k: tuple(v.shape) for k, v in ora.state_dict().items()}
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want, name
+    monkeypatch.setattr(torch.hub, "get_dir", lambda: str(tmp_path))
+    with pytest.raises(RuntimeError, match="checkpoints/resnext50_32x4d"):
+        UnetPlusPlus("resnext50_32x4d", encoder_weights="imagenet", classes=2)
+    src = OracleEncoder("resnext50_32x4d", 3)
+    sd = {k: torch.randn_like(v) if v.dtype.is_floating_point else v for k, v in src.state_dict().items()}
+    sd["fc.weight"], sd["fc.bias"] = torch.zeros(1000, 2048), torch.zeros(1000)      # the classification head smp drops
+    (tmp_path / "checkpoints").mkdir()
+    torch.save(sd, tmp_path / "checkpoints" / "resnext50_32x4d-7cdf4587.pth")
+    m = UnetPlusPlus("resnext50_32x4d", encoder_weights="imagenet", classes=2)
+    for k, v in m.encoder.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    with pytest.raises(NotImplementedError, match="not built"):
+        UnetPlusPlus("efficientnet-b0", encoder_weights=None)

@@ -182,3 +182,73 @@ def test_dense_skip_decoder_matches_the_published_recurrence():
         # and through the head, against the whole model
         logits = F.conv2d(out, sd["segmentation_head.0.weight"], sd["segmentation_head.0.bias"], padding=1)
         assert torch.allclose(logits, m(x), atol=1e-5)
+
+
+def test_bottleneck_encoders_have_torchvision_parameter_counts():
+    """Bottleneck ResNets / ResNeXts (the reference's shipped config names resnext101_32x8d,
+    configs/unetplus_config_RGB.yaml:37): the encoder's parameter count equals torchvision's published total for the
+    classification model minus its 2048 x 1000 + 1000 ``fc`` -- 25,557,032 / 44,549,160 / 25,028,904 / 88,791,336 -- which
+    fixes widths, group counts, block counts and where the projection shortcuts sit; key names follow torchvision."""
+    from oracle.unetpp import ResNetEncoder
+    fc = 2048 * 1000 + 1000
+    for name, total in (("resnet50", 25557032), ("resnet101", 44549160), ("resnext50_32x4d", 25028904), ("resnext101_32x8d", 88791336)):
+        enc = ResNetEncoder(name, 3)
+        assert sum(p.numel() for p in enc.parameters()) == total - fc, name
+        assert enc.out_channels == (3, 64, 256, 512, 1024, 2048)
+    enc = ResNetEncoder("resnext101_32x8d", 3)
+    sd = enc.state_dict()
+    assert tuple(sd["layer1.0.conv2.weight"].shape) == (256, 8, 3, 3)          # 32 groups x 8 channels
+    assert tuple(sd["layer4.2.conv2.weight"].shape) == (2048, 64, 3, 3)
+    assert tuple(sd["layer3.22.conv3.weight"].shape) == (1024, 1024, 1, 1) and "layer3.23.conv1.weight" not in sd
+    assert tuple(sd["layer2.0.downsample.0.weight"].shape) == (512, 256, 1, 1) and "layer2.1.downsample.0.weight" not in sd
+    m = UnetPlusPlus("resnext50_32x4d", 3, 2).eval()
+    with torch.no_grad():
+        assert m(torch.zeros(1, 3, 64, 64)).shape == (1, 2, 64, 64)
+
+
+def test_bottleneck_encoder_matches_an_independent_implementation():
+    """resnet50 in ``transformers`` (layer_type="bottleneck", stride on the 3x3 like torchvision v1.5) and in the oracle, same
+    weights -> the same feature maps; the grouped 3x3 of the ResNeXt variants is torch's own ``F.conv2d(groups=32)``."""
+    import pytest
+    transformers = pytest.importorskip("transformers")
+    from oracle.unetpp import ResNetEncoder
+    cfg = transformers.ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[256, 512, 1024, 2048], depths=[3, 4, 6, 3],
+                                    layer_type="bottleneck", hidden_act="relu", downsample_in_first_stage=False,
+                                    downsample_in_bottleneck=False)
+    hf = transformers.ResNetModel(cfg).eval()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.03 if p.dim() == 4 else 0.3) + (1.0 if n.endswith("normalization.weight") else 0.0))
+        for n, b in hf.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+            elif n.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+    src, dst = hf.state_dict(), {}
+
+    def bn(d, s_):
+        for k in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+            dst[f"{d}.{k}"] = src[f"{s_}.normalization.{k}"]
+    dst["conv1.weight"] = src["embedder.embedder.convolution.weight"]
+    bn("bn1", "embedder.embedder")
+    for si, blocks in enumerate([3, 4, 6, 3]):
+        for j in range(blocks):
+            s_, d = f"encoder.stages.{si}.layers.{j}", f"layer{si + 1}.{j}"
+            for c in range(3):
+                dst[f"{d}.conv{c + 1}.weight"] = src[f"{s_}.layer.{c}.convolution.weight"]
+                bn(f"{d}.bn{c + 1}", f"{s_}.layer.{c}")
+            if f"{s_}.shortcut.convolution.weight" in src:
+                dst[f"{d}.downsample.0.weight"] = src[f"{s_}.shortcut.convolution.weight"]
+                bn(f"{d}.downsample.1", f"{s_}.shortcut")
+    enc = ResNetEncoder("resnet50", 3).eval()
+    enc.load_state_dict(dst, strict=True)
+    assert len(enc.state_dict()) == len(src)
+    x = torch.randn(2, 3, 64, 64, generator=g)
+    with torch.no_grad():
+        feats = enc(x)
+        out = hf(x, output_hidden_states=True)
+    assert [tuple(f.shape[1:]) for f in feats[2:]] == [(256, 16, 16), (512, 8, 8), (1024, 4, 4), (2048, 2, 2)]
+    for i in range(4):
+        ref = out.hidden_states[1 + i]
+        assert torch.allclose(feats[2 + i], ref, atol=2e-4 * ref.abs().max().item(), rtol=1e-3), i
