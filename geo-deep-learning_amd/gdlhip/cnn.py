@@ -55,6 +55,123 @@ def _groups(weight: Tensor) -> int:
     return getattr(weight, "_gdl_groups", 1)
 
 
+STEM_BLOCK = 4     # pixels per side of a space-to-depth block
+# A/B switch (tools): GDL_STEM_IM2COL=1 restores the strided-patchify (im2col matrix) + GEMM stems of rounds 1 and 2
+STEM_IM2COL = __import__("os").environ.get("GDL_STEM_IM2COL", "0") == "1"
+
+
+def mark_stem(weight: Tensor, stride: int, pad: int) -> None:
+    """An image stem's parameter ([N, C, k, k] on raw bands, stride s in {2, 4}: torchvision's 7x7 / 2, MiT's 7x7 / 4).  It runs
+    IM2COL-FREE as ordinary 3x3 / stride-1 NHWC convolutions on the SPACE-TO-DEPTH image: 4 x 4 pixel blocks become 16 C
+    channels (a pure re-layout of the image by gdl_patchify with patch = stride = 4 -- nothing is duplicated, where the
+    strided-patchify matrix this path used before held k*k / s*s copies of every pixel), and the e x e = (4 / s)^2 output
+    pixels that share a block are e*e sub-pixel PHASES, each its own 3x3 filter over blocks:
+        input pixel  s * (e B + eps) - pad + r  =  4 (B + j) + d      =>      r = 4 j + d - s eps + pad,   j in {-1, 0, 1}
+        W_phase[n, (jy, jx), (c, dy, dx)] = W[n, c, r(jy, dy, epsy), r(jx, dx, epsx)]  where that tap exists, else 0.
+    Phase (epsy, epsx) writes the output pixels [epsy::e, epsx::e]; the weight gradient is nine-tap row-segment
+    weight-gradient calls on the same strided views, scattered back to the k x k taps (stem_operands / stem_param_grad)."""
+    if STEM_BLOCK % stride:
+        raise ValueError(f"stem stride {stride} does not divide the space-to-depth block {STEM_BLOCK}")
+    weight._gdl_stem = (int(stride), int(pad))
+
+
+_STEM_TABLES: dict = {}
+
+
+def _stem_index(weight: Tensor):
+    """(e, idx, valid): idx[phase, (jy, jx), (c, dy, dx)] = flat index into W[n].reshape(C * k * k) of the source tap.
+    Built once per (C, k, stride, pad, device)."""
+    key = (weight.shape[1], weight.shape[2], *weight._gdl_stem, str(weight.device))
+    hit = _STEM_TABLES.get(key)
+    if hit is None:
+        e, idx, valid = _stem_index_build(weight)
+        # per phase: the filter slots that hold a tap and the taps they hold, as index lists (a boolean mask would cost a
+        # device -> host synchronisation per use)
+        slots = [valid[ph].reshape(-1).nonzero().reshape(-1) for ph in range(e * e)]
+        taps = [idx[ph].reshape(-1)[slots[ph]] for ph in range(e * e)]
+        hit = _STEM_TABLES[key] = (e, idx, valid, slots, taps)
+    return hit[:3]
+
+
+def _stem_lists(weight: Tensor):
+    _stem_index(weight)
+    hit = _STEM_TABLES[(weight.shape[1], weight.shape[2], *weight._gdl_stem, str(weight.device))]
+    return hit[3], hit[4]
+
+
+def _stem_index_build(weight: Tensor):
+    s, pad = weight._gdl_stem
+    n, c, k, _ = weight.shape
+    b, e = STEM_BLOCK, STEM_BLOCK // s
+    lo, hi = -pad, s * (e - 1) - pad + k - 1            # pixel offsets (relative to block 4 B) a filter can touch
+    if lo < -b or hi > 2 * b - 1:
+        raise NotImplementedError(f"stem {k}x{k} / stride {s} / pad {pad} reaches beyond the neighbouring 4-pixel blocks")
+    dev = weight.device
+    eps = torch.arange(e, device=dev).view(e, 1, 1)
+    jj = torch.arange(-1, 2, device=dev).view(1, 3, 1)
+    dd = torch.arange(b, device=dev).view(1, 1, b)
+    r = b * jj + dd - s * eps + pad                                                   # [e, 3, 4]
+    ok = (r >= 0) & (r < k)
+    r = r.clamp(0, k - 1)
+    cc = torch.arange(c, device=dev).view(1, 1, 1, 1, c, 1, 1)
+    ry, rx = r.view(e, 1, 3, 1, 1, b, 1), r.view(1, e, 1, 3, 1, 1, b)
+    idx = (cc * k + ry) * k + rx                                                      # [ey, ex, jy, jx, c, dy, dx]
+    valid = (ok.view(e, 1, 3, 1, 1, b, 1) & ok.view(1, e, 1, 3, 1, 1, b)).expand_as(idx)
+    return e, idx.reshape(e * e, 9, c * b * b), valid.reshape(e * e, 9, c * b * b)
+
+
+def stem_operands(weight: Tensor, cd: torch.dtype, cpad: int, npad: int) -> Tensor:
+    """[e*e, Npad, 9 * Cpad] phase filters of a marked stem in the compute dtype (see mark_stem)."""
+    def build():
+        e, idx, valid = _stem_index(weight)
+        n = weight.shape[0]
+        flat = weight.detach().reshape(n, -1).float()
+        m = torch.zeros((e * e, npad, 9, cpad), device=weight.device, dtype=torch.float32)
+        m[:, :n, :, : idx.shape[-1]] = torch.where(valid.unsqueeze(1), flat[:, idx].permute(1, 0, 2, 3), flat.new_zeros(()))
+        m = m.view(e * e, npad, 9 * cpad)
+        return m if cd == torch.float32 else ops.cast(m, cd)
+    return cached((weight,), f"stemw:{cd}:{cpad}:{npad}", build)
+
+
+def stem_conv(x: Tensor, weight: Tensor, npad: int, **epilogue) -> Tensor:
+    """The stem convolution on the space-to-depth image x [B, H/4, W/4, Cpad] -> [B, H/s, W/s, Npad]: e*e phase convolutions,
+    each writing its strided slice of the output (``epilogue``: gdlhip.ops.conv_gemm's scale / shift / act keywords)."""
+    s, _ = weight._gdl_stem
+    e = STEM_BLOCK // s
+    wq = stem_operands(weight, x.dtype, x.shape[-1], npad)
+    b, hb, wb, _ = x.shape
+    y = torch.empty((b, hb * e, wb * e, npad), device=x.device, dtype=x.dtype)
+    for ph in range(e * e):
+        ops.conv_gemm(x, wq[ph], R=3, S=3, pad=1, out=y[:, ph // e::e, ph % e::e, :], **epilogue)
+    return y
+
+
+def stem_param_grad(x: Tensor, dy: Tensor, weight: Tensor) -> Tensor:
+    """dL/dW of a marked stem from the space-to-depth image and the dense output gradient: one nine-tap weight gradient per
+    phase on the strided view of dy, scattered back to the parameter's k x k taps (every tap has one slot per phase)."""
+    e, idx, _ = _stem_index(weight)
+    slots, taps = _stem_lists(weight)
+    n, cpad = weight.shape[0], x.shape[-1]
+    out = torch.zeros((n, weight[0].numel()), device=x.device, dtype=torch.float32)
+    for ph in range(e * e):
+        dw = ops.conv_wgrad(x, dy[:, ph // e::e, ph % e::e, :], R=3, S=3, pad=1).view(-1, 9, cpad)[:n, :, : idx.shape[-1]]
+        out.index_add_(1, taps[ph], dw.reshape(n, -1).index_select(1, slots[ph]))     # (each tap has one slot per phase)
+    return out.reshape(weight.shape)
+
+
+def space_to_depth_image(img: Tensor, cd: torch.dtype) -> Tensor:
+    """NCHW f32 image -> [B, H/4, W/4, Cpad] in the compute dtype, channel order (c, dy, dx), Cpad = 16 C rounded up to a
+    power of two >= 16 (whole or evenly divided K chunks for the implicit-GEMM kernels)."""
+    b, c, h, w = img.shape
+    if h % STEM_BLOCK or w % STEM_BLOCK:
+        raise ValueError(f"image {h}x{w}: height and width must be multiples of {STEM_BLOCK}")
+    cpad = 16
+    while cpad < c * STEM_BLOCK * STEM_BLOCK:
+        cpad *= 2
+    hb, wb = h // STEM_BLOCK, w // STEM_BLOCK
+    return ops.patchify(img, STEM_BLOCK, 0, hb, wb, cpad, cd, stride=STEM_BLOCK).view(b, hb, wb, cpad)
+
+
 def _is_flat(weight: Tensor) -> bool:
     return weight.dim() == 2 or getattr(weight, "_gdl_flat", False)
 
@@ -64,6 +181,8 @@ def _wshape(weight: Tensor) -> tuple[int, int, int, int]:
     if _is_flat(weight):
         return weight.shape[0], weight[0].numel(), 1, 1
     n, c, r, s = weight.shape
+    if hasattr(weight, "_gdl_stem"):
+        return n, c * STEM_BLOCK * STEM_BLOCK, 3, 3
     return n, c * _groups(weight), r, s
 
 
@@ -73,6 +192,8 @@ def _matrix3(weight: Tensor) -> Tensor:
     if _is_flat(weight):
         return weight.detach().reshape(weight.shape[0], 1, -1)
     n, c, r, s = weight.shape
+    if hasattr(weight, "_gdl_stem"):
+        raise ValueError("a marked stem has one filter per sub-pixel phase: use stem_operands / stem_conv")
     m = conv_weight_matrix(weight).view(n, r * s, c)
     g = _groups(weight)
     if g == 1:
@@ -151,8 +272,11 @@ class _ConvBNTrain(Function):
         cpad, npad = x.shape[-1], pad_to(n, grain(cd))
         if cpad < c or cpad % grain(cd):
             raise ValueError(f"conv input has {cpad} channels, weight expects {c} (padded to a multiple of {grain(cd)})")
-        wq, _ = padded_operands(weight, cd, cpad, npad)
-        y = ops.conv_gemm(x, wq, R=r, S=s, stride=stride, pad=pad)
+        if hasattr(weight, "_gdl_stem"):
+            y = stem_conv(x, weight, npad)
+        else:
+            wq, _ = padded_operands(weight, cd, cpad, npad)
+            y = ops.conv_gemm(x, wq, R=r, S=s, stride=stride, pad=pad)
         world = _world(sync_group) if sync_group is not False else 1
         p_local, p_share, total = y.numel() // npad, None, y.numel() // npad
         in_kernel = world == 1 and running_mean is not None and npad == n   # the statistics kernel updates the buffers itself
@@ -184,10 +308,14 @@ class _ConvBNTrain(Function):
             sg, sb = sg * p_share, sb * p_share      # see gdlhip.nn._ConvBNActTrain.backward
         dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, p_local, out=y)
         dw = None
+        stem = hasattr(weight, "_gdl_stem")
         if ctx.needs_input_grad[1]:
-            dw = _param_grad(ops.conv_wgrad(x, dy, R=r, S=s, stride=stride, pad=pad), weight, cpad)
+            dw = (stem_param_grad(x, dy, weight) if stem else
+                  _param_grad(ops.conv_wgrad(x, dy, R=r, S=s, stride=stride, pad=pad), weight, cpad))
         dx = None
         if ctx.needs_input_grad[0]:
+            if stem:
+                raise NotImplementedError("gdlhip: no gradient with respect to the raw image of a stem convolution")
             dx = _conv_dx(dy, weight, x.dtype, cpad, npad, stride, pad, (x.shape[1], x.shape[2]))
         return dx, dw, dgamma[:n], dbeta[:n], None, None, None, None, None, None, None, None
 
@@ -219,6 +347,10 @@ def conv_bn(x: Tensor, weight: Tensor, norm: nn.Module, *, stride: int = 1, pad:
         return _padvec(scale, npad), _padvec(shift, npad)
     scale, shift = cached((norm.weight, norm.bias, norm.running_mean, norm.running_var), f"bnfold:{npad}", fold)
     act = ACT_NONE if not relu else (ACT_RELU if resid is None else ACT_RESID_RELU)
+    if hasattr(weight, "_gdl_stem"):
+        if resid is not None:
+            raise ValueError("a stem convolution takes no residual operand")
+        return stem_conv(x, weight, npad, scale=scale, shift=shift, act=act)
     return ops.conv_gemm(x, padded_operands(weight, cd, cpad, npad)[0], R=r, S=s, stride=stride, pad=pad, scale=scale,
                          shift=shift, act=act, resid=resid)
 

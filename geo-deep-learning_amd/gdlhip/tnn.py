@@ -174,6 +174,38 @@ def stem_linear(cols: Tensor, weight: Tensor, bias: Tensor, wq: Tensor, out_dtyp
     return _StemLinear.apply(cols, weight, bias, wq, out_dtype)
 
 
+class _StemConv(Function):
+    """Image stem WITHOUT an im2col matrix: y = conv_kxk/stride(image) + b evaluated as sub-pixel-phase 3x3 convolutions on the
+    4 x 4 space-to-depth image (gdlhip.cnn.mark_stem; MiT's 7x7 / 4 is a single phase).  Raw bands carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, xs, weight, bias, out_dtype):
+        from . import cnn
+        n = weight.shape[0]
+        wq = cnn.stem_operands(weight, xs.dtype, xs.shape[-1], n)
+        st, _ = weight._gdl_stem
+        e = cnn.STEM_BLOCK // st
+        b, hb, wb, _ = xs.shape
+        y = torch.empty((b, hb * e, wb * e, n), device=xs.device, dtype=out_dtype)
+        for ph in range(e * e):
+            ops.conv_gemm(xs, wq[ph], R=3, S=3, pad=1, bias=bias.detach(), out=y[:, ph // e::e, ph % e::e, :])
+        ctx.save_for_backward(xs, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import cnn
+        xs, weight = ctx.saved_tensors
+        dy = _dense(_to_cd(g, xs.dtype))
+        db = ops.colsum(dy.reshape(-1, dy.shape[-1]))
+        return None, cnn.stem_param_grad(xs, dy, weight), db, None
+
+
+def stem_conv(xs: Tensor, weight: Tensor, bias: Tensor, out_dtype: torch.dtype) -> Tensor:
+    """xs = gdlhip.cnn.space_to_depth_image(image); weight marked with gdlhip.cnn.mark_stem(weight, stride, pad)."""
+    return _StemConv.apply(xs, weight, bias, out_dtype)
+
+
 # ------------------------------------------------------------------ dynamic SegFormer stem: band weighting + pooling
 class _ChanPool(Function):
     """agg = sum_c softmax_c(s)[c] * conv[c] * cw[c] (DynamicChannelEmbed.forward, mix_transformer.py:823-853) with the

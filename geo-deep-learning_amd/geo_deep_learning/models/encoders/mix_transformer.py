@@ -28,7 +28,7 @@ from torch import Tensor, nn
 from geo_deep_learning.models.segmentation.base import EncoderMixin
 from geo_deep_learning.models.utils import _cl_conv
 from gdlhip import nn as gnn
-from gdlhip import ops, tnn
+from gdlhip import cnn, ops, tnn
 
 
 def _drop_scale(prob: float, training: bool, batch: int, device, mask: Tensor | None) -> Tensor | None:
@@ -163,8 +163,16 @@ class OverlapPatchEmbed(nn.Module):
         cd = gnn.compute_dtype()
         k, s, p = self.patch_size[0], self.stride, self.patch_size[0] // 2
         n = self.proj.weight.shape[0]
-        if self.is_stem:
-            b, c, hi, wi = x.shape  # raw bands, NCHW: im2col-free is impossible with C < one K chunk
+        if self.is_stem and s in (2, 4) and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0 and not cnn.STEM_IM2COL:
+            # raw bands, NCHW, fewer channels than one K chunk: no im2col matrix either -- the image is re-laid into 4 x 4
+            # pixel blocks (16 C channels) and the k x k / s convolution runs as 3x3 phase convolutions on that map
+            b, c, hi, wi = x.shape
+            h, w = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
+            cnn.mark_stem(self.proj.weight, s, p)
+            xs = cnn.space_to_depth_image(ops.image_f32(x, "OverlapPatchEmbed"), cd)
+            y = tnn.stem_conv(xs, self.proj.weight, self.proj.bias, torch.float32)
+        elif self.is_stem:      # odd strides / image sizes: strided patchify (an im2col matrix) + GEMM
+            b, c, hi, wi = x.shape
             h, w = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
             bke = 32 if cd == torch.float32 else 64
             kpad = (c * k * k + bke - 1) // bke * bke

@@ -3,7 +3,8 @@ builds at tasks_with_models/segmentation_unetplus.py:126-131 (same constructor k
 segmentation-models-pytorch 0.5.0 / torchvision, so its checkpoints load).
 
 Everything runs NHWC in the compute dtype on the implicit-GEMM MFMA kernel:
-* stem 7x7/2 on the raw bands = strided patchify + GEMM + BN + ReLU, then the 3x3/2 max-pool kernel;
+* stem 7x7/2 on the raw bands = space-to-depth re-layout (4 x 4 pixel blocks) + four sub-pixel-phase 3x3 implicit-GEMM
+  convolutions + BN + ReLU (no im2col matrix), then the 3x3/2 max-pool kernel;
 * BasicBlock = conv3x3-BN-ReLU, conv3x3-BN, (+ 1x1/s downsample-BN), residual add + ReLU (one kernel in
   training; folded into the second conv's epilogue in eval); Bottleneck = 1x1, (grouped) 3x3 with the stride, 1x1 to
   4 x planes, same tail -- resnet50 / 101, resnext50_32x4d and resnext101_32x8d, the encoder of the reference's shipped
@@ -126,12 +127,19 @@ class ResNetEncoder(nn.Module):
     def forward_nhwc(self, img: Tensor) -> list[Tensor]:
         """NCHW f32 image -> the five NHWC feature maps (strides 2..32) in the compute dtype."""
         cd = gnn.compute_dtype()
-        b, c, h, w = img.shape
-        gh, gw = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
-        kpad = cnn.pad_to(c * 49, cnn.chunk(cd))
-        cols = ops.patchify(ops.image_f32(img, "UnetPlusPlus"), 7, 3, gh, gw, kpad, cd, stride=2).view(b, gh, gw, kpad)
-        cnn.mark_flat(self.conv1.weight)    # the stem parameter is the [64, (c,r,s)] matrix of the patch GEMM
-        x = cnn.conv_bn(cols, self.conv1.weight, self.bn1)
+        # im2col-free stem: the image is re-laid into 4 x 4 pixel blocks (16 C channels) and the 7x7 / 2 convolution runs as
+        # four sub-pixel-phase 3x3 convolutions on that map (gdlhip.cnn.mark_stem)
+        if cnn.STEM_IM2COL:      # A/B: strided patchify (an im2col matrix of 49 / 4 x the image) + GEMM
+            b, c, h, w = img.shape
+            gh, gw = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+            kpad = cnn.pad_to(c * 49, cnn.chunk(cd))
+            cols = ops.patchify(ops.image_f32(img, "UnetPlusPlus"), 7, 3, gh, gw, kpad, cd, stride=2).view(b, gh, gw, kpad)
+            cnn.mark_flat(self.conv1.weight)
+            x = cnn.conv_bn(cols, self.conv1.weight, self.bn1)
+        else:
+            xs = cnn.space_to_depth_image(ops.image_f32(img, "UnetPlusPlus"), cd)
+            cnn.mark_stem(self.conv1.weight, 2, 3)
+            x = cnn.conv_bn(xs, self.conv1.weight, self.bn1)
         feats = [x]
         x = cnn.maxpool3x3s2(x)
         for i in (1, 2, 3, 4):
