@@ -3,7 +3,7 @@
 Drop-in for the reference's models/encoders/mix_transformer.py (same class names, constructor
 arguments, ``get_encoder`` factory and state-dict keys); arithmetic in HIP kernels:
 
-* OverlapPatchEmbed: 7x7/s4 stem on the raw bands via a strided patchify + MFMA GEMM (3..10 input
+* OverlapPatchEmbed: 7x7/s4 stem on the raw bands as a 3x3 convolution on the 4x4 space-to-depth image (3..10 input
   channels are too few for the implicit-GEMM kernel), 3x3/s2 stages 2-4 as implicit-GEMM convs
   straight from the previous stage's NHWC feature; LayerNorm (eps 1e-5) -> f32 token stream.
 * Attention (spatial reduction): q GEMM; K/V from ``LN(sr-conv(x))`` (k=stride=sr implicit-GEMM
@@ -361,11 +361,17 @@ class DynamicChannelEmbed(nn.Module):
         b, c, hi, wi = x.shape
         k, s, p = self.patch_size, self.stride, self.patch_size // 2
         h, w = (hi + 2 * p - k) // s + 1, (wi + 2 * p - k) // s + 1
-        bke = 32 if cd == torch.float32 else 64
-        kpad = (k * k + bke - 1) // bke * bke
-        cols = ops.patchify(ops.image_f32(x, "DynamicChannelEmbed").view(b * c, 1, hi, wi), k, p, h, w, kpad, cd, stride=s)
-        conv = tnn.stem_linear(cols, self.spatial_conv.weight, self.spatial_conv.bias, self._stem_weight(cd, kpad),
-                               torch.float32)
+        planes = ops.image_f32(x, "DynamicChannelEmbed").view(b * c, 1, hi, wi)       # every band is its own one-channel image
+        if s in (2, 4) and hi % 4 == 0 and wi % 4 == 0 and not cnn.STEM_IM2COL:
+            cnn.mark_stem(self.spatial_conv.weight, s, p)                              # im2col-free, like OverlapPatchEmbed
+            conv = tnn.stem_conv(cnn.space_to_depth_image(planes, cd), self.spatial_conv.weight, self.spatial_conv.bias,
+                                 torch.float32)
+        else:
+            bke = 32 if cd == torch.float32 else 64
+            kpad = (k * k + bke - 1) // bke * bke
+            cols = ops.patchify(planes, k, p, h, w, kpad, cd, stride=s)
+            conv = tnn.stem_linear(cols, self.spatial_conv.weight, self.spatial_conv.bias, self._stem_weight(cd, kpad),
+                                   torch.float32)
         agg = tnn.chan_pool(conv.view(b, c, h * w, self.embed_dim), self.get_position_encoding(c, x.device),
                             self.weight_gen, self.channel_attention)
         tok = gnn.to_compute(agg.view(b, h, w, self.embed_dim), cd)
