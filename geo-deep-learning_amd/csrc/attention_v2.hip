@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // `defer` > 0: the running maximum is only raised (and O rescaled) when some row's tile maximum exceeds it by more than
 // `defer` in the exp2 domain -- P stays below 2^defer; with the usual slowly growing maxima most tiles skip the rescale.
 template <int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void flash_fwd3_kernel(const Attn2Args f, const float defer) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 2 ? 2 : 4, 4))) void flash_fwd3_kernel(const Attn2Args f, const float defer) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];   // stage s: K at 2s, V at 2s+1
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
