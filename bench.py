@@ -578,6 +578,12 @@ def main() -> None:
             "by_k_depth": {b: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
                            for b, v in sorted(s.get("by_k", {}).items())},
+            # ... and by layer shape (M = pixels or tokens, N = outputs, K = R*S*C), heaviest first: `achieved` is the average
+            # over THIS mix -- a class that loses its deep-K members to an algebraic rewrite, or gains short-K ones because the
+            # planner found this tile faster for them, moves the average without any layer getting slower
+            "by_layer": [{"shape": t, "launches": v["launches"], "ms": round(v["ms"], 3),
+                          "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)}
+                         for t, v in sorted(s.get("by_shape", {}).items(), key=lambda kv: -kv[1]["ms"])[:14]],
             "other_conv_gemm_variants": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                          for k, v in summ.items() if k != name},

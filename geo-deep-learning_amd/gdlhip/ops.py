@@ -178,7 +178,8 @@ class KernelTimer:
                        + int(a.B) * int(a.Ho) * int(a.Wo) * int(a.N) * oes)
         if a.resid:
             nbytes += nz * int(a.B) * int(a.Ho) * int(a.Wo) * int(a.N) * (2 if a.resid_dtype == BF16 else 4)
-        self.records.append((key, fl.value, e0, e1, int(a.R) * int(a.S) * int(a.C), nbytes))
+        shape = (nz * int(a.B) * int(a.Ho) * int(a.Wo), int(a.N), int(a.R) * int(a.S) * int(a.C), int(a.R), int(a.S), oes, bool(a.resid))
+        self.records.append((key, fl.value, e0, e1, int(a.R) * int(a.S) * int(a.C), nbytes, shape))
 
     @staticmethod
     def _k_bucket(k: int) -> str:
@@ -189,10 +190,13 @@ class KernelTimer:
         12-K-step ViT linears and 100-K-step convolutions, whose achievable rates differ by a factor of two."""
         torch.cuda.synchronize()
         out: dict = {}
-        for key, flops, e0, e1, kdepth, nbytes in self.records:
+        for key, flops, e0, e1, kdepth, nbytes, shape in self.records:
             ms = e0.elapsed_time(e1)
-            s = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0, "by_k": {}})
-            for d in (s, s["by_k"].setdefault(self._k_bucket(kdepth), {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0})):
+            s = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0, "by_k": {}, "by_shape": {}})
+            m_, n_, k_, r_, s_, oes, res = shape
+            tag = f"M{m_} N{n_} K{k_} {r_}x{s_} -> {'bf16' if oes == 2 else 'f32'}{' +resid' if res else ''}"
+            for d in (s, s["by_k"].setdefault(self._k_bucket(kdepth), {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0}),
+                      s["by_shape"].setdefault(tag, {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0})):
                 d["launches"] += 1
                 d["ms"] += ms
                 d["flops"] += flops
