@@ -414,6 +414,7 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
     k.c_tail = 0;
   }
   if (variant == 7) return conv3x3_narrow_launch(k, s);
+  if (variant == 6) return conv_gemm_dual_launch(k, s);
   if (a.dtype == GDL_BF16) {
     if (variant == 4) return conv3x3_sf_launch(k, s);
     if (variant == 3 && k.dbg == 7) return launch_x<bf16_tag, 2, 4, 4, 2, false, true, false, false, true>(k, s);
@@ -452,6 +453,7 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
       !(g_forced_variant >= 2 && g_forced_variant != 5 && a.C % (a.dtype == GDL_BF16 ? 64 : 32) != 0) &&
       !(g_forced_variant == 5 && a.N > 64) &&
       !(g_forced_variant == 4 && !conv3x3_sf_applicable(a)) &&
+      !(g_forced_variant == 6 && !conv_gemm_dual_applicable(a)) &&
       !(g_forced_variant == 7 && !conv3x3_narrow_applicable(a)))
     return g_forced_variant;
   // narrow 3x3 layers on large maps: direct kernel, one staged window per 4 x 64 pixels (HBM-bound layers)

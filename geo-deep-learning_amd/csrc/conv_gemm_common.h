@@ -75,6 +75,9 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // 3x3 shared-staging kernel (conv3x3_sf.hip)
 bool conv3x3_sf_applicable(const gdl_conv_args& a);
 int conv3x3_sf_launch(const KArgs& k, hipStream_t stream);
+// dual-resident 256 x 128 tile, two workgroups per CU (conv_gemm_dual.hip): short-K bf16 layers
+bool conv_gemm_dual_applicable(const gdl_conv_args& a);
+int conv_gemm_dual_launch(const KArgs& k, hipStream_t stream);
 // direct 3x3 kernel for C in {8,16,32} on large dense maps, outputs in 32-channel slices (conv3x3_narrow.hip)
 bool conv3x3_narrow_applicable(const gdl_conv_args& a);
 int conv3x3_narrow_launch(const KArgs& k, hipStream_t stream);
@@ -275,13 +278,33 @@ __device__ __forceinline__ bool conv_epilogue_rows(const KArgs& k, f32x16_t (&ac
 // ReLU / GELU; * DropPath scale; + residual; ReLU) -- results are bit-identical, tests/test_hip_ops.py holds it to that.
 // Not for the training-only extras (aux_out, GELU-gradient multiply): those keep conv_epilogue_rows.
 
-template <int TM, int CH, bool RESID>
+// EF selects how the element-wise terms are decided: 0 = at run time from the arguments (any combination); otherwise the
+// combination is a COMPILE-TIME constant -- bit 0 set, bit 1 = per-channel scale/shift, bit 2 = DropPath scale, bits 3-4 =
+// activation (0 none, 1 ReLU, 2 GELU) -- and the caller guarantees the arguments match it.  With run-time flags hipcc turns
+// every `if (a.scale)` / `if (a.act == ...)` into v_cndmask selects per ELEMENT (about 75 VALU instructions per 8 outputs of
+// which a bias-only layer needs 12), and a wave's epilogue is a serial chain of such groups: measured 10.8 k cycles per 256^2
+// qkv tile of which 12.2 k remained with the global stores removed (profiles/r03b_gemm_epilogue_parts.txt).  Arithmetic and
+// its order are the same in every instantiation: results are bit-identical to EF = 0.
+#ifndef GDL_EPI_MASK
+#define GDL_EPI_MASK 15
+#endif
+#define GDL_EPI_ON(bit) ((GDL_EPI_MASK & (bit)) != 0)
+constexpr int EPI_RUNTIME = 0, EPI_FIXED = 1, EPI_SCALE = 2, EPI_DROPPATH = 4, EPI_RELU = 8, EPI_GELU = 16;
+
+template <int TM, int CH, bool RESID, int EF = EPI_RUNTIME>
 __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_t (&acc)[TM][2], int m0, int n0, int wm, int wn,
                                                         int lane, int64_t out_zoff, unsigned char* lds) {
+  // the two fused multiply-adds of the element-wise chain are written out; nothing else may be contracted: with compile-time
+  // terms "DropPath scale, then + residual" are adjacent and would fuse, with run-time terms (a select in between) they do not
+#pragma clang fp contract(off)
   constexpr int NT = CH == 8 ? 4 : 8;                    // row groups per pass: a pass is 32 rows x 64 channels
   constexpr int LPR = 64 / CH;                           // lanes per row
   const gdl_conv_args& a = k.a;
-  const bool plain = !a.resid && !a.batch_scale;
+  constexpr bool RT = EF == EPI_RUNTIME;
+  const bool has_scale = RT ? a.scale != nullptr : (EF & EPI_SCALE) != 0;
+  const bool has_bs = RT ? a.batch_scale != nullptr : (EF & EPI_DROPPATH) != 0;
+  const int act = RT ? a.act : (EF & EPI_RELU) ? GDL_ACT_RELU : (EF & EPI_GELU) ? GDL_ACT_GELU : GDL_ACT_NONE;
+  const bool plain = !RESID && !has_bs;
   const bool fast = a.dtype == GDL_BF16;
   const int HoWo = a.Ho * a.Wo;
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -298,8 +321,8 @@ __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_
 #pragma unroll
     for (int q = 0; q < CH / 4; ++q) {
       if (a.bias) { const float4 t = *(const float4*)(a.bias + n_l + 4 * q); cb[4 * q] = t.x; cb[4 * q + 1] = t.y; cb[4 * q + 2] = t.z; cb[4 * q + 3] = t.w; }
-      if (a.scale) { const float4 t = *(const float4*)(a.scale + n_l + 4 * q); cs[4 * q] = t.x; cs[4 * q + 1] = t.y; cs[4 * q + 2] = t.z; cs[4 * q + 3] = t.w; }
-      if (a.scale && a.shift) { const float4 t = *(const float4*)(a.shift + n_l + 4 * q); chh[4 * q] = t.x; chh[4 * q + 1] = t.y; chh[4 * q + 2] = t.z; chh[4 * q + 3] = t.w; }
+      if (has_scale) { const float4 t = *(const float4*)(a.scale + n_l + 4 * q); cs[4 * q] = t.x; cs[4 * q + 1] = t.y; cs[4 * q + 2] = t.z; cs[4 * q + 3] = t.w; }
+      if (has_scale && a.shift) { const float4 t = *(const float4*)(a.shift + n_l + 4 * q); chh[4 * q] = t.x; chh[4 * q + 1] = t.y; chh[4 * q + 2] = t.z; chh[4 * q + 3] = t.w; }
     }
   }
   // residual rows of one pass: NT pieces of CH channels (f32 or bf16 in memory) as f32 registers
@@ -310,10 +333,21 @@ __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_
   // (the residual has the OUTPUT's dtype here -- f32 stream + f32 residual, bf16 map + bf16 residual -- so a row group is
   // always one 16-byte load; other combinations keep conv_epilogue_rows)
   constexpr int RW = 4;
+  // addresses = a buffer descriptor on the wave tile's first element (uniform) + ONE per-lane 32-bit offset + a uniform
+  // (scalar) row offset per access: written as per-lane 64-bit `m * stride + n` products -- or as 64-bit pointer sums --
+  // the compiler precomputed the 32 + 32 addresses of a tile ahead of the passes (128 registers) and spilled
+  constexpr int OES = CH == 8 ? 2 : 4;                   // bytes per output element; the residual has the output's dtype here
+  const int m_w = m0 + wm * TM * 32;                     // first row of the wave tile (uniform)
+  const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const unsigned char*)a.resid + ((int64_t)m_w * a.res_sW + n0 + wn * 64) * OES), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((unsigned char*)a.out + ((int64_t)m_w * a.out_sW + out_zoff + n0 + wn * 64) * OES), 0, 0x7fffffff, 0x00020000);
+  const unsigned res_lo = (unsigned)((srow * (int)a.res_sW + CH * slot) * OES);
+  const unsigned out_lo = (unsigned)((srow * (int)a.out_sW + CH * slot) * OES);
+  typedef __attribute__((ext_vector_type(4))) unsigned epi_u4;
   auto load_resid_t = [&](int mp, int t, uint32_t (&rw)[NT][RW]) {
-    const int m = mp + srow + (64 / LPR) * t;
-    const int64_t ro = (int64_t)m * a.res_sW + n_l;
-    const uint4 u = CH == 8 ? *(const uint4*)((const uint16_t*)a.resid + ro) : *(const uint4*)((const float*)a.resid + ro);
+    const unsigned ru = (unsigned)((mp - m_w + (64 / LPR) * t) * (int)a.res_sW * OES);   // uniform
+    const epi_u4 u = __builtin_amdgcn_raw_buffer_load_b128(res_rs, res_lo, ru, 0);
     rw[t][0] = u.x; rw[t][1] = u.y; rw[t][2] = u.z; rw[t][3] = u.w;
   };
   auto resid_value = [&](const uint32_t (&w)[RW], int e) -> float {
@@ -325,7 +359,7 @@ __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_
   // caller): the tile's (at most 256) rows span at most two samples.
   float rs0 = 1.f, rs1 = 1.f;
   int rem0 = 0;                                          // row m belongs to sample b0 + 1 when m - m0 + rem0 >= HoWo
-  if (a.batch_scale) {
+  if (has_bs) {
     const int b0 = m0 / HoWo;
     rem0 = m0 - b0 * HoWo;
     rs0 = a.batch_scale[b0];
@@ -363,15 +397,14 @@ __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_
         const float4 x = *(const float4*)(lds + rr * 256 + ((sl ^ (rr & 7)) << 4));
         v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
       }
-      const int m = mp + rr;
 #pragma unroll
       for (int e = 0; e < CH; ++e) {
-        float x = v[e] * a.alpha + cb[e];
-        if (a.scale) x = x * cs[e] + chh[e];
-        if (a.act == GDL_ACT_RELU) x = fmaxf(x, 0.f);
+        float x = __builtin_fmaf(v[e], a.alpha, cb[e]);
+        if (has_scale) x = __builtin_fmaf(x, cs[e], chh[e]);
+        if (act == GDL_ACT_RELU) x = fmaxf(x, 0.f);
         v[e] = x;
       }
-      if (a.act == GDL_ACT_GELU) {
+      if (act == GDL_ACT_GELU) {
 #pragma unroll
         for (int q = 0; q < CH / 4; ++q) {
           const float4 x4 = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -380,7 +413,7 @@ __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_
         }
       }
       if (!plain) {
-        if (a.batch_scale) {
+        if (has_bs) {
           const float rs = rem0 + (wm * TM + i) * 32 + rr >= HoWo ? rs1 : rs0;
 #pragma unroll
           for (int e = 0; e < CH; ++e) v[e] *= rs;
@@ -389,19 +422,24 @@ __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_
 #pragma unroll
           for (int e = 0; e < CH; ++e) {
             float x = v[e] + resid_value(rva[t], e);
-            if (a.act == GDL_ACT_RESID_RELU) x = fmaxf(x, 0.f);
+            if (act == GDL_ACT_RESID_RELU) x = fmaxf(x, 0.f);
             v[e] = x;
           }
           if (i + 1 < TM) load_resid_t(mp + 32, t, rva);
         }
       }
-      const int64_t off = (int64_t)m * a.out_sW + out_zoff + n_l;
+      const unsigned ou = (unsigned)((i * 32 + (64 / LPR) * t) * (int)a.out_sW * OES);    // uniform (scalar): rows i*32 + step*t of the wave tile
+      epi_u4 o;
       if constexpr (CH == 8) {
-        *(uint4*)((uint16_t*)a.out + off) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                                        pack_bf16x2(v[6], v[7]));
+        o = epi_u4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
       } else {
-        *(float4*)((float*)a.out + off) = make_float4(v[0], v[1], v[2], v[3]);
+        o = epi_u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
       }
+      // the row offset goes into the VECTOR offset (one v_add), not into soffset: hipcc (ROCm 7.2) assumes that a buffer store
+      // with a register soffset cannot have its data registers overwritten too early and pads nothing, but gfx950 does need
+      // the wait states of a >64-bit store -- with `..., out_lo, ou` the VALU instruction behind the store clobbered the
+      // fourth data dword of some lanes (tools/debug/epi_diff.py: wrong values in columns 4k+3 of the t = 1 row groups)
+      __builtin_amdgcn_raw_buffer_store_b128(o, out_rs, out_lo + ou, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -422,6 +460,29 @@ __device__ __forceinline__ bool conv_epilogue_rows2(const KArgs& k, f32x16_t (&a
   // full WAVE tiles only (see the implementation): the wave's TM x 32 rows and 64 channels are all in range.  The decision
   // is per wave -- both epilogues only touch wave-private LDS
   if (m0 + (wm + 1) * TM * 32 > k.M || n0 + (wn + 1) * 64 > a.N) return false;
+  // the combinations the three models' hot layers use get compile-time element-wise terms (k.epi_v2 == 2 keeps the
+  // run-time form for A/B runs); everything else takes the run-time form
+  const bool sc = a.scale != nullptr, bs = a.batch_scale != nullptr, rs = a.resid != nullptr;
+  if (k.epi_v2 != 2) {
+    if (GDL_EPI_ON(1) && !rs && !bs && !sc && a.act == GDL_ACT_NONE) {                       // bias only: qkv, laterals, tap products, data gradients
+      if (out_bf16) conv_epilogue_rows2_impl<TM, 8, false, EPI_FIXED>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
+      else conv_epilogue_rows2_impl<TM, 4, false, EPI_FIXED>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
+      return true;
+    }
+    if (GDL_EPI_ON(2) && !rs && !bs && !sc && a.act == GDL_ACT_GELU && out_bf16) {           // MLP fc1
+      conv_epilogue_rows2_impl<TM, 8, false, EPI_FIXED | EPI_GELU>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
+      return true;
+    }
+    if (GDL_EPI_ON(4) && !rs && !bs && sc && a.act == GDL_ACT_RELU && out_bf16) {            // ConvModule with folded BatchNorm (eval)
+      conv_epilogue_rows2_impl<TM, 8, false, EPI_FIXED | EPI_SCALE | EPI_RELU>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
+      return true;
+    }
+    if (GDL_EPI_ON(8) && rs && sc && a.act == GDL_ACT_NONE && !out_bf16) {                   // proj / fc2: LayerScale (x DropPath) + f32 residual stream
+      if (bs) conv_epilogue_rows2_impl<TM, 4, true, EPI_FIXED | EPI_SCALE | EPI_DROPPATH>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
+      else conv_epilogue_rows2_impl<TM, 4, true, EPI_FIXED | EPI_SCALE>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
+      return true;
+    }
+  }
   if (a.resid) {
     if (out_bf16) conv_epilogue_rows2_impl<TM, 8, true>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
     else conv_epilogue_rows2_impl<TM, 4, true>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
