@@ -39,7 +39,8 @@ __global__ __launch_bounds__(512) void conv3x3_sf_kernel(const KArgs k) {
   const int lwave = wave & 3, half = wave >> 2;      // waves w and w+4 share a SIMD and alternate as loaders
 
   const int lid = xcd_remap(blockIdx.x, k.tiles_m * k.tiles_n);
-  const int tile_n = lid % k.tiles_n, tile_m = lid / k.tiles_n;
+  int tile_m, tile_n;
+  tile_order(k, lid, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const srd_t srd_a = make_srd(a.in, k.in_span);
   const srd_t srd_b = make_srd(a.w, k.w_span);
@@ -224,6 +225,7 @@ int conv3x3_sf_launch(const KArgs& k, hipStream_t stream) {
   KArgs kk = k;
   kk.tiles_m = (k.M + 255) / 256;
   kk.tiles_n = (k.a.N + 255) / 256;
+  kk.n_group = conv_n_group(k.a, 256, 256, 32);
   const size_t lds = 2 * 36 * 1024 + 2 * 256 * 128;
   dim3 grid(kk.tiles_m * kk.tiles_n), block(512);
   if (k.a.dtype == GDL_BF16) {

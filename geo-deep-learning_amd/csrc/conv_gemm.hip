@@ -64,7 +64,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
   const int lid = xcd_remap(blockIdx.x, k.tiles_m * k.tiles_n);
-  const int tile_n = lid % k.tiles_n, tile_m = lid / k.tiles_n;
+  int tile_m, tile_n;
+  tile_order(k, lid, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.y;
   const int z0 = z / a.nz_inner, z1 = z % a.nz_inner;
@@ -309,6 +310,7 @@ int launch_x(const KArgs& k, hipStream_t stream) {
   KArgs kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.a.N + BN - 1) / BN;
+  kk.n_group = conv_n_group(k.a, BM, BN, 32 * (BM * BN >= 65536 ? 1 : BM * BN >= 16384 ? 2 : 4));
   const size_t lds = 2 * (BM + BN) * 128;
   auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA, PP, CT, TP, TL>;
   GDL_SET_MAX_LDS_ONCE(kern, lds);   // one flag per template instantiation of launch_x
@@ -394,6 +396,8 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   k.KT = a.R * a.S * k.kc;
   // "dense" = the (b,oy,ox) -> offset map is linear in m, so no divisions are needed
   k.tap_inner = g_tap_inner;
+  k.n_group = 0;
+  k.tiles_m = k.tiles_n = 0;
   k.dbg = g_dbg;
   k.epi_v2 = g_epi_v2;
   k.probe = g_probe;
@@ -438,6 +442,32 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
 // they still give >= 512 blocks, 128x128 / 4 waves (variant 1) when that gives >= 256 blocks,
 // else 64x64 (variant 0).  Also reports the ALGORITHMIC flops of the call (2*M*N*K, no padding).
 static std::atomic<int> g_forced_variant{-1};
+static std::atomic<int> g_dual_enabled{1};
+extern "C" void gdl_debug_set_conv_dual(int on) { g_dual_enabled = on; }  // A/B hook: dual-resident 256 x 128 tile
+static std::atomic<int> g_ngroup_kb{2560};
+extern "C" void gdl_debug_set_conv_ngroup_kb(int kb) { g_ngroup_kb = kb; }  // A/B hook: weight bytes (KiB) one N group may hold; 0 = no grouping
+namespace gdlconv {
+// The 32 CUs of an XCD run `conc` tiles at a time, arranged as (conc / w) M rows x w N tiles when N is walked in groups of w.
+// They run in step (same k at the same time), so per round the XCD's L2 pulls (conc / w) activation panels plus -- unless the
+// group's w weight panels stay resident (budget: g_ngroup_kb of the 4 MiB L2) -- w weight panels.  Compare "no grouping" with
+// "the widest group that stays resident" and take the cheaper one.
+int conv_n_group(const gdl_conv_args& a, int bm, int bn, int conc) {
+  const int64_t budget = (int64_t)g_ngroup_kb * 1024;
+  if (budget <= 0) return 0;
+  const int64_t kbytes = (int64_t)a.R * a.S * a.C * (int64_t)gdl_elem_size(a.dtype);
+  const int64_t a_panel = bm * kbytes, w_panel = bn * kbytes;
+  const int64_t tiles_n = (a.N + bn - 1) / bn;
+  const int64_t w_fit = budget / w_panel;
+  if (w_fit < 1 || w_fit >= tiles_n) return 0;
+  auto cost = [&](int64_t w) {
+    const int64_t wc = w < conc ? w : conc;
+    return (conc / wc) * a_panel + (w * w_panel <= budget ? 0 : wc * w_panel);
+  };
+  if (cost(w_fit) >= cost(tiles_n)) return 0;
+  const int64_t groups = (tiles_n + w_fit - 1) / w_fit;          // equal-width groups
+  return (int)((tiles_n + groups - 1) / groups);
+}
+}  // namespace gdlconv
 static std::atomic<int> g_sf_enabled{1};
 static std::atomic<int> g_narrow_enabled{1};
 extern "C" void gdl_debug_set_conv_narrow(int on) { g_narrow_enabled = on; }  // A/B hook: direct narrow 3x3 kernel
@@ -467,8 +497,13 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   const bool extra = a.aux_out != nullptr || a.act == GDL_ACT_MUL_GELU_GRAD;
   const bool ctail = a.C % (a.dtype == GDL_BF16 ? 64 : 32) != 0;   // only the small tiles zero-fill a channel tail
   // (tools/bench_conv_variants.py, batch 32: ViT proj / neck 1x1 768 -> 768 with 486-489 tiles: 256^2 92 / 59 us vs 128^2 101 / 67 us)
-  if (!extra && !ctail && a.N % 256 == 0 && (t256 >= 480 || (t256 >= 256 && ksteps >= 32)))
+  if (!extra && !ctail && a.N % 256 == 0 && (t256 >= 480 || (t256 >= 256 && ksteps >= 32))) {
+    // short-K layers with a GELU epilogue (ViT fc1: 12 K-steps, then ~13 k cycles of VALU work per 256^2 tile): two resident
+    // 256 x 128 workgroups per CU put one's epilogue under the other's K loop (+5..9 %, profiles/r04a_bench_short_k_*); for
+    // every other epilogue the 256^2 tile is as fast or faster
+    if (g_dual_enabled && a.act == GDL_ACT_GELU && ksteps <= 16 && t256 >= 1024 && conv_gemm_dual_applicable(a)) return 6;
     return (g_sf_enabled && conv3x3_sf_applicable(a)) ? 4 : 3;   // ping-pong 256^2 (4: 3x3 with shared staging)
+  }
   if (t128 >= 256 && a.N >= 128) return 1;
   // narrow outputs (N <= 64: UNet++ decoder, ResNet layer1, MiT stage 1): a 256 (m) x 64 (n) tile, four waves of
   // 64 x 64 -- one LDS fragment read per MFMA instead of the two of the 64^2 tile's 32 x 32 waves

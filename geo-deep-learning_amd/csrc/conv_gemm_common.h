@@ -14,6 +14,7 @@ struct KArgs {
   int c_tail;   // channels in the last K chunk when C is not a multiple of BKE (else 0): the CT kernels zero-fill
   int KT;       // R*S*kc
   int tiles_m, tiles_n;
+  int n_group;  // tile order: N tiles are walked in groups of n_group (0 = all): [group][tile_m][tile_n in group], see tile_order()
   int in_dense, out_dense, res_dense;
   unsigned in_span, w_span;   // bytes addressed from the (z-offset) operand base: buffer num_records
   int tap_inner;              // K order: 1 = channel chunk outer / filter tap inner (default), 0 = tap outer
@@ -71,6 +72,23 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+
+// Tile order.  lid walks the N tiles of one M row innermost (the blocks of an XCD then share the activation rows through its
+// L2) -- but only n_group of them: when the whole weight matrix does not fit the 4 MiB L2 beside the streaming activations
+// (ViT fc1: 3072 x 768 bf16 = 4.7 MB), every M row would pull every weight panel in again from the Infinity Cache.  With
+// groups, an XCD works through ALL M rows against one L2-resident slice of the weights before it moves to the next slice;
+// the activations are then read once per group instead of once.
+__device__ __forceinline__ void tile_order(const KArgs& k, int lid, int& tile_m, int& tile_n) {
+  const int ng = k.n_group;
+  if (ng <= 0 || ng >= k.tiles_n) { tile_n = lid % k.tiles_n; tile_m = lid / k.tiles_n; return; }
+  const int per_group = k.tiles_m * ng;
+  const int g = lid / per_group, idx = lid - g * per_group;
+  const int width = min(ng, k.tiles_n - g * ng);       // the last group may be narrower
+  tile_m = idx / width;
+  tile_n = g * ng + idx - tile_m * width;
+}
+// host side: N tiles per group for bm x bn tiles of which an XCD runs `conc` at a time (0 = no grouping)
+int conv_n_group(const gdl_conv_args& a, int bm, int bn, int conc);
 
 // 3x3 shared-staging kernel (conv3x3_sf.hip)
 bool conv3x3_sf_applicable(const gdl_conv_args& a);

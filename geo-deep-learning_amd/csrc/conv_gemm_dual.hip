@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dual_kernel(const KArgs k) {
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
   const int lid = xcd_remap(blockIdx.x, k.tiles_m * k.tiles_n);
-  const int tile_n = lid % k.tiles_n, tile_m = lid / k.tiles_n;
+  int tile_m, tile_n;
+  tile_order(k, lid, tile_m, tile_n);
   const int m0 = tile_m * DBM, n0 = tile_n * DBN;
   const int z = blockIdx.y;
   const int z0 = z / a.nz_inner, z1 = z % a.nz_inner;
@@ -220,6 +221,7 @@ int conv_gemm_dual_launch(const KArgs& k, hipStream_t stream) {
   KArgs kk = k;
   kk.tiles_m = (k.M + DBM - 1) / DBM;
   kk.tiles_n = (k.a.N + DBN - 1) / DBN;
+  kk.n_group = conv_n_group(k.a, DBM, DBN, 64);
   dim3 grid(kk.tiles_m * kk.tiles_n, k.a.nz), block(256);
   if (k.in_dense) {
     GDL_SET_MAX_LDS_ONCE(conv_gemm_dual_kernel<true>, DUAL_LDS);

@@ -186,6 +186,12 @@ def load() -> C.CDLL:
     if os.environ.get("GDL_CONV_EPILOGUE") is not None:   # tuning hook: 0 = the round-2 epilogue of the 256^2 tiles
         lib.gdl_debug_set_conv_epilogue.argtypes = [C.c_int]
         lib.gdl_debug_set_conv_epilogue(int(os.environ["GDL_CONV_EPILOGUE"]))
+    if os.environ.get("GDL_CONV_NGROUP_KB") is not None:  # tuning hook: weight KiB per N-tile group of the GEMM tile order (0 = round-3 order)
+        lib.gdl_debug_set_conv_ngroup_kb.argtypes = [C.c_int]
+        lib.gdl_debug_set_conv_ngroup_kb(int(os.environ["GDL_CONV_NGROUP_KB"]))
+    if os.environ.get("GDL_CONV_DUAL") is not None:       # tuning hook: 0 = never pick the dual-resident 256 x 128 tile
+        lib.gdl_debug_set_conv_dual.argtypes = [C.c_int]
+        lib.gdl_debug_set_conv_dual(int(os.environ["GDL_CONV_DUAL"]))
     if os.environ.get("GDL_FLASH_FWD") is not None:       # tuning hook: 2 = the round-2 attention forward (64-query waves)
         lib.gdl_debug_set_flash_fwd.argtypes = [C.c_int, C.c_float]
         lib.gdl_debug_set_flash_fwd(int(os.environ["GDL_FLASH_FWD"]), float(os.environ.get("GDL_FLASH_DEFER", "6")))

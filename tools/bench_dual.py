@@ -48,6 +48,7 @@ lib = _lib.load()
 lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
 lib.gdl_debug_set_conv_dbg.argtypes = [ctypes.c_int]
 lib.gdl_debug_set_conv_epilogue.argtypes = [ctypes.c_int]
+lib.gdl_debug_set_conv_ngroup_kb.argtypes = [ctypes.c_int]
 print(f"batch {B}: us per call (TF/s); v3 = 256^2 ping-pong, v6 = dual-resident 256x128" + "".join(f", v6/dbg{d}" for d in DBG if d))
 tot = {}
 for label, M, K, N, epi in SHAPES:
@@ -63,15 +64,18 @@ for label, M, K, N, epi in SHAPES:
     flops = 2 * M * N * K
     row = {}
     try:
-        for v, d in [(3, 100), (3, 0)] + [(6, d) for d in DBG] + [(-1, 0)]:   # dbg "100": element-wise terms decided at run time (the round-3 epilogue)
+        # dbg "100": element-wise terms decided at run time (the round-3 epilogue); "200": N tiles not grouped (round-3 tile order)
+        for v, d in [(3, 100), (3, 200), (3, 0)] + [(6, d) for d in DBG] + [(-1, 0)]:
             lib.gdl_debug_force_conv_variant(v)
             lib.gdl_debug_set_conv_dbg(d if d < 100 else 0)
             lib.gdl_debug_set_conv_epilogue(2 if d == 100 else 1)
+            lib.gdl_debug_set_conv_ngroup_kb(0 if d in (100, 200) else 2560)
             row[v, d] = timeit(lambda: ops.conv_gemm(x, w, out=out, **kw))
     finally:
         lib.gdl_debug_force_conv_variant(-1)
         lib.gdl_debug_set_conv_dbg(0)
         lib.gdl_debug_set_conv_epilogue(1)
+        lib.gdl_debug_set_conv_ngroup_kb(2560)
     for key, t in row.items():
         tot[key] = tot.get(key, 0) + t
     print(f"  {label:20s} M {M:6d} N {N:5d} K {K:5d} {epi:5s}: " +
