@@ -55,6 +55,20 @@ class GraphedTrainStep:
         optimizer.zero_grad(set_to_none=True)
         if isinstance(getattr(task, "logged", None), dict):
             task.logged.clear()
+        # a trainer's metric sink accumulates logged tensors on the device: captured once, it would add the SAME static buffer at
+        # every replay while the host-side weights stood still.  Logging is detached for warm-up and capture; after a replay the
+        # caller logs `step.loss` itself (MiniTrainer does)
+        trainer = getattr(task, "trainer", None)
+        sink = getattr(trainer, "_collect", None)
+        if sink is not None:
+            trainer._collect = lambda *a, **k: None
+        try:
+            self._capture(task, optimizer, warmup)
+        finally:
+            if sink is not None:
+                trainer._collect = sink
+
+    def _capture(self, task, optimizer, warmup: int) -> None:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -80,9 +94,12 @@ class GraphedTrainStep:
         return loss
 
     def __call__(self, batch: dict[str, Any] | None = None) -> Tensor:
+        """Returns the STATIC loss buffer: the next replay overwrites it (clone it to keep a value)."""
         if batch is not None and batch is not self.static:
             _copy_into(self.static, batch)
+        self.optimizer.sync_lr()        # per-step schedulers (OneCycleLR) write param_groups["lr"] on the host
         self.graph.replay()
+        self.optimizer.note_replay()
         for t in self._rewritten:       # the replay rewrote these through raw pointers: eager code must not trust operands
             gnn.mark_updated(t)         # cached from their earlier values (eval-time BatchNorm folds, packed weights)
         return self.loss

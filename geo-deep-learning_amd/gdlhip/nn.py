@@ -985,6 +985,7 @@ class FusedAdam(torch.optim.Optimizer):
         # memory, so that a hipGraph-captured step (gdlhip.graphs) replays correctly; chunk tables come from pinned memory
         self.capturable = capturable
         self._dev_state: dict = {}    # param group index -> f32[8] {step, lr, b1, b2, eps, wd, bc1, bc2}
+        self._dev_lr: dict = {}       # param group index -> the learning rate last written to the device state
         self._table_bufs: dict = {}   # param group index -> (pinned, device) chunk-table buffers, allocated once
         self._acc = None
         self._tables: dict = {}      # param group index -> (address signature, device chunk table)
@@ -1073,6 +1074,8 @@ class FusedAdam(torch.optim.Optimizer):
                 ops.multi_sumsq(t, self._acc[0:1])
             ops.clip_coef(self._acc[0:1], float(self.max_grad_norm), self._acc[1:2])
             clip = self._acc[1:2]
+        if self.capturable and not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()                # a scheduler's param_groups["lr"] write reaches the device-side hyper-parameters
         for (gi, step), t in tables.items():
             group = self.param_groups[gi]
             if self.capturable:
@@ -1095,12 +1098,26 @@ class FusedAdam(torch.optim.Optimizer):
             step0 = float(steps.pop()) if len(steps) == 1 else 0.0
             st = torch.tensor([step0, g["lr"], *g["betas"], g["eps"], g["weight_decay"], 0.0, 0.0], dtype=torch.float32).to(dev)
             self._dev_state[gi] = st
+            self._dev_lr[gi] = float(g["lr"])
         return st
 
     def sync_lr(self) -> None:
-        """Write the param groups' current learning rates into the device state (call between graph replays after a scheduler step)."""
+        """Write the param groups' current learning rates into the device state when a scheduler changed them (one fill_ on the
+        stream per changed group, nothing otherwise).  Capturable mode reads lr from the device: called at the start of every
+        eager step and by GraphedTrainStep before every replay."""
         for gi, st in self._dev_state.items():
-            st[1:2].fill_(float(self.param_groups[gi]["lr"]))
+            lr = float(self.param_groups[gi]["lr"])
+            if self._dev_lr.get(gi) != lr:
+                st[1:2].fill_(lr)
+                self._dev_lr[gi] = lr
+
+    def note_replay(self) -> None:
+        """A captured step ran: advance the host-side step counts (what state_dict() / checkpoints report) like the device's."""
+        for g in self.param_groups:
+            for p in g["params"]:
+                st = self.state.get(p)
+                if st:
+                    st["step"] += 1
 
     CHUNK = 65536
 

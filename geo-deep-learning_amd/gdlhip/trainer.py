@@ -144,8 +144,15 @@ class MiniTrainer:
 
     def _epoch_means(self, device: torch.device) -> dict[str, float]:
         names = sorted(self._sums)
-        vals = torch.stack([torch.stack([torch.as_tensor(self._sums[n][0], dtype=torch.float64, device=device).reshape(()),
-                                         torch.tensor(self._sums[n][1], dtype=torch.float64, device=device)])
+        if self.world_size > 1:
+            # the reduction must have the same shape on every rank, whatever each rank logged: a rank whose slice of the
+            # validation shards is empty logs nothing and would otherwise skip (or mis-size) the collective the others are in
+            gathered: list = [None] * self.world_size
+            dist.all_gather_object(gathered, names)
+            names = sorted(set().union(*gathered))
+        zero = [0.0, 0.0]
+        vals = torch.stack([torch.stack([torch.as_tensor(self._sums.get(n, zero)[0], dtype=torch.float64, device=device).reshape(()),
+                                         torch.tensor(self._sums.get(n, zero)[1], dtype=torch.float64, device=device)])
                             for n in names]) if names else torch.zeros((0, 2), dtype=torch.float64, device=device)
         if self.world_size > 1 and len(names):
             dist.all_reduce(vals)                        # sync_dist=True

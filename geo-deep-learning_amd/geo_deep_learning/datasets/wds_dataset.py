@@ -215,7 +215,13 @@ class ShardedDataset:
         # rank r then sees only every world-th shard of its own slice; that is not reproduced.)
         shard_list = sorted(self.shard_paths)
         if self.split in ("trn", "val") and torch.distributed.is_available() and torch.distributed.is_initialized():
-            shard_list = shard_list[torch.distributed.get_rank()::torch.distributed.get_world_size()]
+            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+            if self.split == "val" and len(shard_list) < world:
+                # fewer validation shards than ranks: a slice would leave some ranks without a single batch (no metrics, no
+                # monitored value for checkpointing / early stopping).  Every rank validates on all shards instead -- the
+                # rank-averaged epoch means are then the single-process means
+                return shard_list
+            shard_list = shard_list[rank::world]
         return shard_list
 
     def _samples(self, epoch: int) -> Iterator[dict[str, Any]]:

@@ -239,17 +239,35 @@ class UnetPlusPlus(nn.Module):
         torch-hub cache; this build never downloads -- it reads ``<hub>/checkpoints/<name>-*.pth`` when a previous (networked)
         run or the operator put it there, and says where it looked otherwise."""
         import glob
+        import logging
         import os
         pattern = os.path.join(torch.hub.get_dir(), "checkpoints", f"{name}-*.pth")
         found = sorted(glob.glob(pattern))
+        if os.path.isfile(str(weights)):                   # an explicit checkpoint path instead of a weight-set name
+            found, weights = [str(weights)], "imagenet"
+        elif len(found) > 1:
+            # several cached variants (torchvision's IMAGENET1K_V1 / V2, the pre-0.13 files): "the last one in lexical order" is
+            # not a choice.  smp's `imagenet` weights are torchvision's V1 set: take that file, or ask for an explicit path
+            v1 = {"resnet18": ("f37072fd", "5c106cde"), "resnet34": ("b627a593", "333f7ec4"), "resnet50": ("0676ba61", "19c8e357"),
+                  "resnet101": ("63fe2227", "5d3b4d8f"), "resnext50_32x4d": ("7cdf4587",), "resnext101_32x8d": ("8ba56ff5",)}
+            pick = [f for h in v1.get(name, ()) for f in found if f.endswith(f"{name}-{h}.pth")]
+            if not pick:
+                msg = (f"encoder_weights={weights!r}: {len(found)} cached checkpoints match {pattern} and none is torchvision's "
+                       f"IMAGENET1K_V1 file; pass the file to use as encoder_weights=<path>: {found}")
+                raise RuntimeError(msg)
+            found = pick[:1]
         if weights != "imagenet" or not found or in_channels != 3:
             msg = (f"encoder_weights={weights!r}: the reference lets smp download torchvision's {name} checkpoint; this build has no "
                    f"network and found {'no file' if not found else 'a file but in_channels != 3'} at {pattern}. Pass encoder_weights=None "
                    "and load a checkpoint with load_state_dict, or place the torchvision checkpoint there")
             raise RuntimeError(msg)
         sd = torch.load(found[-1], map_location="cpu", weights_only=True)
-        sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
+        meta = getattr(sd, "_metadata", None)
+        sd = type(sd)((k, v) for k, v in sd.items() if not k.startswith("fc."))
+        if meta is not None:
+            sd._metadata = meta                            # the version records load_state_dict's compatibility hooks read
         self.encoder.load_state_dict(sd, strict=True)
+        logging.getLogger(__name__).info("UNet++ encoder %s: loaded %s", name, found[-1])
 
     def forward(self, x: Tensor) -> Tensor:
         if x.shape[2] % 32 or x.shape[3] % 32:

@@ -156,15 +156,17 @@ def init_distributed() -> bool:
 def main(args: list[str] | None = None) -> dict[str, Any]:
     """Run ``fit`` (+ the post-fit test of the best checkpoint).  Returns the trainer's metrics (for tests)."""
     created_group = init_distributed()
-    try:
+    if not created_group:
         return _main(args)
+    import torch.distributed as dist
+    try:
+        out = _main(args)
+        # after_fit: `self.trainer.strategy.barrier()` -- the other ranks wait for rank 0's post-fit test.  Only on the success
+        # path: a rank that raised must not park its peers in a collective until the watchdog fires (and mask its own error)
+        dist.barrier()
+        return out
     finally:
-        if created_group:
-            import torch.distributed as dist
-            try:
-                dist.barrier()            # after_fit: `self.trainer.strategy.barrier()` -- the other ranks wait for rank 0's test
-            finally:
-                dist.destroy_process_group()
+        dist.destroy_process_group()
 
 
 def _main(args: list[str] | None = None) -> dict[str, Any]:

@@ -157,3 +157,24 @@ def test_datamodule_to_device_matches_reference_formula(shards):
             assert torch.equal(batch["image"][i].cpu(), want)
             n += 1
     assert n == 5
+
+
+def test_validation_shards_are_not_sliced_when_fewer_than_ranks(monkeypatch):
+    """Round-3 advisor finding: with fewer validation shards than ranks the rank slice left some ranks without a batch (no
+    metrics, divergent checkpoint decisions).  Every rank then reads all validation shards; training shards stay sliced."""
+    import torch.distributed as dist
+    from geo_deep_learning.datasets.wds_dataset import ShardedDataset
+    ds = object.__new__(ShardedDataset)
+    ds.shard_paths = ["b.tar", "a.tar"]
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda: 4)
+    for rank in range(4):
+        monkeypatch.setattr(dist, "get_rank", lambda rank=rank: rank)
+        ds.split = "val"
+        assert ds._shards() == ["a.tar", "b.tar"]
+        ds.split = "trn"
+        assert ds._shards() == ["a.tar", "b.tar"][rank::4]
+    monkeypatch.setattr(dist, "get_world_size", lambda: 2)
+    monkeypatch.setattr(dist, "get_rank", lambda: 1)
+    ds.split = "val"
+    assert ds._shards() == ["b.tar"]                                  # enough shards: the slice of the reference

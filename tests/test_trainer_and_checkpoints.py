@@ -164,6 +164,39 @@ def _ddp_worker(rank, world, port, tmp, ret):
         dist.destroy_process_group()
 
 
+def _empty_val_rank_worker(rank, world, port, tmp, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import _toy_task as toy
+        torch.manual_seed(0)
+        task = toy.ToyTask(3, torch.nn.CrossEntropyLoss(), optimizer=lambda p: torch.optim.SGD(p, lr=0.1), batchnorm=False)
+        trn = toy.make_batches(4, 8, 3, 1, rank, world)
+        val = toy.make_batches(2, 8, 3, 2) if rank == 0 else []     # rank 1's slice of the validation shards is empty
+        tr = MiniTrainer(max_epochs=2, default_root_dir=tmp)
+        tr.fit(task, train_dataloaders=trn, val_dataloaders=val)
+        ret[rank] = {"val": tr.callback_metrics.get("val_loss"), "best": tr.checkpoint_callback.best_model_path}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_minitrainer_rank_without_validation_batches_does_not_hang(tmp_path):
+    """Round-3 advisor finding: a rank that logged nothing in validation skipped the epoch-mean all-reduce its peers were in
+    (hang) and never saw the monitored metric.  The reduction is now shape-stable (union of the ranks' metric names, zeros for
+    what a rank did not log): both ranks finish, hold the same val_loss (= rank 0's) and agree on the checkpoint."""
+    world, port = 2, 33700 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_empty_val_rank_worker, args=(r, world, port, str(tmp_path), ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0, "a rank hung or failed"
+    assert ret[0]["val"] is not None and ret[1]["val"] is not None and abs(ret[0]["val"] - ret[1]["val"]) < 1e-12
+    assert ret[0]["best"] == ret[1]["best"] and Path(ret[0]["best"]).is_file()
+
+
 def test_minitrainer_ddp_world2_matches_single_process(tmp_path):
     """Two gloo ranks, each on half of every batch, under DDP == one process on the full batches (mean-reduced loss =>
     averaged gradients), metrics averaged over ranks, one checkpoint written by rank 0 and known to both."""
