@@ -49,23 +49,30 @@ RGB_STD = [0.1672, 0.1800, 0.1584]
 WAVELENGTHS = [0.665, 0.549, 0.481]   # configs/dofa_config_RGB.yaml:50
 # whole-model algorithmic flops per tile: train (frozen encoder for DOFA, everything for the others), forward
 MODEL_GF = {"dofa": {"train": 1606.7, "infer": 726.7}, "segformer": {"train": 3 * 121.0, "infer": 121.0},
-            "unetpp": {"train": 3 * UNETPP_R18_FWD_GF, "infer": UNETPP_R18_FWD_GF}}
+            "unetpp": {"train": 3 * UNETPP_R18_FWD_GF, "infer": UNETPP_R18_FWD_GF},
+            # configs[3]: +1.2 GF for the three extra bands of the dynamic patch embedding; configs[4]: SURVEY 8(d), per 1024^2 tile
+            "dofa6": {"train": 1607.9, "infer": 727.9}, "dofa_large": {"train": 14400.0, "infer": 8826.6}}
 MODEL_NAME = {"segformer": "SegFormer-B2 (MiT-B2 + MLP decoder)", "unetpp": "UNet++ (ResNet18 encoder)",
-              "dofa": "DOFA-base + UperNet"}
+              "dofa": "DOFA-base + UperNet", "dofa6": "DOFA-base + UperNet, 6 bands", "dofa_large": "DOFA-large + UperNet, 10 bands, 1024x1024"}
+# (bands, tile size, wavelengths in um) of the DOFA configurations: SURVEY 8(d) -- the reference gives the RGB list only
+WAVELENGTHS6 = [0.665, 0.549, 0.481, 0.842, 1.610, 2.190]
+WAVELENGTHS10 = [0.490, 0.560, 0.665, 0.705, 0.740, 0.783, 0.842, 0.865, 1.610, 2.190]
+MODEL_INPUT = {"dofa6": (6, 512, WAVELENGTHS6), "dofa_large": (10, 1024, WAVELENGTHS10)}
 PMC_TRAFFIC_FILE = ROOT / "profiles" / "pmc_dominant_kernel_traffic.json"   # written by tools/pmc_bench_traffic.py
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=80, help="timed steps (default: ~3 s of training + ~1.6 s of inference at batch 32)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mode", default="both", choices=["both", "train", "infer"])
-    ap.add_argument("--model", default="dofa", choices=["dofa", "segformer", "unetpp"],
+    ap.add_argument("--model", default="dofa", choices=["dofa", "segformer", "unetpp", "dofa6", "dofa_large"],
                     help="dofa = DOFA-base+UperNet (headline, configs[1]); segformer = SegFormer-B2 (configs[2], all parameters trainable); "
-                         "unetpp = UNet++/ResNet18 (configs[0], the reference's CPU smoke case)")
+                         "unetpp = UNet++/ResNet18 (configs[0], the reference's CPU smoke case); dofa6 = configs[3] (6 bands); "
+                         "dofa_large = configs[4] (DOFA-large, 10 bands, 1024x1024 tiles: use --batch 8)")
     ap.add_argument("--no-input-stage", action="store_true", help="skip the PCIe-inclusive leg (host tiles through DeviceInputStage)")
     ap.add_argument("--with-input-stage", action="store_true",
                     help="also time the train step fed by host uint8 tiles through DeviceInputStage (PCIe-inclusive; "
@@ -78,14 +85,18 @@ def parse():
     return ap.parse_args()
 
 
-def synthetic_batch(batch: int, device, seed: int):
-    """uint8 U{0..255} tile -> /255 -> standardise (HIP kernel); mask U{0..4}."""
+def synthetic_batch(batch: int, device, seed: int, model: str = "dofa"):
+    """uint8 U{0..255} tile -> /255 -> standardise (HIP kernel); mask U{0..4}.  Extra bands repeat the RGB
+    statistics cyclically."""
     from geo_deep_learning.utils.tensors import normalize_standardize_u8
+    bands, size, wv = MODEL_INPUT.get(model, (3, 512, WAVELENGTHS))
     g = torch.Generator(device="cpu").manual_seed(seed)
-    u8 = torch.randint(0, 256, (batch, 3, 512, 512), generator=g, dtype=torch.uint8).to(device)
-    mask = torch.randint(0, 5, (batch, 1, 512, 512), generator=g, dtype=torch.int64).to(device)
-    image = normalize_standardize_u8(u8, torch.tensor(RGB_MEAN, device=device), torch.tensor(RGB_STD, device=device))
-    return {"image": image, "mask": mask, "wavelengths": torch.tensor(WAVELENGTHS)}
+    u8 = torch.randint(0, 256, (batch, bands, size, size), generator=g, dtype=torch.uint8).to(device)
+    mask = torch.randint(0, 5, (batch, 1, size, size), generator=g, dtype=torch.int64).to(device)
+    mean = torch.tensor([RGB_MEAN[i % 3] for i in range(bands)], device=device)
+    std = torch.tensor([RGB_STD[i % 3] for i in range(bands)], device=device)
+    image = normalize_standardize_u8(u8, mean, std)
+    return {"image": image, "mask": mask, "wavelengths": torch.tensor(wv)}
 
 
 def timed(fn, steps: int, warmup: int, world: int, device) -> float:
@@ -124,8 +135,10 @@ def build_task(model: str, device, dist_on: bool, local: int, capturable: bool =
                                      loss=DiceLoss(mode="multiclass"), optimizer=opt)
     else:
         from tasks_with_models.segmentation_dofa import SegmentationDOFA
-        task = SegmentationDOFA(encoder="dofa_base", pretrained=False, image_size=(512, 512), num_classes=5,
-                                max_samples=6, loss=DiceLoss(mode="multiclass"), freeze_layers=["encoder"], optimizer=opt)
+        size = MODEL_INPUT.get(model, (3, 512, None))[1]
+        task = SegmentationDOFA(encoder="dofa_large" if model == "dofa_large" else "dofa_base", pretrained=False,
+                                image_size=(size, size), num_classes=5, max_samples=6, loss=DiceLoss(mode="multiclass"),
+                                freeze_layers=["encoder"], optimizer=opt)
     task.configure_model()
     task.to(device)
     if dist_on:
@@ -271,13 +284,14 @@ def side_measurement(model: str, batch_size: int, steps: int, warmup: int, devic
     whole step replayed from a hipGraph (gdlhip.graphs) -- at small batches the eager step is bound by the host issuing
     several hundred launches, not by the GPU."""
     task, optimizer = build_task(model, device, False, 0, capturable=graphs)
-    batch = synthetic_batch(batch_size, device, 43)
+    batch = synthetic_batch(batch_size, device, 43, model)
     train_step, infer_step = make_steps(task, optimizer, lambda: batch, use_bf16)
     dt_t = timed(train_step, steps, warmup, 1, device)
     dt_i = timed(infer_step, steps, warmup, 1, device)
     peak = PEAK_BF16_TFLOPS if use_bf16 else PEAK_F32_TFLOPS
     n = batch_size * steps
-    out = {"per_gpu_batch": batch_size, "train_tiles_per_s": round(n / dt_t, 2), "inference_tiles_per_s": round(n / dt_i, 2),
+    out = {"per_gpu_batch": batch_size, "tile": "x".join(str(v) for v in batch["image"].shape[1:]),
+           "train_tiles_per_s": round(n / dt_t, 2), "inference_tiles_per_s": round(n / dt_i, 2),
            "train_ms_per_step": round(1e3 * dt_t / steps, 3), "inference_ms_per_step": round(1e3 * dt_i / steps, 3),
            "model_flops_utilisation": {"train": round(MODEL_GF[model]["train"] * 1e-3 * n / dt_t / peak, 4),
                                        "infer": round(MODEL_GF[model]["infer"] * 1e-3 * n / dt_i / peak, 4)}}
@@ -430,7 +444,7 @@ def main() -> None:
 
     torch.manual_seed(42 + rank)  # train.py:67 seeds 42
     task, optimizer = build_task(args.model, device, dist_on, local)
-    batch = synthetic_batch(args.batch, device, 42 + rank)
+    batch = synthetic_batch(args.batch, device, 42 + rank, args.model)
     use_bf16 = args.dtype == "bf16"
     train_step, infer_step = make_steps(task, optimizer, lambda: batch, use_bf16)
 
@@ -524,9 +538,10 @@ def main() -> None:
     tiles = args.batch * world * args.steps
     head = "train" if "train" in res else "infer"
     model_name = MODEL_NAME[args.model]
-    cfg_name = {"segformer": "configs[2]", "unetpp": "configs[0]", "dofa": "configs[1]"}[args.model]
+    cfg_name = {"segformer": "configs[2]", "unetpp": "configs[0]", "dofa": "configs[1]", "dofa6": "configs[3]", "dofa_large": "configs[4]"}[args.model]
+    bands_, size_, _ = MODEL_INPUT.get(args.model, (3, 512, None))
     out = {
-        "metric": f"512x512 tiles/s, {model_name}, {head} step",
+        "metric": f"{size_}x{size_} tiles/s, {model_name}, {head} step",
         "value": round(tiles / res[head], 3),
         "unit": "tiles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -534,9 +549,9 @@ def main() -> None:
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {
-            "workload": (f"{model_name}, 3-band RGB 512x512 ({cfg_name}): "
+            "workload": (f"{model_name}, {bands_}-band {size_}x{size_} ({cfg_name}): "
                          + (("training step = fwd + Dice + bwd (every parameter) + clip 1.0 + Adam 6e-5, "
-                             "DropPath/Dropout2d active" if args.model != "dofa" else
+                             "DropPath/Dropout2d active" if not args.model.startswith("dofa") else
                              "training step = fwd + Dice(main)+0.4*Dice(aux) + bwd + clip 1.0 + Adam 6e-5, "
                              "encoder frozen, DropPath/Dropout2d active") if head == "train"
                             else "inference = fwd + softmax/argmax")),
@@ -560,6 +575,12 @@ def main() -> None:
         traffic, traffic_note, pmc_extra = None, "no PMC summary committed", {}
         if PMC_TRAFFIC_FILE.is_file():
             pm = json.loads(PMC_TRAFFIC_FILE.read_text())
+            sys.path.insert(0, str(ROOT / "tools"))
+            from gemm_source_hash import gemm_source_hash
+            if pm.get("gemm_source_hash") != gemm_source_hash():
+                # the committed counters were taken on other kernel sources than the ones that just ran: report nothing
+                pm, traffic_note = {"kernels": []}, ("stale: profiles/pmc_dominant_kernel_traffic.json was measured on other "
+                                                      "conv_gemm sources (gemm_source_hash differs); rerun tools/pmc_bench_traffic.sh")
             for ent in pm.get("kernels", [pm]):          # one entry per implicit-GEMM kernel class (older files: one kernel)
                 if ent.get("kernel_substring", "\0") in name:
                     traffic, traffic_note = ent["hbm_bytes_per_launch"], pm.get("note", ent.get("note", ""))
@@ -590,6 +611,11 @@ def main() -> None:
         }
     if step_roofline:
         out["step_roofline"] = step_roofline
+        # two different utilisations, never to be confused: `model_flops_utilisation` prices the step at the REFERENCE's flops
+        # (1606.7 / 726.7 GF per tile); this one at the flops the step actually EXECUTES after the algebraic
+        # rewrites (low-resolution forms of conv3x3(resize(x)): 58 % of the reference's training flops are never computed)
+        out["executed_flops_utilisation"] = {
+            k: round(v["algorithmic_tflop_per_step"] / (1e3 * res[k] / args.steps) * 1e3 / peak, 4) for k, v in step_roofline.items()}
     if pcie is not None:
         out["pcie_inclusive"] = pcie
     if ddp_info is not None:
@@ -598,10 +624,16 @@ def main() -> None:
         del task, optimizer
         torch.cuda.empty_cache()
         out["hbm_kernels"] = hbm_kernels(device, args.batch)
-        out["by_batch"] = {str(bsz): side_measurement("dofa", bsz, max(args.steps, 10), args.warmup, device, True, graphs=True)
+        side_steps = min(max(args.steps, 10), 20)
+        out["by_batch"] = {str(bsz): side_measurement("dofa", bsz, side_steps, args.warmup, device, True, graphs=True)
                            for bsz in (2, 4, 8)}      # 4 = the per-GPU batch of the reference's own config
-        out["other_models"] = {m: side_measurement(m, args.batch, args.steps, args.warmup, device, True, roofline=True)
+        out["other_models"] = {m: side_measurement(m, args.batch, side_steps, args.warmup, device, True, roofline=True)
                                for m in ("segformer", "unetpp")}
+        # BASELINE configs[3] / configs[4] on one GPU: the 6-band DOFA-base step and the DOFA-large 10-band 1024^2 step (per-GPU
+        # batch 8 = 32 tiles of 512^2 worth of pixels; N = 5330 tokens: attention is a third of the forward's flops there)
+        out["other_models"]["dofa_base_6band"] = side_measurement("dofa6", args.batch, side_steps, args.warmup, device, True, roofline=True)
+        out["other_models"]["dofa_large_1024_10band"] = side_measurement("dofa_large", max(1, args.batch // 4), max(3, side_steps // 2),
+                                                                          min(2, args.warmup), device, True, roofline=True)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
     json_out.write(json.dumps(out) + "\n")

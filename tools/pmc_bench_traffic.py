@@ -9,8 +9,15 @@ taken as reported (uncalibrated per the guide)."""
 import collections
 import csv
 import glob
+import hashlib
 import json
 import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+
+
+from gemm_source_hash import gemm_source_hash  # noqa: E402
 
 root = sys.argv[1]
 # steps the traced command ran (tools/pmc_bench_traffic.sh: --warmup 1 --steps 1 = 2 training steps)
@@ -36,6 +43,7 @@ for _, k, n, fetch, write, hr, mf in rows[:40]:
 # every implicit-GEMM kernel class of the step, keyed by the names bench.py's KernelTimer uses: the bench line takes the
 # entry of whichever class dominates its step
 NAMES = (("conv3x3_sf_kernel<bf16_tag>", "conv3x3_sf_kernel<bf16>"),
+         ("conv_gemm_dual_kernel", "conv_gemm_dual_kernel"),
          ("conv_gemm_kernel<bf16_tag, 2, 4, 4, 2, false, true", "conv_gemm_kernel<bf16,2,4,4,2,pingpong>"),
          ("conv_gemm_kernel<bf16_tag, 2, 2, 2, 2", "conv_gemm_kernel<bf16,2,2,2,2>"),
          ("conv_gemm_kernel<bf16_tag, 2, 2, 1, 1", "conv_gemm_kernel<bf16,2,2,1,1>"),
@@ -58,5 +66,5 @@ for prof_name, bench_name in NAMES:
                     "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write), "l2_hit_rate": round(hr, 4),
                     "mfma_busy_share": round(mf, 4)})
 with open(f"{root}/pmc_dominant_kernel_traffic.json", "w") as f:
-    json.dump({"note": NOTE, "kernels": entries}, f, indent=1)
+    json.dump({"note": NOTE, "gemm_source_hash": gemm_source_hash(), "kernels": entries}, f, indent=1)
 print(json.dumps({"kernels": entries}))
