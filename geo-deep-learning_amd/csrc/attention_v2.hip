@@ -319,10 +319,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 2
     const unsigned char* sv = sk + TILE_BYTES;
     // ---- S^T[key, query] = K . Q^T for two key row tiles
     f32x16_t st[2] = {zero16(), zero16()};
+    // (the two key row tiles interleaved: consecutive MFMAs never share an accumulator; same sums as tile-by-tile)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) st[kt] = MFMA(row_frag(sk, kt, kk, lane), qf[kk], st[kt]);
+      for (int kt = 0; kt < 2; ++kt) st[kt] = MFMA(row_frag(sk, kt, kk, lane), qf[kk], st[kt]);
     // ---- online softmax per query (lane + partner lane^32 hold its 64 scores of this tile)
     if (t == ntiles - 1) {   // only the last tile can hold keys >= N
 #pragma unroll
@@ -387,6 +388,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 2
                                        pack_bf16x2(ot[ct][4 * g + 2] * inv, ot[ct][4 * g + 3] * inv));
     }
 }
+
+// Round 4 tried to take work off the vector ALU (the round-3 analysis called this kernel VALU-bound): softmax scale folded into
+// Q, the running reference subtracted by a fifth MFMA step (a "ones" K column against a Q column holding -m), no per-tile
+// maximum at all (the reference only moves when a row sum leaves [2^-20, 2^20]).  Counters (profiles/r04c_pmc_attention_*):
+// VALU instructions 67.8 M -> 49.8 M per launch (-26 %), MFMAs +12.5 %, and the kernel got SLOWER (226 -> 240 us): the time a
+// wave spends parked at s_waitcnt / barriers went from 39 % to 56 % of its cycles.  A wave's tile is one dependent chain
+// (K fragment reads -> S MFMAs -> exp2 -> V fragment reads -> PV MFMAs) and what the other three waves of the SIMD offer while
+// it waits is exactly that VALU work; with less of it the LDS latencies are exposed.  Requesting all fragments of a phase ahead
+// of its MFMAs needs 32 more registers than the 128 that four waves per SIMD allow (spills: 410 us).  The experiment was
+// removed again; what stayed is the interleaved order of the two S accumulation chains below.
 
 // ------------------------------------------------------------------------------------------------ backward, part 0
 // dvec[b,h,q] = sum_d dO[q,d] * O[q,d]: one wave per (b, q) row, lane = channel within a head

@@ -353,6 +353,34 @@ def test_attention_flash_forward_kernels_agree(B, Nq, Nkv, H):
     assert err3 <= 2.0 * err2 + 1e-3, (err2, err3)
 
 
+def test_attention_flash_reference_drift_and_extremes():
+    """Deferred running maximum (the default forward raises it only when a tile exceeds it by 2^6): (a) scores that creep up by a
+    few units per key tile (many deferred tiles, then a raise); (b) later tiles far BELOW the maximum (their probabilities
+    underflow, as in the exact softmax); (c) scores beyond +-300 (exp2 of a raw score would overflow f32) -- against an f64 softmax."""
+    H, hd, N = 1, 64, 64 * 9 + 5
+    base = rnd(1, N, 3 * hd) * 0.3
+    cases = {}
+    up = base.clone()
+    up[0, :, hd:2 * hd] += torch.linspace(0, 6.0, N).view(N, 1) * 0.5      # key norm grows along the sequence
+    up[0, :, :hd] += 0.5
+    cases["creeping up"] = up
+    down = base.clone()
+    down[0, :64, hd:2 * hd] += 3.0                                          # the first tile holds the dominant keys
+    down[0, :, :hd] += 1.0
+    cases["first tile dominates"] = down
+    big = base.clone() * 40.0
+    cases["huge scores"] = big
+    for name, qkv in cases.items():
+        qkv = q(qkv, torch.bfloat16)
+        o, lse = ops.attention_flash(*ops.split_qkv(qkv.to(DEV, torch.bfloat16)), H, return_lse=True)
+        qq, kk, vv = (t.double() for t in qkv.view(1, N, 3, H, hd).permute(2, 0, 3, 1, 4))
+        sc = qq @ kk.transpose(-1, -2) * hd ** -0.5
+        ref = (sc.softmax(-1) @ vv).transpose(1, 2).reshape(1, N, hd)
+        assert torch.isfinite(o.float()).all(), name
+        close(o, ref.float(), torch.bfloat16, f"forward, {name}")
+        close(lse, torch.logsumexp(sc, -1).float(), torch.float32, f"lse, {name}", scale=max(1.0, sc.abs().max().item()) * 20)
+
+
 def test_attention_flash_spike():
     """one dominant key late in the sequence forces the online-softmax rescale branch."""
     B, N, H, hd = 1, 300, 1, 64
