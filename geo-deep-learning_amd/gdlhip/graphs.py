@@ -44,7 +44,12 @@ class GraphedTrainStep:
     ``capturable=True``.  The returned loss is a static device tensor (read it after the next synchronisation point)."""
 
     def __init__(self, task, optimizer, example_batch: dict[str, Any], *, autocast_dtype: torch.dtype | None = torch.bfloat16,
-                 warmup: int = 3) -> None:
+                 warmup: int = 3, restore_state: bool = False) -> None:
+        """``restore_state``: the warm-up steps are REAL optimizer steps on ``example_batch`` (the capture pass only records).
+        A trainer that captures in the middle of ``fit`` must not train three extra times on its first batch: with
+        ``restore_state`` parameters, buffers, optimizer state (moments, step counts, device-side hyper-parameters), the bf16
+        GEMM operands the optimizer kernel keeps in step with the parameters, and the CUDA RNG state are put back IN PLACE after
+        the capture (the graph holds their addresses), so the first replay is the first training step."""
         if not getattr(optimizer, "capturable", False):
             msg = "GraphedTrainStep needs FusedAdam(capturable=True): step count and learning rate must live on the device"
             raise ValueError(msg)
@@ -56,17 +61,61 @@ class GraphedTrainStep:
         if isinstance(getattr(task, "logged", None), dict):
             task.logged.clear()
         # a trainer's metric sink accumulates logged tensors on the device: captured once, it would add the SAME static buffer at
-        # every replay while the host-side weights stood still.  Logging is detached for warm-up and capture; after a replay the
-        # caller logs `step.loss` itself (MiniTrainer does)
+        # every replay while the host-side weights stood still.  During warm-up and capture the sink only RECORDS what the step
+        # logs (name, static tensor, batch size); after every replay __call__ hands those tensors to the real sink
         trainer = getattr(task, "trainer", None)
         sink = getattr(trainer, "_collect", None)
         if sink is not None:
             trainer._collect = lambda *a, **k: None
+        self.logged_static: list = []      # (name, static tensor, batch size) of every `log` call of the captured step
+        if sink is not None:
+            trainer._collect = lambda name, value, batch_size=None: self.logged_static.append((name, value, batch_size))
+        snap = self._snapshot(task, optimizer) if restore_state else None
         try:
             self._capture(task, optimizer, warmup)
         finally:
             if sink is not None:
                 trainer._collect = sink
+        if snap is not None:
+            self._restore(snap, optimizer)
+
+    @staticmethod
+    def _snapshot(task, optimizer):
+        tensors = list(task.parameters()) + list(task.buffers())
+        state = {}
+        for p, st in optimizer.state.items():
+            state[p] = {k: (v.detach().clone() if isinstance(v, Tensor) else v) for k, v in st.items()}
+        dev = {gi: t.detach().clone() for gi, t in getattr(optimizer, "_dev_state", {}).items()}
+        return {"tensors": [(t, t.detach().clone()) for t in tensors], "opt": state, "dev": dev,
+                "rng": torch.cuda.get_rng_state(), "cpu_rng": torch.get_rng_state()}
+
+    @staticmethod
+    @torch.no_grad()
+    def _restore(snap, optimizer) -> None:
+        for t, saved in snap["tensors"]:
+            t.copy_(saved)
+            gnn.mark_updated(t)
+        for p, st in optimizer.state.items():
+            old = snap["opt"].get(p)
+            for k, v in st.items():
+                if isinstance(v, Tensor):
+                    v.copy_(old[k]) if old is not None else v.zero_()
+                elif k == "step":
+                    st[k] = old[k] if old is not None else 0
+        for gi, t in getattr(optimizer, "_dev_state", {}).items():
+            if gi in snap["dev"]:
+                t.copy_(snap["dev"][gi])
+            else:
+                t[0] = 0.0                 # created during the warm-up: back to "no step taken"
+                t[6:8] = 0.0
+        # the bf16 GEMM operands the optimizer kernel rewrites together with the parameters were captured by address and hold
+        # the warm-up's values: rewrite them from the restored parameters (same element order by construction)
+        for key, val, p in getattr(optimizer, "_shadowed", []):
+            w = p.detach() if p.dim() == 2 else gnn.conv_weight_matrix(p)
+            val.copy_(w.reshape(val.shape))
+            gnn.refresh_shadow(key, val, p)
+        torch.cuda.set_rng_state(snap["rng"])
+        torch.set_rng_state(snap["cpu_rng"])
 
     def _capture(self, task, optimizer, warmup: int) -> None:
         side = torch.cuda.Stream()
@@ -77,6 +126,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        self.logged_static.clear()                      # (the warm-up steps logged eager tensors: only the captured ones count)
         optimizer.zero_grad(set_to_none=True)           # gradients are (re)allocated from the graph's private pool
         with torch.cuda.graph(self.graph):
             self.loss = self._eager(zero=False)
@@ -100,6 +150,10 @@ class GraphedTrainStep:
         self.optimizer.sync_lr()        # per-step schedulers (OneCycleLR) write param_groups["lr"] on the host
         self.graph.replay()
         self.optimizer.note_replay()
+        sink = getattr(getattr(self.task, "trainer", None), "_collect", None)
+        if sink is not None:            # what the captured training_step logged: the static tensors now hold this step's values
+            for name, value, batch_size in self.logged_static:
+                sink(name, value, batch_size)
         for t in self._rewritten:       # the replay rewrote these through raw pointers: eager code must not trust operands
             gnn.mark_updated(t)         # cached from their earlier values (eval-time BatchNorm folds, packed weights)
         return self.loss

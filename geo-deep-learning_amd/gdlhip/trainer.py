@@ -82,11 +82,17 @@ class _Checkpoint:
         self.best_model_score: float | None = None
 
 
+# batch entries the models consume ON THE HOST (the DOFA encoder keys its dynamic patch-embedding weights by the wavelength
+# values): moved to the GPU they would be read back with a blocking copy in every step -- and a read-back cannot be captured
+HOST_BATCH_KEYS = ("wavelengths",)
+
+
 def _to_device(obj: Any, device: torch.device) -> Any:
     if isinstance(obj, Tensor):
         return obj if obj.device == device else obj.to(device, non_blocking=True)
     if isinstance(obj, dict):
-        return {k: _to_device(v, device) for k, v in obj.items()}
+        return {k: (v if k in HOST_BATCH_KEYS and isinstance(v, Tensor) and not v.is_cuda else _to_device(v, device))
+                for k, v in obj.items()}
     if isinstance(obj, (list, tuple)) and obj and isinstance(obj[0], Tensor):
         return type(obj)(_to_device(v, device) for v in obj)
     return obj
@@ -102,7 +108,8 @@ class MiniTrainer:
                  limit_train_batches: int | None = None, limit_val_batches: int | None = None,
                  limit_test_batches: int | None = None, monitor: str = "val_loss", mode: str = "min",
                  checkpoint_filename: str = "model-{epoch:02d}-{val_loss:.3f}", early_stopping_patience: int | None = None,
-                 use_fused_adam: bool = True, fast_dev_run: bool = False, **ignored: Any) -> None:
+                 use_fused_adam: bool = True, fast_dev_run: bool = False, graph_step: str | bool = "auto",
+                 **ignored: Any) -> None:
         self.max_epochs, self.precision = max_epochs, str(precision)
         self.gradient_clip_val, self.sync_batchnorm = gradient_clip_val, sync_batchnorm
         self.accumulate_grad_batches = max(1, int(accumulate_grad_batches))
@@ -113,6 +120,14 @@ class MiniTrainer:
         self.monitor, self.mode = monitor, mode
         self.checkpoint_filename, self.early_stopping_patience = checkpoint_filename, early_stopping_patience
         self.use_fused_adam = use_fused_adam
+        # hipGraph replay of the whole training step (gdlhip.graphs.GraphedTrainStep): "auto" = when the step is launch-bound
+        # (per-GPU batch <= 8, e.g. the reference's own batch 4, configs/dofa_config_RGB.yaml:85: ~550 launches of 5-20 us) and
+        # its shapes are static; True = whenever it can be captured; False = never.  Batches of another shape (a ragged last
+        # batch) run eagerly through the same optimizer.
+        self.graph_step = graph_step
+        self.graph_max_batch = 8
+        self.graphed_steps = 0               # how many training steps were graph replays (tests / logs)
+        self._graphed = None
         if ignored:
             logger.info("MiniTrainer: ignoring trainer options %s", sorted(ignored))
         self.checkpoint_callback = _Checkpoint()
@@ -237,7 +252,11 @@ class MiniTrainer:
             self.estimated_stepping_batches = -1         # iterable loaders (the WebDataset datamodule)
         optimizers, sched_cfgs = model.configure_optimizers()
         opt = optimizers[0]
-        step_opt = self._maybe_fuse(opt, device)
+        self._graph_ok = (self.graph_step not in (False, "off", "false", None) and device.type == "cuda" and self.world_size == 1
+                          and self.accumulate_grad_batches == 1)
+        step_opt = self._maybe_fuse(opt, device, capturable=self._graph_ok)
+        self._graph_ok = self._graph_ok and getattr(step_opt, "capturable", False)
+        self._graphed = None
         self._optimizers, self._sched_cfgs = [step_opt], sched_cfgs       # saved with every checkpoint
         best, bad_epochs = None, 0
         for epoch in range(self.max_epochs):
@@ -280,7 +299,7 @@ class MiniTrainer:
             self.checkpoint_callback.best_model_path = paths[0]
             dist.barrier()
 
-    def _maybe_fuse(self, opt: torch.optim.Optimizer, device: torch.device):
+    def _maybe_fuse(self, opt: torch.optim.Optimizer, device: torch.device, capturable: bool = False):
         """torch.optim.Adam -> the fused multi-tensor Adam + clip kernels on the same param groups."""
         if not (self.use_fused_adam and device.type == "cuda" and type(opt) is torch.optim.Adam):
             return opt
@@ -289,7 +308,7 @@ class MiniTrainer:
             return opt
         from gdlhip.nn import FusedAdam
         fused = FusedAdam(opt.param_groups, lr=g0["lr"], betas=g0["betas"], eps=g0["eps"],
-                          weight_decay=g0["weight_decay"], max_grad_norm=self.gradient_clip_val)
+                          weight_decay=g0["weight_decay"], max_grad_norm=self.gradient_clip_val, capturable=capturable)
         fused.param_groups = opt.param_groups            # the scheduler keeps writing `lr` into these dicts
         return fused
 
@@ -326,12 +345,25 @@ class MiniTrainer:
                 if cfg.get("interval") == "step" and self.global_step % int(cfg.get("frequency", 1)) == 0:
                     self._step_scheduler(cfg, {})
 
+        def after_step() -> None:
+            self.global_step += 1
+            for cfg in sched_cfgs:
+                if cfg.get("interval") == "step" and self.global_step % int(cfg.get("frequency", 1)) == 0:
+                    self._step_scheduler(cfg, {})
+
         step_opt.zero_grad(set_to_none=True)
         pending = False
         for i, batch in self._batches(loader, "train"):
             batch = model.on_before_batch_transfer(batch, 0) if hasattr(model, "on_before_batch_transfer") else batch
             batch = _to_device(batch, device)
             batch = model.on_after_batch_transfer(batch, 0) if hasattr(model, "on_after_batch_transfer") else batch
+            if self._graph_ok and self._graph_step(model, step_opt, batch, device):
+                after_step()
+                continue
+            if self._graphed is not None:
+                # an eager step between replays (ragged batch): `p.grad` still names the graph's static gradient buffers, which
+                # hold the last replay's gradients -- backward would ADD to them
+                step_opt.zero_grad(set_to_none=True)
             with self._autocast(device):
                 loss = model.training_step(batch, i)
             (loss / self.accumulate_grad_batches).backward()
@@ -342,6 +374,41 @@ class MiniTrainer:
         if pending:              # Lightning steps on the last batch of an epoch even when the accumulation window is not full
             optimizer_step()
         self.training = False
+
+    def _graph_step(self, model, step_opt, batch, device) -> bool:
+        """One training step as a hipGraph replay; False = this batch has to run eagerly (no graph yet and the batch is too
+        large for "auto", another shape than the captured one, or the capture failed)."""
+        from gdlhip.graphs import GraphedTrainStep
+        tensors = {k: v for k, v in batch.items() if isinstance(v, Tensor) and v.is_cuda} if isinstance(batch, dict) else {}
+        if not tensors:
+            return False
+        if self._graphed is None:
+            lead = max(v.shape[0] for v in tensors.values() if v.dim() > 0)
+            if self.graph_step == "auto" and lead > self.graph_max_batch:
+                self._graph_ok = False       # GPU-bound step: a graph buys nothing and doubles the activation memory
+                return False
+            amp = torch.bfloat16 if self.precision in ("bf16-mixed", "bf16", "16-mixed", "16") else None
+            try:
+                self._graphed = GraphedTrainStep(model, step_opt, batch, autocast_dtype=amp, warmup=2, restore_state=True)
+            except Exception as exc:  # noqa: BLE001  (anything the capture cannot record: fall back to eager steps for good)
+                logger.warning("MiniTrainer: hipGraph capture of the training step failed (%s: %s); running eagerly",
+                               type(exc).__name__, exc)
+                self._graph_ok, self._graphed = False, None
+                return False
+            logger.info("MiniTrainer: training step captured into a hipGraph (per-GPU batch %d)", lead)
+        static = self._graphed.static
+        for k, v in tensors.items():
+            s = static.get(k)
+            if not isinstance(s, Tensor) or s.shape != v.shape or s.dtype != v.dtype:
+                return False                 # e.g. the ragged last batch of an epoch
+        for k, v in batch.items():           # host-side entries (wavelengths) are baked into the captured step
+            if isinstance(v, Tensor) and not v.is_cuda:
+                s = static.get(k)
+                if not isinstance(s, Tensor) or s.shape != v.shape or not torch.equal(s, v):
+                    return False
+        self._graphed(batch)
+        self.graphed_steps += 1
+        return True
 
     @torch.no_grad()
     def _run_eval(self, model, loader, split: str, device) -> dict[str, float]:

@@ -82,6 +82,11 @@ def _grad_check(name, grad, ref_norm, ref_sample, n):
     assert bad.mean() <= 0.01, (name, float(bad.mean()))
 
 
+# pinned counts of argmax mismatches (observed on MI355X, round 4, `pytest -s`: 0 of 262144 / 0 of 1048576 pixels, although 0 / 127
+# pixels have a top-2 margin below the logit tolerance): the masks ARE bit-exact
+MULTIBAND_MAX_MISMATCH = {"dofa_base": 0, "dofa_large": 0}
+
+
 def _mask_check(got_mask, ref_logits, ref_mask, max_mismatch=None):
     """Bit-exact wherever the reference's top-2 margin exceeds the logit tolerance; the mismatches that remain (pixels
     whose two best logits are closer than any two f32 summation orders can resolve) are COUNTED, printed (pytest -s / the
@@ -316,7 +321,9 @@ def test_base_512_eval_f32(base_model, golden_dir):
     np.testing.assert_allclose(_sub(r.aux, 1, 8, 3), g["aux_s8"], atol=LOGIT_TOL, rtol=0)
     assert (r.out.cpu() - o.out).abs().max().item() < LOGIT_TOL
     assert (r.aux.cpu() - o.aux).abs().max().item() < LOGIT_TOL
-    _mask_check(gnn.predict_mask(r.out), o.out, g["mask"])
+    # observed (round 4, `pytest -s`): 0 of 524288 pixels differ from the real reference's mask, although 166 pixels have a top-2
+    # margin below the logit tolerance -- pinned: the full-size mask is bit-exact, not merely "exact where decidable"
+    _mask_check(gnn.predict_mask(r.out), o.out, g["mask"], max_mismatch=0)
 
 
 def test_base_512_eval_bf16(base_model, golden_dir):
@@ -423,7 +430,12 @@ def test_multiband_configs_match_oracle(encoder, size, bands, tol):
     top2 = yo.topk(2, dim=1).values
     decided = ((top2[:, 0] - top2[:, 1]) > 2 * tol * scale).numpy()
     want = yo.softmax(1).argmax(1).numpy()
-    assert (gnn.predict_mask(y).cpu().numpy() == want)[decided].all()
+    got = gnn.predict_mask(y).cpu().numpy()
+    n_bad = int((got != want).sum())
+    print(f"mask check ({encoder}, {bands} bands, {size}^2): {n_bad} of {want.size} pixels differ, {int((~decided).sum())} pixels "
+          f"have a top-2 margin <= {2 * tol * scale:g}; max logit error {(y.cpu() - yo).abs().max().item():.2e}")
+    assert (got == want)[decided].all()
+    assert n_bad <= MULTIBAND_MAX_MISMATCH[encoder], n_bad
     assert (yb.float().cpu() - yo).abs().max().item() < 0.08 * yo.abs().max().item()
     assert (gnn.predict_mask(yb).cpu().numpy() == want).mean() > 0.95
 

@@ -1343,24 +1343,17 @@ def _rel_l2(got, ref):
     return float((got - ref).norm() / ref.norm().clamp_min(1e-12))
 
 
-def test_resized_conv_nodes_bf16_at_production_shape():
-    """The two algebraically restructured nodes of DOFA-base + UperNet at their PRODUCTION shapes in bf16 (B = 2): the
+def _resized_conv_nodes_at_production_shape(dtype):
+    """The two algebraically restructured nodes of DOFA-base + UperNet at their PRODUCTION shapes (B = 2): the
     neck's x4 level (ConvModule 768 -> 768 on a 36^2 map resized to 144^2, multilevel_neck.py:157-158) and UperNet's
     fpn_bottleneck (1024 -> 256 over [144^2, 72^2, 36^2, 18^2], upernet.py:144-152).  Forward through the nine
     low-resolution tap products, backward through the nine gathered maps; reference = torch f32 autograd of
-    interpolate -> (cat ->) conv2d -> batch_norm -> relu on the CPU, fed the SAME bf16-rounded operands.
-    Two references, both printed:
-    (a) plain f32: the forward output is held to 1e-2 (measured 3e-3), dgamma to 1e-2, the other gradients to 6e-2 --
-        a 0.3 % difference of the conv output flips the ReLU mask of every pixel whose BatchNorm output is that close to
-        zero, and a fraction f of flipped pixels costs sqrt(f) of the gradient's L2 norm (0.1 % -> 3 %; measured 3.2 % on
-        dx, dw, dbeta alike, whatever kernel produced them; torch's own bf16 autocast behaves the same);
-    (b) the same f32 graph evaluated AT the build's forward value (its conv output substituted straight-through, so both
-        sides use the same ReLU mask and batch statistics): what remains is the arithmetic of the backward kernels -- bf16
-        gradient storage, the nine gathered maps, the low-resolution GEMMs -- and every tensor is held to 1e-2 (measured:
-        <= 3.4e-3)."""
+    interpolate -> (cat ->) conv2d -> batch_norm -> relu on the CPU, fed the SAME (dtype-rounded) operands.
+    Two references: (a) the plain f32 graph; (b) the same f32 graph evaluated AT the build's forward value (its conv output
+    substituted straight-through, so both sides use the same ReLU mask and batch statistics): what remains is the arithmetic
+    of the backward kernels.  Returns {"<node> <tensor> [<reference>]": relative L2 error}."""
     import copy
     from torch import nn
-    dtype = torch.bfloat16
     B = 2
     res = {}
 
@@ -1434,11 +1427,33 @@ def test_resized_conv_nodes_bf16_at_production_shape():
 
     run_case("fpn_bottleneck", lambda: [t.clone().requires_grad_() for t in lv], fpn_ref, conv_r, bn_r, build_fpn)
     for k, v in res.items():
-        print(f"  bf16 production shape, relative L2: {k:52s} {v:.4f}")
+        print(f"  {str(dtype).split('.')[-1]} production shape, relative L2: {k:52s} {v:.2e}")
+    return res
+
+
+def test_resized_conv_nodes_bf16_at_production_shape():
+    """bf16: (a) plain f32 reference: the forward output is held to 1e-2 (measured 3e-3), dgamma to 1e-2, the other gradients
+    to 6e-2 -- a 0.3 % difference of the conv output flips the ReLU mask of every pixel whose BatchNorm output is that close
+    to zero, and a fraction f of flipped pixels costs sqrt(f) of the gradient's L2 norm (0.1 % -> 3 %; measured 3.2 % on dx,
+    dw, dbeta alike, whatever kernel produced them; torch's own bf16 autocast behaves the same); (b) at the build's forward:
+    every tensor to 1e-2 (measured <= 3.4e-3: bf16 gradient storage, the nine gathered maps, the low-resolution GEMMs)."""
+    res = _resized_conv_nodes_at_production_shape(torch.bfloat16)
 
     def bound(k):
         if "build's forward" in k:
             return 1e-2
         return 1e-2 if (" out " in k or " dgamma " in k) else 6e-2
     bad = {k: v for k, v in res.items() if not v <= bound(k)}
+    assert not bad, bad
+
+
+def test_resized_conv_nodes_f32_at_production_shape():
+    """f32 (round-3 review): the end-to-end gradient tolerance of the model tests is 2e-2 for deep layers because f32 round-off
+    of the forward flips ReLU masks; this test backs it with a TIGHT one.  The same two nodes in f32 against torch autograd
+    evaluated at the build's own forward activations (same masks, same statistics): every gradient and the output within 2e-5
+    relative L2 (the review asked for 1e-3) -- an arithmetic error of the low-resolution backward (gather, tap GEMMs, BatchNorm backward) above that would
+    show here although the model-level test let it pass.  Against the plain f32 graph (its own masks) the bound is 5e-3."""
+    res = _resized_conv_nodes_at_production_shape(torch.float32)
+    # measured (MI355X, round 4): <= 1.5e-6 at the build's forward, <= 7.5e-4 against the plain graph
+    bad = {k: v for k, v in res.items() if not v <= (2e-5 if "build's forward" in k else 5e-3)}
     assert not bad, bad

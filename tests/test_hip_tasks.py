@@ -397,6 +397,46 @@ def test_minitrainer_fit_on_gpu_and_checkpoint_round_trip(tmp_path):
     assert torch.equal(a, bmask) and fresh.logged["val_loss"].item() == task.logged["val_loss"].item()
 
 
+def test_minitrainer_graph_step_auto_matches_eager(tmp_path):
+    """MiniTrainer(graph_step="auto") at the reference's own per-GPU batch 4 (configs/dofa_config_RGB.yaml:85): the training
+    step is captured into a hipGraph on the first batch WITHOUT training on it more than once (warm-up steps undone in place:
+    parameters, Adam moments and step counts, bf16 GEMM operands, RNG), every full batch is a replay, the ragged last batch runs
+    eagerly through the same optimizer, a per-step scheduler's learning rate reaches the captured Adam -- and parameters, epoch
+    means and the step count equal the eager trainer's (graph_step=False) to the tolerance of test_graphed_train_step_matches_eager:
+    the gradient-norm reduction uses float atomics, so the last bits differ from run to run on either side)."""
+    from functools import partial
+    from gdlhip.trainer import seed_everything
+    batches = [synthetic_batch(4, 3, 112, 5, s) for s in (1, 2, 3, 4)] + [synthetic_batch(2, 3, 112, 5, 5)]   # last one ragged
+    for bt in batches:
+        bt["mask"] = (bt["image"][:, :1] * 1.2 + 2).clamp(0, 4).long()
+    runs = {}
+    for mode in (False, "auto"):
+        seed_everything(42)
+        _, task = _dofa_task(optimizer=partial(torch.optim.Adam, lr=1e-3),
+                             scheduler=partial(torch.optim.lr_scheduler.StepLR, step_size=3, gamma=0.5),
+                             scheduler_config={"interval": "step", "frequency": 1})
+        for blk in task.model.encoder.blocks:            # deterministic on both sides
+            blk.drop_prob = 0.0
+        task.model.aux_head.dropout_ratio = 0.0
+        tr = MiniTrainer(max_epochs=2, precision="32", gradient_clip_val=1.0, default_root_dir=str(tmp_path / str(mode)), graph_step=mode)
+        tr.fit(task, train_dataloaders=batches, val_dataloaders=[batches[0]])
+        runs[mode] = (task, tr)
+    (te, tre), (tg, trg) = runs[False], runs["auto"]
+    assert tre.graphed_steps == 0 and trg.graphed_steps == 8 and tre.global_step == trg.global_step == 10
+    # (observed: every one of the ten step losses is bit-identical between the two trainers)
+    assert abs(tre.callback_metrics["train_loss"] - trg.callback_metrics["train_loss"]) < 1e-5
+    assert abs(tre.callback_metrics["val_loss"] - trg.callback_metrics["val_loss"]) < 1e-5
+    pe = dict(te.named_parameters())
+    for n, p in tg.named_parameters():
+        if p.requires_grad:
+            d = (p - pe[n]).abs()
+            assert d.max().item() <= 8e-3 and (d > 1e-4).float().mean().item() < 2e-2, (n, d.max().item())
+    ge, gg = tre._optimizers[0], trg._optimizers[0]
+    assert ge.param_groups[0]["lr"] == gg.param_groups[0]["lr"] == 1e-3 * 0.5 ** 3
+    some = next(p for p in tg.parameters() if p.requires_grad)
+    assert gg.state[some]["step"] == 10 and float(gg.device_state(0)[0]) == 10.0 and abs(float(gg.device_state(0)[1]) - 1.25e-4) < 1e-9
+
+
 def test_eval_after_train_sees_fresh_running_stats():
     """The eval-mode BN fold is cached per layer; the single-GPU statistics kernel updates running_mean / running_var
     through raw pointers.  Sequence of a Lightning run with sanity validation: eval (fills the cache) -> train forward

@@ -193,3 +193,28 @@ def test_dice_loss_properties():
         n = (y == c).sum().item()
         exp += 1 - (2 * n / 5) / (128 / 5 + n)
     assert abs(val - exp / 5) < 1e-6
+
+
+def test_dice_loss_against_independent_f64_numpy_evaluation():
+    """Round-3 review 7(c): smp's published multiclass Dice formula evaluated INDEPENDENTLY -- float64 NumPy,
+    explicit loops over classes, no shared code with oracle/model.py -- on random logits with one class absent from the
+    target (its term is masked out but still divides the mean) and on a batch where a class is absent from both."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for b, c, h, w, absent in ((3, 5, 9, 7, (4,)), (2, 5, 6, 6, (1, 3)), (1, 3, 4, 5, ())):
+        logits = rng.normal(size=(b, c, h, w)) * 3.0
+        present = [k for k in range(c) if k not in absent]
+        target = rng.choice(present, size=(b, h, w))
+        # softmax over classes, float64
+        z = logits - logits.max(axis=1, keepdims=True)
+        p = np.exp(z) / np.exp(z).sum(axis=1, keepdims=True)
+        total = 0.0
+        for k in range(c):
+            yk = (target == k).astype(np.float64)                      # [b, h, w]
+            inter = float((p[:, k] * yk).sum())                        # summed over batch and pixels (smp dims (0, 2))
+            card = float((p[:, k] + yk).sum())
+            dice = (2.0 * inter + 0.0) / max(card + 0.0, 1e-7)         # smooth = 0, eps = 1e-7 clamp on the denominator
+            total += (1.0 - dice) * (1.0 if yk.sum() > 0 else 0.0)     # classes absent from the target contribute 0
+        want = total / c                                               # ... but the mean is over all C classes
+        got = dice_loss_multiclass(torch.from_numpy(logits).float(), torch.from_numpy(target)).item()
+        assert abs(got - want) < 2e-6, (absent, got, want)
