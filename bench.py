@@ -496,6 +496,41 @@ def main() -> None:
         k_ab = max(3, min(args.steps, 5))
         dt_ns = timed(step_no_sync, k_ab, 1, world, device)
         dt_s = timed(train_step, k_ab, 1, world, device)
+        # when does each gradient bucket become ready?  A communication hook stamps an event on the autograd stream the moment
+        # DDP hands it a full bucket (then runs the stock all-reduce); times are relative to the start of backward.  Buckets
+        # that only become ready at the very end of backward are the part of the exchange nothing can hide.
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        stamps: list = []
+
+        def stamp_hook(state, bucket):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            stamps.append((bucket.index(), bucket.buffer().numel() * bucket.buffer().element_size(), ev))
+            return default_hooks.allreduce_hook(state, bucket)
+        bucket_ready = None
+        try:
+            ddp_mod.register_comm_hook(None, stamp_hook)
+            task.train()
+            per_step = []
+            for _ in range(3):
+                stamps.clear()
+                optimizer.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+                    loss = task.training_step(batch, 0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                loss.backward()
+                e1.record()
+                optimizer.step()
+                torch.cuda.synchronize()
+                per_step.append(([(i, nb, round(e0.elapsed_time(ev), 3)) for i, nb, ev in stamps], round(e0.elapsed_time(e1), 3)))
+            last, bwd_ms = per_step[-1]
+            bucket_ready = {"backward_ms": bwd_ms, "bucket_ready_ms": [t for _, _, t in sorted(last)],
+                            "bucket_bytes": [nb for _, nb, _ in sorted(last)],
+                            "note": "ms from the start of backward until DDP has the bucket's last gradient (all-reduce launch); "
+                                    "bucket 0 holds the LAST layers of the model (first gradients of backward)"}
+        except Exception as exc:  # noqa: BLE001  (private-ish torch API; never lose the line over a diagnostic)
+            bucket_ready = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         try:
             log = ddp_mod._get_ddp_logging_data()
             sizes = [x for x in str(log.get("bucket_sizes", "")).replace(",", " ").split() if x]
@@ -507,7 +542,7 @@ def main() -> None:
                     "grad_bytes": nparam * 4, "grad_allreduce_ms_alone": round(1e3 * dt_c / 5, 3),
                     "syncbn_messages_per_step": {"forward": sync_msgs[0], "backward": sync_msgs[1]},
                     "step_ms_with_grad_sync": round(1e3 * dt_s / k_ab, 3), "step_ms_no_sync": round(1e3 * dt_ns / k_ab, 3),
-                    "exposed_grad_comm_ms": round(1e3 * (dt_s - dt_ns) / k_ab, 3), "buckets": buckets}
+                    "exposed_grad_comm_ms": round(1e3 * (dt_s - dt_ns) / k_ab, 3), "buckets": buckets, "bucket_ready": bucket_ready}
 
     pcie = None
     if not args.no_input_stage and "train" in res:
