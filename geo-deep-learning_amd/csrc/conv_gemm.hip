@@ -419,6 +419,7 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   }
   if (variant == 7) return conv3x3_narrow_launch(k, s);
   if (variant == 6) return conv_gemm_dual_launch(k, s);
+  if (variant == 8) return conv_gemm_w4_launch(k, s);
   if (a.dtype == GDL_BF16) {
     if (variant == 4) return conv3x3_sf_launch(k, s);
     if (variant == 3 && k.dbg == 7) return launch_x<bf16_tag, 2, 4, 4, 2, false, true, false, false, true>(k, s);
@@ -442,6 +443,8 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
 // they still give >= 512 blocks, 128x128 / 4 waves (variant 1) when that gives >= 256 blocks,
 // else 64x64 (variant 0).  Also reports the ALGORITHMIC flops of the call (2*M*N*K, no padding).
 static std::atomic<int> g_forced_variant{-1};
+static std::atomic<int> g_w4_enabled{1};
+extern "C" void gdl_debug_set_conv_w4(int on) { g_w4_enabled = on; }  // A/B hook: 256^2 one-wave-per-SIMD tile
 static std::atomic<int> g_dual_enabled{1};
 extern "C" void gdl_debug_set_conv_dual(int on) { g_dual_enabled = on; }  // A/B hook: dual-resident 256 x 128 tile
 static std::atomic<int> g_ngroup_kb{2560};
@@ -484,6 +487,7 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
       !(g_forced_variant == 5 && a.N > 64) &&
       !(g_forced_variant == 4 && !conv3x3_sf_applicable(a)) &&
       !(g_forced_variant == 6 && !conv_gemm_dual_applicable(a)) &&
+      !(g_forced_variant == 8 && !conv_gemm_w4_applicable(a)) &&
       !(g_forced_variant == 7 && !conv3x3_narrow_applicable(a)))
     return g_forced_variant;
   // narrow 3x3 layers on large maps: direct kernel, one staged window per 4 x 64 pixels (HBM-bound layers)
@@ -502,6 +506,10 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
     // 256 x 128 workgroups per CU put one's epilogue under the other's K loop (+5..9 %, profiles/r04a_bench_short_k_*); for
     // every other epilogue the 256^2 tile is as fast or faster
     if (g_dual_enabled && a.act == GDL_ACT_GELU && ksteps <= 16 && t256 >= 1024 && conv_gemm_dual_applicable(a)) return 6;
+    // deep-K layers: one wave per SIMD, every load in an MFMA shadow (conv_gemm_w4.hip): its K-step is ~12 % shorter, its
+    // epilogue (four waves instead of eight) ~1.8 x longer -- it wins from about 40 K-steps on (ViT fc2 +8 %, tap data
+    // gradients +9 %, the 768-channel 3x3 convolutions +2.5 %; tools/bench_w4.py, profiles/r04d_*)
+    if (g_w4_enabled && conv_gemm_w4_applicable(a) && ksteps >= (a.R * a.S > 1 ? 100 : 40)) return 8;
     return (g_sf_enabled && conv3x3_sf_applicable(a)) ? 4 : 3;   // ping-pong 256^2 (4: 3x3 with shared staging)
   }
   if (t128 >= 256 && a.N >= 128) return 1;

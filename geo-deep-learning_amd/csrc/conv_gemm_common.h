@@ -96,6 +96,9 @@ int conv3x3_sf_launch(const KArgs& k, hipStream_t stream);
 // dual-resident 256 x 128 tile, two workgroups per CU (conv_gemm_dual.hip): short-K bf16 layers
 bool conv_gemm_dual_applicable(const gdl_conv_args& a);
 int conv_gemm_dual_launch(const KArgs& k, hipStream_t stream);
+// 256 x 256 tile, one wave per SIMD, every non-MFMA instruction in an MFMA shadow (conv_gemm_w4.hip)
+bool conv_gemm_w4_applicable(const gdl_conv_args& a);
+int conv_gemm_w4_launch(const KArgs& k, hipStream_t stream);
 // direct 3x3 kernel for C in {8,16,32} on large dense maps, outputs in 32-channel slices (conv3x3_narrow.hip)
 bool conv3x3_narrow_applicable(const gdl_conv_args& a);
 int conv3x3_narrow_launch(const KArgs& k, hipStream_t stream);

@@ -192,6 +192,9 @@ def load() -> C.CDLL:
     if os.environ.get("GDL_CONV_DUAL") is not None:       # tuning hook: 0 = never pick the dual-resident 256 x 128 tile
         lib.gdl_debug_set_conv_dual.argtypes = [C.c_int]
         lib.gdl_debug_set_conv_dual(int(os.environ["GDL_CONV_DUAL"]))
+    if os.environ.get("GDL_CONV_W4") is not None:         # tuning hook: 0 = never pick the one-wave-per-SIMD 256^2 tile
+        lib.gdl_debug_set_conv_w4.argtypes = [C.c_int]
+        lib.gdl_debug_set_conv_w4(int(os.environ["GDL_CONV_W4"]))
     if os.environ.get("GDL_FLASH_FWD") is not None:       # tuning hook: 2 = the round-2 attention forward (64-query waves)
         lib.gdl_debug_set_flash_fwd.argtypes = [C.c_int, C.c_float]
         lib.gdl_debug_set_flash_fwd(int(os.environ["GDL_FLASH_FWD"]), float(os.environ.get("GDL_FLASH_DEFER", "6")))

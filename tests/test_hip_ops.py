@@ -72,7 +72,7 @@ def test_linear_epilogues(dtype):
     close(y, 0.5 * base, dtype if dtype == torch.float32 else torch.bfloat16, "alpha / out dtype")
 
 
-@pytest.mark.parametrize("variant", [1, 3, 6])
+@pytest.mark.parametrize("variant", [1, 3, 6, 8])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_epilogue_row_segments(dtype, variant):
     """The coalesced (LDS-transposed) epilogue of the 128^2, 256^2 and dual-resident 256 x 128 (variant 6) tiles: residual in f32 / bf16, DropPath scale with
@@ -82,10 +82,10 @@ def test_conv_epilogue_row_segments(dtype, variant):
     from gdlhip import _lib
     lib = _lib.load()
     lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
-    if variant == 6 and dtype != torch.bfloat16:
-        pytest.skip("the dual-resident tile is a bf16 kernel")
+    if variant in (6, 8) and dtype != torch.bfloat16:
+        pytest.skip("the dual-resident and one-wave-per-SIMD tiles are bf16 kernels")
     B, T, K, N = 3, 1297, 128, 208          # M = 3891 (tail of 51 rows), N % 64 = 16, N % 256 != 0
-    if variant == 3:
+    if variant in (3, 8):
         N = 512                              # the 256^2 tiles need N % 256 == 0
     x, w = q(rnd(B, T, K), dtype), q(rnd(N, K, seed=1), dtype) * 0.1
     bias, scale, shift = rnd(N, seed=2), rnd(N, seed=3), rnd(N, seed=4)
@@ -869,9 +869,11 @@ def test_conv3x3_shared_staging_kernel(dtype, B, H, W, C, N):
 
 @pytest.mark.parametrize("B,H,W,C,N,R,stride", [(2, 37, 23, 64, 128, 3, 1), (1, 50, 50, 768, 256, 1, 1), (3, 16, 16, 192, 200, 3, 1),
                                                 (2, 21, 21, 128, 384, 3, 2), (1, 5, 5, 64, 64, 1, 1)])
-def test_conv_dual_resident_tile(B, H, W, C, N, R, stride):
-    """The 256 x 128 / four-wave tile of which two workgroups share a CU (conv_gemm_dual.hip: weights single-buffered, two
-    barriers per K-step), forced on small shapes: 1x1 dense and 3x3 / strided addressing, M and N tails, epilogue with bias +
+@pytest.mark.parametrize("variant", [6, 8])
+def test_conv_dual_resident_tile(B, H, W, C, N, R, stride, variant):
+    """The 256 x 128 / four-wave tile of which two workgroups share a CU (variant 6, conv_gemm_dual.hip: weights single-buffered,
+    two barriers per K-step) and the 256 x 256 tile with one wave per SIMD (variant 8, conv_gemm_w4.hip: every fragment read and
+    DMA piece behind an MFMA, a tile's pieces spread over two K-steps), forced on small shapes: 1x1 dense and 3x3 / strided addressing, M and N tails, epilogue with bias +
     ReLU + residual -- vs F.conv2d and vs the 128^2 tile (same K order: identical sums)."""
     import ctypes
     from gdlhip import _lib
@@ -887,16 +889,16 @@ def test_conv_dual_resident_tile(B, H, W, C, N, R, stride):
     rn = resid.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
     outs = {}
     try:
-        for v in (6, 1):
+        for v in (variant, 1):
             lib.gdl_debug_force_conv_variant(v)
             for odt in (torch.float32, torch.bfloat16):
                 outs[v, odt] = ops.conv_gemm(xn, wq, R=R, S=R, pad=R // 2, stride=stride, bias=bias.to(DEV), act=ops.ACT_RELU,
                                              resid=rn if odt == torch.bfloat16 else rn.float(), out_dtype=odt)
     finally:
         lib.gdl_debug_force_conv_variant(-1)
-    close(outs[6, torch.float32].permute(0, 3, 1, 2), ref, dtype, "dual-resident tile")
+    close(outs[variant, torch.float32].permute(0, 3, 1, 2), ref, dtype, f"tile variant {variant}")
     for odt in (torch.float32, torch.bfloat16):
-        assert torch.equal(outs[6, odt], outs[1, odt]), f"dual-resident vs 128^2 tile differ ({odt})"
+        assert torch.equal(outs[variant, odt], outs[1, odt]), f"variant {variant} vs 128^2 tile differ ({odt})"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

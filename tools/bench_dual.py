@@ -49,7 +49,7 @@ lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
 lib.gdl_debug_set_conv_dbg.argtypes = [ctypes.c_int]
 lib.gdl_debug_set_conv_epilogue.argtypes = [ctypes.c_int]
 lib.gdl_debug_set_conv_ngroup_kb.argtypes = [ctypes.c_int]
-print(f"batch {B}: us per call (TF/s); v3 = 256^2 ping-pong, v6 = dual-resident 256x128" + "".join(f", v6/dbg{d}" for d in DBG if d))
+print(f"batch {B}: us per call (TF/s); v3 = 256^2 ping-pong (8 waves), v6 = dual-resident 256x128, v8 = 256^2 one wave per SIMD (/d0.5 = second measurement)" + "".join(f", v6/dbg{d}" for d in DBG if d))
 tot = {}
 for label, M, K, N, epi in SHAPES:
     x = torch.randn(1, 1, M, K, device="cuda").to(bf)
@@ -65,9 +65,9 @@ for label, M, K, N, epi in SHAPES:
     row = {}
     try:
         # dbg "100": element-wise terms decided at run time (the round-3 epilogue); "200": N tiles not grouped (round-3 tile order)
-        for v, d in [(3, 100), (3, 200), (3, 0)] + [(6, d) for d in DBG] + [(-1, 0)]:
+        for v, d in [(3, 0)] + [(6, d) for d in DBG] + [(8, 0), (3, 0.5), (8, 0.5), (-1, 0)]:
             lib.gdl_debug_force_conv_variant(v)
-            lib.gdl_debug_set_conv_dbg(d if d < 100 else 0)
+            lib.gdl_debug_set_conv_dbg(int(d) if d < 100 else 0)
             lib.gdl_debug_set_conv_epilogue(2 if d == 100 else 1)
             lib.gdl_debug_set_conv_ngroup_kb(0 if d in (100, 200) else 2560)
             row[v, d] = timeit(lambda: ops.conv_gemm(x, w, out=out, **kw))
@@ -79,5 +79,5 @@ for label, M, K, N, epi in SHAPES:
     for key, t in row.items():
         tot[key] = tot.get(key, 0) + t
     print(f"  {label:20s} M {M:6d} N {N:5d} K {K:5d} {epi:5s}: " +
-          "  ".join(f"v{v}{'/d%d' % d if d else ''} {t:6.1f} ({flops / t / 1e6:5.0f})" for (v, d), t in row.items()), flush=True)
-print("sum: " + "  ".join(f"v{v}{'/d%d' % d if d else ''} {t:.0f} us" for (v, d), t in tot.items()))
+          "  ".join(f"v{v}{'/d%s' % d if d else ''} {t:6.1f} ({flops / t / 1e6:5.0f})" for (v, d), t in row.items()), flush=True)
+print("sum: " + "  ".join(f"v{v}{'/d%s' % d if d else ''} {t:.0f} us" for (v, d), t in tot.items()))

@@ -64,7 +64,7 @@ def run(name, m, k, n, kind, odt, variant, dbg):
     lib.gdl_debug_set_conv_probe(None)
     lib.gdl_debug_set_conv_dbg(0)
     lib.gdl_debug_force_conv_variant(-1)
-    tm = 256 if variant in (2, 3, 4, 6) else 128
+    tm = 256 if variant in (2, 3, 4, 6, 8) else 128
     tn = 128 if variant == 6 else tm
     nb = min(2048, ((m + tm - 1) // tm) * ((n + tn - 1) // tn))
     kl = buf[:4096].view(2048, 2)[:nb].double().cpu()
@@ -91,7 +91,7 @@ def run(name, m, k, n, kind, odt, variant, dbg):
 FULL = len(sys.argv) > 2 and sys.argv[2] == "full"
 if len(sys.argv) > 2 and sys.argv[2] == "dual":   # 256^2 ping-pong (one workgroup per CU) vs the dual-resident 256 x 128 tile
     for shp in SHAPES:
-        for variant, dbg in ((3, 0), (6, 0), (6, 9), (6, 10)):
+        for variant, dbg in ((3, 0), (8, 0), (8, 1)):
             run(*shp, variant, dbg)
     sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "epilogue_parts":   # round-3 epilogue: as is / without its global stores (10) / without residual loads (11)
