@@ -420,6 +420,7 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   if (variant == 7) return conv3x3_narrow_launch(k, s);
   if (variant == 6) return conv_gemm_dual_launch(k, s);
   if (variant == 8) return conv_gemm_w4_launch(k, s);
+  if (variant == 9) return conv_gemm_persist_launch(k, s);
   if (a.dtype == GDL_BF16) {
     if (variant == 4) return conv3x3_sf_launch(k, s);
     if (variant == 3 && k.dbg == 7) return launch_x<bf16_tag, 2, 4, 4, 2, false, true, false, false, true>(k, s);
@@ -445,6 +446,8 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
 static std::atomic<int> g_forced_variant{-1};
 static std::atomic<int> g_w4_enabled{1};
 extern "C" void gdl_debug_set_conv_w4(int on) { g_w4_enabled = on; }  // A/B hook: 256^2 one-wave-per-SIMD tile
+static std::atomic<int> g_persist_enabled{1};
+extern "C" void gdl_debug_set_conv_persist(int on) { g_persist_enabled = on; }  // A/B hook: persistent 256^2 tile for dense 1x1 layers
 static std::atomic<int> g_dual_enabled{1};
 extern "C" void gdl_debug_set_conv_dual(int on) { g_dual_enabled = on; }  // A/B hook: dual-resident 256 x 128 tile
 static std::atomic<int> g_ngroup_kb{2560};
@@ -488,6 +491,7 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
       !(g_forced_variant == 4 && !conv3x3_sf_applicable(a)) &&
       !(g_forced_variant == 6 && !conv_gemm_dual_applicable(a)) &&
       !(g_forced_variant == 8 && !conv_gemm_w4_applicable(a)) &&
+      !(g_forced_variant == 9 && !conv_gemm_persist_applicable(a)) &&
       !(g_forced_variant == 7 && !conv3x3_narrow_applicable(a)))
     return g_forced_variant;
   // narrow 3x3 layers on large maps: direct kernel, one staged window per 4 x 64 pixels (HBM-bound layers)
@@ -510,6 +514,9 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
     // epilogue (four waves instead of eight) ~1.8 x longer -- it wins from about 40 K-steps on (ViT fc2 +8 %, tap data
     // gradients +9 %, the 768-channel 3x3 convolutions +2.5 %; tools/bench_w4.py, profiles/r04d_*)
     if (g_w4_enabled && conv_gemm_w4_applicable(a) && ksteps >= (a.R * a.S > 1 ? 100 : 40)) return 8;
+    // dense 1x1 layers with more tiles than CUs: one persistent workgroup per CU, the next tile's first stage lands under the
+    // epilogue (conv_gemm_persist.hip)
+    if (g_persist_enabled && t256 > 256 && conv_gemm_persist_applicable(a)) return 9;
     return (g_sf_enabled && conv3x3_sf_applicable(a)) ? 4 : 3;   // ping-pong 256^2 (4: 3x3 with shared staging)
   }
   if (t128 >= 256 && a.N >= 128) return 1;

@@ -99,6 +99,9 @@ int conv_gemm_dual_launch(const KArgs& k, hipStream_t stream);
 // 256 x 256 tile, one wave per SIMD, every non-MFMA instruction in an MFMA shadow (conv_gemm_w4.hip)
 bool conv_gemm_w4_applicable(const gdl_conv_args& a);
 int conv_gemm_w4_launch(const KArgs& k, hipStream_t stream);
+// persistent 256 x 256 ping-pong tile for dense 1x1 bf16 layers: next tile's first stage in flight under the epilogue (conv_gemm_persist.hip)
+bool conv_gemm_persist_applicable(const gdl_conv_args& a);
+int conv_gemm_persist_launch(const KArgs& k, hipStream_t stream);
 // direct 3x3 kernel for C in {8,16,32} on large dense maps, outputs in 32-channel slices (conv3x3_narrow.hip)
 bool conv3x3_narrow_applicable(const gdl_conv_args& a);
 int conv3x3_narrow_launch(const KArgs& k, hipStream_t stream);

@@ -158,6 +158,7 @@ class KernelTimer:
                5: "conv_gemm_kernel<{dt},4,1,2,2> (256x64 tiles, narrow outputs)",
                6: "conv_gemm_dual_kernel (256x128 tiles, four waves, two workgroups resident per CU)",
                8: "conv_gemm_w4_kernel (256x256 tiles, one wave per SIMD, every load in an MFMA shadow)",
+               9: "conv_gemm_persist_kernel (256x256 ping-pong tiles, one persistent workgroup per CU, next tile's first stage under the epilogue)",
                7: "conv3x3_narrow_kernel (direct 3x3, C <= 32, one staged window per 4 x 64 pixels x 32 output channels)"}
 
     def __init__(self) -> None:

@@ -72,7 +72,7 @@ def test_linear_epilogues(dtype):
     close(y, 0.5 * base, dtype if dtype == torch.float32 else torch.bfloat16, "alpha / out dtype")
 
 
-@pytest.mark.parametrize("variant", [1, 3, 6, 8])
+@pytest.mark.parametrize("variant", [1, 3, 6, 8, 9])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_epilogue_row_segments(dtype, variant):
     """The coalesced (LDS-transposed) epilogue of the 128^2, 256^2 and dual-resident 256 x 128 (variant 6) tiles: residual in f32 / bf16, DropPath scale with
@@ -82,10 +82,10 @@ def test_conv_epilogue_row_segments(dtype, variant):
     from gdlhip import _lib
     lib = _lib.load()
     lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
-    if variant in (6, 8) and dtype != torch.bfloat16:
-        pytest.skip("the dual-resident and one-wave-per-SIMD tiles are bf16 kernels")
+    if variant in (6, 8, 9) and dtype != torch.bfloat16:
+        pytest.skip("the dual-resident, one-wave-per-SIMD and persistent tiles are bf16 kernels")
     B, T, K, N = 3, 1297, 128, 208          # M = 3891 (tail of 51 rows), N % 64 = 16, N % 256 != 0
-    if variant in (3, 8):
+    if variant in (3, 8, 9):
         N = 512                              # the 256^2 tiles need N % 256 == 0
     x, w = q(rnd(B, T, K), dtype), q(rnd(N, K, seed=1), dtype) * 0.1
     bias, scale, shift = rnd(N, seed=2), rnd(N, seed=3), rnd(N, seed=4)
@@ -899,6 +899,37 @@ def test_conv_dual_resident_tile(B, H, W, C, N, R, stride, variant):
     close(outs[variant, torch.float32].permute(0, 3, 1, 2), ref, dtype, f"tile variant {variant}")
     for odt in (torch.float32, torch.bfloat16):
         assert torch.equal(outs[variant, odt], outs[1, odt]), f"variant {variant} vs 128^2 tile differ ({odt})"
+
+
+@pytest.mark.parametrize("M,N,K", [(10300, 2048, 192), (66000, 512, 64), (20500, 1024, 256), (300, 256, 128)])
+def test_conv_persistent_tile(M, N, K):
+    """The persistent 256^2 tile (variant 9, conv_gemm_persist.hip: one workgroup per CU walks several tiles, the next tile's first
+    stage is in flight under the epilogue): more tiles than CUs (328 / 516 / 324) so that workgroups take a second and third
+    tile, odd / single / even K-step counts, an M tail, bf16 and f32 + residual outputs -- vs the 128^2 tile (same K order:
+    identical sums), and into a channel slice of a wider buffer."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
+    dtype = torch.bfloat16
+    x, w = q(rnd(M, K), dtype).to(DEV, dtype).view(1, 1, M, K), (q(rnd(N, K, seed=1), dtype) * 0.1).to(DEV, dtype)
+    bias, scale = rnd(N, seed=2).to(DEV), rnd(N, seed=3).to(DEV)
+    resid = rnd(M, N, seed=4).to(DEV).view(1, 1, M, N)
+    outs = {}
+    try:
+        for v in (9, 1):
+            lib.gdl_debug_force_conv_variant(v)
+            outs[v, "bf16"] = ops.conv_gemm(x, w, bias=bias, act=ops.ACT_RELU, out_dtype=torch.bfloat16)
+            outs[v, "f32"] = ops.conv_gemm(x, w, bias=bias, scale=scale, resid=resid, out_dtype=torch.float32)
+            wide = torch.zeros(1, 1, M, N + 64, device=DEV, dtype=torch.bfloat16)
+            ops.conv_gemm(x, w, bias=bias, out=wide[..., 32:32 + N])
+            outs[v, "slice"] = wide
+    finally:
+        lib.gdl_debug_force_conv_variant(-1)
+    ref = F.relu(x.view(M, K).float().cpu() @ w.float().cpu().t() + bias.cpu())
+    close(outs[9, "bf16"].view(M, N), ref, dtype, "persistent tile")
+    for key in ("bf16", "f32", "slice"):
+        assert torch.equal(outs[9, key], outs[1, key]), f"persistent tile vs 128^2 tile differ ({key})"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

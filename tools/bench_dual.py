@@ -49,7 +49,7 @@ lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
 lib.gdl_debug_set_conv_dbg.argtypes = [ctypes.c_int]
 lib.gdl_debug_set_conv_epilogue.argtypes = [ctypes.c_int]
 lib.gdl_debug_set_conv_ngroup_kb.argtypes = [ctypes.c_int]
-print(f"batch {B}: us per call (TF/s); v3 = 256^2 ping-pong (8 waves), v6 = dual-resident 256x128, v8 = 256^2 one wave per SIMD (/d0.5 = second measurement)" + "".join(f", v6/dbg{d}" for d in DBG if d))
+print(f"batch {B}: us per call (TF/s); v3 = 256^2 ping-pong (8 waves), v6 = dual-resident 256x128, v8 = 256^2 one wave per SIMD, v9 = persistent 256^2 ping-pong (/d0.5 = second measurement)" + "".join(f", v6/dbg{d}" for d in DBG if d))
 tot = {}
 for label, M, K, N, epi in SHAPES:
     x = torch.randn(1, 1, M, K, device="cuda").to(bf)
@@ -65,7 +65,7 @@ for label, M, K, N, epi in SHAPES:
     row = {}
     try:
         # dbg "100": element-wise terms decided at run time (the round-3 epilogue); "200": N tiles not grouped (round-3 tile order)
-        for v, d in [(3, 0)] + [(6, d) for d in DBG] + [(8, 0), (3, 0.5), (8, 0.5), (-1, 0)]:
+        for v, d in [(3, 0)] + [(6, d) for d in DBG] + [(8, 0), (9, 0), (3, 0.5), (9, 0.5), (-1, 0)]:
             lib.gdl_debug_force_conv_variant(v)
             lib.gdl_debug_set_conv_dbg(int(d) if d < 100 else 0)
             lib.gdl_debug_set_conv_epilogue(2 if d == 100 else 1)
