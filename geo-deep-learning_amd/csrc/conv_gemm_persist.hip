@@ -27,74 +27,85 @@ namespace {
 constexpr int PS_STAGE = 65536;                 // [A: 256 rows | B: 256 rows] x 128 B
 constexpr int PS_LDS = 2 * PS_STAGE + 8192;     // + the epilogue's per-wave constant rows
 
-__global__ __launch_bounds__(512) void conv_gemm_persist_kernel(const KArgs k) {
+__global__ __launch_bounds__(512) void conv_gemm_persist_kernel(const KArgs) {
   constexpr int ES = 2;
   constexpr int TM = 4, TN = 2, WARPS_N = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const gdl_conv_args& a = k.a;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
-  const int ntiles = k.tiles_m * k.tiles_n;
-  const srd_t srd_a = make_srd(a.in, k.in_span);
-  const srd_t srd_b = make_srd(a.w, k.w_span);
-  const unsigned lds_base =
-      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
-
-  // ---- DMA geometry (conv_gemm.hip): loading wave w of a half, piece i covers tile rows (i*4 + w)*8 .. +7; lane l writes LDS
-  //      slot (l & 7) of row +(l >> 3) and fetches source chunk slot ^ swz(row) -- the same chunk for every piece
-  const int lrow = lane >> 3, lslot = lane & 7;
-  const int lwave = wave & 3, half = wave >> 2;      // waves w and w+4 share a SIMD and alternate as loaders
-  const int chunk = lslot ^ ((((lwave & 1) << 2) + (lrow >> 1)) & 7);
-  const unsigned a_row = (unsigned)a.in_sW * ES, b_row = (unsigned)a.w_sN * ES;     // bytes per activation / weight row
-  const unsigned a_lane = (unsigned)(lwave * 8 + lrow) * a_row + chunk * 16;
-  const unsigned b_lane = (unsigned)(lwave * 8 + lrow) * b_row + chunk * 16;
-
-  auto issue = [&](int stage, unsigned a_v, unsigned b_v, unsigned wk) {
-    const unsigned lds_a = lds_base + stage * PS_STAGE + lwave * 1024;
-    const unsigned lds_b = lds_a + 256 * 128;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dma16_buf(a_v + i * 32 * a_row, srd_a, wk, lds_a + i * 4096);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dma16_buf(b_v + i * 32 * b_row, srd_b, wk, lds_b + i * 4096);
-  };
-
-  f32x16_t acc[TM][TN];
-  const int frow = lane & 31, fhalf = lane >> 5;
-  const int fswz = (frow >> 1) & 7;
-  const int a_lds0 = (wm * TM * 32 + frow) * 128;
-  const int b_lds0 = 256 * 128 + (wn * TN * 32 + frow) * 128;
-  uint4 fa[2][TM], fb[2][TN];
-  auto fetch = [&](const unsigned char* st, int kk, int buf) {
-    const int coff = (((2 * kk + fhalf) ^ fswz) << 4);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[buf][i] = *(const uint4*)(st + a_lds0 + i * 32 * 128 + coff);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[buf][j] = *(const uint4*)(st + b_lds0 + j * 32 * 128 + coff);
-  };
-  // FIRST: the tile's first k16 group starts the sums from the constant 0 -- the accumulators are then dead between a tile's
-  // epilogue and the next tile's first MFMAs instead of being 128 zero-filled registers carried around the tile loop
-  auto mfmas = [&](int buf, auto first) {
-    constexpr bool FIRST = decltype(first)::value;
-    const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[buf][j]),
-                                                            __builtin_bit_cast(bf16x8_t, fa[buf][i]), FIRST ? zero : acc[i][j], 0, 0, 0);
-  };
+  typedef const __attribute__((address_space(4))) KArgs* kargs_ptr;
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
 
+  f32x16_t acc[TM][TN];
   int v = blockIdx.x;                       // virtual block index of the current tile
-  int tile_m, tile_n;
-  tile_order(k, xcd_remap(v, ntiles), tile_m, tile_n);
-  int m0 = tile_m * 256, n0 = tile_n * 256;
-  unsigned a_v = a_lane + (unsigned)m0 * a_row, b_v = b_lane + (unsigned)n0 * b_row;
-  if (half == 0) issue(0, a_v, b_v, 0u);
+  bool first_tile = true;
   for (;;) {
+    // Everything but the accumulators and v is RE-DERIVED per tile from the kernel-argument segment and the thread id, behind
+    // an empty asm the optimiser cannot see through.  Written the usual way (geometry computed once in front of the tile
+    // loop) the values stay live across the epilogue and the epilogue's tile-independent terms are hoisted in front of the
+    // loop: 116 scalar + 142 vector spills around the K loop, against 17 / 0 in the one-tile kernel.
+    kargs_ptr kp = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();   // KArgs is the only argument
+    int tid = threadIdx.x;
+    asm volatile("" : "+s"(kp), "+v"(tid));
+    const KArgs& k = *(const KArgs*)kp;
+    const gdl_conv_args& a = k.a;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+    const int ntiles = k.tiles_m * k.tiles_n;
+    const srd_t srd_a = make_srd(a.in, k.in_span);
+    const srd_t srd_b = make_srd(a.w, k.w_span);
+    const unsigned lds_base =
+        __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+
+    // ---- DMA geometry (conv_gemm.hip): loading wave w of a half, piece i covers tile rows (i*4 + w)*8 .. +7; lane l writes LDS
+    //      slot (l & 7) of row +(l >> 3) and fetches source chunk slot ^ swz(row) -- the same chunk for every piece
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int lwave = wave & 3, half = wave >> 2;      // waves w and w+4 share a SIMD and alternate as loaders
+    const int chunk = lslot ^ ((((lwave & 1) << 2) + (lrow >> 1)) & 7);
+    const unsigned a_row = (unsigned)a.in_sW * ES, b_row = (unsigned)a.w_sN * ES;     // bytes per activation / weight row
+    const unsigned a_lane = (unsigned)(lwave * 8 + lrow) * a_row + chunk * 16;
+    const unsigned b_lane = (unsigned)(lwave * 8 + lrow) * b_row + chunk * 16;
+    auto issue = [&](int stage, unsigned a_v, unsigned b_v, unsigned wk) {
+      const unsigned lds_a = lds_base + stage * PS_STAGE + lwave * 1024;
+      const unsigned lds_b = lds_a + 256 * 128;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dma16_buf(a_v + i * 32 * a_row, srd_a, wk, lds_a + i * 4096);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dma16_buf(b_v + i * 32 * b_row, srd_b, wk, lds_b + i * 4096);
+    };
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int fswz = (frow >> 1) & 7;
+    const int a_lds0 = (wm * TM * 32 + frow) * 128;
+    const int b_lds0 = 256 * 128 + (wn * TN * 32 + frow) * 128;
+    uint4 fa[2][TM], fb[2][TN];
+    auto fetch = [&](const unsigned char* st, int kk, int buf) {
+      const int coff = (((2 * kk + fhalf) ^ fswz) << 4);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[buf][i] = *(const uint4*)(st + a_lds0 + i * 32 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[buf][j] = *(const uint4*)(st + b_lds0 + j * 32 * 128 + coff);
+    };
+    // FIRST: the tile's first k16 group starts the sums from the constant 0 -- the accumulators are then dead between a tile's
+    // epilogue and the next tile's first MFMAs instead of being 128 zero-filled registers carried around the tile loop
+    auto mfmas = [&](int buf, auto first) {
+      constexpr bool FIRST = decltype(first)::value;
+      const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[buf][j]),
+                                                              __builtin_bit_cast(bf16x8_t, fa[buf][i]), FIRST ? zero : acc[i][j], 0, 0, 0);
+    };
+
+    int tile_m, tile_n;
+    tile_order(k, xcd_remap(v, ntiles), tile_m, tile_n);
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    const unsigned a_v = a_lane + (unsigned)m0 * a_row, b_v = b_lane + (unsigned)n0 * b_row;
+    if (first_tile && half == 0) issue(0, a_v, b_v, 0u);     // later tiles: issued in front of the previous tile's epilogue
+    first_tile = false;
+
     const unsigned long long t0c = k.probe ? __builtin_readcyclecounter() : 0;
     const unsigned long long t0r = k.probe ? __builtin_amdgcn_s_memrealtime() : 0;
     if (half == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loaders' share of stage 0 has landed
@@ -131,30 +142,27 @@ __global__ __launch_bounds__(512) void conv_gemm_persist_kernel(const KArgs k) {
     // the next tile's first stage goes out now and lands under the epilogue, which stages through stage 1's memory
     const int vn = v + (int)gridDim.x;
     const bool more = vn < ntiles;
-    const int m0c = m0, n0c = n0;
-    if (more) {
-      tile_order(k, xcd_remap(vn, ntiles), tile_m, tile_n);
-      m0 = tile_m * 256;
-      n0 = tile_n * 256;
-      a_v = a_lane + (unsigned)m0 * a_row;
-      b_v = b_lane + (unsigned)n0 * b_row;
-      if (half == 0 && k.dbg != 11) issue(0, a_v, b_v, 0u);
+    if (more && half == 0 && k.dbg != 11) {
+      int tm2, tn2;
+      tile_order(k, xcd_remap(vn, ntiles), tm2, tn2);
+      issue(0, a_lane + (unsigned)(tm2 * 256) * a_row, b_lane + (unsigned)(tn2 * 256) * b_row, 0u);
     }
-    // (the kernel arguments are re-read through an opaque pointer: otherwise the compiler hoists every tile-independent term of
-    // the unrolled epilogue -- some 200 scalar and 150 vector values -- out of the tile loop and spills them around the K loop)
-    const __attribute__((address_space(4))) KArgs* kp =
-        (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();   // KArgs is the only argument
-    int lane_e = lane, wave_e = wave;
-    asm volatile("" : "+s"(kp), "+v"(lane_e), "+s"(wave_e));
-    conv_epilogue<TM, TN, false>(*(const KArgs*)kp, acc, m0c, n0c, wave_e / WARPS_N, wave_e % WARPS_N, lane_e, 0,
-                                 smem + PS_STAGE + wave_e * 8192, smem + 2 * PS_STAGE + wave_e * 1024);
-    if (k.probe && tid == 0 && v < 2048) {
-      k.probe[4096 + v] = __builtin_readcyclecounter() - t0c;
-      k.probe[8192 + 2 * v] = t0r;                                   // tile timeline (100 MHz ticks)
-      k.probe[8192 + 2 * v + 1] = __builtin_amdgcn_s_memrealtime();
+    {
+      kargs_ptr kq = (kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+      int tid_e = threadIdx.x, m0_e = m0, n0_e = n0;
+      asm volatile("" : "+s"(kq), "+v"(tid_e), "+s"(m0_e), "+s"(n0_e));
+      const KArgs& ke = *(const KArgs*)kq;
+      const int wave_e = __builtin_amdgcn_readfirstlane(tid_e >> 6);
+      conv_epilogue<TM, TN, false>(ke, acc, m0_e, n0_e, wave_e / WARPS_N, wave_e % WARPS_N, tid_e & 63, 0,
+                                   smem + PS_STAGE + wave_e * 8192, smem + 2 * PS_STAGE + wave_e * 1024);
+      if (ke.probe && tid_e == 0 && v < 2048) {
+        ke.probe[4096 + v] = __builtin_readcyclecounter() - t0c;
+        ke.probe[8192 + 2 * v] = t0r;                                   // tile timeline (100 MHz ticks)
+        ke.probe[8192 + 2 * v + 1] = __builtin_amdgcn_s_memrealtime();
+      }
+      if (!more) break;
+      if (ke.dbg == 11 && wave_e < 4) first_tile = true;               // tuning: no prefetch under the epilogue
     }
-    if (!more) break;
-    if (half == 0 && k.dbg == 11) issue(0, a_v, b_v, 0u);            // tuning: no prefetch under the epilogue
     v = vn;
   }
 }
