@@ -837,6 +837,16 @@ int64_t span_bytes(int B, int H, int W, int C, int64_t sB, int64_t sH, int64_t s
   return (((int64_t)B - 1) * sB + ((int64_t)H - 1) * sH + ((int64_t)W - 1) * sW + C) * es;
 }
 
+std::atomic<int> g_wgrad_old_splits{0};    // A/B hook: the round-3 split-K rule of the 256^2 kernel
+int wgrad_num_cus() {
+  static int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    return cus;
+  }();
+  return n;
+}
 std::atomic<int> g_wgrad_force_small{0};   // A/B hook: bit 0 = never use the 256^2 kernel, bit 1 = never use the row-segment kernel, bit 3 = N, C >= 256 layers on the 256^2 kernel
 
 // 256^2 tiles for wide bf16 layers whose operands fit 32-bit buffer offsets
@@ -848,12 +858,22 @@ int wgrad_tile(const gdl_wgrad_args& a) {
   return 256;
 }
 
+int rows_seglen(int W);
 // row-segment kernel: every 3x3 / stride 1 / pad 1 layer on a map at least 32 pixels wide
 bool wgrad_rows_ok(const gdl_wgrad_args& a) {
   if (a.dtype != GDL_BF16 || (g_wgrad_force_small & 2)) return false;
   if ((g_wgrad_force_small & 8) && wgrad_tile(a) == 256) return false;   // A/B hook: wide layers on the 256^2 per-tap kernel
   if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.H != a.Ho || a.W != a.Wo || a.W < 32 || a.nz != 1)
     return false;
+  // rows are staged in 16-pixel units: a 36-wide map pays for 48 pixels per row.  Where the per-tap 256^2 kernel exists (N, C >=
+  // 256) it is faster from 20 % padding on (768 -> 768 at 36^2: 563 -> 411 us, profiles/r04e_bench_wgrad_split_rule.txt)
+  if (!g_wgrad_old_splits && wgrad_tile(a) == 256) {
+    const int seglen = rows_seglen(a.W);
+    if (5 * seglen * ((a.W + seglen - 1) / seglen) >= 6 * a.W) return false;
+    // ... and, with the round-4 split rule, for the widest layers at any width (768 -> 768: 1.10-1.15 PF against 0.97-1.02,
+    // 1024 -> 256: 1.14-1.16 against 1.05-1.11; 256 -> 256 stays 4-16 % faster on the row segments)
+    if ((int64_t)a.N * a.C >= 256 * 1024) return false;
+  }
   return span_bytes(a.B, a.H, a.W, a.C, a.in_sB, a.in_sH, a.in_sW, 2) + a.in_sW * 2 <= 0x7ffffff0ll &&
          span_bytes(a.B, a.Ho, a.Wo, a.N, a.dy_sB, a.dy_sH, a.dy_sW, 2) <= 0x7ffffff0ll;
 }
@@ -878,8 +898,29 @@ int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
   }
   const int t = wgrad_tile(a);
   const int64_t tiles = (int64_t)((a.N + t - 1) / t) * a.R * a.S * ((a.C + t - 1) / t) * (a.nz > 1 ? a.nz : 1);
-  int64_t want = ((t == 256 ? 512 : 1024) + tiles - 1) / tiles;   // aim for ~1024 (512 big-tile) blocks
   const int64_t max_by_k = P / (8 * bkp);              // keep >= 8 K-steps per split
+  if (t == 256 && !g_wgrad_old_splits) {
+    // The 256^2 kernel holds a CU alone (512 threads, 128 KiB of LDS), so the split count decides how the launch falls into
+    // rounds of one workgroup per CU.  Round 4: cost model instead of "about 512 workgroups" -- that rule always produced
+    // 512 .. 512 + tiles - 1 of them, i.e. two full rounds plus a nearly empty third (lateral 768 -> 768 at 36^2: 9 tiles x 57
+    // splits = 513 workgroups, 133 us for 49 GF; now 28 splits = 252 workgroups).  Per candidate: rounds x (K-steps of a
+    // split x ~3000 cycles + ~25 k cycles of prologue and f32 partial-tile store) + the reduction pass over `splits` partial
+    // matrices at ~3 TB/s.
+    const int cus = wgrad_num_cus();
+    const int64_t ksteps = (P + bkp - 1) / bkp;
+    const double out_bytes = (double)a.N * a.R * a.S * a.C * 4.0 * (a.nz > 1 ? a.nz : 1);
+    const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(max_by_k, a.nz > 1 ? 64 : 512));
+    int64_t best = 1;
+    double best_us = 1e30;
+    for (int64_t sp = 1; sp <= smax; ++sp) {
+      const int64_t rounds = (tiles * sp + cus - 1) / cus;
+      const double main_us = rounds * ((double)((ksteps + sp - 1) / sp) * 3000.0 + 25000.0) / 1800.0;
+      const double red_us = sp > 1 ? sp * out_bytes / 3.0e6 + 8.0 : 0.0;
+      if (main_us + red_us < best_us) { best_us = main_us + red_us; best = sp; }
+    }
+    return (int)best;
+  }
+  int64_t want = ((t == 256 ? 512 : 1024) + tiles - 1) / tiles;   // aim for ~1024 (512 big-tile) blocks
   if (want > max_by_k) want = max_by_k;
   // few-tile layers (narrow linears over many pixels: MiT stage 1-2) need many splits to fill 256 CUs; the wide
   // reduction kernel makes them cheap.  Batched calls (attention dK / dV) already have nz-fold parallelism.
@@ -892,6 +933,7 @@ int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
 }  // namespace
 
 static std::atomic<int> g_wgrad_force_v1{0};
+extern "C" void gdl_debug_set_wgrad_old_splits(int on) { g_wgrad_old_splits = on; }  // A/B hook: round-3 split-K rule
 extern "C" void gdl_debug_force_wgrad_small(int on) { g_wgrad_force_small = on; }  // A/B hook: 128^2 tiles only
 extern "C" void gdl_debug_force_wgrad_v1(int on) { g_wgrad_force_v1 = on; }  // A/B hook: register-transpose kernel
 

@@ -82,5 +82,49 @@ def main():
         print(f"{name:30s} b={b:2d} GF {flops / 1e9:8.1f}  " + " | ".join(out), flush=True)
 
 
+SPLIT_LAYERS = [  # name, H, W, C, N, R: the layers of the DOFA training step that run on the 256^2 kernel
+    ("neck lateral 768->768 1x1 @36", 36, 36, 768, 768, 1), ("neck taps 768->6912 1x1 @36", 36, 36, 768, 6912, 1),
+    ("fuse taps 256->2304 1x1 @72", 72, 72, 256, 2304, 1), ("fuse taps 256->2304 1x1 @36", 36, 36, 256, 2304, 1),
+    ("fuse taps 256->2304 1x1 @18", 18, 18, 256, 2304, 1), ("lateral 768->256 1x1 @144", 144, 144, 768, 256, 1),
+    ("lateral 768->256 1x1 @72", 72, 72, 768, 256, 1), ("lateral 768->256 1x1 @36", 36, 36, 768, 256, 1),
+    ("neck 768->768 3x3 @36 (rows kernel)", 36, 36, 768, 768, 3), ("neck 768->768 3x3 @18", 18, 18, 768, 768, 3),
+    ("psp bottleneck 1792->256 3x3 @18", 18, 18, 1792, 256, 3), ("fpn 768->256 3x3 @18", 18, 18, 768, 256, 3),
+    ("fpn 256->256 3x3 @36 (rows kernel)", 36, 36, 256, 256, 3),
+]
+
+
+def main_splits():
+    """tools/bench_wgrad.py <batch> splits: split-K rule of the 256^2 kernel, round 3 ("about 512 workgroups") vs the round-4 cost
+    model, and for the 3x3 layers also the per-tap 256^2 kernel instead of the row-segment kernel (mode 8)."""
+    lib = _lib.load()
+    lib.gdl_debug_force_wgrad_small.argtypes = [ctypes.c_int]
+    lib.gdl_debug_set_wgrad_old_splits.argtypes = [ctypes.c_int]
+    print(f"batch {B}: TF/s (us)  round-3 splits | cost model | cost model, 3x3 on the per-tap 256^2 kernel")
+    tot = [0.0, 0.0, 0.0]
+    for name, h, w, c, n, r in SPLIT_LAYERS:
+        x = torch.randn(B, h, w, c, device=DEV).to(bf)
+        dy = torch.randn(B, h, w, n, device=DEV).to(bf)
+        flops = 2 * B * h * w * n * r * r * c
+        out, ref = [], None
+        for i, (old, mode) in enumerate(((1, 0), (0, 0), (0, 8))):
+            lib.gdl_debug_set_wgrad_old_splits(old)
+            lib.gdl_debug_force_wgrad_small(mode)
+            try:
+                t = timeit(lambda: ops.conv_wgrad(x, dy, R=r, S=r, pad=r // 2))
+                got = ops.conv_wgrad(x, dy, R=r, S=r, pad=r // 2)
+            finally:
+                lib.gdl_debug_set_wgrad_old_splits(0)
+                lib.gdl_debug_force_wgrad_small(0)
+            ref = got if ref is None else ref
+            err = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+            tot[i] += t * 1e3
+            out.append(f"{flops / t / 1e9:7.1f} ({t * 1e3:6.0f}) e={err:.0e}")
+        print(f"{name:38s} GF {flops / 1e9:7.1f}  " + " | ".join(out), flush=True)
+    print("sum: " + " | ".join(f"{t:.0f} us" for t in tot))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[2] == "splits":
+        main_splits()
+    else:
+        main()
