@@ -899,22 +899,23 @@ int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
   const int t = wgrad_tile(a);
   const int64_t tiles = (int64_t)((a.N + t - 1) / t) * a.R * a.S * ((a.C + t - 1) / t) * (a.nz > 1 ? a.nz : 1);
   const int64_t max_by_k = P / (8 * bkp);              // keep >= 8 K-steps per split
-  if (t == 256 && !g_wgrad_old_splits) {
-    // The 256^2 kernel holds a CU alone (512 threads, 128 KiB of LDS), so the split count decides how the launch falls into
-    // rounds of one workgroup per CU.  Round 4: cost model instead of "about 512 workgroups" -- that rule always produced
-    // 512 .. 512 + tiles - 1 of them, i.e. two full rounds plus a nearly empty third (lateral 768 -> 768 at 36^2: 9 tiles x 57
-    // splits = 513 workgroups, 133 us for 49 GF; now 28 splits = 252 workgroups).  Per candidate: rounds x (K-steps of a
-    // split x ~3000 cycles + ~25 k cycles of prologue and f32 partial-tile store) + the reduction pass over `splits` partial
-    // matrices at ~3 TB/s.
-    const int cus = wgrad_num_cus();
+  if (a.dtype == GDL_BF16 && !g_wgrad_old_splits) {
+    // Round 4: cost model instead of "about 512 (256^2) / 1024 (128^2) workgroups".  The 256^2 kernel holds a CU alone (512
+    // threads, 128 KiB of LDS), the 128^2 kernel shares it with one other workgroup (64 KiB each), so the split count decides
+    // how the launch falls into rounds of `slots` workgroups -- and the old rule always produced slots * 2 .. slots * 2 + tiles
+    // - 1 of them: two full rounds plus a nearly empty third (lateral 768 -> 768 at 36^2: 9 tiles x 57 splits = 513 workgroups,
+    // 120 us for 49 GF; now 28 splits = 252 workgroups, 89 us).  Per candidate: rounds x (K-steps of a split x cycles per
+    // K-step + prologue and f32 partial-tile store) + the reduction pass over `splits` partial matrices at ~3 TB/s.
+    const int64_t slots = (int64_t)wgrad_num_cus() * (t == 256 ? 1 : 2);
+    const double step_cyc = t == 256 ? 3000.0 : 1700.0, fixed_cyc = t == 256 ? 25000.0 : 11000.0;
     const int64_t ksteps = (P + bkp - 1) / bkp;
     const double out_bytes = (double)a.N * a.R * a.S * a.C * 4.0 * (a.nz > 1 ? a.nz : 1);
     const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(max_by_k, a.nz > 1 ? 64 : 512));
     int64_t best = 1;
     double best_us = 1e30;
     for (int64_t sp = 1; sp <= smax; ++sp) {
-      const int64_t rounds = (tiles * sp + cus - 1) / cus;
-      const double main_us = rounds * ((double)((ksteps + sp - 1) / sp) * 3000.0 + 25000.0) / 1800.0;
+      const int64_t rounds = (tiles * sp + slots - 1) / slots;
+      const double main_us = rounds * ((double)((ksteps + sp - 1) / sp) * step_cyc + fixed_cyc) / 1800.0;
       const double red_us = sp > 1 ? sp * out_bytes / 3.0e6 + 8.0 : 0.0;
       if (main_us + red_us < best_us) { best_us = main_us + red_us; best = sp; }
     }
