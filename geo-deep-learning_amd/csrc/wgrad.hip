@@ -911,15 +911,16 @@ int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
     const int64_t ksteps = (P + bkp - 1) / bkp;
     const double out_bytes = (double)a.N * a.R * a.S * a.C * 4.0 * (a.nz > 1 ? a.nz : 1);
     const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(max_by_k, a.nz > 1 ? 64 : 512));
-    int64_t best = 1;
-    double best_us = 1e30;
-    for (int64_t sp = 1; sp <= smax; ++sp) {
+    auto cost_us = [&](int64_t sp) {
       const int64_t rounds = (tiles * sp + slots - 1) / slots;
       const double main_us = rounds * ((double)((ksteps + sp - 1) / sp) * step_cyc + fixed_cyc) / 1800.0;
-      const double red_us = sp > 1 ? sp * out_bytes / 3.0e6 + 8.0 : 0.0;
-      if (main_us + red_us < best_us) { best_us = main_us + red_us; best = sp; }
-    }
-    return (int)best;
+      return main_us + (sp > 1 ? sp * out_bytes / 3.0e6 + 8.0 : 0.0);
+    };
+    double best_us = 1e30;
+    for (int64_t sp = 1; sp <= smax; ++sp) best_us = std::min(best_us, cost_us(sp));
+    for (int64_t sp = 1; sp <= smax; ++sp)            // the fewest splits within 2 % of the best: less workspace, less reduction traffic
+      if (cost_us(sp) <= 1.02 * best_us) return (int)sp;
+    return 1;
   }
   int64_t want = ((t == 256 ? 512 : 1024) + tiles - 1) / tiles;   // aim for ~1024 (512 big-tile) blocks
   if (want > max_by_k) want = max_by_k;

@@ -155,7 +155,7 @@ def test_packed_weight_cache_rejects_recycled_ids():
 
 
 # ------------------------------------------------------------------ host-side kernel selection (pure host code)
-def _conv_args(B, H, W, C, N, R, dtype=1, stride=1, aux=False):
+def _conv_args(B, H, W, C, N, R, dtype=1, stride=1, aux=False, act=0):
     from gdlhip._lib import ConvArgs
     a = ConvArgs()
     a.inp, a.w, a.out = 0x1000, 0x2000, 0x3000
@@ -168,6 +168,7 @@ def _conv_args(B, H, W, C, N, R, dtype=1, stride=1, aux=False):
     a.w_sN = R * R * C
     a.out_sW, a.out_sH, a.out_sB = N, a.Wo * N, a.Ho * a.Wo * N
     a.alpha, a.nz, a.nz_inner = 1.0, 1, 1
+    a.act = act
     if aux:
         a.aux_out = 0x4000
     return a
@@ -175,19 +176,26 @@ def _conv_args(B, H, W, C, N, R, dtype=1, stride=1, aux=False):
 
 def test_conv_tile_selection(lib):
     """gdl_conv_gemm_plan: which tile a layer gets (0 = 64^2, 1 = 128^2, 3 = 256^2 ping-pong, 4 = 3x3 shared staging,
-    5 = 256x64, 7 = direct 3x3 for C <= 32 on large dense maps) and the algorithmic flops it reports."""
+    5 = 256x64, 6 = dual-resident 256x128, 7 = direct 3x3 for C <= 32 on large dense maps, 8 = 256^2 with one wave per SIMD,
+    9 = persistent 256^2 ping-pong) and the algorithmic flops it reports."""
+    from gdlhip import ops
     import ctypes as C
 
     def plan(*a, **k):
         fl = C.c_int64()
         v = lib.gdl_conv_gemm_plan(C.byref(_conv_args(*a, **k)), C.byref(fl))
         return v, fl.value
-    assert plan(32, 1, 1297, 768, 768, 1)[0] == 3            # ViT proj: 163 x 3 = 489 tiles still take the 256^2 tile (round 3)
+    assert plan(32, 1, 1297, 768, 768, 1)[0] == 9            # ViT proj: 163 x 3 = 489 tiles take the 256^2 tile (round 3), persistent (round 4)
     assert plan(4, 1, 1297, 768, 768, 1)[0] in (0, 1)        # the same layer at the reference's batch of 4: small tiles
-    v, fl = plan(32, 144, 144, 768, 768, 3)                  # DOFA neck conv
-    assert v == 4 and fl == 2 * 32 * 144 * 144 * 768 * 9 * 768
-    assert plan(32, 144, 144, 768, 256, 1)[0] == 3           # lateral 1x1: 256^2 ping-pong
-    assert plan(1, 1, 32 * 1297, 768, 2304, 1)[0] == 3       # ViT qkv
+    v, fl = plan(32, 144, 144, 768, 768, 3)                  # DOFA neck conv: 108 K-steps -> one wave per SIMD (round 4)
+    assert v == 8 and fl == 2 * 32 * 144 * 144 * 768 * 9 * 768
+    assert plan(32, 144, 144, 768, 256, 1)[0] == 9           # lateral 1x1: persistent 256^2 ping-pong (dense 1x1, more tiles than CUs)
+    assert plan(1, 1, 32 * 1297, 768, 2304, 1)[0] == 9       # ViT qkv
+    assert plan(1, 1, 32 * 1297, 768, 3072, 1, act=ops.ACT_GELU)[0] == 6   # ViT fc1: GELU epilogue, 12 K-steps -> two workgroups per CU
+    assert plan(32, 1, 1297, 3072, 768, 1)[0] == 8           # ViT fc2: 48 K-steps -> one wave per SIMD
+    assert plan(32, 36, 36, 768, 768, 3)[0] == 8             # neck 3x3 at 36^2: 108 K-steps
+    assert plan(32, 144, 144, 256, 256, 3)[0] == 4           # FPN 3x3: 36 K-steps stay on the shared-staging kernel
+    assert plan(8, 36, 36, 768, 768, 1)[0] in (0, 1, 3)      # 41 x 3 tiles: fewer tiles than CUs, nothing to be persistent about
     assert plan(32, 256, 256, 64, 64, 3)[0] == 5             # UNet++ decoder: narrow output on a large map
     assert plan(32, 512, 512, 32, 16, 3)[0] == 7             # 32 -> 16 channels at 512^2: direct kernel, one staged window
     assert plan(32, 256, 256, 32, 320, 3)[0] == 7            # its data gradient's shape: outputs in 32-channel slices
@@ -211,7 +219,16 @@ def test_wgrad_split_selection(lib):
         a.dy_sW, a.dy_sH, a.dy_sB = N, W * N, H * W * N
         a.dw_sN, a.nz, a.nz_inner = R * R * Cc, nz, 1
         return lib.gdl_conv_wgrad_workspace(C.byref(a)) // (max(nz, 1) * N * R * R * Cc * 4)
-    assert splits(32, 144, 144, 768, 768) == 3               # 144 tiles of 64x64 -> 3 x 144 = 432 blocks
+    # round 4: the 256^2 per-tap / 1x1 kernel holds a CU alone and its split count comes from a cost model over rounds of 256
+    # workgroups (the old rule always ended in a nearly empty third round: 9 tiles x 57 splits = 513 workgroups)
+    def fill(tiles, sp):
+        blocks = tiles * sp
+        return blocks / (-(-blocks // 256) * 256)
+    assert fill(81, splits(32, 144, 144, 768, 768)) >= 0.9      # widest 3x3 layers: per-tap kernel, 3 x 9 x 3 tiles
+    sp = splits(32, 36, 36, 768, 768, R=1)                      # neck lateral: 9 tiles, ONE round of at most 256 workgroups
+    assert 9 * sp <= 256 and fill(9, sp) >= 0.85
+    assert splits(32, 36, 36, 768, 6912, R=1) == 3              # tap weight gradient: 81 tiles x 3 = 243
+    assert fill(3, splits(32, 144, 144, 768, 256, R=1)) >= 0.9 and splits(32, 144, 144, 768, 256, R=1) < 171
     assert splits(32, 144, 144, 256, 256) == 32
     assert splits(32, 256, 256, 64, 64) == 512               # one tile: all the parallelism comes from split-K
     assert splits(2, 16, 16, 256, 256) <= 1                  # narrow map: per-tap kernel, too few pixels to split

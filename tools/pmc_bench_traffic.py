@@ -44,6 +44,8 @@ for _, k, n, fetch, write, hr, mf in rows[:40]:
 # entry of whichever class dominates its step
 NAMES = (("conv3x3_sf_kernel<bf16_tag>", "conv3x3_sf_kernel<bf16>"),
          ("conv_gemm_dual_kernel", "conv_gemm_dual_kernel"),
+         ("conv_gemm_w4_kernel", "conv_gemm_w4_kernel"),
+         ("conv_gemm_persist_kernel", "conv_gemm_persist_kernel"),
          ("conv_gemm_kernel<bf16_tag, 2, 4, 4, 2, false, true", "conv_gemm_kernel<bf16,2,4,4,2,pingpong>"),
          ("conv_gemm_kernel<bf16_tag, 2, 2, 2, 2", "conv_gemm_kernel<bf16,2,2,2,2>"),
          ("conv_gemm_kernel<bf16_tag, 2, 2, 1, 1", "conv_gemm_kernel<bf16,2,2,1,1>"),
