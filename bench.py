@@ -64,7 +64,7 @@ PMC_TRAFFIC_FILE = ROOT / "profiles" / "pmc_dominant_kernel_traffic.json"   # wr
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=80, help="timed steps (default: ~3 s of training + ~1.6 s of inference at batch 32)")
+    ap.add_argument("--steps", type=int, default=90, help="timed steps (default: ~3.3 s of training + ~1.7 s of inference at batch 32)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
