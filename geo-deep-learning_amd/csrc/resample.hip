@@ -875,6 +875,7 @@ struct TapMArgs {
   const float* addvec;
   int relu;
   int nslots, slot_off[3];        // version 2: byte offsets of the window slots (two for one source, else one per source)
+  int gx, nblk;                   // version 2 (persistent): patches per output row block, patches in all
 };
 
 // the two 1-D weight tables of source k for the block at (oy0, oxb0): TYs [4][12] (+ padding to 64 floats), TXs [COLS][16]
@@ -1081,30 +1082,56 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nchunks = a.N >> 6, nprow = (a.Ho + 3) >> 2;
-  const int nblk = gridDim.x * gridDim.y;
-  const int id = blockIdx.y * gridDim.x + blockIdx.x;
-  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = id & 7, idx = id >> 3;      // XCD-major: neighbouring patch rows share an L2
-  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const int brow = lid / gridDim.x, cb = lid - brow * gridDim.x;
-  const int b = brow / nprow, oy0 = (brow - b * nprow) * 4;
-  const int oxb0 = cb * COLS;
+  const int nblk = a.nblk;
   unsigned char* tile = smem + NSRC * TBL;
   unsigned char* ring = tile + 4 * COLS * 128;
   const unsigned lds_ring = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ring);
-#pragma unroll
-  for (int k = 0; k < NSRC; ++k) {
-    float* TYs = (float*)(smem + k * TBL);
-    if (a.LF[k] == 1) tapm_tables<PXB, 1>(a, k, TYs, TYs + 64, oy0, oxb0, tid);
-    else if (a.LF[k] == 2) tapm_tables<PXB, 2>(a, k, TYs, TYs + 64, oy0, oxb0, tid);
-    else tapm_tables<PXB, 3>(a, k, TYs, TYs + 64, oy0, oxb0, tid);
-  }
-  __syncthreads();
-  // ---- channel-independent state of every source
   const int L = lane & 15, g = lane >> 4;
   bf16x8_t wf[NSRC][NPW][6];                              // weight fragments (B operand: column = pixel L of the patch)
   int raddr[NSRC][NPW][6][2];                             // LDS byte offsets of the z fragment pieces, channel tile 0
-  unsigned doff[NSRC][MAXP];                              // DMA source offsets of this lane's pieces (channel 0)
+  unsigned doff[NSRC][MAXP];                              // DMA source offsets of this lane's pieces (channel 0), for the patch at (set_wr0, set_wc0)
   srd_t srd[NSRC];
+  // PERSISTENT (round 4): a workgroup walks patches vid = blockIdx.x, + gridDim.x, ...  Everything channel-independent -- the
+  // two weight tables, the weight fragments, the fragment and DMA offsets: ~6000 VALU instructions per wave with their runtime
+  // divisions, as much as 26 of the 12 channel steps of a 768-channel patch (PMC: 366 M VALU instructions per launch of which
+  // 115 M in the channel loop) -- is the SAME for every patch whose windows lie inside the image and whose rows have the same
+  // interpolation phase: there only the buffer descriptor moves (by the distance between the patch positions), and the set-up
+  // runs again only for patches that touch the image border or change phase (key < 0 / key differs).
+  int set_key = -2, set_wr0[NSRC], set_wc0[NSRC];
+#pragma unroll
+  for (int k = 0; k < NSRC; ++k) { set_wr0[k] = 0; set_wc0[k] = 0; }
+  for (int vid = blockIdx.x; vid < nblk; vid += gridDim.x) {
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = vid & 7, idx = vid >> 3;      // XCD-major: neighbouring patch rows share an L2
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int brow = lid / a.gx, cb = lid - brow * a.gx;
+  const int b = brow / nprow, oy0 = (brow - b * nprow) * 4;
+  const int oxb0 = cb * COLS;
+  const bool full = oy0 + 4 <= a.Ho && oxb0 + COLS <= a.Wo;
+  int key = full ? 0 : -1;
+#pragma unroll
+  for (int k = 0; k < NSRC; ++k) {
+    const int lf = a.LF[k], win = lf == 1 ? 4 : 3, WC = ((COLS - 4) >> lf) + win;
+    const int wr0 = (oy0 >> lf) - 1, wc0 = (oxb0 >> lf) - 1;
+    if (wr0 < 0 || wc0 < 0 || wr0 + win > a.H[k] || wc0 + WC > a.W[k]) key = -1;
+    else if (key >= 0) key = key * 8 + (oy0 & ((1 << lf) - 1));      // row phase (4-row patches: only factor 8 has two); columns: 16 | oxb0
+  }
+  if (key < 0 || key != set_key) {
+  set_key = key;
+  if (vid != (int)blockIdx.x) __syncthreads();            // the previous patch's fragment set-up / statistics may still read the tables
+  // (the set-up derives everything from an opaque copy of the thread id: otherwise its lane-only subexpressions are hoisted in
+  // front of the patch loop and stay live -- spilled -- across the channel loop)
+  int tid_s = tid;
+  asm volatile("" : "+v"(tid_s));
+  const int lane = tid_s & 63, L = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < NSRC; ++k) {
+    float* TYs = (float*)(smem + k * TBL);
+    if (a.LF[k] == 1) tapm_tables<PXB, 1>(a, k, TYs, TYs + 64, oy0, oxb0, tid_s);
+    else if (a.LF[k] == 2) tapm_tables<PXB, 2>(a, k, TYs, TYs + 64, oy0, oxb0, tid_s);
+    else tapm_tables<PXB, 3>(a, k, TYs, TYs + 64, oy0, oxb0, tid_s);
+  }
+  __syncthreads();
+  // ---- channel-independent state of every source
 #pragma unroll
   for (int k = 0; k < NSRC; ++k) {
     const int lf = a.LF[k], Hi = a.H[k], Wi = a.W[k];
@@ -1139,6 +1166,7 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
       }
     }
     const int wr0 = (oy0 >> lf) - 1, wcb0 = (oxb0 >> lf) - 1;
+    set_wr0[k] = wr0; set_wc0[k] = wcb0;
     const int nrows = win * WC * 9;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
@@ -1151,7 +1179,14 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
       const bool ok = R < nrows && row >= 0 && row < Hi && col >= 0 && col < Wi;
       doff[k][i] = ok ? (unsigned)((((row * Wi + col) * 9 + t) * a.N) * 2 + chunk * 16) : kTmOob;
     }
-    srd[k] = make_srd(a.z[k] + (int64_t)b * Hi * Wi * 9 * a.N, (unsigned)((int64_t)Hi * Wi * 9 * a.N * 2));
+  }
+  }
+  // the image's buffer descriptor, moved from the set-up patch to this one (interior patches only: every piece stays inside)
+#pragma unroll
+  for (int k = 0; k < NSRC; ++k) {
+    const int lf = a.LF[k], Hi = a.H[k], Wi = a.W[k];
+    const int64_t shift = ((int64_t)(((oy0 >> lf) - 1) - set_wr0[k]) * Wi + (((oxb0 >> lf) - 1) - set_wc0[k])) * 9 * a.N;
+    srd[k] = make_srd(a.z[k] + (int64_t)b * Hi * Wi * 9 * a.N + shift, (unsigned)((int64_t)Hi * Wi * 9 * a.N * 2));
   }
   auto issue = [&](int it) {
     const int c = it / NSRC, k = it - c * NSRC;
@@ -1173,7 +1208,6 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[j2][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nit = nchunks * NSRC;
-  const bool full = oy0 + 4 <= a.Ho && oxb0 + COLS <= a.Wo;
   issue(0);
   for (int it = 0; it < nit; ++it) {
     const int c = it / NSRC, k = it - c * NSRC;
@@ -1268,6 +1302,8 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
         stats[((int64_t)lid * 2 + which) * a.N + c0 + ch] = t;
       }
     }
+  }
+  __syncthreads();                                        // the next patch's first window overwrites slot 0, its statistics the tile
   }
 }
 
@@ -1597,6 +1633,17 @@ static bool gather_mfma_launch(const void* dy, int dtype, int B, int Ho, int Wo,
 }
 
 // shared launcher; stats != nullptr: per-block partial sums of the outputs ([rows][2][N] f32, rows = gdl_resize_conv3x3_fwd_sum_bn_rows)
+static int g_tapsum_persist = 1;
+extern "C" void gdl_debug_set_tapsum_persist(int on) { g_tapsum_persist = on; }  // A/B hook: 0 = one workgroup per patch (round 3)
+static int tapsum_num_cus() {
+  static int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    return cus;
+  }();
+  return n;
+}
 static int tapsum_launch(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N, void* out, int Ho, int Wo,
                          const float* addvec, int relu, float* stats, hipStream_t st) {
   GDL_CHECK_ARG(zs && hs && ws && out && nsrc >= 1 && nsrc <= 3, "gdl_resize_conv3x3_fwd_sum: 1..3 sources");
@@ -1643,7 +1690,10 @@ static int tapsum_launch(const void* const* zs, const int* hs, const int* ws, in
       for (int j = 0; j < m.nslots; ++j) { m.slot_off[j] = ring; ring += window_bytes_lf(cols, m.LF[nsrc == 1 ? 0 : j]); }
       const size_t lds = (size_t)nsrc * (256 + cols * 64) + 4 * cols * 128 + ring;
       GDL_CHECK_ARG(lds <= 160 * 1024 || !stats, "gdl_resize_conv3x3_fwd_sum_bn: LDS budget exceeded");
-      const dim3 grid((unsigned)((Wo + cols - 1) / cols), (unsigned)(B * ((Ho + 3) / 4)));
+      m.gx = (Wo + cols - 1) / cols;
+      m.nblk = m.gx * B * ((Ho + 3) / 4);
+      const int resident = tapsum_num_cus() * (nsrc == 1 ? 3 : 1);       // workgroups a launch keeps resident (launch bounds)
+      const dim3 grid((unsigned)(g_tapsum_persist && m.nblk > resident ? resident : m.nblk));
       if (lds > 160 * 1024) {
         // (does not happen for 1..3 sources of factors 2 / 4 / 8; version 1 below would take over)
       } else

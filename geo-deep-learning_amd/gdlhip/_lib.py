@@ -201,6 +201,9 @@ def load() -> C.CDLL:
     if os.environ.get("GDL_FLASH_FWD") is not None:       # tuning hook: 2 = the round-2 attention forward (64-query waves)
         lib.gdl_debug_set_flash_fwd.argtypes = [C.c_int, C.c_float]
         lib.gdl_debug_set_flash_fwd(int(os.environ["GDL_FLASH_FWD"]), float(os.environ.get("GDL_FLASH_DEFER", "6")))
+    if os.environ.get("GDL_TAPSUM_PERSIST") is not None:  # tuning hook: 0 = one workgroup per patch in the forward gather-sum (round 3)
+        lib.gdl_debug_set_tapsum_persist.argtypes = [C.c_int]
+        lib.gdl_debug_set_tapsum_persist(int(os.environ["GDL_TAPSUM_PERSIST"]))
     if os.environ.get("GDL_GATHER_MFMA") is not None:     # tuning hook: 0 = the VALU gathers of the low-resolution backward
         lib.gdl_debug_set_gather_mfma.argtypes = [C.c_int]
         lib.gdl_debug_set_gather_mfma(int(os.environ["GDL_GATHER_MFMA"]))
