@@ -1188,7 +1188,8 @@ def test_resize_conv3x3_bwd_gather_two_pass(dtype, B, Hi, Wi, N, f):
 @pytest.mark.parametrize("B,H,W,N,factors,vec", [(2, 16, 24, 64, (2,), 0), (1, 36, 36, 128, (4,), 0), (2, 16, 16, 64, (8,), 0),
                                                  (2, 16, 24, 64, (2, 4, 8), 0), (1, 8, 8, 72, (4, 2), 0), (2, 12, 20, 64, (4,), 4),
                                                  (1, 2, 2, 64, (2,), 0), (1, 18, 14, 64, (2,), 0), (1, 8, 72, 128, (4,), 0),
-                                                 (2, 32, 48, 192, (8, 4), 0), (1, 144, 144, 64, (2, 4, 8), 0)])
+                                                 (2, 32, 48, 192, (8, 4), 0), (1, 144, 144, 64, (2, 4, 8), 0),
+                                                 (4, 240, 256, 64, (4,), 0), (3, 160, 192, 128, (8,), 0)])   # 3840 / 1440 patches: persistent workgroups take several
 def test_resize_conv3x3_fwd_sum(dtype, B, H, W, N, factors, vec, mfma):
     """sum_k sum_t shift_t(bilinear(z_k,t)) (gdl_resize_conv3x3_fwd_sum), the pixel side of the low-resolution forward of
     conv3x3(pad 1)(bilinear resize(x)) (multilevel_neck.py:157-158, upernet.py:144-152): vs torch's interpolate / pad / slice
@@ -1351,7 +1352,8 @@ def test_conv_epilogue_v2_bit_identical_to_round2_epilogue(dtype):
         lib.gdl_debug_force_conv_variant(-1)
 
 
-@pytest.mark.parametrize("B,H,W,N,factors", [(2, 16, 24, 64, (2,)), (1, 36, 36, 128, (4,)), (2, 18, 14, 192, (2,)), (2, 32, 48, 64, (8, 4))])
+@pytest.mark.parametrize("B,H,W,N,factors", [(2, 16, 24, 64, (2,)), (1, 36, 36, 128, (4,)), (2, 18, 14, 192, (2,)), (2, 32, 48, 64, (8, 4)),
+                                             (4, 240, 256, 64, (4,)), (2, 144, 160, 64, (2, 4, 8))])   # more patches than resident workgroups
 def test_resize_conv3x3_fwd_sum_with_batchnorm_statistics(B, H, W, N, factors):
     """gdl_resize_conv3x3_fwd_sum_bn: the gather-sum with train-mode BatchNorm statistics as a side output -- same output
     bits as the plain call, mean / biased variance / running statistics equal to nn.BatchNorm2d's on that (bf16) output."""
