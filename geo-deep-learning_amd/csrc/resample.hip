@@ -1003,9 +1003,11 @@ __device__ __forceinline__ void tapm_to_tile(const TapMArgs& a, f32x4_t (&acc)[P
     for (int nt = 0; nt < 4; ++nt) {
       const int ch = 16 * nt + 4 * g;
       float v[4];
+      const float4 av = a.addvec ? *(const float4*)(a.addvec + c0 + ch) : make_float4(0.f, 0.f, 0.f, 0.f);   // (c0 + ch) % 4 == 0
+      const float add[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        v[i] = acc[j2][nt][i] + (a.addvec ? a.addvec[c0 + ch + i] : 0.f);
+        v[i] = acc[j2][nt][i] + add[i];
         if (a.relu) v[i] = fmaxf(v[i], 0.f);
       }
       *(uint2*)(tile + pp * 128 + ((((ch >> 3) ^ (pp & 7))) << 4) + (ch & 7) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
@@ -1074,8 +1076,12 @@ __global__ __launch_bounds__(256, PXB == 8 ? 3 : 4) void resize_conv3x3_fwd_sum_
 // grid = (ceil(Wo / (4 PXB)), B * ceil(Ho / 4)); dynamic LDS = NSRC * (256 + 256 PXB) tables + 512 PXB tile bytes + the window
 // slots: one source -> two slots used alternately; several sources -> one slot per source (step (chunk, k) reads slot k while
 // the next step's window lands in another one)
-template <int PXB, int NSRC>
+// LF0 (single source only): the factor as a template parameter -- the fragment count per channel tile, the DMA piece count and
+// the window slot then need no run-time branches (0 = read a.LF[k] at run time)
+template <int PXB, int NSRC, int LF0 = 0>
 __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum_mfma2_kernel(const TapMArgs a, float* stats) {
+  static_assert(LF0 == 0 || NSRC == 1, "compile-time factor: one source");
+  auto lf_of = [&](int k) { return LF0 ? LF0 : a.LF[k]; };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int COLS = 4 * PXB, TBL = 256 + COLS * 64, NPW = PXB / 4;
   constexpr int MAXP = PXB == 8 ? 9 : 12;                 // DMA pieces per wave and window (factor 2 needs 4 x 16 blocks)
@@ -1110,7 +1116,7 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
   int key = full ? 0 : -1;
 #pragma unroll
   for (int k = 0; k < NSRC; ++k) {
-    const int lf = a.LF[k], win = lf == 1 ? 4 : 3, WC = ((COLS - 4) >> lf) + win;
+    const int lf = lf_of(k), win = lf == 1 ? 4 : 3, WC = ((COLS - 4) >> lf) + win;
     const int wr0 = (oy0 >> lf) - 1, wc0 = (oxb0 >> lf) - 1;
     if (wr0 < 0 || wc0 < 0 || wr0 + win > a.H[k] || wc0 + WC > a.W[k]) key = -1;
     else if (key >= 0) key = key * 8 + (oy0 & ((1 << lf) - 1));      // row phase (4-row patches: only factor 8 has two); columns: 16 | oxb0
@@ -1126,15 +1132,15 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
 #pragma unroll
   for (int k = 0; k < NSRC; ++k) {
     float* TYs = (float*)(smem + k * TBL);
-    if (a.LF[k] == 1) tapm_tables<PXB, 1>(a, k, TYs, TYs + 64, oy0, oxb0, tid_s);
-    else if (a.LF[k] == 2) tapm_tables<PXB, 2>(a, k, TYs, TYs + 64, oy0, oxb0, tid_s);
+    if (lf_of(k) == 1) tapm_tables<PXB, 1>(a, k, TYs, TYs + 64, oy0, oxb0, tid_s);
+    else if (lf_of(k) == 2) tapm_tables<PXB, 2>(a, k, TYs, TYs + 64, oy0, oxb0, tid_s);
     else tapm_tables<PXB, 3>(a, k, TYs, TYs + 64, oy0, oxb0, tid_s);
   }
   __syncthreads();
   // ---- channel-independent state of every source
 #pragma unroll
   for (int k = 0; k < NSRC; ++k) {
-    const int lf = a.LF[k], Hi = a.H[k], Wi = a.W[k];
+    const int lf = lf_of(k), Hi = a.H[k], Wi = a.W[k];
     const bool w4 = lf == 1;
     const int win = w4 ? 4 : 3, na = 3 * win;
     const int WC = ((COLS - 4) >> lf) + win;
@@ -1184,17 +1190,17 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
   // the image's buffer descriptor, moved from the set-up patch to this one (interior patches only: every piece stays inside)
 #pragma unroll
   for (int k = 0; k < NSRC; ++k) {
-    const int lf = a.LF[k], Hi = a.H[k], Wi = a.W[k];
+    const int lf = lf_of(k), Hi = a.H[k], Wi = a.W[k];
     const int64_t shift = ((int64_t)(((oy0 >> lf) - 1) - set_wr0[k]) * Wi + (((oxb0 >> lf) - 1) - set_wc0[k])) * 9 * a.N;
     srd[k] = make_srd(a.z[k] + (int64_t)b * Hi * Wi * 9 * a.N + shift, (unsigned)((int64_t)Hi * Wi * 9 * a.N * 2));
   }
   auto issue = [&](int it) {
     const int c = it / NSRC, k = it - c * NSRC;
-    const unsigned dst = lds_ring + a.slot_off[it % a.nslots];
+    const unsigned dst = lds_ring + (NSRC == 1 ? (it & 1) * a.slot_off[1] : a.slot_off[it % a.nslots]);   // one source: two slots, slot_off[0] = 0
 #pragma unroll
     for (int kk = 0; kk < NSRC; ++kk) {
       if (kk != k) continue;                               // (static source index for the register arrays)
-      const int lf = a.LF[kk], win = lf == 1 ? 4 : 3;
+      const int lf = lf_of(kk), win = lf == 1 ? 4 : 3;
       const int npieces = (win * (((COLS - 4) >> lf) + win) * 9 + 7) >> 3;
 #pragma unroll
       for (int i = 0; i < MAXP; ++i) {
@@ -1227,11 +1233,11 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
     }
     __syncthreads();                                      // ... everyone's; nobody reads the other slot or the tile any more
     if (it + 1 < nit) issue(it + 1);
-    const unsigned char* stage = ring + a.slot_off[it % a.nslots];
+    const unsigned char* stage = ring + (NSRC == 1 ? (it & 1) * a.slot_off[1] : a.slot_off[it % a.nslots]);
 #pragma unroll
     for (int kk = 0; kk < NSRC; ++kk) {
       if (kk != k) continue;
-      const int nks = a.LF[kk] == 1 ? 6 : 5;
+      const int nks = lf_of(kk) == 1 ? 6 : 5;
 #pragma unroll
       for (int j2 = 0; j2 < NPW; ++j2) {
 #pragma unroll
@@ -1664,7 +1670,7 @@ static int tapsum_launch(const void* const* zs, const int* hs, const int* ws, in
   GDL_CHECK_ARG(Wo % run == 0, "gdl_resize_conv3x3_fwd_sum: Wo must be a multiple of the largest factor");
   bool img_ok = (uintptr_t)out % 16 == 0;
   for (int k = 0; k < nsrc; ++k) img_ok = img_ok && (int64_t)s.H[k] * s.W[k] * 9 * N * 2 < 0x7ffffff0ll;   // 32-bit buffer offsets per image
-  const bool mfma_ok = dtype == GDL_BF16 && N % 64 == 0 && img_ok && (int64_t)B * ((Ho + 3) / 4) <= 65535;
+  const bool mfma_ok = dtype == GDL_BF16 && N % 64 == 0 && img_ok && (int64_t)B * ((Ho + 3) / 4) <= 65535 && (uintptr_t)addvec % 16 == 0;
   GDL_CHECK_ARG(!stats || mfma_ok, "gdl_resize_conv3x3_fwd_sum_bn: needs bf16, N %% 64 == 0, 16-byte aligned output");
   if (mfma_ok && (g_tapsum_mfma || stats)) {
     TapMArgs m;
@@ -1697,9 +1703,10 @@ static int tapsum_launch(const void* const* zs, const int* hs, const int* ws, in
       if (lds > 160 * 1024) {
         // (does not happen for 1..3 sources of factors 2 / 4 / 8; version 1 below would take over)
       } else
-#define TAPM2(PXB_, NSRC_) do { GDL_SET_MAX_LDS_ONCE((resize_conv3x3_fwd_sum_mfma2_kernel<PXB_, NSRC_>), 160 * 1024);                 \
-    hipLaunchKernelGGL((resize_conv3x3_fwd_sum_mfma2_kernel<PXB_, NSRC_>), grid, dim3(256), lds, st, m, stats); } while (0)
-      if (nsrc == 1) TAPM2(4, 1); else if (nsrc == 2) TAPM2(4, 2); else TAPM2(4, 3);
+#define TAPM2(PXB_, NSRC_, LF_) do { GDL_SET_MAX_LDS_ONCE((resize_conv3x3_fwd_sum_mfma2_kernel<PXB_, NSRC_, LF_>), 160 * 1024);                 \
+    hipLaunchKernelGGL((resize_conv3x3_fwd_sum_mfma2_kernel<PXB_, NSRC_, LF_>), grid, dim3(256), lds, st, m, stats); } while (0)
+      if (nsrc == 1 && m.LF[0] == 2) TAPM2(4, 1, 2); else if (nsrc == 1 && m.LF[0] == 3) TAPM2(4, 1, 3); else if (nsrc == 1) TAPM2(4, 1, 1);
+      else if (nsrc == 2) TAPM2(4, 2, 0); else TAPM2(4, 3, 0);
 #undef TAPM2
       if (lds <= 160 * 1024) {
         GDL_CHECK_LAUNCH("gdl_resize_conv3x3_fwd_sum");
