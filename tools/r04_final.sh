@@ -3,7 +3,7 @@
 # kernel statistics of the training step and of the inference step, the per-layer conv / wgrad tables of the three models, and
 # the per-kernel PMC traffic passes.  Everything lands under gpurun_out/r04z.      tools/r04_final.sh [notest] [pmc] [plans]
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04z
+O=$R/gpurun_out/${RUN:-r04z}
 mkdir -p $O
 cd $R
 case " $* " in *" pmc "*) bash $R/tools/pmc_bench_traffic.sh > $O/pmc.log 2>&1; tail -60 $O/pmc.log > $O/pmc_summary.txt
@@ -16,7 +16,7 @@ T0=$(date +%s)
 timeout 1500 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
 echo "default bench.py wall clock: $(( $(date +%s) - T0 )) s" | tee $O/bench_wall_clock.txt
 cat $O/bench.json | cut -c1-400
-bash $R/tools/r03_profile.sh r04z > $O/profile_summary.txt 2>&1
+bash $R/tools/r03_profile.sh ${RUN:-r04z} > $O/profile_summary.txt 2>&1
 case " $* " in *" plans "*)
 for m in dofa segformer unetpp; do timeout 300 python tools/log_conv_plans.py $m 32 > $O/conv_plans_$m.txt 2>&1; done ;; esac
 ls $O
