@@ -17,7 +17,8 @@ Besides the contract fields the line carries (N = 1 only, all measured in this s
   roofline      dominant MFMA kernel by HIP events on the launch stream; `traffic` = HBM bytes per launch from the
                 committed rocprofv3 PMC passes (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), see --help
   hbm_kernels   the HBM-bound kernels of the step at their DOFA shapes: algorithmic GB/s vs the 8 TB/s peak
-  by_batch      the same train / inference step at the reference config's per-GPU batch 4 (dofa_config_RGB.yaml:85)
+  by_batch      the same train / inference step at per-GPU batch 2 / 4 / 8 (4 = the reference config's, dofa_config_RGB.yaml:85):
+                headline numbers = the trainer's default path there (hipGraph replay), `eager` = the step launched from Python
   other_models  SegFormer-B2 (configs[2]) and UNet++/ResNet18 (configs[0]) steps at batch 32
   cpu_baseline  the CPU oracle on this box's cores: 2 warm-ups, median of 5
 """
@@ -307,6 +308,14 @@ def side_measurement(model: str, batch_size: int, steps: int, warmup: int, devic
                                "inference_tiles_per_s": round(n / dt_ge, 2), "inference_ms_per_step": round(1e3 * dt_ge / steps, 3),
                                "note": "forward + loss + backward + clip + Adam (resp. forward + argmax) captured once, replayed per step"}
             del gt, ge
+            # the trainer's default at per-GPU batch <= 8 IS the captured step (MiniTrainer(graph_step="auto")): the entry's
+            # headline numbers are that path's, the eager step (host-bound at these sizes: 312-450 tiles/s at batch 4
+            # depending on the box's CPU, for the same 8.5 ms of GPU work) is reported beside it
+            out["eager"] = {k: out[k] for k in ("train_tiles_per_s", "inference_tiles_per_s", "train_ms_per_step", "inference_ms_per_step")}
+            out.update({k: v for k, v in out["hipgraph"].items() if k != "note"})
+            out["default_path"] = "hipgraph replay (MiniTrainer(graph_step='auto') at per-GPU batch <= 8); `eager` = the same step launched from Python"
+            out["model_flops_utilisation"] = {"train": round(MODEL_GF[model]["train"] * 1e-3 * n / dt_g / peak, 4),
+                                              "infer": round(MODEL_GF[model]["infer"] * 1e-3 * n / dt_ge / peak, 4)}
         except Exception as exc:  # noqa: BLE001  (report, do not lose the eager numbers)
             out["hipgraph"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     if roofline:

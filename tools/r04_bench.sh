@@ -15,7 +15,7 @@ for k, v in d.get("step_roofline", {}).items():
     print(k, "frac_of_bound", v["frac_of_bound"], [(o["op"], o["ms"], o["frac_of_own_bound"]) for o in v["top_ops"]])
 print("pcie", d.get("pcie_inclusive", {}).get("train_tiles_per_s"))
 for b, v in d.get("by_batch", {}).items():
-    print("batch", b, "eager %.1f / %.1f" % (v["train_tiles_per_s"], v["inference_tiles_per_s"]), "graph", v.get("hipgraph"))
+    print("batch", b, "default path %.1f / %.1f" % (v["train_tiles_per_s"], v["inference_tiles_per_s"]), "eager", v.get("eager"), v.get("default_path", "")[:20])
 for m, v in d.get("other_models", {}).items():
     print(m, v.get("tile"), "batch", v["per_gpu_batch"], "train %.1f infer %.1f" % (v["train_tiles_per_s"], v["inference_tiles_per_s"]), "MFU", v["model_flops_utilisation"],
           {k: (x["frac_of_bound"], [(o["op"], o["ms"], o["frac_of_own_bound"]) for o in x["top_ops"]]) for k, x in v.get("roofline", {}).items()})
