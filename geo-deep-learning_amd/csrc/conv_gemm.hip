@@ -525,3 +525,26 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   if (!extra && a.N <= 64 && ((M + 255) / 256) * a.nz >= 256) return 5;
   return 0;
 }
+
+// Can this call emit BatchNorm partial statistics from its epilogue, and how many partial rows?  Mirrors the conditions under
+// which EVERY wave of the launch takes the coalesced epilogue (conv_epilogue_rows2) with whole wave tiles.
+extern "C" int64_t gdl_conv_gemm_stats_rows(const gdl_conv_args* ap) {
+  if (!ap || !g_epi_v2 || g_forced_variant >= 0) return 0;
+  const gdl_conv_args& a = *ap;
+  if (a.dtype != GDL_BF16 || a.out_dtype != GDL_BF16 || a.resid || a.scale || a.shift || a.batch_scale || a.aux_out ||
+      a.act != GDL_ACT_NONE || a.nz != 1 || a.N % 16 != 0)
+    return 0;
+  if (!(a.out_sH == (int64_t)a.Wo * a.out_sW && a.out_sB == (int64_t)a.Ho * a.out_sH)) return 0;             // pixel-dense output
+  if ((uintptr_t)a.out % 16 != 0 || a.out_sW % 8 != 0 || (uintptr_t)a.bias % 16 != 0) return 0;
+  const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
+  const int v = gdl_conv_gemm_plan(ap, nullptr);
+  int bm, bn, tm;
+  if (v == 3 || v == 4 || v == 8 || v == 9) { bm = 256; bn = 256; tm = 4; }
+  else if (v == 1) { bm = 128; bn = 128; tm = 2; }
+  else return 0;
+  if (M % bm != 0 || a.N % bn != 0) return 0;
+  // (the 2 GiB operand split of gdl_conv_gemm would number the rows of the second half from zero)
+  const int64_t es = 2;
+  if ((((int64_t)a.B - 1) * a.in_sB + ((int64_t)a.H - 1) * a.in_sH + ((int64_t)a.W - 1) * a.in_sW + a.C) * es > 0x7ffffff0ll) return 0;
+  return M / (32 * tm);
+}

@@ -316,6 +316,10 @@ __device__ __forceinline__ bool conv_epilogue_rows(const KArgs& k, f32x16_t (&ac
 #endif
 #define GDL_EPI_ON(bit) ((GDL_EPI_MASK & (bit)) != 0)
 constexpr int EPI_RUNTIME = 0, EPI_FIXED = 1, EPI_SCALE = 2, EPI_DROPPATH = 4, EPI_RELU = 8, EPI_GELU = 16;
+// EPI_STATS (bf16 outputs, 8-channel layout): the wave also writes the sum and the sum of squares of its (bf16-rounded) outputs
+// per channel -- one partial row [2][N] per 32 * TM output pixels in a.stats_partial: train-mode BatchNorm statistics
+// without a pass over the convolution's output (gdl_conv_gemm_stats_rows says when)
+constexpr int EPI_STATS = 32;
 
 template <int TM, int CH, bool RESID, int EF = EPI_RUNTIME>
 __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_t (&acc)[TM][2], int m0, int n0, int wm, int wn,
@@ -393,6 +397,7 @@ __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_
   }
   // ONE buffer: row group t of the next pass is requested right after row group t of this pass has been consumed and BEFORE
   // its store is issued, so a wait for it never has to cover a store issued behind it
+  float st1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, st2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // EPI_STATS
   uint32_t rva[NT][RW];
   if constexpr (RESID) {
 #pragma unroll
@@ -461,6 +466,15 @@ __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_
       } else {
         o = epi_u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
       }
+      if constexpr ((EF & EPI_STATS) != 0 && CH == 8) {
+        const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __uint_as_float(ow[e] << 16), hi = __uint_as_float(ow[e] & 0xffff0000u);
+          st1[2 * e] += lo; st2[2 * e] = __builtin_fmaf(lo, lo, st2[2 * e]);
+          st1[2 * e + 1] += hi; st2[2 * e + 1] = __builtin_fmaf(hi, hi, st2[2 * e + 1]);
+        }
+      }
       // the row offset goes into the VECTOR offset (one v_add), not into soffset: hipcc (ROCm 7.2) assumes that a buffer store
       // with a register soffset cannot have its data registers overwritten too early and pads nothing, but gfx950 does need
       // the wait states of a >64-bit store -- with `..., out_lo, ou` the VALU instruction behind the store clobbered the
@@ -468,6 +482,23 @@ __device__ __forceinline__ void conv_epilogue_rows2_impl(const KArgs& k, f32x16_
       __builtin_amdgcn_raw_buffer_store_b128(o, out_rs, out_lo + ou, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if constexpr ((EF & EPI_STATS) != 0 && CH == 8) {
+    // lanes with equal (lane & 7) hold the same 8 channels (rows differ): fold lane bits 3, 4, 5 in a fixed order, then lanes
+    // 0-7 write the wave's 64 channels of its partial row
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o2 = 8; o2 < 64; o2 <<= 1) { st1[e] += __shfl_xor(st1[e], o2, 64); st2[e] += __shfl_xor(st2[e], o2, 64); }
+    }
+    if (lane < 8) {
+      const int64_t row = (int64_t)(m0 + wm * TM * 32) / (TM * 32);
+      float* dst = a.stats_partial + (row * 2) * a.N + n0 + wn * 64 + lane * 8;
+      *(float4*)dst = make_float4(st1[0], st1[1], st1[2], st1[3]);
+      *(float4*)(dst + 4) = make_float4(st1[4], st1[5], st1[6], st1[7]);
+      *(float4*)(dst + a.N) = make_float4(st2[0], st2[1], st2[2], st2[3]);
+      *(float4*)(dst + a.N + 4) = make_float4(st2[4], st2[5], st2[6], st2[7]);
+    }
   }
 }
 
@@ -489,6 +520,10 @@ __device__ __forceinline__ bool conv_epilogue_rows2(const KArgs& k, f32x16_t (&a
   // the combinations the three models' hot layers use get compile-time element-wise terms (k.epi_v2 == 2 keeps the
   // run-time form for A/B runs); everything else takes the run-time form
   const bool sc = a.scale != nullptr, bs = a.batch_scale != nullptr, rs = a.resid != nullptr;
+  if (a.stats_partial) {           // (the host only sets it for bias-only bf16 calls made of whole wave tiles: gdl_conv_gemm_stats_rows)
+    conv_epilogue_rows2_impl<TM, 8, false, EPI_FIXED | EPI_STATS>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);
+    return true;
+  }
   if (k.epi_v2 != 2) {
     if (GDL_EPI_ON(1) && !rs && !bs && !sc && a.act == GDL_ACT_NONE) {                       // bias only: qkv, laterals, tap products, data gradients
       if (out_bf16) conv_epilogue_rows2_impl<TM, 8, false, EPI_FIXED>(k, acc, m0, n0, wm, wn, lane, out_zoff, lds);

@@ -34,7 +34,7 @@ class ConvArgs(C.Structure):
         ("nz", c_i), ("nz_inner", c_i),
         ("in_sZ0", c_l), ("in_sZ1", c_l), ("w_sZ0", c_l), ("w_sZ1", c_l),
         ("out_sZ0", c_l), ("out_sZ1", c_l),
-        ("aux_out", c_p),
+        ("aux_out", c_p), ("stats_partial", c_p),
     ]
 
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "gdl_last_error": (C.c_char_p, []),
     "gdl_conv_gemm": (c_i, [C.POINTER(ConvArgs), c_p]),
     "gdl_conv_gemm_plan": (c_i, [C.POINTER(ConvArgs), C.POINTER(c_l)]),
+    "gdl_conv_gemm_stats_rows": (c_l, [C.POINTER(ConvArgs)]),
     "gdl_conv_wgrad_workspace": (c_l, [C.POINTER(WgradArgs)]),
     "gdl_conv_wgrad": (c_i, [C.POINTER(WgradArgs), c_p]),
     "gdl_layernorm_fwd": (c_i, [c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_i, c_f, c_p]),

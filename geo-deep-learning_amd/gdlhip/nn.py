@@ -306,7 +306,19 @@ def _cba_conv(x, weight, cb, pad, up4, sync_group, running_mean, running_var, mo
     if up4:        # other resize factors: the upsampled map is a temporary of the forward only (backward works on x)
         return ops.conv_gemm(ops.bilinear(x, (up4 * x.shape[1], up4 * x.shape[2])), gemm_weight(weight, cd), R=r, S=s, pad=pad,
                              bias=cb), None
+    if FUSE_CONV_STATS and cd == torch.bfloat16:
+        # the batch statistics as a side output of the convolution's epilogue (per-wave partial sums of the bf16 outputs)
+        # wherever the launch is made of whole tiles on the coalesced-epilogue kernels: no statistics pass over y
+        y, partials, rows = ops.conv_gemm(x, gemm_weight(weight, cd), R=r, S=s, pad=pad, bias=cb, want_stats=True)
+        if not rows:
+            return y, None
+        own = (_world(sync_group) if sync_group is not False else 1) == 1
+        return y, ops.bn_stats_finalize(partials, rows, n, y.numel() // n, running_mean if own else None,
+                                        running_var if own else None, momentum)
     return ops.conv_gemm(x, gemm_weight(weight, cd), R=r, S=s, pad=pad, bias=cb), None
+
+
+FUSE_CONV_STATS = os.environ.get("GDL_CONV_STATS", "1") != "0"   # A/B switch: False / GDL_CONV_STATS=0 = a separate statistics pass over every convolution output (round 3)
 
 
 def _cba_grads(x, weight, dy, pad, up4, need_dx, need_dw):

@@ -94,9 +94,12 @@ def conv_gemm(x: Tensor, w: Tensor, *, R: int = 1, S: int = 1, stride: int = 1, 
               bias: Tensor | None = None, scale: Tensor | None = None, shift: Tensor | None = None,
               act: int = ACT_NONE, batch_scale: Tensor | None = None, resid: Tensor | None = None,
               out: Tensor | None = None, out_dtype: torch.dtype | None = None,
-              alpha: float = 1.0, aux_out: Tensor | None = None) -> Tensor:
+              alpha: float = 1.0, aux_out: Tensor | None = None, want_stats: bool = False):
     """out = epilogue(conv(x, w)); x NHWC [B,H,W,C], w [N, R*S*C] (K order r,s,c).
-    ``aux_out`` (same shape / dtype / strides as out) receives the pre-activation values."""
+    ``aux_out`` (same shape / dtype / strides as out) receives the pre-activation values.
+    ``want_stats``: returns (out, partials, rows) -- when the call can emit them (gdl_conv_gemm_stats_rows: bf16, bias-only
+    epilogue, whole tiles) `partials` [rows, 2, N] f32 holds per-channel sums and sums of squares of the bf16 outputs for
+    bn_stats_finalize (train-mode BatchNorm statistics without a pass over `out`); otherwise (out, None, 0)."""
     _need_cuda(x, w)
     two_d = x.dim() == 2
     x4 = _nhwc4(x, "conv_gemm input")
@@ -141,10 +144,16 @@ def conv_gemm(x: Tensor, w: Tensor, *, R: int = 1, S: int = 1, stride: int = 1, 
             raise ValueError("conv_gemm: aux_out must match out in shape, strides and dtype")
         a.aux_out = x4a.data_ptr()
     a.nz, a.nz_inner = 1, 1
+    partials, rows = None, 0
+    if want_stats:
+        rows = int(_lib.load().gdl_conv_gemm_stats_rows(C.byref(a)))
+        if rows:
+            partials = torch.empty((rows, 2, N), device=x.device, dtype=torch.float32)
+            a.stats_partial = partials.data_ptr()
     _launch_conv_gemm(a, "gdl_conv_gemm")
     if two_d and out4 is out:
-        return out.view(Wo, N)
-    return out
+        out = out.view(Wo, N)
+    return (out, partials, rows) if want_stats else out
 
 
 class KernelTimer:
@@ -304,6 +313,18 @@ def bn_stats(x: Tensor, running_mean: Tensor | None = None, running_var: Tensor 
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     check(lib.gdl_bn_stats(_p(x), dt(x), P, Cc, sP, _p(mean), _p(var), _p(running_mean),
                            _p(running_var), momentum, _p(ws), nbytes, _stream()), "gdl_bn_stats")
+    return mean, var
+
+
+def bn_stats_finalize(partials: Tensor, rows: int, channels: int, pixels: int, running_mean: Tensor | None = None,
+                      running_var: Tensor | None = None, momentum: float = 0.1):
+    """(mean, biased var) from [rows, 2, C] partial sums written by a producing kernel (conv_gemm(want_stats=True)); updates the
+    running buffers like bn_stats."""
+    _need_cuda(partials)
+    mean = torch.empty(channels, device=partials.device, dtype=torch.float32)
+    var = torch.empty_like(mean)
+    check(_lib.load().gdl_bn_stats_finalize(_p(partials), rows, channels, pixels, _p(mean), _p(var), _p(running_mean),
+                                            _p(running_var), momentum, _stream()), "gdl_bn_stats_finalize")
     return mean, var
 
 

@@ -83,9 +83,17 @@ typedef struct {
   int64_t in_sZ0, in_sZ1, w_sZ0, w_sZ1, out_sZ0, out_sZ1;
   void* aux_out; /* optional: alpha*acc + bias, i.e. the value BEFORE scale/shift/act (same dtype and
                     strides as out), saved for the backward pass (GELU input, LayerScale input) */
+  float* stats_partial; /* optional, only where gdl_conv_gemm_stats_rows() > 0: [rows][2][N] f32 partial sums (sum, sum of
+                           squares) of the bf16-ROUNDED outputs over 32 * TM output pixels each -- the train-mode BatchNorm
+                           statistics of a ConvModule without a pass over its output (models/utils.py:10-52); reduce with
+                           gdl_bn_stats_finalize(partials, rows, N, B * Ho * Wo, ...) */
 } gdl_conv_args;
 
 int gdl_conv_gemm(const gdl_conv_args* a, gdl_stream_t stream);
+/* Number of partial rows gdl_conv_gemm writes to `stats_partial` for this call, 0 when the call cannot emit statistics
+ * (bf16 in / out, bias-only epilogue, pixel-dense output, whole 128 / 256-pixel tiles on the coalesced-epilogue kernels).
+ * `stats_partial` itself is ignored by the query. */
+int64_t gdl_conv_gemm_stats_rows(const gdl_conv_args* a);
 /* Which kernel variant the call above will launch (0 = 64x64 tiles, 1 = 128x128, 3 = 256x256 with alternating loader
  * halves, 4 = 256x256 3x3 with shared activation staging, 5 = 256x64 for narrow outputs) and its algorithmic flops
  * 2*M*N*K (for roofline accounting in bench.py). */

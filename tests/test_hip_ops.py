@@ -901,6 +901,41 @@ def test_conv_dual_resident_tile(B, H, W, C, N, R, stride, variant):
         assert torch.equal(outs[variant, odt], outs[1, odt]), f"variant {variant} vs 128^2 tile differ ({odt})"
 
 
+@pytest.mark.parametrize("B,H,W,C,N,R,expect", [(8, 72, 72, 768, 256, 1, True),     # 1x1, 162 x 1 tiles of 256^2 -> 128^2 tile
+                                              (32, 72, 72, 256, 256, 1, True),    # 648 tiles: persistent 256^2 tile
+                                              (8, 72, 72, 256, 256, 3, True),     # 3x3
+                                              (8, 36, 36, 768, 768, 3, True),     # K = 6912, 81 x 6 tiles of 128^2
+                                              (32, 36, 36, 768, 256, 1, True),    # 324 x 2 tiles of 128^2
+                                              (2, 36, 36, 768, 256, 1, False),    # too few tiles: 64^2 kernel, register epilogue
+                                              (1, 25, 25, 256, 256, 1, False),    # M = 625: no whole tiles -> no statistics
+                                              (2, 36, 36, 256, 200, 1, False)])   # N tail
+def test_conv_gemm_emits_batchnorm_partial_statistics(B, H, W, C, N, R, expect):
+    """conv_gemm(want_stats=True): the train-mode BatchNorm statistics of a ConvModule (models/utils.py:10-52) as a side output of
+    the convolution's epilogue -- per-wave partial sums of the bf16-ROUNDED outputs, reduced by bn_stats_finalize: same output
+    bits as the plain call, mean / biased variance equal to bn_stats on that output, running statistics updated alike."""
+    dtype = torch.bfloat16
+    x = q(rnd(B, H, W, C), dtype).to(DEV, dtype)
+    w = (q(rnd(N, R * R * C, seed=1), dtype) * 0.05).to(DEV, dtype)
+    bias = rnd(N, seed=2).to(DEV)
+    y0 = ops.conv_gemm(x, w, R=R, S=R, pad=R // 2, bias=bias)
+    y, partials, rows = ops.conv_gemm(x, w, R=R, S=R, pad=R // 2, bias=bias, want_stats=True)
+    assert torch.equal(y, y0)
+    assert (rows > 0) == expect, rows
+    if not rows:
+        assert partials is None
+        return
+    rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    rm2, rv2 = rm.clone(), rv.clone()
+    mean, var = ops.bn_stats_finalize(partials, rows, N, B * H * W, rm, rv, 0.1)
+    mean_r, var_r = ops.bn_stats(y0, rm2, rv2, 0.1)
+    yf = y0.float().reshape(-1, N).cpu().double()
+    close(mean.cpu(), yf.mean(0).float(), torch.float32, "mean vs f64 of the stored outputs")
+    close(var.cpu(), yf.var(0, unbiased=False).float(), torch.float32, "variance vs f64 of the stored outputs")
+    assert (mean - mean_r).abs().max().item() <= 1e-5 * mean_r.abs().max().item() + 1e-6
+    assert (var - var_r).abs().max().item() <= 1e-4 * var_r.abs().max().item()
+    assert (rm - rm2).abs().max().item() <= 1e-6 and (rv - rv2).abs().max().item() <= 1e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(10300, 2048, 192), (66000, 512, 64), (20500, 1024, 256), (300, 256, 128)])
 def test_conv_persistent_tile(M, N, K):
     """The persistent 256^2 tile (variant 9, conv_gemm_persist.hip: one workgroup per CU walks several tiles, the next tile's first
