@@ -205,6 +205,30 @@ def test_conv_tile_selection(lib):
     assert plan(32, 128, 128, 768, 3072, 1, aux=True)[0] in (0, 1)   # training epilogue: never the 256^2 tiles
 
 
+def test_conv_stats_rows_selection(lib):
+    """gdl_conv_gemm_stats_rows (pure host code): which calls can emit BatchNorm partial statistics from their epilogue, and how
+    many partial rows (one per 32 * TM output pixels: 128 on the 256^2 kernels, 64 on the 128^2 kernel)."""
+    import ctypes as C
+
+    def rows(*a, bias=0x5000, **k):
+        args = _conv_args(*a, **k)
+        args.bias = bias
+        return lib.gdl_conv_gemm_stats_rows(C.byref(args))
+    m144 = 32 * 144 * 144
+    assert rows(32, 144, 144, 768, 256, 1) == m144 // 128        # UperNet lateral: persistent 256^2 tile
+    assert rows(32, 144, 144, 256, 256, 3) == m144 // 128        # FPN 3x3: shared-staging kernel
+    assert rows(32, 36, 36, 768, 768, 3) == 32 * 36 * 36 // 128  # neck 3x3: one wave per SIMD
+    assert rows(32, 36, 36, 768, 256, 1) == 32 * 36 * 36 // 64   # 162 tiles of 256^2 are too few: 128^2 tile, 64 pixels per row
+    assert rows(32, 144, 144, 768, 256, 1, dtype=0) == 0         # f32 parity path
+    assert rows(32, 144, 144, 768, 200, 1) == 0                  # N tail
+    assert rows(1, 25, 25, 256, 256, 1) == 0                     # no whole tiles
+    assert rows(32, 6, 6, 768, 256, 1) == 0                      # pyramid-pooling branch: 64^2 tiles, register epilogue
+    assert rows(32, 144, 144, 768, 256, 1, act=1) == 0           # anything but a bias-only epilogue
+    a = _conv_args(32, 144, 144, 768, 256, 1)
+    a.bias, a.resid = 0x5000, 0x6000
+    assert lib.gdl_conv_gemm_stats_rows(C.byref(a)) == 0          # residual operand (fpn_bottleneck's native level)
+
+
 def test_wgrad_split_selection(lib):
     """gdl_conv_wgrad_workspace = splits * N * R*S*C * 4: the row-segment kernel aims at two blocks per CU."""
     import ctypes as C
