@@ -199,7 +199,8 @@ class OpAccounting:
         try:
             if name in ("conv_gemm", "linear"):
                 x, w = a[0], a[1]
-                m = (ret.numel() // w.shape[0]) if isinstance(ret, torch.Tensor) else 0
+                out = ret[0] if isinstance(ret, tuple) else ret        # conv_gemm(want_stats=True) returns (out, partials, rows)
+                m = (out.numel() // w.shape[0]) if isinstance(out, torch.Tensor) else 0
                 return 2 * m * w.shape[0] * w.shape[1]
             if name == "conv_wgrad":
                 x, dy = a[0], a[1]

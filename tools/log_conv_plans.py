@@ -37,13 +37,14 @@ def logged(x, w, **kw):
     N = w.shape[0]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    out = orig(x, w, **kw)
+    ret = orig(x, w, **kw)
     e1.record()
+    out = ret[0] if isinstance(ret, tuple) else ret          # want_stats=True returns (out, partials, rows)
     o4 = out if out.dim() == 4 else out.reshape(1, 1, -1, out.shape[-1])
     key = (Bq, H, W, Cc, N, R, S, stride, pad, str(x.dtype).replace("torch.", ""), str(out.dtype).replace("torch.", ""),
            "resid" if kw.get("resid") is not None else "", o4.shape[1] * o4.shape[2] * Bq)
     rows.setdefault(key, []).append((e0, e1))
-    return out
+    return ret
 
 
 orig_w = ops.conv_wgrad
