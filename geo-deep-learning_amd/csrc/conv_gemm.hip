@@ -367,6 +367,12 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   GDL_CHECK_ARG(a.act != GDL_ACT_MUL_GELU_GRAD || (a.resid && !a.aux_out),
                 "gdl_conv_gemm: GDL_ACT_MUL_GELU_GRAD takes the pre-activation tensor in `resid`");
   GDL_CHECK_ARG((int64_t)a.B * a.Ho * a.Wo < (1ll << 31), "gdl_conv_gemm: M too large");
+  // `stats_partial` selects an epilogue that ignores resid / scale / shift / batch_scale / act and writes bf16 whole wave tiles
+  // only: a call that does not qualify (or whose tile variant was switched by a debug hook between the caller's query and this
+  // launch) must fail here, not return wrong outputs and uninitialised statistics rows
+  GDL_CHECK_ARG(!a.stats_partial || gdl_conv_gemm_stats_rows(ap) > 0,
+                "gdl_conv_gemm: stats_partial set on a call that cannot emit BatchNorm statistics (gdl_conv_gemm_stats_rows() == 0: "
+                "needs bf16 in/out, bias-only epilogue, pixel-dense 16-byte aligned output, whole 128/256-row tiles)");
   GDL_CHECK_ARG(a.pad == 0 || a.R * a.S <= 32, "gdl_conv_gemm: padded filters are limited to 32 taps (got %dx%d)", a.R, a.S);
   // operands are addressed through 32-bit buffer offsets: each must span < 2 GiB (split the batch otherwise)
   const int64_t kSpanMax = 0x7ffffff0ll;

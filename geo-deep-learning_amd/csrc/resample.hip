@@ -1671,7 +1671,8 @@ static int tapsum_launch(const void* const* zs, const int* hs, const int* ws, in
   bool img_ok = (uintptr_t)out % 16 == 0;
   for (int k = 0; k < nsrc; ++k) img_ok = img_ok && (int64_t)s.H[k] * s.W[k] * 9 * N * 2 < 0x7ffffff0ll;   // 32-bit buffer offsets per image
   const bool mfma_ok = dtype == GDL_BF16 && N % 64 == 0 && img_ok && (int64_t)B * ((Ho + 3) / 4) <= 65535 && (uintptr_t)addvec % 16 == 0;
-  GDL_CHECK_ARG(!stats || mfma_ok, "gdl_resize_conv3x3_fwd_sum_bn: needs bf16, N %% 64 == 0, 16-byte aligned output");
+  GDL_CHECK_ARG(!stats || mfma_ok, "gdl_resize_conv3x3_fwd_sum_bn: needs bf16, N %% 64 == 0, 16-byte aligned output and per-channel "
+                "addend (bias), sources below 2 GiB per image, B * ceil(Ho / 4) <= 65535");
   if (mfma_ok && (g_tapsum_mfma || stats)) {
     TapMArgs m;
     int lfmin = 3;

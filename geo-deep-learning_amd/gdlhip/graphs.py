@@ -70,12 +70,31 @@ class GraphedTrainStep:
         self.logged_static: list = []      # (name, static tensor, batch size) of every `log` call of the captured step
         if sink is not None:
             trainer._collect = lambda name, value, batch_size=None: self.logged_static.append((name, value, batch_size))
+        # the snapshot is taken whenever the caller wants a clean fallback: a capture that raises after its warm-up steps has
+        # already trained on `example_batch` (parameters, moments, step counts, BN running statistics, RNG all advanced) and its
+        # gradients may live in a graph pool that dies with the failed graph -- both are undone before the exception leaves
         snap = self._snapshot(task, optimizer) if restore_state else None
+        # host-side bookkeeping of training_step (sample counters) runs during the warm-up and the capture pass only: after the
+        # capture `training_step` never executes on the host again.  The counters are put back here and advanced per replay by
+        # the task's `on_graph_replay(batch)` hook (see __call__); training_step must otherwise be free of host side effects
+        host_counters = {k: getattr(task, k) for k in ("train_samples_count",) if isinstance(getattr(task, k, None), int)}
         try:
             self._capture(task, optimizer, warmup)
+        except BaseException:
+            # torch.cuda.graph's __exit__ has ended the stream capture by now (it runs capture_end in its finally path); the
+            # restoring copies below are ordinary eager work on the current stream
+            torch.cuda.synchronize()
+            optimizer.zero_grad(set_to_none=True)
+            self.graph = None
+            if snap is not None:
+                self._restore(snap, optimizer)
+            raise
         finally:
             if sink is not None:
                 trainer._collect = sink
+            if restore_state:
+                for k, v in host_counters.items():
+                    setattr(task, k, v)
         if snap is not None:
             self._restore(snap, optimizer)
 
@@ -106,7 +125,12 @@ class GraphedTrainStep:
             if gi in snap["dev"]:
                 t.copy_(snap["dev"][gi])
             else:
-                t[0] = 0.0                 # created during the warm-up: back to "no step taken"
+                # created during the warm-up: back to the step count the restored HOST state reports (what device_state() would
+                # have seeded it with; 0 for a fresh optimizer, the loaded count after load_state_dict / an eager prefix) -- a
+                # constant 0 would restart the bias correction at step 1 under warm moments
+                steps = {st["step"] for p in optimizer.param_groups[gi]["params"]
+                         if (st := optimizer.state.get(p)) and isinstance(st.get("step"), (int, float))}
+                t[0] = float(steps.pop()) if len(steps) == 1 else 0.0
                 t[6:8] = 0.0
         # the bf16 GEMM operands the optimizer kernel rewrites together with the parameters were captured by address and hold
         # the warm-up's values: rewrite them from the restored parameters (same element order by construction)
@@ -156,6 +180,9 @@ class GraphedTrainStep:
                 sink(name, value, batch_size)
         for t in self._rewritten:       # the replay rewrote these through raw pointers: eager code must not trust operands
             gnn.mark_updated(t)         # cached from their earlier values (eval-time BatchNorm folds, packed weights)
+        hook = getattr(self.task, "on_graph_replay", None)
+        if hook is not None:            # host bookkeeping the captured training_step can no longer do (sample counters)
+            hook(self.static)
         return self.loss
 
 

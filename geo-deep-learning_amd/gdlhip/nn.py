@@ -294,7 +294,7 @@ def _cba_conv(x, weight, cb, pad, up4, sync_group, running_mean, running_var, mo
         # conv3x3(resize(x)) = sum_t shift_t(resize(W_t x)): nine tap products as ONE 1x1 convolution over the
         # LOW-resolution pixels (1 / up4^2 of the MACs), then one gather-sum pass writes the full-resolution output
         z, size = ops.conv_gemm(x, tap_weight(weight, cd)), (up4 * x.shape[1], up4 * x.shape[2])
-        if FUSE_TAPSUM_STATS and ops.resize_conv3x3_fwd_bn_ok(cd, n):
+        if FUSE_TAPSUM_STATS and ops.resize_conv3x3_fwd_bn_ok(cd, n, cb):
             # ... and the batch statistics of the output come out of the same pass (per-block partial sums)
             own = (_world(sync_group) if sync_group is not False else 1) == 1
             y, mean, var = ops.resize_conv3x3_fwd_sum_bn([z], size, addvec=cb, running_mean=running_mean if own else None,

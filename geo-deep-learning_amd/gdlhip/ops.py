@@ -484,8 +484,11 @@ def resize_conv3x3_fwd_sum_bn(zs: list[Tensor], size: tuple[int, int], addvec: T
     return out, mean, var
 
 
-def resize_conv3x3_fwd_bn_ok(z_dtype: torch.dtype, N: int) -> bool:
-    """The statistics variant runs on the matrix-core kernel only: bf16 and N % 64 == 0."""
+def resize_conv3x3_fwd_bn_ok(z_dtype: torch.dtype, N: int, addvec: Tensor | None = None) -> bool:
+    """The statistics variant runs on the matrix-core kernel only: bf16, N % 64 == 0 and a per-channel addend (bias) the
+    kernel can fetch with 16-byte loads (a bias that is a view at an odd offset falls back to the separate statistics pass)."""
+    if addvec is not None and addvec.data_ptr() % 16:
+        return False
     return z_dtype == torch.bfloat16 and N % 64 == 0
 
 

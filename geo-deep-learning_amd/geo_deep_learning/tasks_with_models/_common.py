@@ -102,6 +102,15 @@ class SegmentationTaskHooks:
         self.log_dict(metrics, batch_size=bs, prog_bar=False, logger=True, on_step=False, sync_dist=True,
                       rank_zero_only=True)
 
+    # ------------------------------------------------------------------ captured steps
+    def on_graph_replay(self, batch: dict[str, Any]) -> None:
+        """Called by ``gdlhip.graphs.GraphedTrainStep`` after every hipGraph replay of the training step: ``training_step`` itself
+        does not run on the host any more, so its host-side bookkeeping (the sample counter of segmentation_dofa.py:234) is
+        advanced here.  Anything else ``training_step`` does must live on the device."""
+        img = batch.get("image") if isinstance(batch, dict) else None
+        if isinstance(img, Tensor):
+            self.train_samples_count += int(img.shape[0])
+
     # ------------------------------------------------------------------ epoch ends
     def on_train_epoch_end(self) -> None:
         logger.info("Training epoch complete. Processed %d samples", self.train_samples_count)

@@ -613,3 +613,58 @@ def test_graphed_train_step_matches_eager():
     gs = GraphedTrainStep(ts, osx, batches[0], autocast_dtype=None, warmup=1)
     losses = {round(gs(batches[0]).item(), 7) for _ in range(6)}
     assert len(losses) > 1, losses                                 # lr = 0: the only thing that changes is the Dropout2d draw
+
+
+def test_failed_graph_capture_leaves_training_state_untouched():
+    """Round-4 advisor finding: the warm-up steps of a capture are real optimizer steps.  When the capture pass then raises,
+    GraphedTrainStep(restore_state=True) must hand back the model, the Adam moments / step counts, the BN running statistics and
+    the RNG exactly as they were (MiniTrainer falls back to eager steps and must not have trained on its first batch already);
+    and after a SUCCESSFUL capture the task's sample counter only counts replays (training_step no longer runs on the host)."""
+    from gdlhip.graphs import GraphedTrainStep
+    _, task = _dofa_task(freeze=("encoder",))
+    task.trainer = _Trainer(True)
+    params = [p for p in task.parameters() if p.requires_grad]
+    opt = gnn.FusedAdam(params, lr=1e-2, max_grad_norm=1.0, capturable=True)
+    batch = _to_dev(synthetic_batch(2, 3, 112, 5, 77))
+    batch["mask"] = batch["mask"].long()
+    # one eager step first: the optimizer state exists and is warm (step 1) before the capture is attempted
+    task.train()
+    task.training_step(batch, 0).backward()
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    before = {n: t.detach().clone() for n, t in list(task.named_parameters()) + list(task.named_buffers())}
+    moments = {p: (opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone(), opt.state[p]["step"]) for p in params}
+    rng, count0 = torch.cuda.get_rng_state().clone(), task.train_samples_count
+    real_step = task.training_step
+
+    def failing_step(b, i):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("something the capture cannot record")
+        return real_step(b, i)
+
+    task.training_step = failing_step
+    with pytest.raises(RuntimeError, match="cannot record"):
+        GraphedTrainStep(task, opt, batch, autocast_dtype=None, warmup=2, restore_state=True)
+    task.training_step = real_step
+    assert not torch.cuda.is_current_stream_capturing()
+    for n, t in list(task.named_parameters()) + list(task.named_buffers()):
+        assert torch.equal(t, before[n]), n
+    for p in params:
+        assert torch.equal(opt.state[p]["exp_avg"], moments[p][0]) and torch.equal(opt.state[p]["exp_avg_sq"], moments[p][1])
+        assert opt.state[p]["step"] == moments[p][2] == 1 and p.grad is None
+    assert float(opt.device_state(0)[0]) == 1.0          # the device step count follows the restored host count, not 0
+    assert torch.equal(torch.cuda.get_rng_state(), rng) and task.train_samples_count == count0
+    # the eager fallback still trains from here
+    l0 = task.training_step(batch, 0)
+    l0.backward()
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    assert float(opt.device_state(0)[0]) == 2.0 and opt.state[params[0]]["step"] == 2
+    # ... and a capture that succeeds counts samples per replay only
+    count1 = task.train_samples_count
+    gs = GraphedTrainStep(task, opt, batch, autocast_dtype=None, warmup=2, restore_state=True)
+    assert task.train_samples_count == count1 and float(opt.device_state(0)[0]) == 2.0
+    for _ in range(3):
+        gs(batch)
+    assert task.train_samples_count == count1 + 3 * 2 and float(opt.device_state(0)[0]) == 5.0
