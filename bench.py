@@ -13,7 +13,12 @@ A "step" is one pass of the hot path over one synthetic batch that is already re
 `value` is the TRAINING throughput of the whole job (tiles/s over all ranks); the inference
 throughput measured the same way is reported alongside.  Rank 0 prints ONE JSON line.
 
-Besides the contract fields the line carries (N = 1 only, all measured in this same process):
+The stdout line is the SHORT form (< ~3 KB: contract keys, `roofline`, `cpu_baseline`, then one number per extra, the most
+important ones last -- see compact_line); the LONG form with every table below goes to bench_details.json beside this file
+(and to gpurun_out/bench_details.json when that directory exists).  `value` always covers exactly --steps steps; when those
+take less than --min-seconds (3 s) the same steps are timed again over a longer run and reported under `sustained`.
+
+Besides the contract fields the long form carries (N = 1 only, all measured in this same process):
   roofline      dominant MFMA kernel by HIP events on the launch stream; `traffic` = HBM bytes per launch from the
                 committed rocprofv3 PMC passes (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), see --help
   hbm_kernels   the HBM-bound kernels of the step at their DOFA shapes: algorithmic GB/s vs the 8 TB/s peak
@@ -26,6 +31,7 @@ Besides the contract fields the line carries (N = 1 only, all measured in this s
 from __future__ import annotations
 
 import argparse
+import math
 import json
 import os
 import statistics
@@ -80,6 +86,11 @@ def parse():
                          "reported beside `value`, never as `value`)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="take the multi-GPU code path (RCCL group, SyncBatchNorm, DDP) even with one rank (self-test)")
+    ap.add_argument("--min-seconds", type=float, default=3.0,
+                    help="when --steps steps take less than this, ALSO time a longer run of the same step (reported under `sustained`; "
+                         "`value` always covers exactly --steps steps); 0 = off")
+    ap.add_argument("--details", default=None, help="where the long form goes (default: bench_details.json beside bench.py, and "
+                                                     "gpurun_out/bench_details.json when that directory exists)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip hbm_kernels / by_batch / other_models (profiling runs)")
@@ -426,6 +437,66 @@ def cpu_baseline(warm: int = 2, reps: int = 5):
             "inference_value": round(2 / t_inf, 4)}
 
 
+def compact_line(out: dict, details: list) -> dict:
+    """The ONE stdout line, kept under ~3 KB so that a driver that stores only a tail of stdout still holds every headline
+    value; everything else (by_layer, by_k_depth, other_models' op tables, hbm_kernels, ddp.bucket_ready, ...) is the long form
+    in bench_details.json.  Key order: the contract's keys first, then the extras with the most important ones LAST (a stored
+    tail of 2000 characters then holds inference rate, both utilisations, the sustained run, step-level roofline fractions,
+    small batches and the other BASELINE configs)."""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config")
+    line = {k: out[k] for k in head if k in out}
+    if "config" in line:
+        cfg = dict(line["config"])
+        cfg["workload"] = cfg["workload"][:150]
+        line["config"] = cfg
+    sr = out.get("step_roofline") or {}
+    r = out.get("roofline")
+    if r:
+        line["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches",
+                                             "avg_launch_us", "algorithmic_bytes_per_launch_avg", "share_of_step_time") if k in r}
+        line["roofline"]["kernel"] = str(r.get("kernel", ""))[:48]
+        for k in ("l2_hit_rate", "mfma_busy_share"):
+            if k in (r.get("pmc") or {}):
+                line["roofline"][k] = r["pmc"][k]
+        for k, v in sr.items():      # (scalars: the whole step against the sum over its ops of max(bytes / 8 TB/s, flops / 2.5 PF/s))
+            line["roofline"][f"step_frac_of_bound_{k}"] = v.get("frac_of_bound")
+        top = (r.get("by_layer") or [])[:4]
+        line["roofline"]["by_layer_tflops"] = {str(e["shape"])[:40]: e["tflops"] for e in top}
+        line["roofline"]["other_variants_tflops"] = {str(k)[:28]: v["tflops"] for k, v in (r.get("other_conv_gemm_variants") or {}).items()}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {**{k: v for k, v in cb.items() if k != "sample"}, "sample": cb["sample"][:150]}
+    line["details"] = details
+    hk = out.get("hbm_kernels")
+    if hk:
+        line["hbm_kernels_gb_per_s"] = {k.split(" ")[0]: v["gb_per_s"] for k, v in hk.items()}
+    d = out.get("ddp")
+    if d:
+        line["ddp"] = {k: d[k] for k in ("ranks", "rccl_version", "syncbn_messages_per_step", "step_ms_with_grad_sync", "step_ms_no_sync",
+                                         "exposed_grad_comm_ms", "grad_allreduce_ms_alone", "graphed") if k in d}
+    om = out.get("other_models")
+    if om:
+        line["other_models"] = {k: {"train": v.get("train_tiles_per_s"), "infer": v.get("inference_tiles_per_s"), "b": v.get("per_gpu_batch"),
+                                    "frac_of_bound": {kk: vv.get("frac_of_bound") for kk, vv in (v.get("roofline") or {}).items()}}
+                                for k, v in om.items()}
+    bb = out.get("by_batch")
+    if bb:
+        line["by_batch"] = {k: {"train": v.get("train_tiles_per_s"), "infer": v.get("inference_tiles_per_s"),
+                                "eager_train": (v.get("eager") or {}).get("train_tiles_per_s")} for k, v in bb.items()}
+    if "pcie_inclusive" in out:
+        line["pcie_inclusive"] = {"train_tiles_per_s": out["pcie_inclusive"]["train_tiles_per_s"]}
+    if sr:
+        line["step_roofline"] = {k: {"frac_of_bound": v.get("frac_of_bound"), "bound_ms": v.get("bound_ms"),
+                                     "top_op": (v.get("top_ops") or [{}])[0].get("op")} for k, v in sr.items()}
+    if "sustained" in out:
+        line["sustained"] = {k: v for k, v in out["sustained"].items() if k != "note"}
+    for k in ("executed_flops_utilisation", "model_flops_utilisation", "inference_ms_per_step", "inference_tiles_per_s"):
+        if k in out:
+            line[k] = out[k]
+    return line
+
+
 def main() -> None:
     args = parse()
     # RCCL prints a version banner to the C-level stdout of every rank: keep a private handle on the real stdout for
@@ -473,6 +544,14 @@ def main() -> None:
         res["train"] = dt
     if args.mode in ("both", "infer"):
         res["infer"] = timed(infer_step, args.steps, args.warmup, world, device)
+    # `value` times EXACTLY --steps steps (the driver's contract).  A caller that passes a small K (the driver: 20 steps = 0.7 s)
+    # gets a second, longer measurement of the same steps beside it: as many steps as make the timed region >= 3 s
+    sustained = {}
+    if args.min_seconds > 0:
+        for key, fn in (("train", train_step), ("infer", infer_step)):
+            if key in res and res[key] < args.min_seconds:
+                k_long = int(math.ceil(args.min_seconds / (res[key] / args.steps)))
+                sustained[key] = (k_long, timed(fn, k_long, 0, world, device))
 
     step_roofline = None
     if not args.no_extras and world == 1:
@@ -681,7 +760,24 @@ def main() -> None:
                                                                           min(2, args.warmup), device, True, roofline=True)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
-    json_out.write(json.dumps(out) + "\n")
+    if sustained:
+        out["sustained"] = {("train" if k == "train" else "inference") + "_tiles_per_s": round(args.batch * world * n / dt, 3)
+                            for k, (n, dt) in sustained.items()}
+        out["sustained"].update({"steps": {k: n for k, (n, _) in sustained.items()},
+                                 "timed_region_s": {k: round(dt, 3) for k, (_, dt) in sustained.items()},
+                                 "note": "`value` covers exactly --steps steps; these are the same steps timed over >= "
+                                         f"{args.min_seconds:g} s (barrier + synchronize on both sides, max over ranks)"})
+    details_paths = [Path(args.details)] if args.details else [ROOT / "bench_details.json"] + (
+        [ROOT / "gpurun_out" / "bench_details.json"] if (ROOT / "gpurun_out").is_dir() else [])
+    written = []
+    for dp in details_paths:
+        try:
+            dp.write_text(json.dumps(out, indent=1) + "\n")
+            written.append(str(dp.relative_to(ROOT)) if dp.is_relative_to(ROOT) else str(dp))
+        except OSError as exc:
+            print(f"bench.py: could not write {dp}: {exc}", file=sys.stderr)
+    line = compact_line(out, written)
+    json_out.write(json.dumps(line, separators=(",", ":")) + "\n")
     json_out.flush()
     if dist_on:
         dist.destroy_process_group()
