@@ -292,21 +292,62 @@ mix_transformer_encoders = {
 }
 
 
+PRETRAINED_SETTINGS = ("imagenet",)      # mix_transformer.py:587-596: one published weight set per variant
+
+
+def pretrained_checkpoint_path(name: str) -> tuple[str | None, list[str]]:
+    """Where the ImageNet weights of ``name`` are looked for.  The reference calls ``model_zoo.load_url`` on
+    ``github.com/qubvel/segmentation_models.pytorch/releases/download/v0.0.2/<name>.pth`` (mix_transformer.py:587-596,746),
+    which caches the file as ``<torch hub dir>/checkpoints/<name>.pth``.  This build never opens a network connection: it reads
+    that same cache location (or the file ``$GDL_MIT_CHECKPOINT`` names; a directory there is searched for ``<name>.pth``)."""
+    import os
+    from pathlib import Path
+    env = os.environ.get("GDL_MIT_CHECKPOINT")
+    candidates = []
+    if env:
+        candidates.append(str(Path(env) / f"{name}.pth") if Path(env).is_dir() else env)
+    candidates.append(str(Path(torch.hub.get_dir()) / "checkpoints" / f"{name}.pth"))
+    for path in candidates:
+        if Path(path).is_file():
+            return path, candidates
+    return None, candidates
+
+
 def get_encoder(name: str, in_channels: int = 3, depth: int = 5, weights: str | None = None,
-                output_stride: int = 32) -> MixVisionTransformerEncoder:  # noqa: ARG001
-    """mix_transformer.py:711-759 (pretrained weights need network access: load a checkpoint instead)."""
+                output_stride: int = 32) -> MixVisionTransformerEncoder:
+    """mix_transformer.py:711-759.  ``weights="imagenet"`` (what configs/segformer_config_RGB.yaml:46 asks for) loads the
+    published checkpoint from torch-hub's cache location without downloading (see ``pretrained_checkpoint_path``); like the
+    reference, pretrained weights are only defined for 3-band input (a warning otherwise) and the classifier ``head.*`` entries
+    of the checkpoint are dropped (:580-585)."""
+    import warnings
     try:
         entry = mix_transformer_encoders[name]
     except KeyError as err:
         msg = f"Wrong encoder name `{name}`, supported encoders: {list(mix_transformer_encoders.keys())}"
         raise KeyError(msg) from err
-    if weights is not None:
-        msg = ("pretrained MiT weights are downloaded from github.com in the reference; this build has no "
-               "network: pass weights=None and load a checkpoint with load_state_dict")
-        raise RuntimeError(msg)
     params = dict(entry["params"])
     params.update(in_channels=in_channels, depth=depth)
-    return entry["encoder"](**params)
+    encoder = entry["encoder"](**params)
+    if weights is not None:
+        if in_channels == 3:
+            if weights not in PRETRAINED_SETTINGS:
+                msg = (f"Wrong pretrained weights `{weights}` for encoder `{name}`. Available options are: "
+                       f"{list(PRETRAINED_SETTINGS)}")
+                raise KeyError(msg)
+            path, candidates = pretrained_checkpoint_path(name)
+            if path is None:
+                msg = (f"weights='{weights}' needs the published checkpoint {name}.pth "
+                       f"(https://github.com/qubvel/segmentation_models.pytorch/releases/download/v0.0.2/{name}.pth); this build "
+                       f"does not download: put it at {candidates[-1]} or point GDL_MIT_CHECKPOINT at it, or pass weights=None")
+                raise RuntimeError(msg)
+            encoder.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+        else:
+            warnings.warn("MixVisionTransformer encoder does not support pretrained weights for non-RGB input channels",
+                          stacklevel=2)
+    encoder.set_in_channels(in_channels)
+    if output_stride != 32:
+        encoder.make_dilated()           # raises ValueError like the reference (:565-568,755-757)
+    return encoder
 
 
 class DynamicChannelEmbed(nn.Module):

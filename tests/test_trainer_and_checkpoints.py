@@ -283,3 +283,64 @@ def test_accumulation_tail_early_stopping_and_metric_sink(tmp_path):
     assert isinstance(tr._sums["x"][0], torch.Tensor)
     means = tr._epoch_means(torch.device("cpu"))
     assert abs(means["x"] - 2.5) < 1e-12 and abs(means["y"] - 1.5) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ MiT ImageNet weights
+# the model section of the reference's shipped SegFormer config (configs/segformer_config_RGB.yaml:41-66), restated as data
+SEGFORMER_MODEL_SECTION = {
+    "class_path": "tasks_with_models.segmentation_segformer.SegmentationSegformer",
+    "init_args": {"encoder": "mit_b0", "image_size": [512, 512], "in_channels": 3, "weights": "imagenet", "max_samples": 6,
+                  "num_classes": 5, "freeze_layers": None, "use_dynamic_encoder": False,
+                  "loss": {"class_path": "segmentation_models_pytorch.losses.DiceLoss", "init_args": {"mode": "multiclass"}},
+                  "optimizer": {"class_path": "torch.optim.Adam", "init_args": {"lr": 6e-5}},
+                  "scheduler": {"class_path": "torch.optim.lr_scheduler.ReduceLROnPlateau",
+                                "init_args": {"mode": "min", "factor": 0.5, "patience": 3}}}}
+
+
+def test_mit_imagenet_weights_come_from_the_hub_cache(tmp_path, monkeypatch):
+    """`weights: imagenet` of configs/segformer_config_RGB.yaml:46.  The reference downloads
+    .../segmentation_models.pytorch/releases/download/v0.0.2/<name>.pth into torch-hub's cache with model_zoo.load_url and drops
+    the checkpoint's classifier `head.*` (mix_transformer.py:580-596,732-746).  This build reads the same cache location (or
+    $GDL_MIT_CHECKPOINT), never downloads, and fails with the path it wants when the file is not there."""
+    from geo_deep_learning.models.encoders import mix_transformer as mit
+    from oracle.segformer import SegFormerSegmentationModel as OracleSegFormer
+    monkeypatch.setattr(torch.hub, "get_dir", lambda: str(tmp_path / "hub"))
+    monkeypatch.delenv("GDL_MIT_CHECKPOINT", raising=False)
+    # no file: loud, with the path
+    with pytest.raises(RuntimeError, match="mit_b0.pth") as err:
+        mit.get_encoder("mit_b0", weights="imagenet")
+    assert str(tmp_path / "hub" / "checkpoints" / "mit_b0.pth") in str(err.value) and "GDL_MIT_CHECKPOINT" in str(err.value)
+    with pytest.raises(KeyError, match="Wrong pretrained weights"):
+        mit.get_encoder("mit_b0", weights="ssl")
+    with pytest.raises(KeyError, match="Wrong encoder name"):
+        mit.get_encoder("mit_b9", weights="imagenet")
+    with pytest.warns(UserWarning, match="non-RGB"):      # the reference warns and keeps the random init (:747-752)
+        mit.get_encoder("mit_b0", in_channels=4, weights="imagenet")
+    with pytest.raises(ValueError, match="dilated"):
+        mit.get_encoder("mit_b0", output_stride=16)
+    # a checkpoint in the published layout: the encoder's own keys + the ImageNet classifier head
+    torch.manual_seed(3)
+    src = OracleSegFormer("mit_b0", 3, 5).encoder.state_dict()
+    ckpt = {k: torch.randn_like(v) if v.is_floating_point() else v.clone() for k, v in src.items()}
+    ckpt["head.weight"], ckpt["head.bias"] = torch.randn(1000, 256), torch.randn(1000)
+    (tmp_path / "hub" / "checkpoints").mkdir(parents=True)
+    torch.save(ckpt, tmp_path / "hub" / "checkpoints" / "mit_b0.pth")
+    enc = mit.get_encoder("mit_b0", weights="imagenet")
+    sd = enc.state_dict()
+    assert sorted(sd) == sorted(k for k in ckpt if not k.startswith("head."))
+    assert all(torch.equal(sd[k], ckpt[k]) for k in sd)
+    # ... the environment variable wins (file or directory), and the reference's shipped model section builds unchanged
+    other = tmp_path / "elsewhere"
+    other.mkdir()
+    ckpt2 = {k: (v + 1 if v.is_floating_point() else v) for k, v in ckpt.items()}
+    torch.save(ckpt2, other / "mit_b0.pth")
+    monkeypatch.setenv("GDL_MIT_CHECKPOINT", str(other))
+    task = gdl_train.instantiate(SEGFORMER_MODEL_SECTION)
+    task.configure_model()
+    got = task.model.encoder.state_dict()
+    assert all(torch.equal(got[k], ckpt2[k]) for k in got)
+    monkeypatch.setenv("GDL_MIT_CHECKPOINT", str(other / "mit_b0.pth"))
+    assert torch.equal(mit.get_encoder("mit_b0", weights="imagenet").state_dict()["norm4.weight"], ckpt2["norm4.weight"])
+    # use_dynamic_encoder=True takes stages 2-4 / blocks / norms from the same checkpoint (mix_transformer.py:862-895)
+    dyn = mit.DynamicMixTransformer("mit_b0", weights="imagenet")
+    assert torch.equal(dyn.state_dict()["block1.0.attn.q.weight"], ckpt2["block1.0.attn.q.weight"])
