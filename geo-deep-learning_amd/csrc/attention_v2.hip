@@ -399,6 +399,164 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 2
 // of its MFMAs needs 32 more registers than the 128 that four waves per SIMD allow (spills: 410 us).  The experiment was
 // removed again; what stayed is the interleaved order of the two S accumulation chains below.
 
+// ------------------------------------------------------------------------------------------------ forward, round 5
+// The round-3 kernel with the two GEMMs of a wave SOFTWARE-PIPELINED across key tiles: S of tile t+1 is issued to the matrix
+// pipe BEFORE the softmax of tile t, so a wave's own exp2 / max / row-sum VALU work runs under its own MFMAs instead of behind
+// them (round-4 counters: a 32-query wave spent 39 % of its cycles parked on the chain K fragments -> S -> softmax -> V fragments
+// -> PV; only the other waves of the SIMD filled those gaps).  Same tiles, same arithmetic, same order of every sum as
+// flash_fwd3_kernel -- bit-identical results.  What changes:
+//   * two S accumulator sets (current / next, roles swapped every tile: the loop is unrolled by two, no register copies);
+//   * K runs one tile ahead of V in the LDS: at the top of iteration t the block has K[t+1] and V[t]; it then requests K[t+2]
+//     into the slot of K[t] and V[t+1] into the slot of V[t-1] (both last read in iteration t-1, which the barrier closes).
+//     Still two K and two V stages = 32 KiB;
+//   * QLDS = false: Q fragments in registers, three waves per SIMD (the second S set costs 32 registers: 168 available);
+//     QLDS = true : Q fragments re-read from a wave-private 4 KiB LDS tile each iteration, four waves per SIMD (128 registers).
+template <int NW, bool QLDS>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void flash_fwd4_kernel(const Attn2Args f, const float defer) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES + (QLDS ? NW * 4096 : 16)];   // K stages 0,1 | V stages 2,3 | Q
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int blk, bh;
+  decode_block((f.Nq + 32 * NW - 1) / (32 * NW), f.B * f.H, blk, bh);
+  const int b = bh / f.H, h = bh % f.H;
+  const int q0 = blk * (32 * NW) + wave * 32;
+  const bool active = q0 < f.Nq;                                   // wave-uniform; idle waves still stage and sync
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const uint16_t* qbase = f.q + (int64_t)b * f.q_sB + (int64_t)h * 64;
+  const srd_t srd_k = make_srd(f.k + (int64_t)b * f.k_sB + (int64_t)h * 64, (unsigned)(((int64_t)f.N - 1) * f.k_sN * 2 + 128));
+  const srd_t srd_v = make_srd(f.v + (int64_t)b * f.v_sB + (int64_t)h * 64, (unsigned)(((int64_t)f.N - 1) * f.v_sN * 2 + 128));
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+  unsigned char* qtile = smem + 4 * TILE_BYTES + (QLDS ? wave * 4096 : 0);
+
+  bf16x8_t qf[4];   // B operand of S^T: lane (query frow, half) holds channels 16kk + 8 half ..
+  {
+    const int q = q0 + frow;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < f.Nq) v = *(const uint4*)(qbase + (int64_t)q * f.q_sN + kk * 16 + fhalf * 8);
+      if (QLDS) *(uint4*)(qtile + frow * 128 + (((2 * kk + fhalf) ^ tr_swz(frow)) << 4)) = v;
+      else qf[kk] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+  auto issue_k = [&](int stage, int kv0) {   // 8 pieces per tile, dealt round-robin to the NW waves
+#pragma unroll
+    for (int i = 0; i < (8 + NW - 1) / NW; ++i) {
+      const int p = wave + NW * i;
+      if (p < 8) stage_piece(srd_k, f.k_sN * 2, kv0, f.N, p, lds_base + stage * TILE_BYTES, lane);
+    }
+  };
+  auto issue_v = [&](int stage, int kv0) {
+#pragma unroll
+    for (int i = 0; i < (8 + NW - 1) / NW; ++i) {
+      const int p = wave + NW * i;
+      if (p < 8) stage_piece(srd_v, f.v_sN * 2, kv0, f.N, p, lds_base + (2 + stage) * TILE_BYTES, lane);
+    }
+  };
+  // S^T[key, query] = K . Q^T for the two key row tiles of one staged K tile (interleaved: consecutive MFMAs never share
+  // an accumulator; same sums as tile-by-tile)
+  auto scores = [&](f32x16_t (&st)[2], int kstage) {
+    const unsigned char* sk = smem + kstage * TILE_BYTES;
+    st[0] = zero16(); st[1] = zero16();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8_t qb = QLDS ? row_frag(qtile, 0, kk, lane) : qf[kk];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) st[kt] = MFMA(row_frag(sk, kt, kk, lane), qb, st[kt]);
+    }
+  };
+  f32x16_t ot[2] = {zero16(), zero16()};   // O^T accumulators [channel tile]: rows = channels, column = query
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sl2 = f.scale_log2e;
+  const int ntiles = (f.N + 63) / 64;
+  f32x16_t sa[2], sb[2];
+
+  // one key tile: `cur` holds S of tile t (issued one iteration ago), `nxt` receives S of tile t+1 first
+  auto tile = [&](int t, f32x16_t (&cur)[2], f32x16_t (&nxt)[2]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                         // K[t+1] and V[t] are in the LDS; every wave is done with K[t] and V[t-1]
+    if (t + 2 < ntiles) issue_k(t & 1, (t + 2) * 64);
+    if (t + 1 < ntiles) issue_v((t + 1) & 1, (t + 1) * 64);
+    if (!active) return;
+    if (t + 1 < ntiles) scores(nxt, (t + 1) & 1);
+    const unsigned char* sv = smem + (2 + (t & 1)) * TILE_BYTES;
+    // ---- online softmax per query (lane + partner lane^32 hold its 64 scores of this tile)
+    if (t == ntiles - 1) {   // only the last tile can hold keys >= N
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+          cur[kt][r] = key < f.N ? cur[kt][r] : -INFINITY;
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cur[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float m_new = fmaxf(m_run, mx);
+    if (defer > 0.f && __all((m_new - m_run) * sl2 <= defer)) m_new = m_run;   // (-inf start: never deferred)
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
+    m_run = m_new;
+    const float mc = m_new * sl2;
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(cur[kt][r], sl2, -mc));
+        cur[kt][r] = p;
+        lsum += p;
+      }
+    l_run = l_run * alpha + lsum;
+    if (!__all(alpha == 1.f)) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[ct][r] *= alpha;
+    }
+    // ---- O^T[ch, query] += V^T . P^T : A = transposed V fragments, B = the probabilities in registers
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const bf16x8_t pb = acc_as_b(cur[kt], sl);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) ot[ct] = MFMA(col_frag(sv, ct, kt, sl, lane), pb, ot[ct]);
+      }
+  };
+
+  issue_k(0, 0);
+  issue_v(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (ntiles > 1) issue_k(1, 64);
+  if (active) scores(sa, 0);
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(t, sa, sb);
+    if (t + 1 < ntiles) tile(t + 1, sb, sa);
+  }
+  if (!active) return;
+  const float l = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l;
+  const int q = q0 + frow;
+  if (q >= f.Nq) return;
+  if (f.lse && fhalf == 0)
+    f.lse[(int64_t)bh * f.Nq + q] = (m_run * sl2 + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+  uint16_t* orow = f.out + (int64_t)b * f.o_sB + (int64_t)q * f.o_sN + (int64_t)h * 64;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = ct * 32 + 8 * g + 4 * fhalf;
+      *(uint2*)(orow + d) = make_uint2(pack_bf16x2(ot[ct][4 * g] * inv, ot[ct][4 * g + 1] * inv),
+                                       pack_bf16x2(ot[ct][4 * g + 2] * inv, ot[ct][4 * g + 3] * inv));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward, part 0
 // dvec[b,h,q] = sum_d dO[q,d] * O[q,d]: one wave per (b, q) row, lane = channel within a head
 __global__ __launch_bounds__(256) void flash_bwd_dot_kernel(const Attn2Args f) {
@@ -653,12 +811,14 @@ int dkv_qsplit(int B, int H, int Nq, int Nkv) {
 
 bool strides_ok(int64_t a, int64_t b) { return a % 8 == 0 && b % 8 == 0; }
 
-int g_flash_fwd = 3;          // A/B hook (gdl_debug_set_flash_fwd): 2 = the round-2 kernel (64-query waves), 3 = 32-query waves
+constexpr int kFlashFwdDefault = 3;
+int g_flash_fwd = kFlashFwdDefault;   // A/B hook (gdl_debug_set_flash_fwd): 2 = the round-2 kernel (64-query waves), 3 = 32-query waves,
+                                      // 4 / 5 = round 5, key tiles software-pipelined (Q in registers / in the LDS); < 0 = the default
 float g_flash_defer = 6.f;    // deferred running maximum (see flash_fwd3_kernel); 0 = exact online softmax, bit-identical to 2
 
 }  // namespace
 
-extern "C" void gdl_debug_set_flash_fwd(int version, float defer) { g_flash_fwd = version; g_flash_defer = defer; }
+extern "C" void gdl_debug_set_flash_fwd(int version, float defer) { g_flash_fwd = version < 0 ? kFlashFwdDefault : version; g_flash_defer = defer; }
 
 extern "C" int gdl_flash_attn_fwd2(const void* q, int64_t q_sB, int64_t q_sN, const void* k, int64_t k_sB, int64_t k_sN,
                                    const void* v, int64_t v_sB, int64_t v_sN, void* o, int64_t o_sB, int64_t o_sN,
@@ -679,7 +839,11 @@ extern "C" int gdl_flash_attn_fwd2(const void* q, int64_t q_sB, int64_t q_sN, co
   // less-padded 3-wave blocks at N = 1297), fewer only when the whole query range is shorter than that
   const int nw = Nq > 128 ? 4 : 2;
   const unsigned grid = (unsigned)((Nq + 64 * nw - 1) / (64 * nw) * B * H);
-  if (g_flash_fwd >= 3) {      // 32-query waves, four per SIMD
+  if (g_flash_fwd >= 4 && Nq > 64) {      // round 5: S of the next key tile issued before the softmax of the current one
+    const dim3 g4((unsigned)((Nq + 127) / 128 * B * H));
+    if (g_flash_fwd == 5) hipLaunchKernelGGL((flash_fwd4_kernel<4, true>), g4, dim3(256), 0, (hipStream_t)stream, f, g_flash_defer);
+    else hipLaunchKernelGGL((flash_fwd4_kernel<4, false>), g4, dim3(256), 0, (hipStream_t)stream, f, g_flash_defer);
+  } else if (g_flash_fwd >= 3) {      // 32-query waves, four per SIMD
     if (Nq > 64) hipLaunchKernelGGL(flash_fwd3_kernel<4>, dim3((unsigned)((Nq + 127) / 128 * B * H)), dim3(256), 0, (hipStream_t)stream, f, g_flash_defer);
     else hipLaunchKernelGGL(flash_fwd3_kernel<2>, dim3((unsigned)((Nq + 63) / 64 * B * H)), dim3(128), 0, (hipStream_t)stream, f, g_flash_defer);
   } else if (nw == 4) hipLaunchKernelGGL(flash_fwd2_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, f);

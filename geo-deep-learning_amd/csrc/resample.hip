@@ -1323,13 +1323,40 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
 // products of two small tables, and -- as in the forward kernel (version 2) -- a block walks all channel chunks with the next
 // window in flight and everything channel-independent in registers.  One block = four neighbouring pixels of one
 // low-resolution row (one per wave).  Output layout = the two-pass kernels': [B, Hi, Wi, 9 N], tap block 8 - t.
+//
+// BN = true (round 5): the gradient that is gathered is the BatchNorm(+ReLU) backward of the incoming one, formed on the way
+// into the LDS -- dy = ga rs (dz [bn(x) > 0] - mean(dz') - xhat mean(dz' xhat)) per element from dz and the convolution output
+// x, with four per-channel constants (bn_bwd_coef_kernel).  The separate bn_bwd_dx pass (read dz, read x, write dy: 3 GB at
+// the neck's x4 level) and this kernel's read of dy are replaced by one read of dz and x here.  The LDS-DMA cannot transform,
+// so this variant stages through registers: a lane always fetches source chunk (lane & 7) -- its eight channels and their
+// constants stay in registers for a whole channel step -- and the bank swizzle moves to the LDS side of the write.
 struct GatherMArgs {
   const uint16_t* dy;
   uint16_t* g;
   int B, Ho, Wo, N, Hi, Wi;
+  const uint16_t* x;      // BN: the convolution output the statistics were taken from, same layout as dy
+  const float* coef;      // BN: [N / 8][4][8] = {a, thr, c2, c3} per channel (bn_bwd_coef_kernel)
 };
 
-template <int LF>
+// dy = a * (x a > thr ? dz : 0) - (c2 x + c3):  a = gamma rstd, thr = a mean - beta (-inf without ReLU),
+// c2 = a rstd k2, c3 = a k1 - c2 mean with k1 = sum(dz') / P, k2 = sum(dz' xhat) / P   (bn_bwd_dx of norm.hip, refactored)
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          int relu, const float* __restrict__ dgamma_sum,
+                                                          const float* __restrict__ dbeta_sum, double inv_p, int N, float* __restrict__ coef) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= N) return;
+  const double rs = 1.0 / sqrt((double)var[ch] + (double)eps), a = (double)gamma[ch] * rs;
+  const double k1 = (double)dbeta_sum[ch] * inv_p, k2 = (double)dgamma_sum[ch] * inv_p;
+  const double c2 = a * k2 * rs, c3 = a * k1 - c2 * (double)mean[ch];
+  float* o = coef + (ch >> 3) * 32 + (ch & 7);
+  o[0] = (float)a;
+  o[8] = relu ? (float)(a * (double)mean[ch] - (double)beta[ch]) : -INFINITY;
+  o[16] = (float)c2;
+  o[24] = (float)c3;
+}
+
+template <int LF, bool BN = false>
 __global__ __launch_bounds__(256, 2) void resize_conv3x3_bwd_gather_mfma_kernel(const GatherMArgs a) {
   constexpr int F = 1 << LF, WINB = 2 * F + 2, NKS = WINB / 2, QB = 4;
   constexpr int WCOLS = F * (QB - 1) + WINB;                         // window columns of the block
@@ -1419,12 +1446,75 @@ __global__ __launch_bounds__(256, 2) void resize_conv3x3_bwd_gather_mfma_kernel(
       if (wave + 4 * i < NPIECES) dma16_buf(doff[i], srd, (unsigned)(c * 128), lds_ring + (c & 1) * SLOT + (wave + 4 * i) * 1024);
     }
   };
+  // ---- BN: register staging.  Lane = (row lane >> 3 of the piece, source chunk lane & 7)
+  typedef __attribute__((ext_vector_type(4))) unsigned gb_u4;
+  constexpr int MAXPB = BN ? MAXP : 1;
+  unsigned boff[MAXPB], bdst[MAXPB];
+  gb_u4 rdz[MAXPB], rxv[MAXPB];
+  float ca[8], cthr[8], cc2[8], cc3[8];
+  __amdgpu_buffer_rsrc_t rs_dz, rs_x;
+  if constexpr (BN) {
+    const unsigned img_bytes = (unsigned)((int64_t)a.Ho * a.Wo * a.N * 2);
+    rs_dz = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (int64_t)b * a.Ho * a.Wo * a.N), 0, img_bytes, 0x00020000);
+    rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)b * a.Ho * a.Wo * a.N), 0, img_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int R = (wave + 4 * i) * 8 + (lane >> 3);
+      const int wy = R / WCOLS, wc = R - wy * WCOLS;
+      const int py = py0 + wy, px = pxb0 + wc;
+      const bool ok = R < NROWS && py >= 0 && py < a.Ho && px >= 0 && px < a.Wo;
+      boff[i] = ok ? (unsigned)(((py * a.Wo + px) * a.N) * 2 + (lane & 7) * 16) : kTmOob;
+      bdst[i] = (unsigned)((wave + 4 * i) * 1024 + (lane >> 3) * 128 + (((lane & 7) ^ tm_swz(R)) << 4));
+    }
+  }
+  auto bn_load = [&](int c) {
+    if constexpr (BN) {
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) {
+        if (wave + 4 * i < NPIECES) {
+          rdz[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dz, boff[i], c * 128, 0);
+          rxv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, boff[i], c * 128, 0);
+        }
+      }
+      const float4* cp = (const float4*)(a.coef + ((int64_t)c * 8 + (lane & 7)) * 32);
+      const float4 t0 = cp[0], t1 = cp[1], t2 = cp[2], t3 = cp[3], t4 = cp[4], t5 = cp[5], t6 = cp[6], t7 = cp[7];
+      ca[0] = t0.x; ca[1] = t0.y; ca[2] = t0.z; ca[3] = t0.w; ca[4] = t1.x; ca[5] = t1.y; ca[6] = t1.z; ca[7] = t1.w;
+      cthr[0] = t2.x; cthr[1] = t2.y; cthr[2] = t2.z; cthr[3] = t2.w; cthr[4] = t3.x; cthr[5] = t3.y; cthr[6] = t3.z; cthr[7] = t3.w;
+      cc2[0] = t4.x; cc2[1] = t4.y; cc2[2] = t4.z; cc2[3] = t4.w; cc2[4] = t5.x; cc2[5] = t5.y; cc2[6] = t5.z; cc2[7] = t5.w;
+      cc3[0] = t6.x; cc3[1] = t6.y; cc3[2] = t6.z; cc3[3] = t6.w; cc3[4] = t7.x; cc3[5] = t7.y; cc3[6] = t7.z; cc3[7] = t7.w;
+    }
+  };
+  auto bn_store = [&](int c) {
+    if constexpr (BN) {
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) {
+        if (wave + 4 * i < NPIECES) {
+          const unsigned dzw[4] = {rdz[i].x, rdz[i].y, rdz[i].z, rdz[i].w}, xw[4] = {rxv[i].x, rxv[i].y, rxv[i].z, rxv[i].w};
+          uint32_t pk[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x0 = __uint_as_float(xw[e] << 16), x1 = __uint_as_float(xw[e] & 0xffff0000u);
+            const float g0 = __uint_as_float(dzw[e] << 16), g1 = __uint_as_float(dzw[e] & 0xffff0000u);
+            const float m0 = x0 * ca[2 * e] > cthr[2 * e] ? g0 : 0.f, m1 = x1 * ca[2 * e + 1] > cthr[2 * e + 1] ? g1 : 0.f;
+            const float o0 = fmaf(ca[2 * e], m0, -fmaf(cc2[2 * e], x0, cc3[2 * e]));
+            const float o1 = fmaf(ca[2 * e + 1], m1, -fmaf(cc2[2 * e + 1], x1, cc3[2 * e + 1]));
+            pk[e] = boff[i] == kTmOob ? 0u : pack_bf16x2(o0, o1);      // out-of-image / padding rows stay zeros, as the DMA leaves them
+          }
+          *(uint4*)(ring + (c & 1) * SLOT + bdst[i]) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+      }
+    }
+  };
   const int nchunks = a.N >> 6;
-  issue(0);
+  if constexpr (BN) { bn_load(0); bn_store(0); }
+  else issue(0);
   for (int c = 0; c < nchunks; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!BN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                 // chunk c landed; nobody reads the other slot or the tile
-    if (c + 1 < nchunks) issue(c + 1);
+    if (c + 1 < nchunks) {
+      if constexpr (BN) bn_load(c + 1);
+      else issue(c + 1);
+    }
     const unsigned char* stage = ring + (c & 1) * SLOT;
     f32x4_t acc[4];
 #pragma unroll
@@ -1458,6 +1548,7 @@ __global__ __launch_bounds__(256, 2) void resize_conv3x3_bwd_gather_mfma_kernel(
         *(uint4*)(a.g + ((((int64_t)b * a.Hi + qy) * a.Wi + qx) * 9 + tb) * a.N + c * 64 + chunk * 8) = v;
       }
     }
+    if (BN && c + 1 < nchunks) bn_store(c + 1);       // into the slot last read in iteration c - 1 (two barriers ago)
   }
 }
 
@@ -1619,23 +1710,56 @@ extern "C" int gdl_resize_conv3x3_bwd_gather_one_pass(int dtype, int B, int Ho, 
   return gather_mfma_ok(dtype, B, Ho, Wo, N, Hi, Wi) ? 1 : 0;
 }
 
-static bool gather_mfma_launch(const void* dy, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi, int Wi, hipStream_t s) {
-  if (!gather_mfma_ok(dtype, B, Ho, Wo, N, Hi, Wi) || (uintptr_t)dy % 16 || (uintptr_t)g % 16) return false;
+static bool gather_mfma_launch(const void* dy, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi, int Wi, hipStream_t s,
+                               const void* bn_x = nullptr, const float* bn_coef = nullptr) {
+  if (!gather_mfma_ok(dtype, B, Ho, Wo, N, Hi, Wi) || (uintptr_t)dy % 16 || (uintptr_t)g % 16 || (uintptr_t)bn_x % 16) return false;
   const int f = Ho / Hi;
-  GatherMArgs a = {(const uint16_t*)dy, (uint16_t*)g, B, Ho, Wo, N, Hi, Wi};
+  GatherMArgs a = {(const uint16_t*)dy, (uint16_t*)g, B, Ho, Wo, N, Hi, Wi, (const uint16_t*)bn_x, bn_coef};
   const dim3 grid((unsigned)((Wi + 3) / 4), (unsigned)(B * Hi));
   if (f == 2) {
     constexpr int pieces = (6 * (2 * 3 + 6) + 7) / 8;
     const size_t lds = 6 * 1024 + 2 * pieces * 1024;
-    GDL_SET_MAX_LDS_ONCE(resize_conv3x3_bwd_gather_mfma_kernel<1>, 160 * 1024);
-    hipLaunchKernelGGL(resize_conv3x3_bwd_gather_mfma_kernel<1>, grid, dim3(256), lds, s, a);
+    if (bn_x) {
+      GDL_SET_MAX_LDS_ONCE((resize_conv3x3_bwd_gather_mfma_kernel<1, true>), 160 * 1024);
+      hipLaunchKernelGGL((resize_conv3x3_bwd_gather_mfma_kernel<1, true>), grid, dim3(256), lds, s, a);
+    } else {
+      GDL_SET_MAX_LDS_ONCE(resize_conv3x3_bwd_gather_mfma_kernel<1>, 160 * 1024);
+      hipLaunchKernelGGL(resize_conv3x3_bwd_gather_mfma_kernel<1>, grid, dim3(256), lds, s, a);
+    }
   } else {
     constexpr int pieces = (10 * (4 * 3 + 10) + 7) / 8;
     const size_t lds = 6 * 1024 + 2 * pieces * 1024;
-    GDL_SET_MAX_LDS_ONCE(resize_conv3x3_bwd_gather_mfma_kernel<2>, 160 * 1024);
-    hipLaunchKernelGGL(resize_conv3x3_bwd_gather_mfma_kernel<2>, grid, dim3(256), lds, s, a);
+    if (bn_x) {
+      GDL_SET_MAX_LDS_ONCE((resize_conv3x3_bwd_gather_mfma_kernel<2, true>), 160 * 1024);
+      hipLaunchKernelGGL((resize_conv3x3_bwd_gather_mfma_kernel<2, true>), grid, dim3(256), lds, s, a);
+    } else {
+      GDL_SET_MAX_LDS_ONCE(resize_conv3x3_bwd_gather_mfma_kernel<2>, 160 * 1024);
+      hipLaunchKernelGGL(resize_conv3x3_bwd_gather_mfma_kernel<2>, grid, dim3(256), lds, s, a);
+    }
   }
   return true;
+}
+
+// The gather of gdl_resize_conv3x3_bwd_gather applied to the BatchNorm(+ReLU) backward of dz, without that gradient ever being
+// written: see resize_conv3x3_bwd_gather_mfma_kernel<LF, true>.  Only where gdl_resize_conv3x3_bwd_gather_one_pass() says 1.
+extern "C" int gdl_resize_conv3x3_bwd_gather_bn(const void* dz, const void* x, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi,
+                                                int Wi, const float* mean, const float* var, const float* gamma, const float* beta,
+                                                float eps, int relu, const float* dgamma_sum, const float* dbeta_sum, int64_t P_total,
+                                                float* coef_ws, gdl_stream_t stream) {
+  GDL_CHECK_ARG(dz && x && g && mean && var && gamma && beta && dgamma_sum && dbeta_sum && coef_ws,
+                "gdl_resize_conv3x3_bwd_gather_bn: null pointer");
+  GDL_CHECK_ARG(B > 0 && Ho > 0 && Wo > 0 && Hi > 0 && Wi > 0 && N > 0 && P_total > 0, "gdl_resize_conv3x3_bwd_gather_bn: bad dims");
+  GDL_CHECK_ARG(gather_mfma_ok(dtype, B, Ho, Wo, N, Hi, Wi) && (uintptr_t)dz % 16 == 0 && (uintptr_t)x % 16 == 0 &&
+                    (uintptr_t)g % 16 == 0 && (uintptr_t)coef_ws % 16 == 0,
+                "gdl_resize_conv3x3_bwd_gather_bn: needs the one-pass matrix-core form (bf16, N %% 64 == 0, factor 2 or 4, "
+                "gdl_resize_conv3x3_bwd_gather_one_pass() == 1) and 16-byte aligned pointers");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, mean, var, gamma, beta, eps, relu, dgamma_sum,
+                     dbeta_sum, 1.0 / (double)P_total, N, coef_ws);
+  const bool ok = gather_mfma_launch(dz, dtype, B, Ho, Wo, N, g, Hi, Wi, s, x, coef_ws);
+  GDL_CHECK_ARG(ok, "gdl_resize_conv3x3_bwd_gather_bn: launch refused");
+  GDL_CHECK_LAUNCH("gdl_resize_conv3x3_bwd_gather_bn");
+  return GDL_OK;
 }
 
 // shared launcher; stats != nullptr: per-block partial sums of the outputs ([rows][2][N] f32, rows = gdl_resize_conv3x3_fwd_sum_bn_rows)

@@ -98,6 +98,8 @@ SIGNATURES = {
                                c_l, c_l, c_l, c_i, c_p]),
     "gdl_resize_conv3x3_bwd_gather": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "gdl_resize_conv3x3_bwd_gather_one_pass": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "gdl_resize_conv3x3_bwd_gather_bn": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p,
+                                               c_l, c_p, c_p]),
     "gdl_resize_conv3x3_bwd_gather_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "gdl_resize_conv3x3_bwd_gather2": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_l, c_p]),
     "gdl_resize_conv3x3_fwd_sum": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p]),

@@ -321,7 +321,22 @@ def _cba_conv(x, weight, cb, pad, up4, sync_group, running_mean, running_var, mo
 FUSE_CONV_STATS = os.environ.get("GDL_CONV_STATS", "1") != "0"   # A/B switch: False / GDL_CONV_STATS=0 = a separate statistics pass over every convolution output (round 3)
 
 
-def _cba_grads(x, weight, dy, pad, up4, need_dx, need_dw):
+FUSE_BN_BWD_GATHER = os.environ.get("GDL_FUSE_BN_BWD_GATHER", "1") != "0"   # A/B switch: 0 = separate bn_bwd_dx pass (round 4)
+
+
+def _bn_bwd_and_grads(x, weight, y, gout, mean, var, g, b, eps, relu, sg, sb, p_local, pad, up4, need_dx, need_dw):
+    """BatchNorm(+ReLU) backward of a training ConvModule followed by its convolution's gradients.  For the resized 3x3
+    members (up4) the BN backward is formed inside the gather kernel that consumes it (round 5: one HBM pass instead of
+    bn_bwd_dx's three + the gather's read); everything else writes dy in place of y and hands it to _cba_grads."""
+    if (up4 and FUSE_BN_BWD_GATHER and (need_dx or need_dw) and y.dim() == 4 and gout.is_contiguous()
+            and ops.resize_conv3x3_bwd_gather_bn_ok(gout, (x.shape[1], x.shape[2]))):
+        maps = ops.resize_conv3x3_bwd_gather_bn(gout, y, (x.shape[1], x.shape[2]), mean, var, g, b, eps, relu, sg, sb, p_local)
+        return _cba_grads(x, weight, None, pad, up4, need_dx, need_dw, maps=maps)
+    dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, p_local, out=y)
+    return _cba_grads(x, weight, dy, pad, up4, need_dx, need_dw)
+
+
+def _cba_grads(x, weight, dy, pad, up4, need_dx, need_dw, maps=None):
     """(dx, dw) of the conv of a training ConvModule from the gradient dy of its output (BatchNorm backward already applied)."""
     n, c, r, s = weight.shape
     dx = dw = None
@@ -329,7 +344,7 @@ def _cba_grads(x, weight, dy, pad, up4, need_dx, need_dw):
         # both gradients as GEMMs over the LOW-resolution pixels: the resize and the tap shifts act on pixels, the
         # weights on channels, so dx = sum_t W_t^T G_t and dW_t = sum_q G_t[q] (x) x[q] with G_t = resize^T shift_t^T dy
         # (ops.resize_conv3x3_bwd): 1/16 of the MACs of the full-resolution data gradient + phase weight gradients
-        dx, dw = ops.resize_conv3x3_bwd(x, dy, dgrad_weight(weight, x.dtype) if need_dx else None, want_dw=need_dw)
+        dx, dw = ops.resize_conv3x3_bwd(x, dy, dgrad_weight(weight, x.dtype) if need_dx else None, want_dw=need_dw, g=maps)
     else:
         if need_dx:
             dx = ops.conv_gemm(dy, dgrad_weight(weight, x.dtype), R=r, S=s, pad=r - 1 - pad)
@@ -386,12 +401,12 @@ class _ConvBNActTrain(Function):
             # the kernel divides the two sums by p_local: scaling them by p_local / P_global makes that the global mean
             sg, sb = sync_sum_pair(dgamma, dbeta, sync_group or None)
             sg, sb = sg * p_share, sb * p_share
-        dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, p_local, out=y)
         dbias = None
         if has_bias and ctx.needs_input_grad[2]:
             # a bias feeding train-mode BN has an analytically zero gradient
             dbias = torch.zeros(n, device=x.device, dtype=torch.float32)
-        dx, dw = _cba_grads(x, weight, dy, pad, up4, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx, dw = _bn_bwd_and_grads(x, weight, y, gout, mean, var, g, b, eps, relu, sg, sb, p_local, pad, up4,
+                                   ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
@@ -456,10 +471,9 @@ class _ConvBNActGroupTrain(Function):
             c = weight.shape[0]
             sg, sb = packed[off:off + c] * p_share, packed[off + c:off + 2 * c] * p_share
             off += 2 * c
-            dy = ops.bn_bwd_dx(y, gout, mean, var, gamma.detach(), beta.detach(), eps, relu, sg.contiguous(), sb.contiguous(),
-                               p_local, out=y)
             need = ctx.needs_input_grad[2 + 7 * i:2 + 7 * i + 7]
-            dx, dw = _cba_grads(x, weight, dy, pad, up4, need[0], need[1])
+            dx, dw = _bn_bwd_and_grads(x, weight, y, gout, mean, var, gamma.detach(), beta.detach(), eps, relu, sg.contiguous(),
+                                       sb.contiguous(), p_local, pad, up4, need[0], need[1])
             dbias = torch.zeros(c, device=x.device, dtype=torch.float32) if has_bias and need[2] else None
             grads += [dx, dw, dbias, dgamma, dbeta, None, None]
         return (None, None, *grads)

@@ -414,13 +414,40 @@ def resize_conv3x3_bwd_gather(dy: Tensor, in_size: tuple[int, int]) -> Tensor:
     return g
 
 
-def resize_conv3x3_bwd(x_lo: Tensor, dy: Tensor, w_dgrad: Tensor | None, want_dw: bool = True):
+def resize_conv3x3_bwd_gather_bn_ok(dz: Tensor, in_size: tuple[int, int]) -> bool:
+    """Shapes the BatchNorm-backward-fused gather takes (= the one-pass matrix-core gather: bf16, N % 64 == 0, factor 2 / 4)."""
+    if dz.dim() != 4 or dz.dtype != torch.bfloat16 or not dz.is_contiguous():
+        return False
+    B, Ho, Wo, N = dz.shape
+    return bool(_lib.load().gdl_resize_conv3x3_bwd_gather_one_pass(dt(dz), B, Ho, Wo, N, in_size[0], in_size[1]))
+
+
+def resize_conv3x3_bwd_gather_bn(dz: Tensor, y: Tensor, in_size: tuple[int, int], mean, var, gamma, beta, eps, relu, dgamma_sum,
+                                 dbeta_sum, p_total) -> Tensor:
+    """resize_conv3x3_bwd_gather(bn_bwd_dx(y, dz, ...)) in one kernel: the BatchNorm(+ReLU) backward is applied to dz while it is
+    staged, its result is never written (gdl_resize_conv3x3_bwd_gather_bn).  dz, y dense NHWC bf16 of one shape."""
+    _need_cuda(dz, y)
+    if dz.shape != y.shape or dz.dtype != y.dtype or not (dz.is_contiguous() and y.is_contiguous()):
+        raise ValueError("resize_conv3x3_bwd_gather_bn: dz and y must be dense NHWC tensors of one shape and dtype")
+    B, Ho, Wo, N = dz.shape
+    Hi, Wi = in_size
+    g = torch.empty((B, Hi, Wi, 9 * N), device=dz.device, dtype=dz.dtype)
+    coef = torch.empty(4 * N, device=dz.device, dtype=torch.float32)
+    check(_lib.load().gdl_resize_conv3x3_bwd_gather_bn(_p(dz), _p(y), dt(dz), B, Ho, Wo, N, _p(g), Hi, Wi, _p(mean), _p(var), _p(gamma),
+                                                       _p(beta), eps, int(relu), _p(dgamma_sum), _p(dbeta_sum), p_total, _p(coef),
+                                                       _stream()), "gdl_resize_conv3x3_bwd_gather_bn")
+    return g
+
+
+def resize_conv3x3_bwd(x_lo: Tensor, dy: Tensor | None, w_dgrad: Tensor | None, want_dw: bool = True, g: Tensor | None = None):
     """(dx_lo, dw) of y = conv3x3(pad 1)(bilinear resize(x_lo -> dy's size)) from dy, as GEMMs over the LOW-resolution
-    pixels.  ``w_dgrad`` [C, 9 * N] (gdl_pack_dgrad operand; None = no data gradient); dw [N, 9 * C] f32."""
+    pixels.  ``w_dgrad`` [C, 9 * N] (gdl_pack_dgrad operand; None = no data gradient); dw [N, 9 * C] f32.  ``g``: the nine
+    gathered maps when the caller already has them (resize_conv3x3_bwd_gather_bn), dy is then unused."""
     x4 = _nhwc4(x_lo, "resize_conv3x3_bwd x")
     B, Hi, Wi, Cc = x4.shape
-    N = dy.shape[-1]
-    g = resize_conv3x3_bwd_gather(dy, (Hi, Wi))
+    if g is None:
+        g = resize_conv3x3_bwd_gather(dy, (Hi, Wi))
+    N = g.shape[-1] // 9
     dx = conv_gemm(g, w_dgrad) if w_dgrad is not None else None
     dw = None
     if want_dw:

@@ -268,6 +268,18 @@ int gdl_resize_conv3x3_bwd_gather(const void* dy, int dtype, int B, int Ho, int 
 /* 1 when gdl_resize_conv3x3_bwd_gather runs its one-pass matrix-core form for this shape (bf16, N % 64 == 0, factor 2 or 4:
  * dy read once, no intermediate) -- the caller then skips the two-pass entry and its workspace */
 int gdl_resize_conv3x3_bwd_gather_one_pass(int dtype, int B, int Ho, int Wo, int N, int Hi, int Wi);
+/* gdl_resize_conv3x3_bwd_gather of the BatchNorm(+ReLU) BACKWARD of dz, without that gradient ever existing in memory: for a
+ * training ConvModule whose convolution is conv3x3(resize(x)) (multilevel_neck.py:56-67,157-158: conv -> BN -> ReLU), the
+ * gradient that reaches the convolution is dy = gamma rstd (dz [bn(x) > 0] - sum(dz')/P - xhat sum(dz' xhat)/P) -- what
+ * gdl_bn_bwd_dx writes -- and it is only ever consumed by this gather.  The kernel forms dy per element from dz and the saved
+ * convolution output x on the way into its staging buffer (one read of dz and x instead of read dz, read x, write dy, read dy).
+ * Arguments as gdl_bn_bwd_dx (dgamma_sum / dbeta_sum = the outputs of gdl_bn_bwd_reduce, P_total their pixel count) +
+ * gdl_resize_conv3x3_bwd_gather; coef_ws: 4 * N floats of scratch (16-byte aligned).  Only where
+ * gdl_resize_conv3x3_bwd_gather_one_pass() == 1 (bf16, N % 64 == 0, factor 2 or 4); fails otherwise. */
+int gdl_resize_conv3x3_bwd_gather_bn(const void* dz, const void* x, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi, int Wi,
+                                     const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                                     int relu, const float* dgamma_sum, const float* dbeta_sum, int64_t P_total, float* coef_ws,
+                                     gdl_stream_t stream);
 /* the same result in two separable passes (rows, then columns) through a workspace of three [B,Hi,Wo,N] maps: fewer
  * multiply-adds per loaded vector; the intermediate is rounded to dy's dtype */
 int64_t gdl_resize_conv3x3_bwd_gather_workspace(int dtype, int B, int Wo, int N, int Hi);

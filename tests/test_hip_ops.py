@@ -335,12 +335,19 @@ def test_attention_flash_forward_kernels_agree(B, Nq, Nkv, H):
     qd, kvd = q(qh, dtype).to(DEV, dtype), q(kvh, dtype).to(DEV, dtype)
     outs = {}
     try:
-        for tag, ver, defer in (("r2", 2, 0.0), ("r3 exact", 3, 0.0), ("r3 deferred", 3, 6.0)):
+        for tag, ver, defer in (("r2", 2, 0.0), ("r3 exact", 3, 0.0), ("r3 deferred", 3, 6.0), ("r5 exact", 4, 0.0),
+                                ("r5 deferred", 4, 6.0), ("r5q exact", 5, 0.0), ("r5q deferred", 5, 6.0)):
             lib.gdl_debug_set_flash_fwd(ver, defer)
             outs[tag] = ops.attention_flash(qd, kvd[..., :D], kvd[..., D:], H, return_lse=True)
     finally:
-        lib.gdl_debug_set_flash_fwd(3, 6.0)
+        lib.gdl_debug_set_flash_fwd(-1, 6.0)      # back to the build's default forward
     assert torch.equal(outs["r3 exact"][0], outs["r2"][0]) and torch.equal(outs["r3 exact"][1], outs["r2"][1])
+    # round 5 (S of the next key tile issued before the softmax of the current one; Q fragments in registers / in the LDS):
+    # the same MFMAs and f32 operations in the same order per query row -- bit-identical, exact and deferred
+    for r5 in ("r5", "r5q"):
+        assert torch.equal(outs[f"{r5} exact"][0], outs["r2"][0]) and torch.equal(outs[f"{r5} exact"][1], outs["r2"][1]), r5
+        assert torch.equal(outs[f"{r5} deferred"][0], outs["r3 deferred"][0]), r5
+        assert torch.equal(outs[f"{r5} deferred"][1], outs["r3 deferred"][1]), r5
 
     def heads(t, n):
         return t.float().cpu().reshape(B, n, H, hd).transpose(1, 2)
@@ -1216,6 +1223,52 @@ def test_resize_conv3x3_bwd_gather_two_pass(dtype, B, Hi, Wi, N, f):
         print(f"max |error|: one-pass {(outs['mfma'] - ref).abs().max().item():.3e}, two-pass {(outs[True] - ref).abs().max().item():.3e}")
     if dtype == torch.float32:
         assert (outs[True] - outs[False]).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("B,Hi,Wi,N,f", [(2, 5, 7, 64, 4), (2, 9, 6, 128, 2), (1, 36, 36, 192, 4), (2, 1, 1, 64, 4), (1, 2, 13, 128, 4),
+                                         (1, 37, 18, 64, 2)])
+def test_resize_conv3x3_bwd_gather_with_batchnorm_backward_fused(B, Hi, Wi, N, f, relu):
+    """Round 5: gdl_resize_conv3x3_bwd_gather_bn = gather(bn_bwd_dx(y, dz)) in one kernel (the BatchNorm + ReLU backward is applied
+    while dz is staged; its result never exists in memory).  Against (a) the two launches it replaces, which round the same f32
+    values to bf16 at the same place (only the order of the f32 operations differs), and (b) the definition in f32 torch:
+    autograd of relu(batch_norm(y)) contracted with dz, gathered through the transposed resize + tap shifts."""
+    dtype = torch.bfloat16
+    Ho, Wo = f * Hi, f * Wi
+    y = q(rnd(B, Ho, Wo, N, seed=5) * 1.5 + rnd(N, seed=6) * 0.7, dtype)             # per-channel means far from zero
+    dz = q(rnd(B, Ho, Wo, N, seed=7), dtype)
+    gamma, beta = rnd(N, seed=8) * 0.8 + 0.2, rnd(N, seed=9) * 0.5                    # some negative gammas
+    eps = 1e-5
+    yd, dzd, gd, bd = y.to(DEV, dtype), dz.to(DEV, dtype), gamma.to(DEV), beta.to(DEV)
+    mean, var = ops.bn_stats(yd)
+    dgs, dbs = ops.bn_bwd_reduce(yd, dzd, mean, var, gd, bd, eps, relu)
+    P = B * Ho * Wo
+    assert ops.resize_conv3x3_bwd_gather_bn_ok(dzd, (Hi, Wi))
+    fused = ops.resize_conv3x3_bwd_gather_bn(dzd, yd, (Hi, Wi), mean, var, gd, bd, eps, relu, dgs, dbs, P)
+    dy2 = ops.bn_bwd_dx(yd, dzd, mean, var, gd, bd, eps, relu, dgs, dbs, P)
+    two = ops.resize_conv3x3_bwd_gather(dy2, (Hi, Wi))
+    scale = two.float().abs().max().item()
+    diff = (fused.float() - two.float()).abs()
+    assert diff.max().item() <= 2e-2 * scale, (diff.max().item(), scale)
+    assert (diff > 4e-3 * scale).float().mean().item() < 2e-2           # bf16 rounding of a few dy elements, not a different formula
+    # definition (f32, CPU)
+    yr = y.clone().requires_grad_(True)
+    out = F.batch_norm(yr.permute(0, 3, 1, 2), None, None, gamma, beta, True, 0.1, eps)
+    out = F.relu(out) if relu else out
+    (dy_ref,) = torch.autograd.grad(out, yr, dz.permute(0, 3, 1, 2))
+    x = torch.zeros(B, N, Hi, Wi, requires_grad=True)
+    padded = F.pad(F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False), (1, 1, 1, 1))
+    dyn = dy_ref.permute(0, 3, 1, 2)
+    ref = torch.empty(B, Hi, Wi, 9 * N)
+    for r in range(3):
+        for s3 in range(3):
+            (gx,) = torch.autograd.grad((padded[:, :, r:r + Ho, s3:s3 + Wo] * dyn).sum(), x, retain_graph=True)
+            t = 3 * r + s3
+            ref[..., (8 - t) * N:(9 - t) * N] = gx.permute(0, 2, 3, 1)
+    # ReLU decisions at |bn(y)| ~ 1e-7 may differ between two f32 evaluations: bound the share, hold the rest to bf16
+    err = (fused.float().cpu() - ref).abs()
+    rs = ref.abs().max().item()
+    assert (err > 2e-2 * rs).float().mean().item() < 1e-3, (err.max().item(), rs)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

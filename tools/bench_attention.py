@@ -45,10 +45,12 @@ for name, B, N, H in (("DOFA-base 512^2 (N=1297, 12 heads, batch 32)", 32, 1297,
     # 3 + deferred running maximum (threshold in the exp2 domain)
     res = {}
     # 2 = round 2 (64-query waves), 3 = round 3 (32-query waves; exact / deferred running maximum)
-    for tag, ver, defer in (("v2", 2, 0.0), ("v3", 3, 0.0), ("v3 defer 6", 3, 6.0), ("v3 defer 6 again", 3, 6.0)):
+    # 4 / 5 = round 5: S of tile t+1 issued before the softmax of tile t (Q fragments in registers / re-read from the LDS)
+    for tag, ver, defer in (("v2", 2, 0.0), ("v3", 3, 0.0), ("v3 defer 6", 3, 6.0), ("v4 defer 6", 4, 6.0), ("v5 defer 6", 5, 6.0),
+                            ("v3 defer 6 again", 3, 6.0), ("v4 defer 6 again", 4, 6.0), ("v5 defer 6 again", 5, 6.0)):
         lib.gdl_debug_set_flash_fwd(ver, defer)
         res[tag] = (timeit(lambda: ops.attention_flash(q, k, v, H, return_lse=True)), ops.attention_flash(q, k, v, H, return_lse=True))
-    lib.gdl_debug_set_flash_fwd(3, 6.0)
+    lib.gdl_debug_set_flash_fwd(-1, 6.0)
     ref = torch.nn.functional.scaled_dot_product_attention(*(t.view(B, N, H, 64).transpose(1, 2).float() for t in (q, k, v)))
     ref = ref.transpose(1, 2).reshape(B, N, D)
     print("   forward schedules: " + " | ".join(
