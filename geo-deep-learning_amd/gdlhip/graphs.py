@@ -11,6 +11,17 @@ record forward + loss + backward + clipping + Adam as they are.
 Rules (torch.cuda.graphs): static input buffers (new batches are COPIED into them), no host read-backs inside the step, a
 few eager warm-up steps on a side stream first (lazy initialisations, cached weight casts, kernel attributes).  DropPath /
 Dropout2d draws use torch's graph-safe Philox generator: each replay draws fresh masks.
+
+Under DistributedDataParallel (round 5; the reference's own deployment shape is `devices: -1` with per-GPU batch 4,
+configs/dofa_config_RGB.yaml:5,13,85) the WHOLE step is captured, collectives included: RCCL's all-reduce / broadcast kernels
+are ordinary stream work and torch's NCCL process group records them (and the event edges between its communication stream and
+the compute stream) into the graph -- DDP's bucket all-reduces keep overlapping with the rest of backward inside the replay,
+the SyncBatchNorm statistics messages sit where they sat, and a replay is one launch per rank.  What torch asks for
+(CUDA-graphs notes, "Usage with DistributedDataParallel"): the DDP wrapper constructed on a side stream, >= 11 eager DDP
+iterations before the capture (the reducer rebuilds its buckets after the first one and samples its run-time statistics with
+events during the first ten), async error handling of the process group off.  Only the `nccl` backend can be captured (gloo
+moves tensors through the host); ranks agree on the outcome of the capture with one all-reduce, so either all replay or all run
+eagerly (see ``ddp_warmup`` / ``capturable_process_group`` below and MiniTrainer._graph_step).
 """
 
 from __future__ import annotations
@@ -21,6 +32,39 @@ import torch
 from torch import Tensor
 
 from . import nn as gnn
+
+
+DDP_WARMUP = 11      # eager DDP iterations torch wants before a whole-network capture (see the module docstring)
+
+
+def find_ddp(module: torch.nn.Module):
+    """The DistributedDataParallel wrapper inside a task (``task.model`` under MiniTrainer / Lightning), or None."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.parallel.DistributedDataParallel):
+            return m
+    return None
+
+
+def capturable_process_group(group=None) -> bool:
+    """True when collectives on ``group`` are stream work a hipGraph can record: the nccl (= RCCL) backend."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    try:
+        return str(dist.get_backend(group)).lower() == "nccl"
+    except (RuntimeError, ValueError):
+        return False
+
+
+def ddp_on_side_stream(module: torch.nn.Module, **ddp_kwargs) -> torch.nn.parallel.DistributedDataParallel:
+    """DistributedDataParallel(module) constructed under a side stream, as a later whole-backward capture needs (the reducer's
+    bucket buffers and hooks must not be tied to the stream the capture runs on)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ddp = torch.nn.parallel.DistributedDataParallel(module, **ddp_kwargs)
+    torch.cuda.current_stream().wait_stream(side)
+    return ddp
 
 
 def _clone_static(batch: dict[str, Any]) -> dict[str, Any]:
@@ -53,6 +97,12 @@ class GraphedTrainStep:
         if not getattr(optimizer, "capturable", False):
             msg = "GraphedTrainStep needs FusedAdam(capturable=True): step count and learning rate must live on the device"
             raise ValueError(msg)
+        self.ddp = find_ddp(task)
+        if self.ddp is not None:
+            if not capturable_process_group(self.ddp.process_group):
+                msg = "GraphedTrainStep under DistributedDataParallel needs the nccl (RCCL) backend: gloo collectives pass through the host"
+                raise ValueError(msg)
+            warmup = max(warmup, DDP_WARMUP)
         self.task, self.optimizer, self.autocast_dtype = task, optimizer, autocast_dtype
         self.static = _clone_static(example_batch)
         task.train()
@@ -152,7 +202,11 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         self.logged_static.clear()                      # (the warm-up steps logged eager tensors: only the captured ones count)
         optimizer.zero_grad(set_to_none=True)           # gradients are (re)allocated from the graph's private pool
-        with torch.cuda.graph(self.graph):
+        # under DDP the process group's watchdog thread polls the events of earlier collectives while this thread records:
+        # "thread_local" restricts the capture-unsafe-call check to the capturing thread (backward still runs on the autograd
+        # engine's device thread: work launched into a capturing stream is recorded whichever thread launches it)
+        mode = "thread_local" if self.ddp is not None else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss = self._eager(zero=False)
         self._rewritten = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
         self._rewritten += [b for m in task.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training

@@ -321,7 +321,11 @@ def _cba_conv(x, weight, cb, pad, up4, sync_group, running_mean, running_var, mo
 FUSE_CONV_STATS = os.environ.get("GDL_CONV_STATS", "1") != "0"   # A/B switch: False / GDL_CONV_STATS=0 = a separate statistics pass over every convolution output (round 3)
 
 
-FUSE_BN_BWD_GATHER = os.environ.get("GDL_FUSE_BN_BWD_GATHER", "1") != "0"   # A/B switch: 0 = separate bn_bwd_dx pass (round 4)
+# A/B switch, OFF by default: measured SLOWER than the two launches it replaces (round 5, same-box A/B, profiles/r05a_*: 881-883
+# vs 890-892 train tiles/s).  The gather's windows overlap 3.4x (10 x 22 output pixels staged per 4 x 16 footprint): the LDS-DMA
+# re-reads them from L2 for free, the register-staged BN form recomputes ~10 VALU operations per element 3.4 times with two
+# waves per SIMD and no DMA overlap.  Kept with its parity test as the measured reference for that design.
+FUSE_BN_BWD_GATHER = os.environ.get("GDL_FUSE_BN_BWD_GATHER", "0") == "1"
 
 
 def _bn_bwd_and_grads(x, weight, y, gout, mean, var, g, b, eps, relu, sg, sb, p_local, pad, up4, need_dx, need_dw):

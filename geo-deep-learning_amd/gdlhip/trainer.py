@@ -109,7 +109,7 @@ class MiniTrainer:
                  limit_test_batches: int | None = None, monitor: str = "val_loss", mode: str = "min",
                  checkpoint_filename: str = "model-{epoch:02d}-{val_loss:.3f}", early_stopping_patience: int | None = None,
                  use_fused_adam: bool = True, fast_dev_run: bool = False, graph_step: str | bool = "auto",
-                 **ignored: Any) -> None:
+                 force_ddp: bool = False, **ignored: Any) -> None:
         self.max_epochs, self.precision = max_epochs, str(precision)
         self.gradient_clip_val, self.sync_batchnorm = gradient_clip_val, sync_batchnorm
         self.accumulate_grad_batches = max(1, int(accumulate_grad_batches))
@@ -124,8 +124,11 @@ class MiniTrainer:
         # (per-GPU batch <= 8, e.g. the reference's own batch 4, configs/dofa_config_RGB.yaml:85: ~550 launches of 5-20 us) and
         # its shapes are static; True = whenever it can be captured; False = never.  Batches of another shape (a ragged last
         # batch) run eagerly through the same optimizer.
+        # Under DDP (round 5) the captured step includes the collectives; only the nccl (RCCL) backend can be recorded, the ranks
+        # agree on the capture's outcome, and a failed capture leaves the training state untouched (gdlhip.graphs).
         self.graph_step = graph_step
         self.graph_max_batch = 8
+        self.force_ddp = force_ddp           # wrap in DDP even with ONE rank (the single-GPU RCCL tests of the capture path)
         self.graphed_steps = 0               # how many training steps were graph replays (tests / logs)
         self._graphed = None
         if ignored:
@@ -239,12 +242,20 @@ class MiniTrainer:
         model.configure_model()
         model.to(device)
         train_loader, val_loader = self._loaders(datamodule, train_dataloaders, val_dataloaders)
-        if self.world_size > 1:
+        want_graph = self.graph_step not in (False, "off", "false", None) and device.type == "cuda" and self.accumulate_grad_batches == 1
+        self._ddp_active = self.world_size > 1 or (self.force_ddp and dist.is_available() and dist.is_initialized())
+        if self._ddp_active:
             if self.sync_batchnorm:
                 model.model = nn.SyncBatchNorm.convert_sync_batchnorm(model.model)
             ddp_kw = {"device_ids": [device.index]} if device.type == "cuda" else {}
-            model.model = nn.parallel.DistributedDataParallel(model.model, gradient_as_bucket_view=True,
-                                                              find_unused_parameters=False, **ddp_kw)
+            ddp_kw.update(gradient_as_bucket_view=True, find_unused_parameters=False)
+            if want_graph:
+                from gdlhip.graphs import capturable_process_group, ddp_on_side_stream
+                want_graph = capturable_process_group()      # gloo: the step stays eager
+            if want_graph:
+                model.model = ddp_on_side_stream(model.model, **ddp_kw)      # (what a later whole-backward capture needs)
+            else:
+                model.model = nn.parallel.DistributedDataParallel(model.model, **ddp_kw)
         try:
             per_epoch = len(train_loader)
             self.estimated_stepping_batches = math.ceil(per_epoch / self.accumulate_grad_batches) * self.max_epochs
@@ -252,8 +263,7 @@ class MiniTrainer:
             self.estimated_stepping_batches = -1         # iterable loaders (the WebDataset datamodule)
         optimizers, sched_cfgs = model.configure_optimizers()
         opt = optimizers[0]
-        self._graph_ok = (self.graph_step not in (False, "off", "false", None) and device.type == "cuda" and self.world_size == 1
-                          and self.accumulate_grad_batches == 1)
+        self._graph_ok = want_graph
         step_opt = self._maybe_fuse(opt, device, capturable=self._graph_ok)
         self._graph_ok = self._graph_ok and getattr(step_opt, "capturable", False)
         self._graphed = None
@@ -388,14 +398,26 @@ class MiniTrainer:
                 self._graph_ok = False       # GPU-bound step: a graph buys nothing and doubles the activation memory
                 return False
             amp = torch.bfloat16 if self.precision in ("bf16-mixed", "bf16", "16-mixed", "16") else None
+            failure = None
             try:
+                # (under DDP the warm-up is raised to the 11 eager iterations torch asks for; all of them are undone)
                 self._graphed = GraphedTrainStep(model, step_opt, batch, autocast_dtype=amp, warmup=2, restore_state=True)
             except Exception as exc:  # noqa: BLE001  (anything the capture cannot record: fall back to eager steps for good)
-                logger.warning("MiniTrainer: hipGraph capture of the training step failed (%s: %s); running eagerly",
-                               type(exc).__name__, exc)
-                self._graph_ok, self._graphed = False, None
+                failure, self._graphed = f"{type(exc).__name__}: {exc}", None
+            if getattr(self, "_ddp_active", False) and self.world_size > 1:
+                # every rank ran the same warm-up collectives and then recorded (not ran) the captured ones: the process group is
+                # in step.  One all-reduce decides for everybody -- a rank replaying while another launches eagerly is legal for
+                # RCCL (same kernels in the same order) but a rank that FAILED would otherwise train differently
+                flag = torch.tensor([0.0 if failure else 1.0], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if flag.item() < 1.0 and failure is None:
+                    failure, self._graphed = "the capture failed on another rank", None
+            if failure is not None:
+                logger.warning("MiniTrainer: hipGraph capture of the training step failed (%s); running eagerly", failure)
+                self._graph_ok = False
                 return False
-            logger.info("MiniTrainer: training step captured into a hipGraph (per-GPU batch %d)", lead)
+            logger.info("MiniTrainer: training step captured into a hipGraph (per-GPU batch %d%s)", lead,
+                        ", DDP collectives included" if getattr(self, "_ddp_active", False) else "")
         static = self._graphed.static
         for k, v in tensors.items():
             s = static.get(k)
