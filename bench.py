@@ -156,8 +156,8 @@ def build_task(model: str, device, dist_on: bool, local: int, capturable: bool =
     if dist_on:
         # Lightning's `sync_batchnorm: true` + DDPStrategy(gradient_as_bucket_view=true)
         task.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(task.model)
-        task.model = torch.nn.parallel.DistributedDataParallel(
-            task.model, device_ids=[local], gradient_as_bucket_view=True, find_unused_parameters=False)
+        from gdlhip.graphs import ddp_on_side_stream      # (side stream: what a whole-step hipGraph capture under DDP needs)
+        task.model = ddp_on_side_stream(task.model, device_ids=[local], gradient_as_bucket_view=True, find_unused_parameters=False)
     (optimizer,), _ = task.configure_optimizers()
     return task, optimizer
 
@@ -524,7 +524,10 @@ def main() -> None:
     from gdlhip import ops
 
     torch.manual_seed(42 + rank)  # train.py:67 seeds 42
-    task, optimizer = build_task(args.model, device, dist_on, local)
+    # at the reference's own per-GPU batch (4) the DDP step is launch-bound: the line then also times the step replayed from a
+    # hipGraph that contains the RCCL collectives (MiniTrainer's default there); needs the device-side optimizer state
+    ddp_graph = dist_on and args.batch <= 8
+    task, optimizer = build_task(args.model, device, dist_on, local, capturable=ddp_graph)
     batch = synthetic_batch(args.batch, device, 42 + rank, args.model)
     use_bf16 = args.dtype == "bf16"
     train_step, infer_step = make_steps(task, optimizer, lambda: batch, use_bf16)
@@ -591,10 +594,13 @@ def main() -> None:
         from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
         stamps: list = []
 
+        stamping = [True]      # (a comm hook cannot be unregistered: after the measurement it only forwards to the stock all-reduce)
+
         def stamp_hook(state, bucket):
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            stamps.append((bucket.index(), bucket.buffer().numel() * bucket.buffer().element_size(), ev))
+            if stamping[0] and not torch.cuda.is_current_stream_capturing():
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                stamps.append((bucket.index(), bucket.buffer().numel() * bucket.buffer().element_size(), ev))
             return default_hooks.allreduce_hook(state, bucket)
         bucket_ready = None
         try:
@@ -620,6 +626,7 @@ def main() -> None:
                                     "bucket 0 holds the LAST layers of the model (first gradients of backward)"}
         except Exception as exc:  # noqa: BLE001  (private-ish torch API; never lose the line over a diagnostic)
             bucket_ready = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+        stamping[0] = False
         try:
             log = ddp_mod._get_ddp_logging_data()
             sizes = [x for x in str(log.get("bucket_sizes", "")).replace(",", " ").split() if x]
@@ -632,6 +639,29 @@ def main() -> None:
                     "syncbn_messages_per_step": {"forward": sync_msgs[0], "backward": sync_msgs[1]},
                     "step_ms_with_grad_sync": round(1e3 * dt_s / k_ab, 3), "step_ms_no_sync": round(1e3 * dt_ns / k_ab, 3),
                     "exposed_grad_comm_ms": round(1e3 * (dt_s - dt_ns) / k_ab, 3), "buckets": buckets, "bucket_ready": bucket_ready}
+
+    if ddp_info is not None and ddp_graph:
+        from gdlhip.graphs import GraphedTrainStep
+        failure, gt = None, None
+        try:
+            gt = GraphedTrainStep(task, optimizer, batch, autocast_dtype=torch.bfloat16 if use_bf16 else None)
+        except Exception as exc:  # noqa: BLE001  (report, keep the line)
+            failure = f"{type(exc).__name__}: {exc}"[:300]
+        if world > 1:      # all ranks replay or none does
+            flag = torch.tensor([0.0 if failure else 1.0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if flag.item() < 1.0:
+                failure, gt = failure or "the capture failed on another rank", None
+        if gt is not None:
+            k_g = max(args.steps, 20)
+            dt_g = timed(lambda: gt(), k_g, 3, world, device)
+            ddp_info["graphed"] = {"train_tiles_per_s": round(args.batch * world * k_g / dt_g, 2), "ms_per_step": round(1e3 * dt_g / k_g, 3),
+                                   "eager_ms_per_step": ddp_info["step_ms_with_grad_sync"],
+                                   "note": "whole DDP step (forward, SyncBN messages, backward with bucket all-reduces, clip, Adam) "
+                                           "replayed from ONE hipGraph per rank"}
+            del gt
+        else:
+            ddp_info["graphed"] = {"error": failure}
 
     pcie = None
     if not args.no_input_stage and "train" in res:

@@ -1873,6 +1873,92 @@ static int tapsum_launch(const void* const* zs, const int* hs, const int* ws, in
   return GDL_OK;
 }
 
+// ---- the same sum for ANY resize ratio (round 5): out[b, oy, ox, n] (+)= sum_(r,s) bilinear(z_(r,s))[oy + r - 1, ox + s - 1].
+// The kernels above are built around an integer factor (a cell of F output columns shares its source columns); DOFA-large's
+// top FPN level is int(73 * 0.5) = 36 pixels wide against 292 (models/utils.py:106-110: x 8.11), which sent the whole
+// `fpn_bottleneck` to the unfused path (concat buffer + a K = 9 * 4096 convolution at full resolution).  This is the plain
+// gather form -- per output vector 9 taps x 4 corners = 36 loads, f32 accumulation in a fixed order -- for the ONE level of a
+// pyramid that needs it: the source is small (it is the level being upsampled ~8 x) and stays in L2.
+template <typename V, int VEC>
+__global__ __launch_bounds__(256) void resize_conv3x3_fwd_sum_any_kernel(const void* __restrict__ z, int Hi, int Wi, int N, void* out,
+                                                                         int Ho, int Wo, int accumulate,
+                                                                         const float* __restrict__ addvec, int relu) {
+  const int cv = N / VEC;
+  const int j0 = blockIdx.x * 256 + threadIdx.x;
+  if (j0 >= Wo * cv) return;
+  const int b = blockIdx.y / Ho, oy = blockIdx.y - b * Ho;
+  const int ox = j0 / cv, c = (j0 - ox * cv) * VEC;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  const int64_t pix = 9ll * N;
+  const int64_t zb = (int64_t)b * Hi * Wi * pix + c;
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  int xs0[3], xs1[3]; float lxs[3]; bool xin[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) {
+    const int px = ox + s3 - 1;
+    xin[s3] = px >= 0 && px < Wo;
+    xs0[s3] = xs1[s3] = 0; lxs[s3] = 0.f;
+    if (xin[s3]) src_index(rx, px, Wi, xs0[s3], xs1[s3], lxs[s3]);
+  }
+#pragma unroll 1
+  for (int r = 0; r < 3; ++r) {
+    const int py = oy + r - 1;
+    if (py < 0 || py >= Ho) continue;              // the convolution's zero padding (uniform over the block)
+    int y0, y1; float ly;
+    src_index(ry, py, Hi, y0, y1, ly);
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+      if (!xin[s3]) continue;
+      const int64_t t = (int64_t)(3 * r + s3) * N;
+      float v00[VEC], v01[VEC], v10[VEC], v11[VEC];
+      V::ld(z, zb + ((int64_t)y0 * Wi + xs0[s3]) * pix + t, v00);
+      V::ld(z, zb + ((int64_t)y0 * Wi + xs1[s3]) * pix + t, v01);
+      V::ld(z, zb + ((int64_t)y1 * Wi + xs0[s3]) * pix + t, v10);
+      V::ld(z, zb + ((int64_t)y1 * Wi + xs1[s3]) * pix + t, v11);
+      const float lx = lxs[s3];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float top = v00[e] + lx * (v01[e] - v00[e]), bot = v10[e] + lx * (v11[e] - v10[e]);
+        acc[e] += top + ly * (bot - top);
+      }
+    }
+  }
+  const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * N + c;
+  if (accumulate) {
+    float prev[VEC];
+    V::ld(out, o, prev);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] += prev[e];
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    if (addvec) acc[e] += addvec[c + e];
+    if (relu) acc[e] = fmaxf(acc[e], 0.f);
+  }
+  V::st(out, o, acc);
+}
+
+extern "C" int gdl_resize_conv3x3_fwd_sum_any(const void* z, int hs, int ws, int dtype, int B, int N, void* out, int Ho, int Wo,
+                                              int accumulate, const float* addvec, int relu, gdl_stream_t stream) {
+  GDL_CHECK_ARG(z && out && hs > 0 && ws > 0 && B > 0 && N > 0 && Ho > 0 && Wo > 0, "gdl_resize_conv3x3_fwd_sum_any: bad args");
+  GDL_CHECK_ARG(dtype == GDL_F32 || dtype == GDL_BF16, "gdl_resize_conv3x3_fwd_sum_any: bad dtype");
+  const int vec = dtype == GDL_BF16 ? 8 : 4;
+  GDL_CHECK_ARG(N % vec == 0 && (uintptr_t)z % 16 == 0 && (uintptr_t)out % 16 == 0,
+                "gdl_resize_conv3x3_fwd_sum_any: N must be a multiple of the 16-byte vector, pointers 16-byte aligned");
+  GDL_CHECK_ARG((int64_t)B * Ho <= 65535, "gdl_resize_conv3x3_fwd_sum_any: B * Ho must fit one grid dimension");
+  const dim3 grid((unsigned)(((int64_t)Wo * (N / vec) + 255) / 256), (unsigned)(B * Ho));
+  if (dtype == GDL_BF16)
+    hipLaunchKernelGGL((resize_conv3x3_fwd_sum_any_kernel<V8, 8>), grid, dim3(256), 0, (hipStream_t)stream, z, hs, ws, N, out, Ho, Wo,
+                       accumulate, addvec, relu);
+  else
+    hipLaunchKernelGGL((resize_conv3x3_fwd_sum_any_kernel<V4<float>, 4>), grid, dim3(256), 0, (hipStream_t)stream, z, hs, ws, N, out, Ho,
+                       Wo, accumulate, addvec, relu);
+  GDL_CHECK_LAUNCH("gdl_resize_conv3x3_fwd_sum_any");
+  return GDL_OK;
+}
+
 extern "C" int gdl_resize_conv3x3_fwd_sum(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N,
                                           void* out, int Ho, int Wo, const float* addvec, int relu, gdl_stream_t stream) {
   return tapsum_launch(zs, hs, ws, nsrc, dtype, B, N, out, Ho, Wo, addvec, relu, nullptr, (hipStream_t)stream);
@@ -2007,7 +2093,7 @@ extern "C" int gdl_resize_conv3x3_bwd_gather(const void* dy, int dtype, int B, i
                 "gdl_resize_conv3x3_bwd_gather: N must be a multiple of the 16-byte vector, pointers 16-byte aligned");
   GDL_CHECK_ARG((int64_t)B * Hi <= 65535, "gdl_resize_conv3x3_bwd_gather: B * Hi must fit one grid dimension");
   const int nx = 2 * ((Wo + Wi - 1) / Wi) + 4;
-  GDL_CHECK_ARG(nx <= 20, "gdl_resize_conv3x3_bwd_gather: resize factors above 8 are not instantiated");
+  GDL_CHECK_ARG(nx <= 24, "gdl_resize_conv3x3_bwd_gather: resize factors above 10 are not instantiated");
   const dim3 grid((unsigned)((Wi * (N / vec) + 255) / 256), (unsigned)(B * Hi));
   hipStream_t s = (hipStream_t)stream;
   if (gather_mfma_launch(dy, dtype, B, Ho, Wo, N, g, Hi, Wi, s)) {
@@ -2016,9 +2102,11 @@ extern "C" int gdl_resize_conv3x3_bwd_gather(const void* dy, int dtype, int B, i
   }
 #define GATHER(V, VEC, NX, WXL) hipLaunchKernelGGL((resize_conv3x3_bwd_gather_kernel<V, VEC, NX, WXL>), grid, dim3(256), 0, s, dy, Ho, Wo, N, g, Hi, Wi)
   if (dtype == GDL_BF16) {
-    if (nx <= 8) GATHER(V8, 8, 8, false); else if (nx <= 12) GATHER(V8, 8, 12, false); else GATHER(V8, 8, 20, true);
+    if (nx <= 8) GATHER(V8, 8, 8, false); else if (nx <= 12) GATHER(V8, 8, 12, false); else if (nx <= 20) GATHER(V8, 8, 20, true);
+    else GATHER(V8, 8, 24, true);                  // non-integer factors just above 8 (DOFA-large: 36 -> 292)
   } else {
-    if (nx <= 8) GATHER(V4<float>, 4, 8, false); else if (nx <= 12) GATHER(V4<float>, 4, 12, false); else GATHER(V4<float>, 4, 20, true);
+    if (nx <= 8) GATHER(V4<float>, 4, 8, false); else if (nx <= 12) GATHER(V4<float>, 4, 12, false);
+    else if (nx <= 20) GATHER(V4<float>, 4, 20, true); else GATHER(V4<float>, 4, 24, true);
   }
 #undef GATHER
   GDL_CHECK_LAUNCH("gdl_resize_conv3x3_bwd_gather");
@@ -2041,7 +2129,7 @@ extern "C" int gdl_resize_conv3x3_bwd_gather2(const void* dy, int dtype, int B, 
   GDL_CHECK_ARG(ws_bytes >= gdl_resize_conv3x3_bwd_gather_workspace(dtype, B, Wo, N, Hi), "gdl_resize_conv3x3_bwd_gather2: workspace too small");
   GDL_CHECK_ARG((int64_t)B * Hi <= 65535, "gdl_resize_conv3x3_bwd_gather2: B * Hi must fit one grid dimension");
   const int nx = 2 * ((Wo + Wi - 1) / Wi) + 4;
-  GDL_CHECK_ARG(nx <= 20, "gdl_resize_conv3x3_bwd_gather2: resize factors above 8 are not instantiated");
+  GDL_CHECK_ARG(nx <= 24, "gdl_resize_conv3x3_bwd_gather2: resize factors above 10 are not instantiated");
   const int64_t plane = (int64_t)B * Hi * Wo * N;
   hipStream_t s = (hipStream_t)stream;
   if (gather_mfma_launch(dy, dtype, B, Ho, Wo, N, g, Hi, Wi, s)) {      // one pass on the matrix cores: the workspace stays unused
@@ -2053,10 +2141,12 @@ extern "C" int gdl_resize_conv3x3_bwd_gather2(const void* dy, int dtype, int B, 
 #define COLS(V, VEC, NX, WXL) hipLaunchKernelGGL((resize_conv3x3_bwd_cols_kernel<V, VEC, NX, WXL>), grid2, dim3(256), 0, s, ws, Wo, N, g, Hi, Wi, plane)
   if (dtype == GDL_BF16) {
     hipLaunchKernelGGL((resize_conv3x3_bwd_rows_kernel<V8, 8>), grid1, dim3(256), 0, s, dy, Ho, Wo, N, ws, Hi, plane);
-    if (nx <= 8) COLS(V8, 8, 8, false); else if (nx <= 12) COLS(V8, 8, 12, false); else COLS(V8, 8, 20, true);
+    if (nx <= 8) COLS(V8, 8, 8, false); else if (nx <= 12) COLS(V8, 8, 12, false); else if (nx <= 20) COLS(V8, 8, 20, true);
+    else COLS(V8, 8, 24, true);
   } else {
     hipLaunchKernelGGL((resize_conv3x3_bwd_rows_kernel<V4<float>, 4>), grid1, dim3(256), 0, s, dy, Ho, Wo, N, ws, Hi, plane);
-    if (nx <= 8) COLS(V4<float>, 4, 8, false); else if (nx <= 12) COLS(V4<float>, 4, 12, false); else COLS(V4<float>, 4, 20, true);
+    if (nx <= 8) COLS(V4<float>, 4, 8, false); else if (nx <= 12) COLS(V4<float>, 4, 12, false);
+    else if (nx <= 20) COLS(V4<float>, 4, 20, true); else COLS(V4<float>, 4, 24, true);
   }
 #undef COLS
   GDL_CHECK_LAUNCH("gdl_resize_conv3x3_bwd_gather2");

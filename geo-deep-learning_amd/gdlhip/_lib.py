@@ -103,6 +103,7 @@ SIGNATURES = {
     "gdl_resize_conv3x3_bwd_gather_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i]),
     "gdl_resize_conv3x3_bwd_gather2": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_l, c_p]),
     "gdl_resize_conv3x3_fwd_sum": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_p]),
+    "gdl_resize_conv3x3_fwd_sum_any": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
     "gdl_resize_conv3x3_fwd_sum_bn_rows": (c_l, [c_i, c_i, c_i]),
     "gdl_resize_conv3x3_fwd_sum_bn": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_f, c_p]),
     "gdl_bn_stats_finalize": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p, c_p, c_p, c_f, c_p]),

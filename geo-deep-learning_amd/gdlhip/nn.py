@@ -584,10 +584,12 @@ class _ConcatResizeConvBNTrain(Function):
 
 
 def _tapsum_levels_ok(levels) -> bool:
-    """levels[0] native, 1..3 further levels each upsampled by one integer factor of 2 / 4 / 8 (ops.resize_conv3x3_fwd_sum)."""
+    """levels[0] native, 1..3 further levels each upsampled: by an integer factor of 2 / 4 / 8 (one pass for all of them) or by
+    any other ratio up to 10 (one plain gather pass each) -- ops.resize_conv3x3_fwd_sum."""
     B, H, W, _ = levels[0].shape
     return (FUSE_TAPSUM and 2 <= len(levels) <= 4
-            and all(ops.resize_conv3x3_fwd_ok((lv.shape[1], lv.shape[2]), (H, W), B) for lv in levels[1:]))
+            and all(ops.resize_conv3x3_fwd_ok((lv.shape[1], lv.shape[2]), (H, W), B)
+                    or ops.resize_conv3x3_any_ok((lv.shape[1], lv.shape[2]), (H, W), B) for lv in levels[1:]))
 
 
 def concat_resize_conv_bn_act(levels: list[Tensor], conv: nn.Conv2d, norm: nn.Module, *, relu: bool = True) -> Tensor:
@@ -596,7 +598,7 @@ def concat_resize_conv_bn_act(levels: list[Tensor], conv: nn.Conv2d, norm: nn.Mo
     size = (levels[0].shape[1], levels[0].shape[2])
     def factor_ok(lv):
         fy, fx = size[0] / lv.shape[1], size[1] / lv.shape[2]
-        return (lv.shape[1], lv.shape[2]) == size or (1.0 < fy <= 8.0 and 1.0 < fx <= 8.0)
+        return (lv.shape[1], lv.shape[2]) == size or (1.0 < fy <= ops.MAX_ANY_RESIZE and 1.0 < fx <= ops.MAX_ANY_RESIZE)
     ok = (FUSE_CONCAT_BWD and norm.training and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.bias is None
           and conv.weight.shape[0] % 8 == 0 and all(lv.is_contiguous() and factor_ok(lv) for lv in levels)
           and levels[0].shape[0] * max(lv.shape[1] for lv in levels) <= 65535)
@@ -626,7 +628,7 @@ def concat_resize_conv_bn_act(levels: list[Tensor], conv: nn.Conv2d, norm: nn.Mo
     if not ok:
         if FUSE_CONCAT_BWD and norm.training:
             warn_unfused("3x3 ConvModule over a concat of resized levels", f"levels {[tuple(lv.shape) for lv in levels]}: needs "
-                         "contiguous levels, resize factors <= 8, N % 8 == 0 and batch * rows <= 65535")
+                         "contiguous levels, resize factors <= 10, N % 8 == 0 and batch * rows <= 65535")
         return conv_bn_act(concat_upsample(levels, size), conv, norm, relu=relu)
     sync_group = norm.process_group if isinstance(norm, nn.SyncBatchNorm) else False
     momentum = 0.1 if norm.momentum is None else norm.momentum

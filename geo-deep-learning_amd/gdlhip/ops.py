@@ -460,7 +460,9 @@ def resize_conv3x3_bwd(x_lo: Tensor, dy: Tensor | None, w_dgrad: Tensor | None, 
 def resize_conv3x3_fwd_sum(zs: list[Tensor], size: tuple[int, int], addvec: Tensor | None = None, relu: bool = False) -> Tensor:
     """sum_k sum_t shift_t(bilinear(zs[k][..., t*N:(t+1)*N] -> size)) (+ addvec, ReLU): the pixel side of
     conv3x3(pad 1)(bilinear resize(x)) once the nine tap products z = [W_0 x, ..., W_8 x] exist at low resolution
-    (gdl_resize_conv3x3_fwd_sum).  zs: 1..3 dense [B, h_k, w_k, 9 N] maps of one dtype, integer factors 2 / 4 / 8."""
+    (gdl_resize_conv3x3_fwd_sum).  zs: 1..3 dense [B, h_k, w_k, 9 N] maps of one dtype.  Sources whose size divides ``size`` by
+    2 / 4 / 8 go through the cell kernels (matrix cores in bf16) in ONE pass; any other ratio (DOFA-large's 36 -> 292) is added
+    by the plain gather kernel, one pass per such source (gdl_resize_conv3x3_fwd_sum_any)."""
     _need_cuda(*zs)
     if not 1 <= len(zs) <= 3:
         raise ValueError("resize_conv3x3_fwd_sum: 1..3 sources")
@@ -473,13 +475,24 @@ def resize_conv3x3_fwd_sum(zs: list[Tensor], size: tuple[int, int], addvec: Tens
         if z.shape[0] != B or z.shape[3] != N9 or z.dtype != z4[0].dtype or not z.is_contiguous():
             raise ValueError("resize_conv3x3_fwd_sum: sources must be contiguous NHWC maps with equal batch, channels and dtype")
     out = torch.empty((B, size[0], size[1], N), device=zs[0].device, dtype=zs[0].dtype)
-    n = len(z4)
-    ptrs = (C.c_void_p * 3)(*([z.data_ptr() for z in z4] + [None] * (3 - n)))
-    hs = (C.c_int * 3)(*([z.shape[1] for z in z4] + [1] * (3 - n)))
-    ws = (C.c_int * 3)(*([z.shape[2] for z in z4] + [1] * (3 - n)))
-    check(_lib.load().gdl_resize_conv3x3_fwd_sum(ptrs, hs, ws, n, dt(z4[0]), B, N, _p(out), size[0], size[1],
-                                                 _p(_f32vec(addvec, N, "addvec")), int(relu), _stream()),
-          "gdl_resize_conv3x3_fwd_sum")
+    cell = [z for z in z4 if resize_conv3x3_fwd_ok((z.shape[1], z.shape[2]), size, B)]
+    other = [z for z in z4 if not resize_conv3x3_fwd_ok((z.shape[1], z.shape[2]), size, B)]
+    lib = _lib.load()
+    av = _f32vec(addvec, N, "addvec")
+    if cell:
+        n = len(cell)
+        ptrs = (C.c_void_p * 3)(*([z.data_ptr() for z in cell] + [None] * (3 - n)))
+        hs = (C.c_int * 3)(*([z.shape[1] for z in cell] + [1] * (3 - n)))
+        ws = (C.c_int * 3)(*([z.shape[2] for z in cell] + [1] * (3 - n)))
+        # (addvec and the ReLU belong to the LAST pass over `out`)
+        check(lib.gdl_resize_conv3x3_fwd_sum(ptrs, hs, ws, n, dt(cell[0]), B, N, _p(out), size[0], size[1],
+                                             _p(None if other else av), int(relu and not other), _stream()),
+              "gdl_resize_conv3x3_fwd_sum")
+    for i, z in enumerate(other):
+        last = i == len(other) - 1
+        check(lib.gdl_resize_conv3x3_fwd_sum_any(_p(z), z.shape[1], z.shape[2], dt(z), B, N, _p(out), size[0], size[1],
+                                                 int(bool(cell) or i > 0), _p(av if last else None), int(relu and last), _stream()),
+              "gdl_resize_conv3x3_fwd_sum_any")
     return out
 
 
@@ -523,6 +536,16 @@ def resize_conv3x3_fwd_ok(lo: tuple[int, int], size: tuple[int, int], B: int) ->
     """Shapes gdl_resize_conv3x3_fwd_sum takes: one integer factor of 2, 4 or 8 in both directions, B * rows in one grid dim."""
     f = size[0] // max(lo[0], 1)
     return f in (2, 4, 8) and lo[0] * f == size[0] and lo[1] * f == size[1] and B * size[0] <= 65535
+
+
+MAX_ANY_RESIZE = 10.0     # the backward gather's widest window instantiation (2 * ceil(factor) + 4 <= 24 columns)
+
+
+def resize_conv3x3_any_ok(lo: tuple[int, int], size: tuple[int, int], B: int) -> bool:
+    """Upsampling ratios the low-resolution forms of conv3x3(resize(x)) take at all: any real factor in (1, 10] per direction
+    (forward: resize_conv3x3_fwd_sum's plain gather pass; backward: the gather kernels' window instantiations)."""
+    fy, fx = size[0] / max(lo[0], 1), size[1] / max(lo[1], 1)
+    return 1.0 < fy <= MAX_ANY_RESIZE and 1.0 < fx <= MAX_ANY_RESIZE and B * size[0] <= 65535
 
 
 def copy_cast(x: Tensor, out: Tensor | None = None, out_dtype: torch.dtype | None = None) -> Tensor:

@@ -262,7 +262,7 @@ int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int Wi, int C,
  * dW_t = sum_q G_t[q] (x) x[q] where G_t = U^T S_t^T dy.  This is the gather that builds the nine maps: dy dense
  * [B,Ho,Wo,N] -> g dense [B,Hi,Wi,9*N], tap block 8 - t (= gdl_pack_dgrad's flipped tap order, so the data gradient is
  * gdl_conv_gemm(g, w_dgrad) as a 1x1 convolution with K = 9 N, and the weight gradient nine 1x1 gdl_conv_wgrad calls on
- * channel slices of g).  Resize factors up to 8.  Deterministic. */
+ * channel slices of g).  Any real resize factor up to 10 (non-integer ratios included).  Deterministic. */
 int gdl_resize_conv3x3_bwd_gather(const void* dy, int dtype, int B, int Ho, int Wo, int N, void* g, int Hi, int Wi,
                                   gdl_stream_t stream);
 /* 1 when gdl_resize_conv3x3_bwd_gather runs its one-pass matrix-core form for this shape (bf16, N % 64 == 0, factor 2 or 4:
@@ -293,6 +293,12 @@ int gdl_resize_conv3x3_bwd_gather2(const void* dy, int dtype, int B, int Ho, int
  * convolution's zero padding) for 1..3 sources of one dtype, optional ReLU, dense [B,Ho,Wo,N].  Deterministic. */
 int gdl_resize_conv3x3_fwd_sum(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N, void* out,
                                int Ho, int Wo, const float* addvec, int relu, gdl_stream_t stream);
+/* The same sum for ONE source at ANY upsampling ratio (plain gather: 9 taps x 4 bilinear corners per output vector, f32
+ * accumulation): the level of a pyramid whose size does not divide the output's -- DOFA-large's top FPN level is
+ * int(73 * 0.5) = 36 wide against 292 (models/utils.py:106-110, upernet.py:144-152).  accumulate != 0: out += the sum (after
+ * gdl_resize_conv3x3_fwd_sum wrote the integer-factor levels); addvec / relu as above, applied after the accumulation. */
+int gdl_resize_conv3x3_fwd_sum_any(const void* z, int hs, int ws, int dtype, int B, int N, void* out, int Ho, int Wo, int accumulate,
+                                   const float* addvec, int relu, gdl_stream_t stream);
 /* the same with the train-mode BatchNorm statistics of the result as a side output (models/utils.py:10-52, ConvModule = conv ->
  * BatchNorm -> ReLU): per-channel mean / biased variance of `out` (and the running-stat update of nn.BatchNorm2d when the
  * running buffers are given) from per-block partial sums -- no separate pass over the output.  bf16, N % 64 == 0.

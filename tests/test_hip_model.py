@@ -420,11 +420,14 @@ def test_multiband_configs_match_oracle(encoder, size, bands, tol):
     model = model.to(DEV).eval()
     batch = synthetic_batch(1, bands, size, 5, seed)
     x = batch["image"].to(DEV)
+    warned = set(gnn._WARNED_FALLBACK)
     with torch.no_grad():
         yo = ref(batch["image"], batch["wavelengths"]).out
         y = model(x, batch["wavelengths"]).out
         with torch.autocast("cuda", dtype=torch.bfloat16):
             yb = model(x, batch["wavelengths"]).out
+    # round 5: DOFA-large's 292 / 146 / 73 / 36 pyramid (x 8.11 for the top level) no longer sends `fpn_bottleneck` to its unfused path
+    assert set(gnn._WARNED_FALLBACK) == warned, set(gnn._WARNED_FALLBACK) - warned
     scale = max(1.0, yo.abs().max().item())
     assert (y.cpu() - yo).abs().max().item() < tol * scale
     top2 = yo.topk(2, dim=1).values

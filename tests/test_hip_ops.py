@@ -1317,6 +1317,111 @@ def test_resize_conv3x3_fwd_sum(dtype, B, H, W, N, factors, vec, mfma):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,N,lows", [(2, 73, 73, 64, [(9, 9)]), (1, 40, 56, 64, [(20, 28), (10, 14), (5, 6)]),
+                                          (2, 37, 29, 72, [(9, 7), (4, 3)]), (1, 292, 292, 64, [(146, 146), (73, 73), (36, 36)])])
+def test_resize_conv3x3_fwd_sum_any_ratio(dtype, B, H, W, N, lows):
+    """Round 5: sources whose size does NOT divide the output's (DOFA-large's FPN pyramid is 292 / 146 / 73 / 36:
+    models/utils.py:106-110 gives int(73 * 0.5) = 36, i.e. x 8.11) -- integer-factor sources still take the one-pass cell kernels,
+    every other source one plain gather pass that accumulates into the same output; addvec / ReLU after the last pass.
+    vs torch's interpolate / pad / slice per tap."""
+    zs = [q(rnd(B, h, w, 9 * N, seed=20 + h), dtype) for h, w in lows]
+    assert not all(ops.resize_conv3x3_fwd_ok((h, w), (H, W), B) for h, w in lows)
+    ref = torch.zeros(B, N, H, W)
+    for z in zs:
+        zt = z.view(B, z.shape[1], z.shape[2], 9, N).permute(0, 3, 4, 1, 2)
+        for t in range(9):
+            up = F.pad(F.interpolate(zt[:, t], size=(H, W), mode="bilinear", align_corners=False), (1, 1, 1, 1))
+            ref += up[:, :, t // 3:t // 3 + H, t % 3:t % 3 + W]
+    ref = ref.permute(0, 2, 3, 1)
+    add = rnd(N, seed=5)
+    zd = [z.to(DEV, dtype) for z in zs]
+    y = ops.resize_conv3x3_fwd_sum(zd, (H, W))
+    y2 = ops.resize_conv3x3_fwd_sum(zd, (H, W), addvec=add.to(DEV), relu=True)
+    close(y, ref, dtype, "tap sum, any ratio")
+    for name, sl in (("top", (slice(None), 0)), ("bottom", (slice(None), -1)), ("left", (slice(None), slice(None), 0)),
+                     ("right", (slice(None), slice(None), -1))):
+        close(y[sl], ref[sl], dtype, f"tap sum {name} line", scale=ref.abs().max().item())
+    close(y2, F.relu(ref + add), dtype, "tap sum + shift + ReLU, any ratio")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Hi,Wi,N,Ho,Wo", [(2, 9, 9, 64, 73, 73), (1, 5, 6, 64, 40, 56), (1, 36, 36, 64, 292, 292), (2, 4, 3, 72, 37, 29),
+                                             (1, 7, 7, 64, 10, 10)])
+def test_resize_conv3x3_bwd_gather_any_ratio(dtype, B, Hi, Wi, N, Ho, Wo):
+    """The nine gathered maps G_t = resize^T shift_t^T dy for non-integer resize ratios up to 10 (36 -> 292 needs a window of 22
+    columns: the NX = 24 instantiations), single-pass and two-pass kernels, vs the definition through torch autograd."""
+    dy = q(rnd(B, Ho, Wo, N, seed=3), dtype)
+    dyd = dy.to(DEV, dtype)
+    outs = {}
+    try:
+        for two in (True, False):
+            ops.GATHER_TWO_PASS = two
+            outs[two] = ops.resize_conv3x3_bwd_gather(dyd, (Hi, Wi)).float().cpu()
+    finally:
+        ops.GATHER_TWO_PASS = True
+    x = torch.zeros(B, N, Hi, Wi, requires_grad=True)
+    padded = F.pad(F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False), (1, 1, 1, 1))
+    dyn = dy.permute(0, 3, 1, 2)
+    ref = torch.empty(B, Hi, Wi, 9 * N)
+    for r in range(3):
+        for s3 in range(3):
+            (gx,) = torch.autograd.grad((padded[:, :, r:r + Ho, s3:s3 + Wo] * dyn).sum(), x, retain_graph=True)
+            t = 3 * r + s3
+            ref[..., (8 - t) * N:(9 - t) * N] = gx.permute(0, 2, 3, 1)
+    close(outs[False], ref, dtype, "single-pass gather, any ratio")
+    close(outs[True], ref, dtype, "two-pass gather, any ratio")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_concat_resize_conv_with_a_non_integer_level(dtype):
+    """UperNet `fpn_bottleneck` (upernet.py:144-152) over a DOFA-large-shaped pyramid in miniature (37 / 18 / 9 / 4: the top
+    level's x 9.25 is no integer factor, like 292 / 36): eval and train forward + every gradient through the per-level
+    low-resolution forms -- no concat buffer, no `runs UNFUSED` warning -- vs torch autograd of interpolate -> cat -> conv2d ->
+    batch_norm -> relu."""
+    import copy
+    warned = set(gnn._WARNED_FALLBACK)
+    B, C, N, sizes = 2, 64, 64, [(37, 37), (18, 18), (9, 9), (4, 4)]
+    lv = [q(rnd(B, C, h, w, seed=30 + h), dtype) for h, w in sizes]
+    conv_r, bn_r = torch.nn.Conv2d(4 * C, N, 3, padding=1, bias=False), torch.nn.BatchNorm2d(N)
+    with torch.no_grad():
+        conv_r.weight.copy_(q(rnd(N, 4 * C, 3, 3, seed=1) * 0.05, dtype))
+        bn_r.weight.copy_(rnd(N, seed=2).abs() + 0.5)
+        bn_r.bias.copy_(rnd(N, seed=3) * 0.1)
+    conv, bn = copy.deepcopy(conv_r).to(DEV), copy.deepcopy(bn_r).to(DEV)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def reference(train):
+        xs = [t.clone().requires_grad_(True) for t in lv]
+        cat = torch.cat([xs[0]] + [F.interpolate(t, size=sizes[0], mode="bilinear", align_corners=False) for t in xs[1:]], 1)
+        bn_r.train(train)
+        return xs, F.relu(bn_r(conv_r(cat)))
+
+    def ours(train):
+        xs = [t.permute(0, 2, 3, 1).contiguous().to(DEV, dtype).requires_grad_(True) for t in lv]
+        bn.train(train)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            out = gnn.concat_resize_conv_bn_act(xs, conv, bn)
+        assert set(gnn._WARNED_FALLBACK) == warned, "the node fell back to its UNFUSED path"
+        return xs, out
+    with torch.no_grad():
+        _, ref_e = reference(False)
+        _, got_e = ours(False)
+    close(got_e.permute(0, 3, 1, 2), ref_e, dtype, "eval forward")
+    xs_r, ref_t = reference(True)
+    xs_o, got_t = ours(True)
+    close(got_t.permute(0, 3, 1, 2), ref_t, dtype, "train forward")
+    go = q(rnd(*ref_t.shape, seed=9), dtype)
+    ref_t.backward(go)
+    got_t.backward(go.permute(0, 2, 3, 1).contiguous().to(DEV, got_t.dtype))
+    gt = 1e-3 if dtype == torch.float32 else 4e-2
+    for j, (a, b) in enumerate(zip(xs_o, xs_r)):
+        err = (a.grad.float().cpu().permute(0, 3, 1, 2) - b.grad).norm().item()
+        assert err <= gt * b.grad.norm().item(), (j, err, b.grad.norm().item())
+    err = (conv.weight.grad.float().cpu() - conv_r.weight.grad).norm().item()
+    assert err <= gt * conv_r.weight.grad.norm().item(), ("weight", err)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("up", [2, 4])
 def test_resized_conv_eval_and_train_forward_at_low_resolution(dtype, up):
     """ConvModule(3x3, bias) on a bilinearly upsampled input (multilevel_neck.py:157-158), forward through the nine

@@ -306,9 +306,12 @@ def test_multiband_configs_train_step(encoder, size, bands, batch):
     lo.backward()
     crit = gnn.DiceLoss(mode="multiclass")
     x, yd = b["image"].to(DEV), y.to(DEV)
+    warned = set(gnn._WARNED_FALLBACK)
     r = model(x, b["wavelengths"], masks, aux)
     loss = crit(r.out, yd) + 0.4 * crit(r.aux, yd)
     loss.backward()
+    # round 5: no node of either config runs its UNFUSED path (DOFA-large's x 8.11 FPN level goes through the any-ratio kernels)
+    assert set(gnn._WARNED_FALLBACK) == warned, set(gnn._WARNED_FALLBACK) - warned
     scale = max(1.0, o.out.abs().max().item())
     tol = 1e-3 if encoder == "dofa_base" else 2e-3
     assert (r.out.detach().cpu() - o.out.detach()).abs().max().item() < tol * scale
@@ -668,3 +671,52 @@ def test_failed_graph_capture_leaves_training_state_untouched():
     for _ in range(3):
         gs(batch)
     assert task.train_samples_count == count1 + 3 * 2 and float(opt.device_state(0)[0]) == 5.0
+
+
+def test_ddp_training_step_captured_with_rccl_collectives(tmp_path):
+    """Round 5: the reference's deployment shape is DDP (`devices: -1`, `sync_batchnorm: true`) at per-GPU batch 4
+    (configs/dofa_config_RGB.yaml:5-13,85), where the eager step is bound by ~470 launches.  MiniTrainer(graph_step="auto") now
+    captures the WHOLE step under DistributedDataParallel -- bucket all-reduces and buffer broadcasts included -- when the
+    process group is RCCL (`nccl`).  Here on a one-rank RCCL group (the box has one GPU): wrapper built on a side stream, eleven
+    eager DDP iterations before the capture (all undone), every full batch a replay, and the trained parameters / epoch means
+    equal the eager DDP trainer's to the tolerance of test_minitrainer_graph_step_auto_matches_eager."""
+    import os
+    from functools import partial
+    import torch.distributed as dist
+    from gdlhip.graphs import find_ddp
+    from gdlhip.trainer import seed_everything
+    batches = [synthetic_batch(4, 3, 112, 5, s) for s in (1, 2, 3, 4)] + [synthetic_batch(2, 3, 112, 5, 5)]   # last one ragged
+    for bt in batches:
+        bt["mask"] = (bt["image"][:, :1] * 1.2 + 2).clamp(0, 4).long()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 2000))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    runs = {}
+    try:
+        for mode in (False, "auto"):
+            seed_everything(42)
+            _, task = _dofa_task(optimizer=partial(torch.optim.Adam, lr=1e-3),
+                                 scheduler=partial(torch.optim.lr_scheduler.StepLR, step_size=3, gamma=0.5),
+                                 scheduler_config={"interval": "step", "frequency": 1})
+            for blk in task.model.encoder.blocks:            # deterministic on both sides
+                blk.drop_prob = 0.0
+            task.model.aux_head.dropout_ratio = 0.0
+            tr = MiniTrainer(max_epochs=2, precision="32", gradient_clip_val=1.0, default_root_dir=str(tmp_path / str(mode)),
+                             graph_step=mode, sync_batchnorm=True, force_ddp=True)
+            tr.fit(task, train_dataloaders=batches, val_dataloaders=[batches[0]])
+            assert find_ddp(task) is not None and any(isinstance(m, torch.nn.SyncBatchNorm) for m in task.modules())
+            runs[mode] = (task, tr)
+    finally:
+        dist.destroy_process_group()
+    (te, tre), (tg, trg) = runs[False], runs["auto"]
+    assert tre.graphed_steps == 0 and trg.graphed_steps == 8 and tre.global_step == trg.global_step == 10
+    assert abs(tre.callback_metrics["train_loss"] - trg.callback_metrics["train_loss"]) < 1e-5
+    assert abs(tre.callback_metrics["val_loss"] - trg.callback_metrics["val_loss"]) < 1e-5
+    pe = dict(te.named_parameters())
+    for n, p in tg.named_parameters():
+        if p.requires_grad:
+            d = (p - pe[n]).abs()
+            assert d.max().item() <= 8e-3 and (d > 1e-4).float().mean().item() < 2e-2, (n, d.max().item())
+    gg = trg._optimizers[0]
+    some = next(p for p in tg.parameters() if p.requires_grad)
+    assert gg.state[some]["step"] == 10 and float(gg.device_state(0)[0]) == 10.0
