@@ -389,6 +389,157 @@ __global__ __launch_bounds__(256) void bn_bwd_dx(const void* __restrict__ x, con
   }
 }
 
+// ---------------------------------------------------------------- small maps: the whole BatchNorm in ONE launch per direction
+// Round 5.  At the reference's own per-GPU batch of 4 (configs/dofa_config_RGB.yaml:85) fourteen of the 21 train-mode
+// ConvModules of DOFA + UperNet have at most 36 x 36 x 4 = 5184 pixels: their BatchNorm is five launches forward (partial
+// statistics, final, normalise) and backward (partial sums, final, dx) of 5-10 us each, shorter than the gap between two
+// dependent launches -- in eager mode and inside a hipGraph alike.  Here one workgroup owns FOUR channels over ALL pixels:
+// pass 1 accumulates the sums (f32 per thread, f64 across the block, like the multi-block kernels), the statistics are
+// finished in LDS, pass 2 re-reads its 8 B / pixel column (just read: L2) and writes the result.  grid = C / 4 workgroups of
+// 256 threads, a thread strides 256 pixels with four loads in flight.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const void* __restrict__ x, void* y, int64_t P, int C, int64_t x_sP,
+                                                           int64_t y_sP, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int relu,
+                                                           float* __restrict__ mean, float* __restrict__ var, float* running_mean,
+                                                           float* running_var, float momentum) {
+  __shared__ double ps[256][4], pq[256][4];
+  __shared__ float smu[4], ssc[4], sbe[4];
+  const int t = threadIdx.x, c = blockIdx.x * 4;
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  int64_t p = t;
+  for (; p + 3 * 256 < P; p += 4 * 256) {
+    float v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load4<T>(x, (p + 256 * u) * x_sP + c, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[j] += v[u][j]; q[j] += v[u][j] * v[u][j]; }
+  }
+  for (; p < P; p += 256) {
+    float v[4];
+    load4<T>(x, p * x_sP + c, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { ps[t][j] = (double)s[j]; pq[t][j] = (double)q[j]; }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {                 // fixed-order tree: deterministic
+    if (t < o) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ps[t][j] += ps[t + o][j]; pq[t][j] += pq[t + o][j]; }
+    }
+    __syncthreads();
+  }
+  if (t < 4) {
+    const double m = ps[0][t] / (double)P;
+    double v = pq[0][t] / (double)P - m * m;
+    v = v > 0 ? v : 0;
+    mean[c + t] = (float)m;
+    var[c + t] = (float)v;
+    if (running_mean) {
+      const double unb = P > 1 ? v * (double)P / (double)(P - 1) : v;
+      running_mean[c + t] = (float)((1.0 - momentum) * running_mean[c + t] + momentum * m);
+      running_var[c + t] = (float)((1.0 - momentum) * running_var[c + t] + momentum * unb);
+    }
+    smu[t] = (float)m;
+    ssc[t] = rsqrtf((float)v + eps) * gamma[c + t];   // the same f32 expressions as bn_apply_kernel: identical outputs
+    sbe[t] = beta[c + t];
+  }
+  __syncthreads();
+  float mu[4], sc[4], be[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { mu[j] = smu[j]; sc[j] = ssc[j]; be[j] = sbe[j]; }
+  for (p = t; p < P; p += 256) {
+    float v[4];
+    load4<T>(x, p * x_sP + c, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float o = (v[j] - mu[j]) * sc[j] + be[j];
+      v[j] = relu ? fmaxf(o, 0.f) : o;
+    }
+    store4<T>(y, p * y_sP + c, v);
+  }
+}
+
+// backward: dbeta = sum g', dgamma = sum g' xhat (written out: they are the parameter gradients), then
+// dx = gamma rstd (g' - dbeta / P - xhat dgamma / P), g' = dy [bn(x) > 0]; same per-element expressions as bn_bwd_partial / bn_bwd_dx
+template <typename T>
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy, void* dx, int64_t P,
+                                                           int C, int64_t x_sP, int64_t dy_sP, int64_t dx_sP,
+                                                           const float* __restrict__ mean, const float* __restrict__ var,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                           int relu, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double ps[256][4], pq[256][4];
+  __shared__ float sk1[4], sk2[4];
+  const int t = threadIdx.x, c = blockIdx.x * 4;
+  float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; rs[j] = rsqrtf(var[c + j] + eps); ga[j] = gamma[c + j]; be[j] = beta[c + j]; }
+  float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  int64_t p = t;
+  for (; p + 256 < P; p += 2 * 256) {
+    float v[2][4], g[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { load4<T>(x, (p + 256 * u) * x_sP + c, v[u]); load4<T>(dy, (p + 256 * u) * dy_sP + c, g[u]); }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (v[u][j] - mu[j]) * rs[j];
+        const float gg = (relu && !(xh * ga[j] + be[j] > 0.f)) ? 0.f : g[u][j];
+        s[j] += gg; q[j] += gg * xh;
+      }
+  }
+  for (; p < P; p += 256) {
+    float v[4], g[4];
+    load4<T>(x, p * x_sP + c, v);
+    load4<T>(dy, p * dy_sP + c, g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (v[j] - mu[j]) * rs[j];
+      const float gg = (relu && !(xh * ga[j] + be[j] > 0.f)) ? 0.f : g[j];
+      s[j] += gg; q[j] += gg * xh;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { ps[t][j] = (double)s[j]; pq[t][j] = (double)q[j]; }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ps[t][j] += ps[t + o][j]; pq[t][j] += pq[t + o][j]; }
+    }
+    __syncthreads();
+  }
+  if (t < 4) {
+    const float db = (float)ps[0][t], dg = (float)pq[0][t];
+    dbeta[c + t] = db;
+    dgamma[c + t] = dg;
+    const float invP = 1.0f / (float)P;
+    sk1[t] = db * invP;
+    sk2[t] = dg * invP;
+  }
+  __syncthreads();
+  float k1[4], k2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { k1[j] = sk1[j]; k2[j] = sk2[j]; }
+  for (p = t; p < P; p += 256) {
+    float v[4], g[4];
+    load4<T>(x, p * x_sP + c, v);
+    load4<T>(dy, p * dy_sP + c, g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (v[j] - mu[j]) * rs[j];
+      const float gg = (relu && !(xh * ga[j] + be[j] > 0.f)) ? 0.f : g[j];
+      v[j] = ga[j] * rs[j] * (gg - k1[j] - xh * k2[j]);
+    }
+    store4<T>(dx, p * dx_sP + c, v);
+  }
+}
+
 // pixel splits of the elementwise BN kernels: ~4096 blocks in total, >= 16 pixels per wave
 int bn_ew_splits(int64_t P, int C) {
   const int cg = (C + 255) / 256;
@@ -436,6 +587,42 @@ extern "C" int gdl_layernorm_fwd(const float* x, int64_t x_stride, const float* 
 
 extern "C" int64_t gdl_bn_stats_workspace(int64_t P, int C) {
   return (int64_t)bn_nsplit(P, C) * 2 * C * sizeof(float);
+}
+
+// One-launch train-mode BatchNorm(+ReLU) for small maps (see bn_small_fwd_kernel): statistics, running-estimate update and the
+// normalised output.  y may alias x.  mean / var [C] are outputs (saved for the backward).
+extern "C" int gdl_bn_small_fwd(const void* x, void* y, int dtype, int64_t P, int C, int64_t x_sP, int64_t y_sP, const float* gamma,
+                                const float* beta, float eps, int relu, float* mean, float* var, float* running_mean,
+                                float* running_var, float momentum, gdl_stream_t stream) {
+  GDL_CHECK_ARG(x && y && gamma && beta && mean && var, "gdl_bn_small_fwd: null pointer");
+  GDL_CHECK_ARG(dtype == GDL_F32 || dtype == GDL_BF16, "gdl_bn_small_fwd: bad dtype");
+  GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && y_sP % 4 == 0 && P > 0, "gdl_bn_small_fwd: C and strides must be multiples of 4");
+  if (dtype == GDL_BF16)
+    hipLaunchKernelGGL(bn_small_fwd_kernel<uint16_t>, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, x, y, P, C, x_sP, y_sP, gamma, beta,
+                       eps, relu, mean, var, running_mean, running_var, momentum);
+  else
+    hipLaunchKernelGGL(bn_small_fwd_kernel<float>, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, x, y, P, C, x_sP, y_sP, gamma, beta,
+                       eps, relu, mean, var, running_mean, running_var, momentum);
+  GDL_CHECK_LAUNCH("gdl_bn_small_fwd");
+  return GDL_OK;
+}
+
+// One-launch backward of the same: dgamma / dbeta [C] (f32 outputs) and dx (may alias x or dy).  Single-process statistics only
+// (under SyncBatchNorm the sums cross the ranks between the two passes: gdl_bn_bwd_reduce + gdl_bn_bwd_dx).
+extern "C" int gdl_bn_small_bwd(const void* x, const void* dy, void* dx, int dtype, int64_t P, int C, int64_t x_sP, int64_t dy_sP,
+                                int64_t dx_sP, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                                int relu, float* dgamma, float* dbeta, gdl_stream_t stream) {
+  GDL_CHECK_ARG(x && dy && dx && mean && var && gamma && beta && dgamma && dbeta, "gdl_bn_small_bwd: null pointer");
+  GDL_CHECK_ARG(dtype == GDL_F32 || dtype == GDL_BF16, "gdl_bn_small_bwd: bad dtype");
+  GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && dy_sP % 4 == 0 && dx_sP % 4 == 0 && P > 0, "gdl_bn_small_bwd: C and strides must be multiples of 4");
+  if (dtype == GDL_BF16)
+    hipLaunchKernelGGL(bn_small_bwd_kernel<uint16_t>, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, x, dy, dx, P, C, x_sP, dy_sP, dx_sP,
+                       mean, var, gamma, beta, eps, relu, dgamma, dbeta);
+  else
+    hipLaunchKernelGGL(bn_small_bwd_kernel<float>, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, x, dy, dx, P, C, x_sP, dy_sP, dx_sP,
+                       mean, var, gamma, beta, eps, relu, dgamma, dbeta);
+  GDL_CHECK_LAUNCH("gdl_bn_small_bwd");
+  return GDL_OK;
 }
 
 extern "C" int gdl_bn_stats(const void* x, int dtype, int64_t P, int C, int64_t x_sP, float* mean,

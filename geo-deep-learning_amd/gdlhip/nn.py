@@ -306,7 +306,9 @@ def _cba_conv(x, weight, cb, pad, up4, sync_group, running_mean, running_var, mo
     if up4:        # other resize factors: the upsampled map is a temporary of the forward only (backward works on x)
         return ops.conv_gemm(ops.bilinear(x, (up4 * x.shape[1], up4 * x.shape[2])), gemm_weight(weight, cd), R=r, S=s, pad=pad,
                              bias=cb), None
-    if FUSE_CONV_STATS and cd == torch.bfloat16:
+    small = (sync_group is False or _world(sync_group) == 1) and x.dim() == 4 and ops.BN_SMALL_MAX_PIXELS > 0 and \
+        x.shape[0] * ((x.shape[1] + 2 * pad - r) + 1) * ((x.shape[2] + 2 * pad - s) + 1) <= ops.BN_SMALL_MAX_PIXELS
+    if FUSE_CONV_STATS and cd == torch.bfloat16 and not small:     # (small maps: the whole BatchNorm is ONE launch, ops.bn_small_fwd)
         # the batch statistics as a side output of the convolution's epilogue (per-wave partial sums of the bf16 outputs)
         # wherever the launch is made of whole tiles on the coalesced-epilogue kernels: no statistics pass over y
         y, partials, rows = ops.conv_gemm(x, gemm_weight(weight, cd), R=r, S=s, pad=pad, bias=cb, want_stats=True)
@@ -382,10 +384,20 @@ class _ConvBNActTrain(Function):
                 update_running_stats(running_mean, running_var, mean, var, momentum, total)
             p_share = p_local / total          # this rank's share of the global pixel count (device scalar)
         else:
-            mean, var = stats_done if stats_done is not None else ops.bn_stats(y, running_mean, running_var, momentum)
+            out = None
+            if stats_done is None and ops.bn_small_ok(y):
+                # a small map (the reference's own per-GPU batch of 4 makes most decoder layers small): statistics, running
+                # estimates and the normalised output in ONE launch
+                out, mean, var = ops.bn_small_fwd(y, gamma.detach(), beta.detach(), eps, relu, running_mean, running_var, momentum)
+            else:
+                mean, var = stats_done if stats_done is not None else ops.bn_stats(y, running_mean, running_var, momentum)
             if running_mean is not None:     # written through raw pointers: invalidate the eval-mode fold cache
                 mark_updated(running_mean)
                 mark_updated(running_var)
+            if out is not None:
+                ctx.save_for_backward(x, weight, y, mean, var, gamma, beta)
+                ctx.cfg = (pad, relu, eps, conv_bias is not None, sync_group, world, p_local, p_share, up4)
+                return out
         out = ops.bn_apply(y, mean, var, gamma.detach(), beta.detach(), eps, relu)
         ctx.save_for_backward(x, weight, y, mean, var, gamma, beta)
         ctx.cfg = (pad, relu, eps, conv_bias is not None, sync_group, world, p_local, p_share, up4)
@@ -399,6 +411,12 @@ class _ConvBNActTrain(Function):
         if gout.dtype != y.dtype:
             gout = to_compute(gout, y.dtype)
         g, b = gamma.detach(), beta.detach()
+        if world == 1 and ops.bn_small_ok(y) and not (up4 and FUSE_BN_BWD_GATHER):
+            # small map: sums, parameter gradients and dy (written over y) in ONE launch
+            dy, dgamma, dbeta = ops.bn_small_bwd(y, gout, mean, var, g, b, eps, relu, out=y)
+            dbias = torch.zeros(n, device=x.device, dtype=torch.float32) if has_bias and ctx.needs_input_grad[2] else None
+            dx, dw = _cba_grads(x, weight, dy, pad, up4, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+            return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
         dgamma, dbeta = ops.bn_bwd_reduce(y, gout, mean, var, g, b, eps, relu)
         sg, sb = dgamma, dbeta
         if world > 1:

@@ -10,6 +10,7 @@ argument checks (dofa_v2.py:439-441, multilevel_neck.py:141-146).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 from torch import Tensor
@@ -337,6 +338,46 @@ def bn_apply(x: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, beta: Tensor, 
     check(_lib.load().gdl_bn_apply(_p(x), _p(out), dt(x), P, Cc, sP, sPo, _p(mean), _p(var),
                                    _p(gamma), _p(beta), eps, int(relu), _stream()), "gdl_bn_apply")
     return out
+
+
+BN_SMALL_MAX_PIXELS = int(os.environ.get("GDL_BN_SMALL_PIXELS", "8192"))   # A/B hook: 0 = always the multi-launch kernels
+
+
+def bn_small_ok(x: Tensor) -> bool:
+    """Maps the one-launch BatchNorm kernels take: at most BN_SMALL_MAX_PIXELS pixels (each workgroup walks ALL pixels of its
+    four channels: beyond a few thousand the many-workgroup kernels win)."""
+    if x.dim() < 2 or x.shape[-1] % 4:
+        return False
+    return 0 < x.numel() // x.shape[-1] <= BN_SMALL_MAX_PIXELS
+
+
+def bn_small_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu: bool, running_mean: Tensor | None = None,
+                 running_var: Tensor | None = None, momentum: float = 0.1):
+    """Train-mode BatchNorm(+ReLU) of a small map in ONE launch: (out, mean, biased var); updates the running buffers."""
+    _need_cuda(x)
+    P, Cc, sP = _pix(x, "bn_small_fwd x")
+    out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    _, _, sPo = _pix(out, "bn_small_fwd out")
+    mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    var = torch.empty_like(mean)
+    check(_lib.load().gdl_bn_small_fwd(_p(x), _p(out), dt(x), P, Cc, sP, sPo, _p(gamma), _p(beta), eps, int(relu), _p(mean), _p(var),
+                                       _p(running_mean), _p(running_var), momentum, _stream()), "gdl_bn_small_fwd")
+    return out, mean, var
+
+
+def bn_small_bwd(x: Tensor, dy: Tensor, mean, var, gamma, beta, eps, relu, out: Tensor | None = None):
+    """Backward of bn_small_fwd in ONE launch: (dx, dgamma, dbeta).  ``out`` may be x (dx then replaces the saved conv output)."""
+    P, Cc, sP = _pix(x, "bn_small_bwd x")
+    _, _, sPd = _pix(dy, "bn_small_bwd dy")
+    if dy.dtype != x.dtype:
+        raise ValueError("bn_small_bwd: dy dtype must match x")
+    dx = out if out is not None else torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    _, _, sPx = _pix(dx, "bn_small_bwd dx")
+    dgamma = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    check(_lib.load().gdl_bn_small_bwd(_p(x), _p(dy), _p(dx), dt(x), P, Cc, sP, sPd, sPx, _p(mean), _p(var), _p(gamma), _p(beta), eps,
+                                       int(relu), _p(dgamma), _p(dbeta), _stream()), "gdl_bn_small_bwd")
+    return dx, dgamma, dbeta
 
 
 def bn_bwd_reduce(x, dy, mean, var, gamma, beta, eps, relu):

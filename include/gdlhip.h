@@ -157,6 +157,18 @@ int gdl_bn_bwd_dx(const void* x, const void* dy, void* dx, int dtype, int64_t P,
                   const float* gamma, const float* beta, float eps, int relu,
                   const float* dgamma_sum, const float* dbeta_sum, int64_t P_total,
                   gdl_stream_t stream);
+/* The whole train-mode BatchNorm(+ReLU) of a SMALL map in one launch per direction (one workgroup = four channels over all
+ * pixels: statistics, running-estimate update, normalised output / sums, parameter gradients, dx).  For the maps of at most a
+ * few thousand pixels that a per-GPU batch of 4 (configs/dofa_config_RGB.yaml:85) gives most ConvModules of the decoder
+ * (models/utils.py:10-52, upernet.py:62-127): the three launches of each direction above are shorter than the gap between
+ * dependent launches there.  Same arithmetic as gdl_bn_stats + gdl_bn_apply resp. gdl_bn_bwd_reduce + gdl_bn_bwd_dx.
+ * Single-process statistics only (SyncBatchNorm exchanges the sums between the two passes). */
+int gdl_bn_small_fwd(const void* x, void* y, int dtype, int64_t P, int C, int64_t x_sP, int64_t y_sP, const float* gamma,
+                     const float* beta, float eps, int relu, float* mean, float* var, float* running_mean, float* running_var,
+                     float momentum, gdl_stream_t stream);
+int gdl_bn_small_bwd(const void* x, const void* dy, void* dx, int dtype, int64_t P, int C, int64_t x_sP, int64_t dy_sP, int64_t dx_sP,
+                     const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
+                     float* dgamma, float* dbeta, gdl_stream_t stream);
 
 /* ---- transformer-block backward (timm Block dofa_v2.py:248-263, MiT Block mix_transformer.py:160-221) ----
  * Column reductions (parameter gradients) go through per-block partials in `ws`

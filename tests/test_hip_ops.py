@@ -442,6 +442,52 @@ def test_batchnorm_train(dtype, B, H, W, C):
         close(dx.permute(0, 3, 1, 2), xr.grad, dtype, "bn dx", scale=xr.grad.abs().max().item() + 1e-3)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("B,H,W,C", [(4, 36, 36, 256), (4, 1, 1, 256), (2, 3, 3, 768), (4, 18, 18, 768), (1, 1, 1, 64), (3, 37, 5, 12)])
+def test_batchnorm_small_map_single_launch(dtype, B, H, W, C, relu):
+    """Round 5: gdl_bn_small_fwd / gdl_bn_small_bwd -- the whole train-mode BatchNorm(+ReLU) of a small map in one launch per
+    direction.  Outputs, saved statistics and running estimates equal the multi-launch kernels' (same per-element f32
+    expressions; the sums are formed in another order: f32 tolerance), and both match torch's batch_norm autograd."""
+    x = q(rnd(B, H, W, C) * 2 + 0.5, dtype)
+    g, b = rnd(C, seed=1), rnd(C, seed=2)
+    rm, rv = rnd(C, seed=3) * 0.1, rnd(C, seed=4).abs() + 0.5
+    dy = q(rnd(B, H, W, C, seed=5), dtype)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    yr = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    yr = F.relu(yr) if relu else yr
+    yr.backward(dy.permute(0, 3, 1, 2))
+    xd, gd, bd, dyd = x.to(DEV, dtype), g.to(DEV), b.to(DEV), dy.to(DEV, dtype)
+    assert ops.bn_small_ok(xd)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    y, mean, var = ops.bn_small_fwd(xd, gd, bd, 1e-5, relu, rmd, rvd, 0.1)
+    rm2, rv2 = rm.to(DEV), rv.to(DEV)
+    mean2, var2 = ops.bn_stats(xd, rm2, rv2, 0.1)
+    y2 = ops.bn_apply(xd, mean2, var2, gd, bd, 1e-5, relu)
+    close(mean, mean2, torch.float32, "mean vs multi-launch")
+    close(var, var2, torch.float32, "var vs multi-launch", scale=max(var2.abs().max().item(), 1e-3))
+    close(rmd, rm_ref, torch.float32, "running_mean")
+    close(rvd, rv_ref, torch.float32, "running_var")
+    close(y, y2, dtype, "fwd vs multi-launch")
+    close(y.permute(0, 3, 1, 2), yr, dtype, "fwd vs torch")
+    if B * H * W > 2:
+        dx, dg, db = ops.bn_small_bwd(xd, dyd, mean2, var2, gd, bd, 1e-5, relu)
+        dg2, db2 = ops.bn_bwd_reduce(xd, dyd, mean2, var2, gd, bd, 1e-5, relu)
+        dx2 = ops.bn_bwd_dx(xd, dyd, mean2, var2, gd, bd, 1e-5, relu, dg2, db2, B * H * W)
+        close(dg, dg2, torch.float32, "dgamma vs multi-launch", scale=max(dg2.abs().max().item(), 1.0))
+        close(db, db2, torch.float32, "dbeta vs multi-launch", scale=max(db2.abs().max().item(), 1.0))
+        close(dx, dx2, dtype, "dx vs multi-launch", scale=dx2.float().abs().max().item() + 1e-3)
+        close(dg, gr.grad, dtype, "dgamma")
+        close(db, br.grad, dtype, "dbeta")
+        close(dx.permute(0, 3, 1, 2), xr.grad, dtype, "dx vs torch", scale=xr.grad.abs().max().item() + 1e-3)
+        # in place over x (what the ConvModule node does with its saved convolution output)
+        xin = xd.clone()
+        dx3, _, _ = ops.bn_small_bwd(xin, dyd, mean2, var2, gd, bd, 1e-5, relu, out=xin)
+        assert dx3.data_ptr() == xin.data_ptr() and torch.equal(dx3, dx)
+
+
 def test_bn_fold_matches_eval_bn():
     C = 96
     g, b, rm, rv = rnd(C), rnd(C, seed=1), rnd(C, seed=2), rnd(C, seed=3).abs() + 0.3
