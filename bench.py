@@ -156,8 +156,14 @@ def build_task(model: str, device, dist_on: bool, local: int, capturable: bool =
     if dist_on:
         # Lightning's `sync_batchnorm: true` + DDPStrategy(gradient_as_bucket_view=true)
         task.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(task.model)
-        from gdlhip.graphs import ddp_on_side_stream      # (side stream: what a whole-step hipGraph capture under DDP needs)
-        task.model = ddp_on_side_stream(task.model, device_ids=[local], gradient_as_bucket_view=True, find_unused_parameters=False)
+        ddp_kw = dict(device_ids=[local], gradient_as_bucket_view=True, find_unused_parameters=False)
+        if capturable:
+            # a later whole-step hipGraph capture needs wrapper construction, warm-up and capture on ONE side stream: main() makes
+            # that stream (ddp.gdl_stream) the current one for everything it times
+            from gdlhip.graphs import ddp_on_side_stream
+            task.model = ddp_on_side_stream(task.model, **ddp_kw)
+        else:
+            task.model = torch.nn.parallel.DistributedDataParallel(task.model, **ddp_kw)
     (optimizer,), _ = task.configure_optimizers()
     return task, optimizer
 
@@ -528,6 +534,8 @@ def main() -> None:
     # hipGraph that contains the RCCL collectives (MiniTrainer's default there); needs the device-side optimizer state
     ddp_graph = dist_on and args.batch <= 8
     task, optimizer = build_task(args.model, device, dist_on, local, capturable=ddp_graph)
+    if ddp_graph:
+        torch.cuda.set_stream(task.model.gdl_stream)      # (see build_task)
     batch = synthetic_batch(args.batch, device, 42 + rank, args.model)
     use_bf16 = args.dtype == "bf16"
     train_step, infer_step = make_steps(task, optimizer, lambda: batch, use_bf16)
@@ -646,7 +654,9 @@ def main() -> None:
         try:
             gt = GraphedTrainStep(task, optimizer, batch, autocast_dtype=torch.bfloat16 if use_bf16 else None)
         except Exception as exc:  # noqa: BLE001  (report, keep the line)
+            import traceback
             failure = f"{type(exc).__name__}: {exc}"[:300]
+            print("bench.py: DDP step capture failed:\n" + traceback.format_exc(), file=sys.stderr)
         if world > 1:      # all ranks replay or none does
             flag = torch.tensor([0.0 if failure else 1.0], device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)

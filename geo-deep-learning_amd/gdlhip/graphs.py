@@ -57,13 +57,18 @@ def capturable_process_group(group=None) -> bool:
 
 
 def ddp_on_side_stream(module: torch.nn.Module, **ddp_kwargs) -> torch.nn.parallel.DistributedDataParallel:
-    """DistributedDataParallel(module) constructed under a side stream, as a later whole-backward capture needs (the reducer's
-    bucket buffers and hooks must not be tied to the stream the capture runs on)."""
+    """DistributedDataParallel(module) constructed under a dedicated side stream, kept as ``ddp.gdl_stream``.  DDP creates (and
+    stashes) every parameter's AccumulateGrad node at construction and autograd runs such a node on the stream it was created
+    on: a whole-backward capture only works when wrapper construction, warm-up iterations and the capture itself use ONE
+    non-default stream (measured, round 5: with the wrapper built on one side stream and the capture on torch.cuda.graph's own,
+    the capture dies with hipErrorStreamCaptureUnsupported).  GraphedTrainStep picks ``gdl_stream`` up; a trainer should run its
+    eager DDP steps under it too (gradient producer and AccumulateGrad then share a stream: no cross-stream waits)."""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         ddp = torch.nn.parallel.DistributedDataParallel(module, **ddp_kwargs)
     torch.cuda.current_stream().wait_stream(side)
+    ddp.gdl_stream = side
     return ddp
 
 
@@ -98,9 +103,15 @@ class GraphedTrainStep:
             msg = "GraphedTrainStep needs FusedAdam(capturable=True): step count and learning rate must live on the device"
             raise ValueError(msg)
         self.ddp = find_ddp(task)
+        self.capture_stream = None
         if self.ddp is not None:
             if not capturable_process_group(self.ddp.process_group):
                 msg = "GraphedTrainStep under DistributedDataParallel needs the nccl (RCCL) backend: gloo collectives pass through the host"
+                raise ValueError(msg)
+            self.capture_stream = getattr(self.ddp, "gdl_stream", None)
+            if self.capture_stream is None:
+                msg = ("GraphedTrainStep under DistributedDataParallel needs the wrapper built by gdlhip.graphs.ddp_on_side_stream "
+                       "(wrapper construction, warm-up and capture must share one non-default stream)")
                 raise ValueError(msg)
             warmup = max(warmup, DDP_WARMUP)
         self.task, self.optimizer, self.autocast_dtype = task, optimizer, autocast_dtype
@@ -130,10 +141,20 @@ class GraphedTrainStep:
         host_counters = {k: getattr(task, k) for k in ("train_samples_count",) if isinstance(getattr(task, k, None), int)}
         try:
             self._capture(task, optimizer, warmup)
-        except BaseException:
-            # torch.cuda.graph's __exit__ has ended the stream capture by now (it runs capture_end in its finally path); the
-            # restoring copies below are ordinary eager work on the current stream
-            torch.cuda.synchronize()
+        except BaseException as exc:
+            # A Python exception inside the captured step: torch.cuda.graph's __exit__ has ended the capture (measured on gfx950:
+            # the stream is out of capture, the partial graph is dropped) and the restoring copies below are ordinary eager work.
+            # A HIP error inside the captured step (a host read-back, a synchronising call) is different: the capture is
+            # INVALIDATED, capture_end raises before torch leaves its stream context, and HIP keeps reporting the stream as
+            # capturing -- _leave_broken_capture puts the current stream back and ends the capture by hand; if the device still
+            # refuses to synchronise the process cannot train on and says so instead of failing somewhere else later
+            self._leave_broken_capture()
+            try:
+                torch.cuda.synchronize()
+            except RuntimeError as sync_exc:
+                msg = ("hipGraph capture of the training step failed with a HIP error inside the capture and left the device in "
+                       f"capture state ({type(sync_exc).__name__}); restart with graph_step=False.  Original error: {exc}")
+                raise RuntimeError(msg) from exc
             optimizer.zero_grad(set_to_none=True)
             self.graph = None
             if snap is not None:
@@ -147,6 +168,33 @@ class GraphedTrainStep:
                     setattr(task, k, v)
         if snap is not None:
             self._restore(snap, optimizer)
+
+    def _leave_broken_capture(self) -> None:
+        """After capture_end raised (capture invalidated by a HIP error): torch.cuda.graph.__exit__ did not restore the current
+        stream, and on ROCm 7 the capture stream stays in `invalidated` state.  Best effort: leave the stream context and call
+        hipStreamEndCapture once more on the capture stream (it returns the invalidation error and resets the state)."""
+        ctx, self._capture_ctx = getattr(self, "_capture_ctx", None), None
+        if ctx is None or not torch.cuda.is_current_stream_capturing():
+            return
+        stream = torch.cuda.current_stream()
+        try:
+            ctx.stream_ctx.__exit__(None, None, None)
+        except Exception:  # noqa: BLE001
+            pass
+        try:      # the allocator still routes this stream's allocations to the dead graph's pool
+            torch._C._cuda_endAllocateToPool(stream.device_index, self.graph.pool())
+        except Exception:  # noqa: BLE001  (private API; the pool then simply stays alive)
+            pass
+        try:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            graph = ctypes.c_void_p()
+            hip.hipStreamEndCapture(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(graph))
+            if graph.value:
+                hip.hipGraphDestroy(graph)
+            hip.hipGetLastError()
+        except OSError:
+            pass
 
     @staticmethod
     def _snapshot(task, optimizer):
@@ -192,7 +240,7 @@ class GraphedTrainStep:
         torch.set_rng_state(snap["cpu_rng"])
 
     def _capture(self, task, optimizer, warmup: int) -> None:
-        side = torch.cuda.Stream()
+        side = self.capture_stream or torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
@@ -204,10 +252,14 @@ class GraphedTrainStep:
         optimizer.zero_grad(set_to_none=True)           # gradients are (re)allocated from the graph's private pool
         # under DDP the process group's watchdog thread polls the events of earlier collectives while this thread records:
         # "thread_local" restricts the capture-unsafe-call check to the capturing thread (backward still runs on the autograd
-        # engine's device thread: work launched into a capturing stream is recorded whichever thread launches it)
+        # engine's device thread: work launched into a capturing stream is recorded whichever thread launches it).  The capture
+        # runs on the stream the DDP wrapper was built on (see ddp_on_side_stream)
         mode = "thread_local" if self.ddp is not None else "global"
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):
+        ctx = torch.cuda.graph(self.graph, capture_error_mode=mode, **({"stream": self.capture_stream} if self.capture_stream else {}))
+        self._capture_ctx = ctx
+        with ctx:
             self.loss = self._eager(zero=False)
+        self._capture_ctx = None
         self._rewritten = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
         self._rewritten += [b for m in task.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training
                             for b in (m.running_mean, m.running_var) if b is not None]

@@ -16,10 +16,12 @@ Host logic only -- no tensor arithmetic of the hot path lives here.
 
 from __future__ import annotations
 
+import contextlib
 import logging
 import math
 import os
 import random
+import traceback
 from pathlib import Path
 from typing import Any
 
@@ -243,6 +245,7 @@ class MiniTrainer:
         model.to(device)
         train_loader, val_loader = self._loaders(datamodule, train_dataloaders, val_dataloaders)
         want_graph = self.graph_step not in (False, "off", "false", None) and device.type == "cuda" and self.accumulate_grad_batches == 1
+        self._stream = None
         self._ddp_active = self.world_size > 1 or (self.force_ddp and dist.is_available() and dist.is_initialized())
         if self._ddp_active:
             if self.sync_batchnorm:
@@ -253,7 +256,9 @@ class MiniTrainer:
                 from gdlhip.graphs import capturable_process_group, ddp_on_side_stream
                 want_graph = capturable_process_group()      # gloo: the step stays eager
             if want_graph:
-                model.model = ddp_on_side_stream(model.model, **ddp_kw)      # (what a later whole-backward capture needs)
+                # wrapper construction, every training / validation step and the capture share ONE side stream (gdlhip.graphs)
+                model.model = ddp_on_side_stream(model.model, **ddp_kw)
+                self._stream = model.model.gdl_stream
             else:
                 model.model = nn.parallel.DistributedDataParallel(model.model, **ddp_kw)
         try:
@@ -340,7 +345,24 @@ class MiniTrainer:
                 break
             yield i, batch
 
+    @contextlib.contextmanager
+    def _on_stream(self):
+        """Run a phase on the trainer's stream (the DDP wrapper's, when a captured DDP step is planned), ordered after what the
+        default stream did before and before what it does next."""
+        st = getattr(self, "_stream", None)
+        if st is None:
+            yield
+            return
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            yield
+        torch.cuda.current_stream().wait_stream(st)
+
     def _run_train_epoch(self, model, loader, step_opt, opt, sched_cfgs, device) -> None:
+        with self._on_stream():
+            self._train_epoch(model, loader, step_opt, opt, sched_cfgs, device)
+
+    def _train_epoch(self, model, loader, step_opt, opt, sched_cfgs, device) -> None:
         model.train()
         self.training = True
         fused_clip = step_opt is not opt
@@ -404,6 +426,8 @@ class MiniTrainer:
                 self._graphed = GraphedTrainStep(model, step_opt, batch, autocast_dtype=amp, warmup=2, restore_state=True)
             except Exception as exc:  # noqa: BLE001  (anything the capture cannot record: fall back to eager steps for good)
                 failure, self._graphed = f"{type(exc).__name__}: {exc}", None
+                logger.debug("capture traceback", exc_info=True)
+                self.capture_traceback = traceback.format_exc()[-3000:]
             if getattr(self, "_ddp_active", False) and self.world_size > 1:
                 # every rank ran the same warm-up collectives and then recorded (not ran) the captured ones: the process group is
                 # in step.  One all-reduce decides for everybody -- a rank replaying while another launches eagerly is legal for
@@ -432,8 +456,12 @@ class MiniTrainer:
         self.graphed_steps += 1
         return True
 
-    @torch.no_grad()
     def _run_eval(self, model, loader, split: str, device) -> dict[str, float]:
+        with self._on_stream():
+            return self._eval_epoch(model, loader, split, device)
+
+    @torch.no_grad()
+    def _eval_epoch(self, model, loader, split: str, device) -> dict[str, float]:
         model.eval()
         self.training = False
         step = model.validation_step if split == "val" else model.test_step

@@ -658,9 +658,9 @@ def test_failed_graph_capture_leaves_training_state_untouched():
         assert opt.state[p]["step"] == moments[p][2] == 1 and p.grad is None
     assert float(opt.device_state(0)[0]) == 1.0          # the device step count follows the restored host count, not 0
     assert torch.equal(torch.cuda.get_rng_state(), rng) and task.train_samples_count == count0
-    # the eager fallback still trains from here
-    l0 = task.training_step(batch, 0)
-    l0.backward()
+    # the eager fallback still trains from here (the loss is not kept: a live autograd graph holds AccumulateGrad nodes of the
+    # default stream, and a later capture with such nodes around crashes inside hipStreamEndCapture on ROCm 7)
+    task.training_step(batch, 0).backward()
     opt.step()
     opt.zero_grad(set_to_none=True)
     assert float(opt.device_state(0)[0]) == 2.0 and opt.state[params[0]]["step"] == 2
@@ -709,7 +709,8 @@ def test_ddp_training_step_captured_with_rccl_collectives(tmp_path):
     finally:
         dist.destroy_process_group()
     (te, tre), (tg, trg) = runs[False], runs["auto"]
-    assert tre.graphed_steps == 0 and trg.graphed_steps == 8 and tre.global_step == trg.global_step == 10
+    assert trg.graphed_steps == 8, getattr(trg, "capture_traceback", "no traceback recorded")
+    assert tre.graphed_steps == 0 and tre.global_step == trg.global_step == 10
     assert abs(tre.callback_metrics["train_loss"] - trg.callback_metrics["train_loss"]) < 1e-5
     assert abs(tre.callback_metrics["val_loss"] - trg.callback_metrics["val_loss"]) < 1e-5
     pe = dict(te.named_parameters())

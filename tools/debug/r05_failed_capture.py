@@ -64,7 +64,8 @@ loss.backward()
 opt.step()
 opt.zero_grad(set_to_none=True)
 torch.cuda.synchronize()
-say("eager step after the failure ok, loss", float(loss))
+say("eager step after the failure ok, loss", float(loss.detach()))
+del loss      # (a live autograd graph keeps default-stream AccumulateGrad nodes: a later capture then crashes in hipStreamEndCapture)
 gs = GraphedTrainStep(task, opt, batch, autocast_dtype=None, warmup=2, restore_state=True)
 for _ in range(3):
     gs(batch)
