@@ -156,7 +156,9 @@ def build_task(model: str, device, dist_on: bool, local: int, capturable: bool =
     if dist_on:
         # Lightning's `sync_batchnorm: true` + DDPStrategy(gradient_as_bucket_view=true)
         task.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(task.model)
-        ddp_kw = dict(device_ids=[local], gradient_as_bucket_view=True, find_unused_parameters=False)
+        # (device_ids=None: with it set, DDP's forward moves the host-side `wavelengths` tensor to the GPU and the encoder reads it
+        # back with a blocking copy every step -- round 5 finding, see gdlhip/trainer.py)
+        ddp_kw = dict(gradient_as_bucket_view=True, find_unused_parameters=False)
         if capturable:
             # a later whole-step hipGraph capture needs wrapper construction, warm-up and capture on ONE side stream: main() makes
             # that stream (ddp.gdl_stream) the current one for everything it times

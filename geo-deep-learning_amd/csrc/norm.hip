@@ -361,8 +361,9 @@ __global__ __launch_bounds__(256) void bn_bwd_dx(const void* __restrict__ x, con
                                                  const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, float eps, int relu,
                                                  const float* __restrict__ dgamma,
-                                                 const float* __restrict__ dbeta) {
-  const float invP = 1.0f / (float)P_total;
+                                                 const float* __restrict__ dbeta, const float* __restrict__ total_dev) {
+  // SyncBatchNorm: the sums are global and so is the pixel count, which only exists on the device (ranks with ragged batches)
+  const float invP = total_dev ? 1.0f / total_dev[0] : 1.0f / (float)P_total;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const LaneMap lm = lane_map(lane, C, blockIdx.x);
   const int c = lm.c;
@@ -396,63 +397,97 @@ __global__ __launch_bounds__(256) void bn_bwd_dx(const void* __restrict__ x, con
 // dependent launches -- in eager mode and inside a hipGraph alike.  Here one workgroup owns FOUR channels over ALL pixels:
 // pass 1 accumulates the sums (f32 per thread, f64 across the block, like the multi-block kernels), the statistics are
 // finished in LDS, pass 2 re-reads its 8 B / pixel column (just read: L2) and writes the result.  grid = C / 4 workgroups of
-// 256 threads, a thread strides 256 pixels with four loads in flight.
+// 1024 threads, a thread strides 1024 pixels with four loads in flight in BOTH passes (the first version -- 256 threads, an
+// un-unrolled second pass -- was one dependent L2 round trip per pixel and LOST to the three short launches inside a hipGraph:
+// 450 vs 461 tiles/s at batch 4, profiles/r05c_*).
+constexpr int BNS_T = 1024;      // threads per workgroup of the small-map kernels (16 waves: 5 pixels per thread at 36 x 36 x 4)
+
+// block-wide sum of 8 values per thread (4 channels x {first, second} sum): f32 butterflies inside each wave (what the
+// multi-workgroup kernels do inside a workgroup), then the 16 wave results in f64 through LDS in a fixed order -- deterministic.
+// Result valid in every thread.
+__device__ __forceinline__ void bns_block_sum(const float (&s)[4], const float (&q)[4], double (&out)[8], float (*red)[8]) {
+  float v[8] = {s[0], s[1], s[2], s[3], q[0], q[1], q[2], q[3]};
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[j] += __shfl_xor(v[j], o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[w][j] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    double t = 0;
+#pragma unroll 1
+    for (int k = 0; k < BNS_T / 64; ++k) t += (double)red[k][j];
+    out[j] = t;
+  }
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const void* __restrict__ x, void* y, int64_t P, int C, int64_t x_sP,
-                                                           int64_t y_sP, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps, int relu,
-                                                           float* __restrict__ mean, float* __restrict__ var, float* running_mean,
-                                                           float* running_var, float momentum) {
-  __shared__ double ps[256][4], pq[256][4];
-  __shared__ float smu[4], ssc[4], sbe[4];
+__global__ __launch_bounds__(BNS_T) void bn_small_fwd_kernel(const void* __restrict__ x, void* y, int64_t P, int C, int64_t x_sP,
+                                                             int64_t y_sP, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, int relu,
+                                                             float* __restrict__ mean, float* __restrict__ var, float* running_mean,
+                                                             float* running_var, float momentum) {
+  __shared__ float red[BNS_T / 64][8];
   const int t = threadIdx.x, c = blockIdx.x * 4;
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   int64_t p = t;
-  for (; p + 3 * 256 < P; p += 4 * 256) {
+  for (; p + 3 * BNS_T < P; p += 4 * BNS_T) {
     float v[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) load4<T>(x, (p + 256 * u) * x_sP + c, v[u]);
+    for (int u = 0; u < 4; ++u) load4<T>(x, (p + BNS_T * u) * x_sP + c, v[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j) { s[j] += v[u][j]; q[j] += v[u][j] * v[u][j]; }
   }
-  for (; p < P; p += 256) {
+  for (; p < P; p += BNS_T) {
     float v[4];
     load4<T>(x, p * x_sP + c, v);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { ps[t][j] = (double)s[j]; pq[t][j] = (double)q[j]; }
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {                 // fixed-order tree: deterministic
-    if (t < o) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { ps[t][j] += ps[t + o][j]; pq[t][j] += pq[t + o][j]; }
-    }
-    __syncthreads();
-  }
-  if (t < 4) {
-    const double m = ps[0][t] / (double)P;
-    double v = pq[0][t] / (double)P - m * m;
-    v = v > 0 ? v : 0;
-    mean[c + t] = (float)m;
-    var[c + t] = (float)v;
-    if (running_mean) {
-      const double unb = P > 1 ? v * (double)P / (double)(P - 1) : v;
-      running_mean[c + t] = (float)((1.0 - momentum) * running_mean[c + t] + momentum * m);
-      running_var[c + t] = (float)((1.0 - momentum) * running_var[c + t] + momentum * unb);
-    }
-    smu[t] = (float)m;
-    ssc[t] = rsqrtf((float)v + eps) * gamma[c + t];   // the same f32 expressions as bn_apply_kernel: identical outputs
-    sbe[t] = beta[c + t];
-  }
-  __syncthreads();
+  double acc[8];
+  bns_block_sum(s, q, acc, red);
   float mu[4], sc[4], be[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { mu[j] = smu[j]; sc[j] = ssc[j]; be[j] = sbe[j]; }
-  for (p = t; p < P; p += 256) {
+  for (int j = 0; j < 4; ++j) {
+    const double m = acc[j] / (double)P;
+    double v = acc[4 + j] / (double)P - m * m;
+    v = v > 0 ? v : 0;
+    if (t == 0) {
+      mean[c + j] = (float)m;
+      var[c + j] = (float)v;
+      if (running_mean) {
+        const double unb = P > 1 ? v * (double)P / (double)(P - 1) : v;
+        running_mean[c + j] = (float)((1.0 - momentum) * running_mean[c + j] + momentum * m);
+        running_var[c + j] = (float)((1.0 - momentum) * running_var[c + j] + momentum * unb);
+      }
+    }
+    mu[j] = (float)m;
+    sc[j] = rsqrtf((float)v + eps) * gamma[c + j];   // the same f32 expressions as bn_apply_kernel: identical outputs
+    be[j] = beta[c + j];
+  }
+  p = t;
+  for (; p + 3 * BNS_T < P; p += 4 * BNS_T) {          // pass 2: the column was just read (L2); four loads in flight again
+    float v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load4<T>(x, (p + BNS_T * u) * x_sP + c, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float o = (v[u][j] - mu[j]) * sc[j] + be[j];
+        v[u][j] = relu ? fmaxf(o, 0.f) : o;
+      }
+      store4<T>(y, (p + BNS_T * u) * y_sP + c, v[u]);
+    }
+  }
+  for (; p < P; p += BNS_T) {
     float v[4];
     load4<T>(x, p * x_sP + c, v);
 #pragma unroll
@@ -467,23 +502,22 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const void* __restric
 // backward: dbeta = sum g', dgamma = sum g' xhat (written out: they are the parameter gradients), then
 // dx = gamma rstd (g' - dbeta / P - xhat dgamma / P), g' = dy [bn(x) > 0]; same per-element expressions as bn_bwd_partial / bn_bwd_dx
 template <typename T>
-__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy, void* dx, int64_t P,
-                                                           int C, int64_t x_sP, int64_t dy_sP, int64_t dx_sP,
-                                                           const float* __restrict__ mean, const float* __restrict__ var,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                           int relu, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double ps[256][4], pq[256][4];
-  __shared__ float sk1[4], sk2[4];
+__global__ __launch_bounds__(BNS_T) void bn_small_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy, void* dx, int64_t P,
+                                                             int C, int64_t x_sP, int64_t dy_sP, int64_t dx_sP,
+                                                             const float* __restrict__ mean, const float* __restrict__ var,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                             int relu, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[BNS_T / 64][8];
   const int t = threadIdx.x, c = blockIdx.x * 4;
   float mu[4], rs[4], ga[4], be[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; rs[j] = rsqrtf(var[c + j] + eps); ga[j] = gamma[c + j]; be[j] = beta[c + j]; }
   float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   int64_t p = t;
-  for (; p + 256 < P; p += 2 * 256) {
+  for (; p + BNS_T < P; p += 2 * BNS_T) {
     float v[2][4], g[2][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { load4<T>(x, (p + 256 * u) * x_sP + c, v[u]); load4<T>(dy, (p + 256 * u) * dy_sP + c, g[u]); }
+    for (int u = 0; u < 2; ++u) { load4<T>(x, (p + BNS_T * u) * x_sP + c, v[u]); load4<T>(dy, (p + BNS_T * u) * dy_sP + c, g[u]); }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -493,7 +527,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const void* __restric
         s[j] += gg; q[j] += gg * xh;
       }
   }
-  for (; p < P; p += 256) {
+  for (; p < P; p += BNS_T) {
     float v[4], g[4];
     load4<T>(x, p * x_sP + c, v);
     load4<T>(dy, p * dy_sP + c, g);
@@ -504,29 +538,34 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const void* __restric
       s[j] += gg; q[j] += gg * xh;
     }
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { ps[t][j] = (double)s[j]; pq[t][j] = (double)q[j]; }
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (t < o) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { ps[t][j] += ps[t + o][j]; pq[t][j] += pq[t + o][j]; }
-    }
-    __syncthreads();
-  }
-  if (t < 4) {
-    const float db = (float)ps[0][t], dg = (float)pq[0][t];
-    dbeta[c + t] = db;
-    dgamma[c + t] = dg;
-    const float invP = 1.0f / (float)P;
-    sk1[t] = db * invP;
-    sk2[t] = dg * invP;
-  }
-  __syncthreads();
+  double acc[8];
+  bns_block_sum(s, q, acc, red);
   float k1[4], k2[4];
+  const float invP = 1.0f / (float)P;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { k1[j] = sk1[j]; k2[j] = sk2[j]; }
-  for (p = t; p < P; p += 256) {
+  for (int j = 0; j < 4; ++j) {
+    const float db = (float)acc[j], dg = (float)acc[4 + j];
+    if (t == 0) { dbeta[c + j] = db; dgamma[c + j] = dg; }
+    k1[j] = db * invP;
+    k2[j] = dg * invP;
+  }
+  p = t;
+  for (; p + BNS_T < P; p += 2 * BNS_T) {
+    float v[2][4], g[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { load4<T>(x, (p + BNS_T * u) * x_sP + c, v[u]); load4<T>(dy, (p + BNS_T * u) * dy_sP + c, g[u]); }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (v[u][j] - mu[j]) * rs[j];
+        const float gg = (relu && !(xh * ga[j] + be[j] > 0.f)) ? 0.f : g[u][j];
+        v[u][j] = ga[j] * rs[j] * (gg - k1[j] - xh * k2[j]);
+      }
+      store4<T>(dx, (p + BNS_T * u) * dx_sP + c, v[u]);
+    }
+  }
+  for (; p < P; p += BNS_T) {
     float v[4], g[4];
     load4<T>(x, p * x_sP + c, v);
     load4<T>(dy, p * dy_sP + c, g);
@@ -537,6 +576,40 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const void* __restric
       v[j] = ga[j] * rs[j] * (gg - k1[j] - xh * k2[j]);
     }
     store4<T>(dx, p * dx_sP + c, v);
+  }
+}
+
+// ---------------------------------------------------------------- SyncBatchNorm message (round 5)
+// One rank's statistics as the count-weighted message that is summed over the ranks: [n mean | n E[x^2] | n] (2 C + 1 floats),
+// and the global statistics back out of the summed message (+ the running-estimate update with the unbiased variance and the
+// global count, which never leaves the device).  Replaces ~5 + ~10 one-line torch kernels per layer: with 21 train-mode
+// BatchNorms that was ~300 launches of a DDP + SyncBatchNorm step (configs/dofa_config_RGB.yaml:5-13).
+__global__ __launch_bounds__(256) void syncbn_pack_kernel(const float* __restrict__ mean, const float* __restrict__ var, float n, int C,
+                                                          float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    const float m = mean[c];
+    out[c] = m * n;
+    out[C + c] = (var[c] + m * m) * n;
+  }
+  if (c == 0) out[2 * C] = n;
+}
+
+__global__ __launch_bounds__(256) void syncbn_unpack_kernel(const float* __restrict__ packed, int C, float* __restrict__ mean,
+                                                            float* __restrict__ var, float* running_mean, float* running_var,
+                                                            float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float total = packed[2 * C];
+  const float m = packed[c] / total;
+  float v = packed[C + c] / total - m * m;
+  v = v > 0.f ? v : 0.f;
+  mean[c] = m;
+  var[c] = v;
+  if (running_mean) {
+    const float denom = total - 1.f > 1.f ? total - 1.f : 1.f;
+    running_mean[c] = running_mean[c] * (1.f - momentum) + m * momentum;
+    running_var[c] = running_var[c] * (1.f - momentum) + v * (momentum * total / denom);
   }
 }
 
@@ -598,10 +671,10 @@ extern "C" int gdl_bn_small_fwd(const void* x, void* y, int dtype, int64_t P, in
   GDL_CHECK_ARG(dtype == GDL_F32 || dtype == GDL_BF16, "gdl_bn_small_fwd: bad dtype");
   GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && y_sP % 4 == 0 && P > 0, "gdl_bn_small_fwd: C and strides must be multiples of 4");
   if (dtype == GDL_BF16)
-    hipLaunchKernelGGL(bn_small_fwd_kernel<uint16_t>, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, x, y, P, C, x_sP, y_sP, gamma, beta,
+    hipLaunchKernelGGL(bn_small_fwd_kernel<uint16_t>, dim3(C / 4), dim3(BNS_T), 0, (hipStream_t)stream, x, y, P, C, x_sP, y_sP, gamma, beta,
                        eps, relu, mean, var, running_mean, running_var, momentum);
   else
-    hipLaunchKernelGGL(bn_small_fwd_kernel<float>, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, x, y, P, C, x_sP, y_sP, gamma, beta,
+    hipLaunchKernelGGL(bn_small_fwd_kernel<float>, dim3(C / 4), dim3(BNS_T), 0, (hipStream_t)stream, x, y, P, C, x_sP, y_sP, gamma, beta,
                        eps, relu, mean, var, running_mean, running_var, momentum);
   GDL_CHECK_LAUNCH("gdl_bn_small_fwd");
   return GDL_OK;
@@ -616,12 +689,28 @@ extern "C" int gdl_bn_small_bwd(const void* x, const void* dy, void* dx, int dty
   GDL_CHECK_ARG(dtype == GDL_F32 || dtype == GDL_BF16, "gdl_bn_small_bwd: bad dtype");
   GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && dy_sP % 4 == 0 && dx_sP % 4 == 0 && P > 0, "gdl_bn_small_bwd: C and strides must be multiples of 4");
   if (dtype == GDL_BF16)
-    hipLaunchKernelGGL(bn_small_bwd_kernel<uint16_t>, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, x, dy, dx, P, C, x_sP, dy_sP, dx_sP,
+    hipLaunchKernelGGL(bn_small_bwd_kernel<uint16_t>, dim3(C / 4), dim3(BNS_T), 0, (hipStream_t)stream, x, dy, dx, P, C, x_sP, dy_sP, dx_sP,
                        mean, var, gamma, beta, eps, relu, dgamma, dbeta);
   else
-    hipLaunchKernelGGL(bn_small_bwd_kernel<float>, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, x, dy, dx, P, C, x_sP, dy_sP, dx_sP,
+    hipLaunchKernelGGL(bn_small_bwd_kernel<float>, dim3(C / 4), dim3(BNS_T), 0, (hipStream_t)stream, x, dy, dx, P, C, x_sP, dy_sP, dx_sP,
                        mean, var, gamma, beta, eps, relu, dgamma, dbeta);
   GDL_CHECK_LAUNCH("gdl_bn_small_bwd");
+  return GDL_OK;
+}
+
+extern "C" int gdl_syncbn_pack(const float* mean, const float* var, double count, int C, float* out, gdl_stream_t stream) {
+  GDL_CHECK_ARG(mean && var && out && C > 0 && count > 0, "gdl_syncbn_pack: bad arguments");
+  hipLaunchKernelGGL(syncbn_pack_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, var, (float)count, C, out);
+  GDL_CHECK_LAUNCH("gdl_syncbn_pack");
+  return GDL_OK;
+}
+
+extern "C" int gdl_syncbn_unpack(const float* packed, int C, float* mean, float* var, float* running_mean, float* running_var,
+                                 float momentum, gdl_stream_t stream) {
+  GDL_CHECK_ARG(packed && mean && var && C > 0 && (!running_mean == !running_var), "gdl_syncbn_unpack: bad arguments");
+  hipLaunchKernelGGL(syncbn_unpack_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, packed, C, mean, var, running_mean,
+                     running_var, momentum);
+  GDL_CHECK_LAUNCH("gdl_syncbn_unpack");
   return GDL_OK;
 }
 
@@ -707,9 +796,28 @@ extern "C" int gdl_bn_bwd_dx(const void* x, const void* dy, void* dx, int dtype,
   (void)total;
   const dim3 g2((C + 255) / 256, bn_ew_splits(P, C));
   if (dtype == GDL_BF16)
-    hipLaunchKernelGGL(bn_bwd_dx<uint16_t>, g2, dim3(256), 0, s, x, dy, dx, P, P_total, C, x_sP, dy_sP, dx_sP, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum);
+    hipLaunchKernelGGL(bn_bwd_dx<uint16_t>, g2, dim3(256), 0, s, x, dy, dx, P, P_total, C, x_sP, dy_sP, dx_sP, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum, (const float*)nullptr);
   else
-    hipLaunchKernelGGL(bn_bwd_dx<float>, g2, dim3(256), 0, s, x, dy, dx, P, P_total, C, x_sP, dy_sP, dx_sP, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum);
+    hipLaunchKernelGGL(bn_bwd_dx<float>, g2, dim3(256), 0, s, x, dy, dx, P, P_total, C, x_sP, dy_sP, dx_sP, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum, (const float*)nullptr);
   GDL_CHECK_LAUNCH("gdl_bn_bwd_dx");
+  return GDL_OK;
+}
+
+// gdl_bn_bwd_dx for SyncBatchNorm: dgamma_sum / dbeta_sum are the all-reduced (global) sums and the global pixel count is read
+// from device memory (total_count: one f32, the count entry of the forward's all-reduced message).
+extern "C" int gdl_bn_bwd_dx_sync(const void* x, const void* dy, void* dx, int dtype, int64_t P, int C, int64_t x_sP, int64_t dy_sP,
+                                  int64_t dx_sP, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                                  int relu, const float* dgamma_sum, const float* dbeta_sum, const float* total_count,
+                                  gdl_stream_t stream) {
+  GDL_CHECK_ARG(x && dy && dx && mean && var && gamma && beta && dgamma_sum && dbeta_sum && total_count, "gdl_bn_bwd_dx_sync: null pointer");
+  GDL_CHECK_ARG(dtype == GDL_F32 || dtype == GDL_BF16, "gdl_bn_bwd_dx_sync: bad dtype");
+  GDL_CHECK_ARG(C % 4 == 0 && x_sP % 4 == 0 && dy_sP % 4 == 0 && dx_sP % 4 == 0 && P > 0, "gdl_bn_bwd_dx_sync: C/strides % 4");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g2((C + 255) / 256, bn_ew_splits(P, C));
+  if (dtype == GDL_BF16)
+    hipLaunchKernelGGL(bn_bwd_dx<uint16_t>, g2, dim3(256), 0, s, x, dy, dx, P, (int64_t)1, C, x_sP, dy_sP, dx_sP, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum, total_count);
+  else
+    hipLaunchKernelGGL(bn_bwd_dx<float>, g2, dim3(256), 0, s, x, dy, dx, P, (int64_t)1, C, x_sP, dy_sP, dx_sP, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum, total_count);
+  GDL_CHECK_LAUNCH("gdl_bn_bwd_dx_sync");
   return GDL_OK;
 }

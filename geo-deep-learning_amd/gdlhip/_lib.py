@@ -94,6 +94,9 @@ SIGNATURES = {
                                 c_p, c_p, c_p, c_l, c_p]),
     "gdl_bn_bwd_dx": (c_i, [c_p, c_p, c_p, c_i, c_l, c_i, c_l, c_l, c_l, c_p, c_p, c_p, c_p, c_f,
                             c_i, c_p, c_p, c_l, c_p]),
+    "gdl_syncbn_pack": (c_i, [c_p, c_p, C.c_double, c_i, c_p, c_p]),
+    "gdl_syncbn_unpack": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_f, c_p]),
+    "gdl_bn_bwd_dx_sync": (c_i, [c_p, c_p, c_p, c_i, c_l, c_i, c_l, c_l, c_l, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p]),
     "gdl_bn_small_fwd": (c_i, [c_p, c_p, c_i, c_l, c_i, c_l, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_f, c_p]),
     "gdl_bn_small_bwd": (c_i, [c_p, c_p, c_p, c_i, c_l, c_i, c_l, c_l, c_l, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),
     "gdl_bilinear_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_i, c_i, c_i,

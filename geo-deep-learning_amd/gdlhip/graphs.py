@@ -34,6 +34,12 @@ from torch import Tensor
 from . import nn as gnn
 
 
+class GraphCaptureFatal(RuntimeError):
+    """A HIP error INSIDE a stream capture (a host read-back, a synchronising call in the step): the capture is invalidated and
+    torch leaves the CUDA generator in capture mode and the allocator routed to the dead graph's pool -- the process cannot be
+    trusted to train on.  Raised instead of falling back to eager steps; rerun with graph_step=False."""
+
+
 DDP_WARMUP = 11      # eager DDP iterations torch wants before a whole-network capture (see the module docstring)
 
 
@@ -148,17 +154,25 @@ class GraphedTrainStep:
             # INVALIDATED, capture_end raises before torch leaves its stream context, and HIP keeps reporting the stream as
             # capturing -- _leave_broken_capture puts the current stream back and ends the capture by hand; if the device still
             # refuses to synchronise the process cannot train on and says so instead of failing somewhere else later
-            self._leave_broken_capture()
+            invalidated = self._leave_broken_capture()
             try:
                 torch.cuda.synchronize()
             except RuntimeError as sync_exc:
                 msg = ("hipGraph capture of the training step failed with a HIP error inside the capture and left the device in "
                        f"capture state ({type(sync_exc).__name__}); restart with graph_step=False.  Original error: {exc}")
-                raise RuntimeError(msg) from exc
+                raise GraphCaptureFatal(msg) from exc
             optimizer.zero_grad(set_to_none=True)
             self.graph = None
             if snap is not None:
                 self._restore(snap, optimizer)
+            if invalidated:
+                # the training state is back, but torch's capture_end never reached its epilogue: the CUDA generator still thinks a
+                # capture is running (the next DropPath draw raises "Offset increment outside graph capture") -- measured on ROCm 7
+                msg = ("hipGraph capture of the training step hit a HIP error inside the capture (a host read-back or a "
+                       "synchronising call in training_step?).  Parameters, optimizer state and buffers were restored, but torch's "
+                       "RNG / allocator capture state cannot be: restart with graph_step=False (MiniTrainer) or fix the step.  "
+                       f"Original error: {type(exc).__name__}: {exc}")
+                raise GraphCaptureFatal(msg) from exc
             raise
         finally:
             if sink is not None:
@@ -169,13 +183,13 @@ class GraphedTrainStep:
         if snap is not None:
             self._restore(snap, optimizer)
 
-    def _leave_broken_capture(self) -> None:
+    def _leave_broken_capture(self) -> bool:
         """After capture_end raised (capture invalidated by a HIP error): torch.cuda.graph.__exit__ did not restore the current
         stream, and on ROCm 7 the capture stream stays in `invalidated` state.  Best effort: leave the stream context and call
         hipStreamEndCapture once more on the capture stream (it returns the invalidation error and resets the state)."""
         ctx, self._capture_ctx = getattr(self, "_capture_ctx", None), None
         if ctx is None or not torch.cuda.is_current_stream_capturing():
-            return
+            return False
         stream = torch.cuda.current_stream()
         try:
             ctx.stream_ctx.__exit__(None, None, None)
@@ -195,6 +209,7 @@ class GraphedTrainStep:
             hip.hipGetLastError()
         except OSError:
             pass
+        return True
 
     @staticmethod
     def _snapshot(task, optimizer):

@@ -221,6 +221,9 @@ def _world(group=None) -> int:
 
 
 # ------------------------------------------------------------------ SyncBatchNorm exchange
+FUSE_SYNC_MESSAGE = os.environ.get("GDL_SYNC_MESSAGE_KERNELS", "1") != "0"   # A/B switch: 0 = the message is built by torch expressions
+
+
 def sync_batch_stats(mean: Tensor, var: Tensor, group=None, count: int | None = None):
     """Merge per-rank batch statistics into global ones (nn.SyncBatchNorm forward): count-weighted, so a
     ragged last batch (ranks with different pixel counts) merges exactly like torch's all_gather of
@@ -228,10 +231,18 @@ def sync_batch_stats(mean: Tensor, var: Tensor, group=None, count: int | None = 
     Returns (global mean, global biased variance, global count); the count stays a 0-dim DEVICE tensor (no host
     read-back: 21 layers per step would mean 21 stream syncs)."""
     n = float(count if count is not None else 1)
+    c = mean.numel()
+    if mean.is_cuda and FUSE_SYNC_MESSAGE:
+        # one pack kernel, the all-reduce, one unpack kernel (the torch expressions below are ~12 one-line launches per layer)
+        packed = torch.empty(2 * c + 1, device=mean.device, dtype=torch.float32)
+        ops.syncbn_pack(mean, var, n, packed)
+        dist.all_reduce(packed, group=group)
+        SYNC_MESSAGES[0] += 1
+        gmean, gvar = ops.syncbn_unpack(packed, c)
+        return gmean, gvar, packed[2 * c]
     packed = torch.cat([mean * n, (var + mean * mean) * n, mean.new_full((1,), n)])
     dist.all_reduce(packed, group=group)
     SYNC_MESSAGES[0] += 1
-    c = mean.numel()
     total = packed[2 * c]
     gmean = (packed[:c] / total).contiguous()
     gvar = (packed[c:2 * c] / total - gmean * gmean).clamp_min_(0).contiguous()
@@ -453,22 +464,37 @@ class _ConvBNActGroupTrain(Function):
             locals_.append(stats_done if stats_done is not None else ops.bn_stats(y))
             counts.append(y.numel() // weight.shape[0])
         # one message: per member [n * mean, n * E[x^2], n]  (count-weighted merge, see sync_batch_stats)
-        packed = torch.cat([t for (mean, var), n in zip(locals_, counts)
-                            for t in (mean * float(n), (var + mean * mean) * float(n), mean.new_full((1,), float(n)))])
+        fused = FUSE_SYNC_MESSAGE and ys[0].is_cuda
+        if fused:      # every member packs its share straight into its slice of the message: no torch arithmetic, no cat
+            packed = torch.empty(sum(2 * w.shape[0] + 1 for (_, w, *_r) in mem), device=ys[0].device, dtype=torch.float32)
+            off = 0
+            for (mean, var), n in zip(locals_, counts):
+                ops.syncbn_pack(mean, var, float(n), packed[off:off + 2 * mean.numel() + 1])
+                off += 2 * mean.numel() + 1
+        else:
+            packed = torch.cat([t for (mean, var), n in zip(locals_, counts)
+                                for t in (mean * float(n), (var + mean * mean) * float(n), mean.new_full((1,), float(n)))])
         dist.all_reduce(packed, group=sync_group or None)
         SYNC_MESSAGES[0] += 1
         outs, saved, cfg, off = [], [], [], 0
         for (x, weight, conv_bias, gamma, beta, rm, rv), (momentum, eps, pad, relu, up4), y, n in zip(mem, metas, ys, counts):
             c = weight.shape[0]
             total = packed[off + 2 * c]
-            gmean = (packed[off:off + c] / total).contiguous()
-            gvar = (packed[off + c:off + 2 * c] / total - gmean * gmean).clamp_min_(0).contiguous()
+            if fused:  # global statistics + the running-estimate update in one kernel
+                gmean, gvar = ops.syncbn_unpack(packed[off:off + 2 * c + 1], c, rm, rv, momentum)
+                if rm is not None:
+                    mark_updated(rm)
+                    mark_updated(rv)
+            else:
+                gmean = (packed[off:off + c] / total).contiguous()
+                gvar = (packed[off + c:off + 2 * c] / total - gmean * gmean).clamp_min_(0).contiguous()
+                if rm is not None:
+                    update_running_stats(rm, rv, gmean, gvar, momentum, total)
             off += 2 * c + 1
-            if rm is not None:
-                update_running_stats(rm, rv, gmean, gvar, momentum, total)
             outs.append(ops.bn_apply(y, gmean, gvar, gamma.detach(), beta.detach(), eps, relu))
             saved += [x, weight, y, gmean, gvar, gamma, beta]
-            cfg.append((pad, relu, eps, conv_bias is not None, n, n / total, up4))
+            cfg.append((pad, relu, eps, conv_bias is not None, n, (total if fused else n / total), up4))
+        ctx.fused_message = fused
         ctx.save_for_backward(*saved)
         ctx.cfg, ctx.sync_group = cfg, sync_group
         return tuple(outs)
@@ -491,11 +517,18 @@ class _ConvBNActGroupTrain(Function):
         for i, ((x, weight, y, mean, var, gamma, beta), (pad, relu, eps, has_bias, p_local, p_share, up4), gout, (dgamma, dbeta)) in \
                 enumerate(zip(mem, ctx.cfg, gs, sums)):
             c = weight.shape[0]
-            sg, sb = packed[off:off + c] * p_share, packed[off + c:off + 2 * c] * p_share
-            off += 2 * c
             need = ctx.needs_input_grad[2 + 7 * i:2 + 7 * i + 7]
-            dx, dw = _bn_bwd_and_grads(x, weight, y, gout, mean, var, gamma.detach(), beta.detach(), eps, relu, sg.contiguous(),
-                                       sb.contiguous(), p_local, pad, up4, need[0], need[1])
+            if ctx.fused_message:
+                # p_share holds the GLOBAL count (a device scalar: the count entry of the forward message): the backward-dx kernel
+                # divides the all-reduced sums by it itself -- no scaling launches, the message slices are used in place
+                dy = ops.bn_bwd_dx_sync(y, gout, mean, var, gamma.detach(), beta.detach(), eps, relu, packed[off:off + c],
+                                        packed[off + c:off + 2 * c], p_share.reshape(1), out=y)
+                dx, dw = _cba_grads(x, weight, dy, pad, up4, need[0], need[1])
+            else:
+                sg, sb = packed[off:off + c] * p_share, packed[off + c:off + 2 * c] * p_share
+                dx, dw = _bn_bwd_and_grads(x, weight, y, gout, mean, var, gamma.detach(), beta.detach(), eps, relu, sg.contiguous(),
+                                           sb.contiguous(), p_local, pad, up4, need[0], need[1])
+            off += 2 * c
             dbias = torch.zeros(c, device=x.device, dtype=torch.float32) if has_bias and need[2] else None
             grads += [dx, dw, dbias, dgamma, dbeta, None, None]
         return (None, None, *grads)

@@ -340,6 +340,42 @@ def bn_apply(x: Tensor, mean: Tensor, var: Tensor, gamma: Tensor, beta: Tensor, 
     return out
 
 
+def syncbn_pack(mean: Tensor, var: Tensor, count: float, out: Tensor) -> None:
+    """out[0:C] = count * mean, out[C:2C] = count * (var + mean^2), out[2C] = count: one rank's share of the SyncBatchNorm message
+    (out: a contiguous f32 slice of 2 C + 1 elements of the message buffer)."""
+    c = mean.numel()
+    if out.numel() != 2 * c + 1 or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("syncbn_pack: out must be a contiguous f32 slice of 2 C + 1 elements")
+    check(_lib.load().gdl_syncbn_pack(_p(mean), _p(var), float(count), c, _p(out), _stream()), "gdl_syncbn_pack")
+
+
+def syncbn_unpack(packed: Tensor, channels: int, running_mean: Tensor | None = None, running_var: Tensor | None = None,
+                  momentum: float = 0.1):
+    """(global mean, global biased var) from the all-reduced message slice [sum n mean | sum n E[x^2] | sum n]; the running
+    estimates are updated with the unbiased variance over the global count (which stays on the device)."""
+    if packed.numel() != 2 * channels + 1 or packed.dtype != torch.float32 or not packed.is_contiguous():
+        raise ValueError("syncbn_unpack: packed must be a contiguous f32 slice of 2 C + 1 elements")
+    mean = torch.empty(channels, device=packed.device, dtype=torch.float32)
+    var = torch.empty_like(mean)
+    check(_lib.load().gdl_syncbn_unpack(_p(packed), channels, _p(mean), _p(var), _p(running_mean), _p(running_var), momentum, _stream()),
+          "gdl_syncbn_unpack")
+    return mean, var
+
+
+def bn_bwd_dx_sync(x, dy, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_sum, total_count: Tensor, out: Tensor | None = None):
+    """bn_bwd_dx with the all-reduced sums and the GLOBAL pixel count read from device memory (``total_count``: one f32 element,
+    e.g. entry 2 C of the forward message)."""
+    P, Cc, sP = _pix(x, "bn_bwd x")
+    _, _, sPd = _pix(dy, "bn_bwd dy")
+    dx = out if out is not None else torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    _, _, sPx = _pix(dx, "bn_bwd dx")
+    if total_count.dtype != torch.float32 or total_count.numel() != 1:
+        raise ValueError("bn_bwd_dx_sync: total_count must be one f32 element on the device")
+    check(_lib.load().gdl_bn_bwd_dx_sync(_p(x), _p(dy), _p(dx), dt(x), P, Cc, sP, sPd, sPx, _p(mean), _p(var), _p(gamma), _p(beta), eps,
+                                         int(relu), _p(dgamma_sum), _p(dbeta_sum), _p(total_count), _stream()), "gdl_bn_bwd_dx_sync")
+    return dx
+
+
 BN_SMALL_MAX_PIXELS = int(os.environ.get("GDL_BN_SMALL_PIXELS", "8192"))   # A/B hook: 0 = always the multi-launch kernels
 
 

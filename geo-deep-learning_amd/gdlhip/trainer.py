@@ -250,8 +250,10 @@ class MiniTrainer:
         if self._ddp_active:
             if self.sync_batchnorm:
                 model.model = nn.SyncBatchNorm.convert_sync_batchnorm(model.model)
-            ddp_kw = {"device_ids": [device.index]} if device.type == "cuda" else {}
-            ddp_kw.update(gradient_as_bucket_view=True, find_unused_parameters=False)
+            # device_ids stays None (legal for a module that lives on one device): with device_ids set, DDP's forward moves EVERY
+            # input tensor to that device -- the batch's host-side `wavelengths` (HOST_BATCH_KEYS) too, which the DOFA encoder then
+            # reads back with a blocking copy in every step, and which a hipGraph capture cannot record at all (measured, round 5)
+            ddp_kw = dict(gradient_as_bucket_view=True, find_unused_parameters=False)
             if want_graph:
                 from gdlhip.graphs import capturable_process_group, ddp_on_side_stream
                 want_graph = capturable_process_group()      # gloo: the step stays eager
@@ -410,7 +412,7 @@ class MiniTrainer:
     def _graph_step(self, model, step_opt, batch, device) -> bool:
         """One training step as a hipGraph replay; False = this batch has to run eagerly (no graph yet and the batch is too
         large for "auto", another shape than the captured one, or the capture failed)."""
-        from gdlhip.graphs import GraphedTrainStep
+        from gdlhip.graphs import GraphCaptureFatal, GraphedTrainStep
         tensors = {k: v for k, v in batch.items() if isinstance(v, Tensor) and v.is_cuda} if isinstance(batch, dict) else {}
         if not tensors:
             return False
@@ -424,6 +426,8 @@ class MiniTrainer:
             try:
                 # (under DDP the warm-up is raised to the 11 eager iterations torch asks for; all of them are undone)
                 self._graphed = GraphedTrainStep(model, step_opt, batch, autocast_dtype=amp, warmup=2, restore_state=True)
+            except GraphCaptureFatal:
+                raise                    # the device / RNG state of this process is gone: do not train on as if nothing happened
             except Exception as exc:  # noqa: BLE001  (anything the capture cannot record: fall back to eager steps for good)
                 failure, self._graphed = f"{type(exc).__name__}: {exc}", None
                 logger.debug("capture traceback", exc_info=True)

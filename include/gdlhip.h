@@ -157,6 +157,18 @@ int gdl_bn_bwd_dx(const void* x, const void* dy, void* dx, int dtype, int64_t P,
                   const float* gamma, const float* beta, float eps, int relu,
                   const float* dgamma_sum, const float* dbeta_sum, int64_t P_total,
                   gdl_stream_t stream);
+/* SyncBatchNorm (torch.nn.SyncBatchNorm under `sync_batchnorm: true`, configs/dofa_config_RGB.yaml:13): the cross-rank exchange is
+ * ONE all-reduce(SUM) of a count-weighted message per direction.  gdl_syncbn_pack writes this rank's [count * mean | count * E[x^2] |
+ * count] (2 C + 1 floats) into `out` (a slice of the message buffer); gdl_syncbn_unpack reads the summed message back into the
+ * GLOBAL mean / biased variance and updates the running estimates with the unbiased variance over the global count (which stays
+ * on the device).  gdl_bn_bwd_dx_sync = gdl_bn_bwd_dx with the all-reduced sums and that device-side count (`total_count` points
+ * at entry 2 C of the forward message). */
+int gdl_syncbn_pack(const float* mean, const float* var, double count, int C, float* out, gdl_stream_t stream);
+int gdl_syncbn_unpack(const float* packed, int C, float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                      gdl_stream_t stream);
+int gdl_bn_bwd_dx_sync(const void* x, const void* dy, void* dx, int dtype, int64_t P, int C, int64_t x_sP, int64_t dy_sP, int64_t dx_sP,
+                       const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu,
+                       const float* dgamma_sum, const float* dbeta_sum, const float* total_count, gdl_stream_t stream);
 /* The whole train-mode BatchNorm(+ReLU) of a SMALL map in one launch per direction (one workgroup = four channels over all
  * pixels: statistics, running-estimate update, normalised output / sums, parameter gradients, dx).  For the maps of at most a
  * few thousand pixels that a per-GPU batch of 4 (configs/dofa_config_RGB.yaml:85) gives most ConvModules of the decoder

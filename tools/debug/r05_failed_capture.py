@@ -20,7 +20,7 @@ def say(*a):
 
 import test_hip_tasks as T  # noqa: E402
 from gdlhip import nn as gnn  # noqa: E402
-from gdlhip.graphs import GraphedTrainStep  # noqa: E402
+from gdlhip.graphs import GraphCaptureFatal, GraphedTrainStep  # noqa: E402
 
 _, task = T._dofa_task(freeze=("encoder",))
 task.trainer = T._Trainer(True)
@@ -53,6 +53,10 @@ task.training_step = failing
 try:
     GraphedTrainStep(task, opt, batch, autocast_dtype=None, warmup=2, restore_state=True)
     say("capture unexpectedly succeeded")
+except GraphCaptureFatal as exc:
+    say("capture raised the FATAL error (expected for mode item):", str(exc)[:300])
+    say("parameters restored? device step", float(opt.device_state(0)[0]))
+    sys.exit(0)
 except BaseException as exc:  # noqa: BLE001
     say("capture raised:", type(exc).__name__, str(exc)[:200])
 task.training_step = real

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, experiment 3: failed-capture recovery, DDP capture on one stream, small-map BatchNorm (parity + batch-4 A/B), full suite.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05c; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05d; mkdir -p $O; cd $R
 for m in empty midway item; do
   timeout 300 python tools/debug/r05_failed_capture.py $m > $O/failed_capture_$m.txt 2>&1; echo "failed_capture $m rc=$?" | tee -a $O/summary.txt
   grep -v "^  File\|^Extension\|amdgpu.ids\|Warning\|^  " $O/failed_capture_$m.txt | tail -8 | tee -a $O/summary.txt
