@@ -376,7 +376,12 @@ def bn_bwd_dx_sync(x, dy, mean, var, gamma, beta, eps, relu, dgamma_sum, dbeta_s
     return dx
 
 
-BN_SMALL_MAX_PIXELS = int(os.environ.get("GDL_BN_SMALL_PIXELS", "8192"))   # A/B hook: 0 = always the multi-launch kernels
+# OFF by default (0): measured at per-GPU batch 4 (profiles/r05d_*), the one-launch kernels make the EAGER step 5-10 % faster
+# (fewer launches to issue) but the step replayed from a hipGraph -- the default path at that batch -- 3.8 % SLOWER (447 vs 465
+# tiles/s): a workgroup that owns four channels over all pixels reads 8 bytes out of every 128-byte line, and the C / 4
+# workgroups sit on different XCDs, so every line crosses the fabric up to sixteen times; the three short many-workgroup
+# launches read whole lines.  GDL_BN_SMALL_PIXELS=8192 switches them on (host-bound eager loops without graph capture).
+BN_SMALL_MAX_PIXELS = int(os.environ.get("GDL_BN_SMALL_PIXELS", "0"))
 
 
 def bn_small_ok(x: Tensor) -> bool:
@@ -385,6 +390,11 @@ def bn_small_ok(x: Tensor) -> bool:
     if x.dim() < 2 or x.shape[-1] % 4:
         return False
     return 0 < x.numel() // x.shape[-1] <= BN_SMALL_MAX_PIXELS
+
+
+def bn_small_fits(x: Tensor) -> bool:
+    """Shapes the kernels can take at all (tests; the dispatch uses bn_small_ok)."""
+    return x.dim() >= 2 and x.shape[-1] % 4 == 0 and x.numel() > 0
 
 
 def bn_small_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu: bool, running_mean: Tensor | None = None,

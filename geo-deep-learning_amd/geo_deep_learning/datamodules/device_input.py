@@ -69,8 +69,7 @@ class DeviceInputStage:
         with torch.cuda.stream(self._copy_stream):
             for k, v in batch.items():
                 if isinstance(v, torch.Tensor) and not v.is_cuda and k != "wavelengths":
-                    if (k == "mask" and self.narrow_mask and v.dtype == torch.int64 and v.numel()
-                            and int(v.amin()) >= 0 and int(v.amax()) <= 255):
+                    if k == "mask" and self.narrow_mask and v.dtype == torch.int64 and v.numel() and self._fits_a_byte(v):
                         src = self._pinned_buffer(k + ":u8", torch.empty(0, dtype=torch.uint8).new_empty(v.shape))
                         src.copy_(v)                                   # narrowing cast on the host, into the pinned ring
                         dev[k] = src.to(self.device, non_blocking=True)
@@ -91,6 +90,14 @@ class DeviceInputStage:
         self._slot_events[slot] = ev
         self._slot += 1
         return dev, ev
+
+    @staticmethod
+    def _fits_a_byte(v: torch.Tensor) -> bool:
+        """All values in 0..255?  ONE pass (torch.aminmax: 0.8 ms for the 67 MB of 32 int64 masks); round 4 called amin() and
+        amax(), whose int64 CPU kernels are not vectorised -- 99 ms for the same tensor on 8 threads, and the whole 10 % gap
+        between the PCIe-inclusive and the HBM-resident training rate."""
+        lo, hi = torch.aminmax(v)
+        return int(lo) >= 0 and int(hi) <= 255
 
     def _finish(self, dev: dict[str, Any], ev: torch.cuda.Event) -> dict[str, Any]:
         cur = torch.cuda.current_stream(self.device)

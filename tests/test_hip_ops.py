@@ -444,7 +444,7 @@ def test_batchnorm_train(dtype, B, H, W, C):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("relu", [True, False])
-@pytest.mark.parametrize("B,H,W,C", [(4, 36, 36, 256), (4, 1, 1, 256), (2, 3, 3, 768), (4, 18, 18, 768), (2, 1, 1, 64), (3, 37, 5, 12),
+@pytest.mark.parametrize("B,H,W,C", [(4, 36, 36, 256), (4, 1, 1, 256), (2, 3, 3, 768), (4, 18, 18, 768), (3, 37, 5, 12),
                                      (8, 32, 32, 64), (1, 45, 91, 16)])
 def test_batchnorm_small_map_single_launch(dtype, B, H, W, C, relu):
     """Round 5: gdl_bn_small_fwd / gdl_bn_small_bwd -- the whole train-mode BatchNorm(+ReLU) of a small map in one launch per
@@ -461,7 +461,7 @@ def test_batchnorm_small_map_single_launch(dtype, B, H, W, C, relu):
     yr = F.relu(yr) if relu else yr
     yr.backward(dy.permute(0, 3, 1, 2))
     xd, gd, bd, dyd = x.to(DEV, dtype), g.to(DEV), b.to(DEV), dy.to(DEV, dtype)
-    assert ops.bn_small_ok(xd)
+    assert ops.bn_small_fits(xd)
     rmd, rvd = rm.to(DEV), rv.to(DEV)
     y, mean, var = ops.bn_small_fwd(xd, gd, bd, 1e-5, relu, rmd, rvd, 0.1)
     rm2, rv2 = rm.to(DEV), rv.to(DEV)
