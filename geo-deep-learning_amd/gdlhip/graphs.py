@@ -213,7 +213,13 @@ class GraphedTrainStep:
 
     @staticmethod
     def _snapshot(task, optimizer):
-        tensors = list(task.parameters()) + list(task.buffers())
+        # what the warm-up steps can change: trainable parameters and buffers (BatchNorm running estimates, counters).  Frozen
+        # parameters are left alone ON PURPOSE: restoring them would call mark_updated on them, which invalidates the operands
+        # cached from them (the DOFA dynamic patch-embedding weights of a frozen encoder, bf16 weight copies) -- operands that were
+        # VALID during the capture, i.e. whose addresses the graph holds.  The next eager step would rebuild and free them, and a
+        # replay would read freed memory (round 5: found under DDP, where warm-up, capture and eager steps share one stream and the
+        # allocator reuses the block at once; with the capture on torch's own side stream the block merely was never reused)
+        tensors = [p for p in task.parameters() if p.requires_grad] + list(task.buffers())
         state = {}
         for p, st in optimizer.state.items():
             state[p] = {k: (v.detach().clone() if isinstance(v, Tensor) else v) for k, v in st.items()}
@@ -275,6 +281,9 @@ class GraphedTrainStep:
         with ctx:
             self.loss = self._eager(zero=False)
         self._capture_ctx = None
+        # every operand cache entry that exists now may have been read by the captured kernels through its address (entries that
+        # were valid during the capture were not rebuilt inside it): keep them alive as long as the graph
+        self._cache_refs = [entry[1] for entry in list(gnn._CACHE.values())]
         self._rewritten = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
         self._rewritten += [b for m in task.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training
                             for b in (m.running_mean, m.running_var) if b is not None]
