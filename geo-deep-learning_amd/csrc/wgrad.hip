@@ -624,7 +624,10 @@ struct WRows {
   int ntiles, cchunks;         // ceil(N / 64), ceil(C / 64)
   int seglen, segs_per_row;    // pixels per row segment (multiple of 16, <= 64), ceil(W / seglen)
   int nsegs, segs_per_split;
+  int xcd_group;               // 1: all (n, c) tiles of one pixel range are dealt to ONE XCD (grid.y padded to a multiple of 8)
 };
+
+__device__ __forceinline__ int k_splits_of(const WRows& kk) { return kk.w.splits; }
 
 // Work split: 4 waves, wave (i, j) owns the 32 (n) x 32 (c) quadrant of the 64 x 64 tile for ALL nine taps
 // (9 accumulators = 144 registers), so all four SIMDs carry MFMA work and the kernel stays under 256 registers: two
@@ -641,8 +644,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wi = wave & 1, wj = wave >> 1;            // n half, c half
-  const int n0 = (blockIdx.x % kk.ntiles) * 64, c0 = (blockIdx.x / kk.ntiles) * 64;
-  const int split = blockIdx.y;
+  // Round 5: the ntiles x cchunks tiles of one pixel range read the SAME dy panels (shared by the c chunks) and input rows (shared
+  // by the n tiles).  Dealt out in launch order they land on all eight XCDs and every XCD's L2 fetches every panel again (PMC,
+  // round 4: 3.5 GB fetched per launch of the 256 -> 256 layer at 144^2 for 0.68 GB of operands, L2 hit rate 37 %, the kernel
+  // HBM-bound at 4.85 TB/s).  With xcd_group the hardware's round-robin (workgroup id % 8 = XCD) is inverted: XCD x owns pixel
+  // ranges x, x + 8, ... and runs all their tiles together.
+  int tile = blockIdx.x, split = blockIdx.y;
+  if (kk.xcd_group) {
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int j = lin >> 3;
+    tile = j % (int)gridDim.x;
+    split = (j / (int)gridDim.x) * 8 + (lin & 7);
+    if (split >= k_splits_of(kk)) return;
+  }
+  const int n0 = (tile % kk.ntiles) * 64, c0 = (tile / kk.ntiles) * 64;
   const unsigned xpix = (unsigned)(a.in_sW * 2), dypix = (unsigned)(a.dy_sW * 2);
   const srd_t srd_x = make_srd((const unsigned char*)a.in - xpix, kk.in_span + xpix);
   const srd_t srd_dy = make_srd((const unsigned char*)a.dy, kk.dy_span);
@@ -838,6 +853,7 @@ int64_t span_bytes(int B, int H, int W, int C, int64_t sB, int64_t sH, int64_t s
 }
 
 std::atomic<int> g_wgrad_old_splits{0};    // A/B hook: the round-3 split-K rule of the 256^2 kernel
+std::atomic<int> g_wgrad_rows_xcd{0};      // A/B hook: 1 = the row-segment kernel runs all tiles of a pixel range on one XCD
 int wgrad_num_cus() {
   static int n = [] {
     int dev = 0, cus = 0;
@@ -936,6 +952,7 @@ int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
 
 static std::atomic<int> g_wgrad_force_v1{0};
 extern "C" void gdl_debug_set_wgrad_old_splits(int on) { g_wgrad_old_splits = on; }  // A/B hook: round-3 split-K rule
+extern "C" void gdl_debug_set_wgrad_rows_xcd(int on) { g_wgrad_rows_xcd = on; }      // A/B hook: XCD grouping of the row-segment kernel
 extern "C" void gdl_debug_force_wgrad_small(int on) { g_wgrad_force_small = on; }  // A/B hook: 128^2 tiles only
 extern "C" void gdl_debug_force_wgrad_v1(int on) { g_wgrad_force_v1 = on; }  // A/B hook: register-transpose kernel
 
@@ -993,8 +1010,10 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
     kr.segs_per_row = (a.W + kr.seglen - 1) / kr.seglen;
     kr.nsegs = a.B * a.H * kr.segs_per_row;
     kr.segs_per_split = (kr.nsegs + k.splits - 1) / k.splits;
+    kr.xcd_group = g_wgrad_rows_xcd && k.splits >= 8 ? 1 : 0;
+    const unsigned gy = kr.xcd_group ? (unsigned)((k.splits + 7) / 8 * 8) : (unsigned)k.splits;
     GDL_SET_MAX_LDS_ONCE(wgrad_rows_kernel, 2 * 35840);
-    hipLaunchKernelGGL(wgrad_rows_kernel, dim3(kr.ntiles * kr.cchunks, k.splits), dim3(256), 2 * 35840, s, kr);
+    hipLaunchKernelGGL(wgrad_rows_kernel, dim3(kr.ntiles * kr.cchunks, gy), dim3(256), 2 * 35840, s, kr);
   } else if (wgrad_tile(a) == 256 && !g_wgrad_force_v1) {
     W256 kb;
     kb.w = k;

@@ -572,7 +572,7 @@ def test_wgrad_strided_dy(dtype, C, N):
                                        (3, 64, 64, 64, 16),
                                        # widths that are not multiples of 64 / 16: 144 -> 3 x 48, 72 -> 48 + 24, 100 -> 64 + 36
                                        (2, 7, 144, 256, 256), (2, 9, 72, 64, 128), (1, 11, 36, 320, 64), (2, 6, 100, 64, 64),
-                                       (1, 5, 33, 64, 40)])
+                                       (1, 5, 33, 64, 40), (4, 72, 144, 64, 64), (3, 37, 64, 128, 64)])
 def test_wgrad_row_segment_kernel(B, H, W, C, N):
     """3x3 convs on maps at least 32 pixels wide take the row-segment kernel (all nine taps per block): checked
     against autograd and against the per-tap kernel it replaces (same products, different summation order)."""
@@ -593,6 +593,15 @@ def test_wgrad_row_segment_kernel(B, H, W, C, N):
     finally:
         lib.gdl_debug_force_wgrad_small(0)
     assert (dw - old).abs().max().item() <= 1e-4 * old.abs().max().item()
+    # round 5: all (n, c) tiles of one pixel range dealt to one XCD (a relabelling of the workgroups: bit-identical result)
+    import ctypes
+    lib.gdl_debug_set_wgrad_rows_xcd.argtypes = [ctypes.c_int]
+    lib.gdl_debug_set_wgrad_rows_xcd(1)
+    try:
+        grouped = ops.conv_wgrad(xn, dyn, R=3, S=3, pad=1)
+    finally:
+        lib.gdl_debug_set_wgrad_rows_xcd(0)
+    assert torch.equal(grouped, dw)
     # accumulate into an existing gradient, dy as a channel slice of a wider buffer
     big = torch.zeros(B, H, W, N + 16, device=DEV, dtype=dtype)
     big[..., 8:8 + N] = dyn

@@ -123,8 +123,34 @@ def main_splits():
     print("sum: " + " | ".join(f"{t:.0f} us" for t in tot))
 
 
+def main_xcd():
+    """tools/bench_wgrad.py <batch> xcd: the row-segment kernel with its tiles in launch order (round 4) vs all tiles of a pixel range
+    on one XCD (round 5), interleaved, every 3x3 layer of LAYERS that takes that kernel."""
+    lib = _lib.load()
+    lib.gdl_debug_set_wgrad_rows_xcd.argtypes = [ctypes.c_int]
+    print(f"batch {B}: TF/s (us)  launch order | XCD-grouped | launch order again | XCD-grouped again")
+    for name, h, w, c, n in LAYERS:
+        b = B if h * w * max(c, n) * B * 2 < (1 << 31) else B // 2
+        x = torch.randn(b, h, w, c, device=DEV).to(bf)
+        dy = torch.randn(b, h, w, n, device=DEV).to(bf)
+        flops = 2 * b * h * w * n * 9 * c
+        out, ref = [], None
+        for on in (0, 1, 0, 1):
+            lib.gdl_debug_set_wgrad_rows_xcd(on)
+            try:
+                t = timeit(lambda: ops.conv_wgrad(x, dy, R=3, S=3, pad=1))
+                got = ops.conv_wgrad(x, dy, R=3, S=3, pad=1)
+            finally:
+                lib.gdl_debug_set_wgrad_rows_xcd(0)
+            ref = got if ref is None else ref
+            out.append(f"{flops / t / 1e9:7.1f} ({t * 1e3:6.0f}) ==:{torch.equal(got, ref)}")
+        print(f"{name:30s} b={b:2d} GF {flops / 1e9:8.1f}  " + " | ".join(out), flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "splits":
+    if len(sys.argv) > 2 and sys.argv[2] == "xcd":
+        main_xcd()
+    elif len(sys.argv) > 2 and sys.argv[2] == "splits":
         main_splits()
     else:
         main()
