@@ -853,7 +853,9 @@ int64_t span_bytes(int B, int H, int W, int C, int64_t sB, int64_t sH, int64_t s
 }
 
 std::atomic<int> g_wgrad_old_splits{0};    // A/B hook: the round-3 split-K rule of the 256^2 kernel
-std::atomic<int> g_wgrad_rows_xcd{0};      // A/B hook: 1 = the row-segment kernel runs all tiles of a pixel range on one XCD
+// the row-segment kernel runs all (n, c) tiles of a pixel range on one XCD (round 5, profiles/r05h_*: 256 -> 256 at 144^2
+// 783 -> 745 us, at 128^2 681 -> 607 us, no layer slower; bit-identical).  0 = launch order (GDL_WGRAD_ROWS_XCD=0)
+std::atomic<int> g_wgrad_rows_xcd{1};
 int wgrad_num_cus() {
   static int n = [] {
     int dev = 0, cus = 0;

@@ -593,15 +593,16 @@ def test_wgrad_row_segment_kernel(B, H, W, C, N):
     finally:
         lib.gdl_debug_force_wgrad_small(0)
     assert (dw - old).abs().max().item() <= 1e-4 * old.abs().max().item()
-    # round 5: all (n, c) tiles of one pixel range dealt to one XCD (a relabelling of the workgroups: bit-identical result)
+    # round 5 (the default): all (n, c) tiles of one pixel range dealt to one XCD -- a relabelling of the workgroups, so the
+    # launch-order form (hook 0) must give a bit-identical result
     import ctypes
     lib.gdl_debug_set_wgrad_rows_xcd.argtypes = [ctypes.c_int]
-    lib.gdl_debug_set_wgrad_rows_xcd(1)
+    lib.gdl_debug_set_wgrad_rows_xcd(0)
     try:
-        grouped = ops.conv_wgrad(xn, dyn, R=3, S=3, pad=1)
+        in_launch_order = ops.conv_wgrad(xn, dyn, R=3, S=3, pad=1)
     finally:
-        lib.gdl_debug_set_wgrad_rows_xcd(0)
-    assert torch.equal(grouped, dw)
+        lib.gdl_debug_set_wgrad_rows_xcd(1)
+    assert torch.equal(in_launch_order, dw)
     # accumulate into an existing gradient, dy as a channel slice of a wider buffer
     big = torch.zeros(B, H, W, N + 16, device=DEV, dtype=dtype)
     big[..., 8:8 + N] = dyn

@@ -141,7 +141,7 @@ def main_xcd():
                 t = timeit(lambda: ops.conv_wgrad(x, dy, R=3, S=3, pad=1))
                 got = ops.conv_wgrad(x, dy, R=3, S=3, pad=1)
             finally:
-                lib.gdl_debug_set_wgrad_rows_xcd(0)
+                lib.gdl_debug_set_wgrad_rows_xcd(1)      # (the default)
             ref = got if ref is None else ref
             out.append(f"{flops / t / 1e9:7.1f} ({t * 1e3:6.0f}) ==:{torch.equal(got, ref)}")
         print(f"{name:30s} b={b:2d} GF {flops / 1e9:8.1f}  " + " | ".join(out), flush=True)
