@@ -560,7 +560,7 @@ def main() -> None:
     # `value` times EXACTLY --steps steps (the driver's contract).  A caller that passes a small K (the driver: 20 steps = 0.7 s)
     # gets a second, longer measurement of the same steps beside it: as many steps as make the timed region >= 3 s
     sustained = {}
-    if args.min_seconds > 0:
+    if args.min_seconds > 0 and not args.no_extras:      # (profiling / A-B runs pass --no-extras: exactly their --steps, nothing else)
         for key, fn in (("train", train_step), ("infer", infer_step)):
             if key in res and res[key] < args.min_seconds:
                 k_long = int(math.ceil(args.min_seconds / (res[key] / args.steps)))
