@@ -52,8 +52,10 @@ def test_deferred_sample_keeps_raw_dtype(stats):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("threaded", [True, False], ids=["worker-thread", "consumer-thread"])
 @pytest.mark.parametrize("kind", KINDS)
-def test_device_input_stage_matches_reference(stats, kind):
+def test_device_input_stage_matches_reference(stats, kind, threaded):
+    """(round 5: the host side of the staging on a worker thread -- the default -- and on the consumer thread, as before)"""
     from geo_deep_learning.datamodules.device_input import DeviceInputStage
     g, norm = stats
     proc = SampleProcessor("sensorA", norm, "dofa", defer_normalization=True)
@@ -62,7 +64,7 @@ def test_device_input_stage_matches_reference(stats, kind):
         s = _sample(g, kind)
         s["image_patch.npy"] = np.roll(s["image_patch.npy"], i, axis=2)
         batches.append(collate([proc(s), proc(s)]))
-    stage = DeviceInputStage(batches, "cuda", depth=2)
+    stage = DeviceInputStage(batches, "cuda", depth=2, threaded=threaded)
     ref = torch.from_numpy(g[f"{kind}_dofa_image"])
     n = 0
     for i, b in enumerate(stage):
@@ -81,8 +83,16 @@ def test_device_input_stage_matches_reference(stats, kind):
     wide = dict(batches[0])
     wide["mask"] = batches[0]["mask"].clone()
     wide["mask"].view(-1)[0] = 300
-    (b,) = list(DeviceInputStage([wide], "cuda", depth=1))
+    (b,) = list(DeviceInputStage([wide], "cuda", depth=1, threaded=threaded))
     assert b["mask"].dtype == torch.int64 and int(b["mask"].view(-1)[0]) == 300
+    # an exception in the source iterable reaches the consumer, a consumer that stops early does not hang the worker
+    def broken():
+        yield batches[0]
+        raise KeyError("shard 7 is missing")
+    with pytest.raises(KeyError, match="shard 7"):
+        list(DeviceInputStage(broken(), "cuda", depth=2, threaded=threaded))
+    for b in DeviceInputStage(batches, "cuda", depth=2, threaded=threaded):
+        break
 
 
 @pytest.mark.gpu
