@@ -166,6 +166,8 @@ class DeviceInputStage:
         import queue as queue_mod
         import threading
         q: queue_mod.Queue = queue_mod.Queue(maxsize=self.depth)
+        # (a new thread starts on device 0: it gets the consumer's device -- "cuda" without an index means the current one HERE)
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         stop = threading.Event()
         done = object()
 
@@ -180,7 +182,7 @@ class DeviceInputStage:
 
         def work() -> None:
             try:
-                torch.cuda.set_device(self.device)
+                torch.cuda.set_device(dev_index)
                 for batch in self.batches:
                     if not put(self._stage(batch)):
                         return
