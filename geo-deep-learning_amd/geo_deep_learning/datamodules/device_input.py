@@ -34,7 +34,8 @@ class DeviceInputStage:
     """Iterate device-resident, normalised batches ``depth`` copies ahead of the consumer."""
 
     def __init__(self, batches: Iterable[dict[str, Any]], device: torch.device | str = "cuda", depth: int = 2,
-                 raw_key: str = "image", augment: Any | None = None, narrow_mask: bool = True, threaded: bool = True) -> None:
+                 raw_key: str = "image", augment: Any | None = None, narrow_mask: bool = True, threaded: bool = True,
+                 host_threads: int = 4) -> None:
         self.batches = batches
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -45,6 +46,10 @@ class DeviceInputStage:
         self.augment = augment      # gdlhip.augment.AugmentationSequential: fused with the normalise kernel
         self.narrow_mask = narrow_mask   # int64 masks with values in 0..255 are copied as uint8
         self.threaded = threaded         # stage on a worker thread (False: on the consumer thread, as in round 4)
+        # OpenMP threads of the worker's copy / range-check kernels.  torch's default is one per hardware thread (128 on the GPU
+        # boxes), all of which spin for a while after every parallel region; in a CPU-quota'd container that spinning throttles
+        # the thread that launches the training step (round 5: the staged step took 67-93 ms against 35.7 ms resident)
+        self.host_threads = max(1, int(host_threads))
         self._copy_stream = torch.cuda.Stream(device=self.device)
         self._pinned: dict = {}      # (key, shape, dtype) -> ring of pinned host buffers
         self._slot_events: list = [None] * (self.depth + 1)   # copy-done event of the batch that last used a ring slot
@@ -183,6 +188,7 @@ class DeviceInputStage:
         def work() -> None:
             try:
                 torch.cuda.set_device(dev_index)
+                torch.set_num_threads(self.host_threads)      # (OpenMP: this thread's team only)
                 for batch in self.batches:
                     if not put(self._stage(batch)):
                         return

@@ -47,9 +47,10 @@ def staged(**kw):
 
 
 print(f"resident batch            : {run(lambda: resident, steps):7.2f} ms / step", flush=True)
-for name, kw in (("worker thread, depth 2", dict(depth=2)), ("consumer thread, depth 2", dict(depth=2, threaded=False)),
-                 ("worker thread, depth 4", dict(depth=4)), ("worker thread, int64 masks as they are", dict(depth=2, narrow_mask=False)),
-                 ("worker thread, depth 2 (again)", dict(depth=2))):
+for name, kw in (("worker thread (4 host threads), depth 2", dict(depth=2)), ("consumer thread, depth 2", dict(depth=2, threaded=False)),
+                 ("worker thread, 1 host thread", dict(depth=2, host_threads=1)), ("worker thread, 128 host threads", dict(depth=2, host_threads=128)),
+                 ("worker thread, int64 masks as they are", dict(depth=2, narrow_mask=False)),
+                 ("worker thread (4 host threads) again", dict(depth=2))):
     print(f"{name:42s}: {staged(**kw):7.2f} ms / step", flush=True)
 print(f"resident batch (again)    : {run(lambda: resident, steps):7.2f} ms / step", flush=True)
 # pinned host batches (what a DataLoader(pin_memory=True) hands over): no copy into the ring
