@@ -342,6 +342,36 @@ def test_base_512_eval_bf16(base_model, golden_dir):
     assert agree > 0.97, agree
 
 
+def test_base_512_eval_bf16_no_worse_than_torch_autocast(base_model):
+    """Round-4 review, parity item 2: the benchmarked dtype was only held to "within 6 % of the f32 logits".  Here it is pinned to
+    what the reference itself does in that dtype: the SAME oracle model run by torch under `autocast("cuda", bfloat16)` on this GPU
+    (f32 residual stream, bf16 GEMM operands, f32 accumulation: the reference's `precision: bf16-mixed` path).  Both are
+    approximations of the f32 CPU oracle; the build's error against it must not exceed torch's own by more than a quarter (max and
+    RMS over all 5 x 512 x 512 logits of two tiles), and the two bf16 masks must agree with the f32 mask about equally often."""
+    import copy
+    ref, model, _ = base_model
+    batch = synthetic_batch(2, 3, 512, 5, 77)
+    model.eval()
+    ref.eval()
+    with torch.no_grad():
+        o32 = ref(batch["image"], batch["wavelengths"]).out
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ours = model(batch["image"].to(DEV), batch["wavelengths"]).out.float().cpu()
+        tref = copy.deepcopy(ref).to(DEV).eval()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            theirs = tref(batch["image"].to(DEV), batch["wavelengths"].to(DEV)).out.float().cpu()
+        del tref
+    e_ours, e_torch = (ours - o32), (theirs - o32)
+    mx = (e_ours.abs().max().item(), e_torch.abs().max().item())
+    rms = (e_ours.pow(2).mean().sqrt().item(), e_torch.pow(2).mean().sqrt().item())
+    want = o32.softmax(1).argmax(1)
+    agree = ((ours.softmax(1).argmax(1) == want).float().mean().item(), (theirs.softmax(1).argmax(1) == want).float().mean().item())
+    print(f"bf16 vs the f32 oracle -- build: max {mx[0]:.3e} rms {rms[0]:.3e} mask agreement {agree[0]:.5f}; "
+          f"torch autocast: max {mx[1]:.3e} rms {rms[1]:.3e} mask agreement {agree[1]:.5f}")
+    assert mx[0] <= 1.25 * mx[1] + 1e-3 and rms[0] <= 1.25 * rms[1] + 1e-4, (mx, rms)
+    assert agree[0] >= agree[1] - 5e-3, agree
+
+
 def test_base_512_train_f32(base_model, golden_dir):
     ref, model, sd = base_model
     g = np.load(golden_dir / "dofa_base_512_train.npz")

@@ -1732,6 +1732,71 @@ def test_resized_conv_nodes_bf16_at_production_shape():
     assert not bad, bad
 
 
+def _plain_conv_modules_at_production_shape(dtype):
+    """The PLAIN (not restructured) training ConvModules of UperNet at their production shapes, B = 2: `fpn_convs[0]` (3x3, 256 ->
+    256 on the 144^2 map: shared-staging implicit GEMM forward, BatchNorm statistics / apply, BatchNorm backward sums + dx, the
+    3x3 data gradient and the row-segment weight gradient with its XCD-grouped tiles) and `lateral_convs[0]` (1x1, 768 -> 256 at
+    144^2: persistent tile with the statistics-emitting epilogue, 256^2 weight-gradient tile with split-K) -- conv -> BN(batch
+    statistics) -> ReLU (models/utils.py:10-52, upernet.py:79-101) against torch f32 autograd on the CPU fed the same operands,
+    (a) as a plain f32 graph and (b) evaluated AT the build's own conv output (same ReLU mask and statistics on both sides).
+    Returns {"<module> <tensor> [<reference>]": relative L2 error}."""
+    import copy
+    from torch import nn
+    B, res = 2, {}
+    for tag, cin, cout, k in (("fpn 3x3 256->256 @144", 256, 256, 3), ("lateral 1x1 768->256 @144", 768, 256, 1)):
+        x = q(rnd(B, cin, 144, 144, seed=60 + k), dtype)
+        conv_r, bn_r = nn.Conv2d(cin, cout, k, padding=k // 2, bias=False), nn.BatchNorm2d(cout)
+        with torch.no_grad():
+            conv_r.weight.copy_(q(rnd(cout, cin, k, k, seed=61 + k) * (0.02 if k == 3 else 0.05), dtype))
+            bn_r.weight.copy_(rnd(cout, seed=62 + k).abs() + 0.5)
+            bn_r.bias.copy_(rnd(cout, seed=63 + k) * 0.1)
+        conv, norm = copy.deepcopy(conv_r).to(DEV).to(memory_format=torch.channels_last), copy.deepcopy(bn_r).to(DEV)
+        gy = q(rnd(B, cout, 144, 144, seed=64 + k), dtype)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype).requires_grad_()
+        with torch.no_grad():
+            pre = ops.conv_gemm(xd.detach(), gnn.gemm_weight(conv.weight, dtype), R=k, S=k, pad=k // 2)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            y = gnn.conv_bn_act(xd, conv, norm.train(), relu=True)
+        y.backward(gy.permute(0, 2, 3, 1).contiguous().to(DEV, y.dtype))
+        got = {"out": y.detach().permute(0, 3, 1, 2), "d input": xd.grad.permute(0, 3, 1, 2), "dw": conv.weight.grad,
+               "dgamma": norm.weight.grad, "dbeta": norm.bias.grad}
+        pre_cpu = pre.float().cpu().permute(0, 3, 1, 2)
+        for mode in ("f32", "at the build's forward"):
+            for p_ in list(conv_r.parameters()) + list(bn_r.parameters()):
+                p_.grad = None
+            xr = x.clone().requires_grad_()
+            yc = conv_r(xr)
+            if mode != "f32":
+                yc = yc + (pre_cpu - yc).detach()
+            yr = F.relu(bn_r.train()(yc))
+            yr.backward(gy)
+            ref = {"out": yr.detach(), "d input": xr.grad, "dw": conv_r.weight.grad, "dgamma": bn_r.weight.grad, "dbeta": bn_r.bias.grad}
+            for name, v in got.items():
+                res[f"{tag} {name} [{mode}]"] = _rel_l2(v, ref[name])
+    return res
+
+
+def test_plain_conv_modules_f32_at_production_shape():
+    """Round-4 review, parity item 1: the BatchNorm-backward / data-gradient / weight-gradient chain of the 144^2 ConvModules had
+    per-op tests at toy sizes only, and the model-level gradient tolerance is 2e-2.  Here the two heaviest plain ConvModules at
+    their production shape in f32: within 2e-5 relative L2 of torch autograd evaluated at the build's own forward (same ReLU mask,
+    same statistics: what remains is the arithmetic of the backward kernels), within 5e-3 of the plain f32 graph."""
+    res = _plain_conv_modules_at_production_shape(torch.float32)
+    print({k: f"{v:.2e}" for k, v in res.items()})
+    bad = {k: v for k, v in res.items() if not v <= (2e-5 if "build's forward" in k else 5e-3)}
+    assert not bad, bad
+
+
+def test_plain_conv_modules_bf16_at_production_shape():
+    """The same in the benchmarked dtype: bf16 operands, f32 accumulation, BatchNorm in f32 on the bf16 conv output.  Against f32
+    torch autograd at the build's own forward the remaining error is the bf16 rounding of the stored activations / gradients
+    (<= 1.5e-2 relative L2 for every tensor); against the plain f32 graph <= 3e-2."""
+    res = _plain_conv_modules_at_production_shape(torch.bfloat16)
+    print({k: f"{v:.2e}" for k, v in res.items()})
+    bad = {k: v for k, v in res.items() if not v <= (1.5e-2 if "build's forward" in k else 3e-2)}
+    assert not bad, bad
+
+
 def test_resized_conv_nodes_f32_at_production_shape():
     """f32 (round-3 review): the end-to-end gradient tolerance of the model tests is 2e-2 for deep layers because f32 round-off
     of the forward flips ReLU masks; this test backs it with a TIGHT one.  The same two nodes in f32 against torch autograd
