@@ -1787,6 +1787,7 @@ def test_plain_conv_modules_f32_at_production_shape():
     same statistics: what remains is the arithmetic of the backward kernels), within 5e-3 of the plain f32 graph."""
     res = _plain_conv_modules_at_production_shape(torch.float32)
     print({k: f"{v:.2e}" for k, v in res.items()})
+    # measured (MI355X, round 5): <= 1.4e-6 at the build's forward, <= 5.1e-4 against the plain graph
     bad = {k: v for k, v in res.items() if not v <= (2e-5 if "build's forward" in k else 5e-3)}
     assert not bad, bad
 
@@ -1794,10 +1795,10 @@ def test_plain_conv_modules_f32_at_production_shape():
 def test_plain_conv_modules_bf16_at_production_shape():
     """The same in the benchmarked dtype: bf16 operands, f32 accumulation, BatchNorm in f32 on the bf16 conv output.  Against f32
     torch autograd at the build's own forward the remaining error is the bf16 rounding of the stored activations / gradients
-    (<= 1.5e-2 relative L2 for every tensor); against the plain f32 graph <= 3e-2."""
+    (measured <= 2.4e-3 relative L2 for every tensor; bound 6e-3); against the plain f32 graph measured <= 9.9e-3, bound 2e-2."""
     res = _plain_conv_modules_at_production_shape(torch.bfloat16)
     print({k: f"{v:.2e}" for k, v in res.items()})
-    bad = {k: v for k, v in res.items() if not v <= (1.5e-2 if "build's forward" in k else 3e-2)}
+    bad = {k: v for k, v in res.items() if not v <= (6e-3 if "build's forward" in k else 2e-2)}
     assert not bad, bad
 
 
