@@ -196,7 +196,8 @@ class OpAccounting:
 
     OUT_KW = ("out", "dw", "din", "aux_out", "dq", "dk", "dv")
     SKIP = {"dt", "as_nhwc", "as_nchw", "image_f32", "split_qkv", "flash_ok", "resize_conv3x3_fwd_ok", "resize_conv3x3_fwd_bn_ok",
-            "check", "KernelTimer"}
+            "check", "KernelTimer", "resize_conv3x3_any_ok", "resize_conv3x3_bwd_gather_bn_ok", "bn_small_ok", "bn_small_fits",
+            "dice_lowres_ok"}
 
     def __init__(self) -> None:
         self.records: list = []

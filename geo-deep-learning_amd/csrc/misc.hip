@@ -633,6 +633,138 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------ Dice loss straight from the LOW-resolution logits (round 5)
+// The training step only needs the loss and its gradient, not the [B, K, 512, 512] f32 logits: per head the tail was
+// upsample (write 168 MB) -> dice partial (read 235 MB) -> dice backward (read 235, write 168) -> transposed upsample in two passes
+// (read 168 ...), 350 us per head and two heads per step (dofa.py:89-105, segmentation_dofa.py:226-229).  Both kernels below
+// evaluate the bilinear logit of a full-resolution pixel on the fly from the [B, Hi, Wi, K] f32 map the 1x1 head wrote (13 MB at
+// batch 32: L2 / MALL resident), with the SAME expression as upsample_logits_kernel:
+//   forward  -- the three per-class sums of dice_partial_kernel, same workgroup count and pixel order (the same partial sums);
+//   backward -- one thread per LOW-resolution logit vector gathers wy * wx * dL/dlogit over the full-resolution pixels that
+//               interpolate from it (softmax and Dice coefficients recomputed there): d(low) in one pass, f32, fixed order.
+template <int K>
+__device__ __forceinline__ void bilinear_logits(const float* __restrict__ in, int b, int Hi, int Wi, int y0, int y1, int x0, int x1,
+                                                float ly, float lx, float (&x)[K]) {
+  const float* p00 = in + (((int64_t)b * Hi + y0) * Wi + x0) * K;
+  const float* p01 = in + (((int64_t)b * Hi + y0) * Wi + x1) * K;
+  const float* p10 = in + (((int64_t)b * Hi + y1) * Wi + x0) * K;
+  const float* p11 = in + (((int64_t)b * Hi + y1) * Wi + x1) * K;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+  for (int k = 0; k < K; ++k) x[k] = hy * (hx * p00[k] + lx * p01[k]) + ly * (hx * p10[k] + lx * p11[k]);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void dice_lowres_partial_kernel(const float* __restrict__ low, const int64_t* __restrict__ target,
+                                                                  int B, int Hi, int Wi, int Ho, int Wo, float* __restrict__ ws) {
+  __shared__ float red[4][3 * K];
+  const int64_t total = (int64_t)B * Ho * Wo;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  float I[K], S[K], Nc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) I[k] = S[k] = Nc[k] = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    const int64_t t = i / Wo;
+    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    int y0, y1, x0, x1; float ly, lx;
+    src_index2(ry, oy, Hi, y0, y1, ly);
+    src_index2(rx, ox, Wi, x0, x1, lx);
+    float x[K], mx = -INFINITY;
+    bilinear_logits<K>(low, b, Hi, Wi, y0, y1, x0, x1, ly, lx, x);
+#pragma unroll
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, x[k]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { x[k] = expf(x[k] - mx); s += x[k]; }
+    const float inv = 1.f / s;
+    const int y = (int)target[i];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float pk = x[k] * inv;
+      S[k] += pk;
+      if (y == k) { I[k] += pk; Nc[k] += 1.f; }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float a = wave_sum(I[k]), bsum = wave_sum(S[k]), c = wave_sum(Nc[k]);
+    if (lane == 0) { red[wv][k] = a; red[wv][K + k] = bsum; red[wv][2 * K + k] = c; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 * K)
+    ws[(int64_t)blockIdx.x * 3 * K + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+constexpr int DICE_LOWRES_MAXW = 36;     // gather window bound (2 * factor + 4 <= 36: upsampling factors up to 16)
+
+template <int K>
+__global__ __launch_bounds__(256) void dice_lowres_bwd_kernel(const float* __restrict__ low, const int64_t* __restrict__ target, int B,
+                                                              int Hi, int Wi, int Ho, int Wo, const float* __restrict__ sums,
+                                                              float eps, const float* __restrict__ upstream, float grad_scale,
+                                                              float* __restrict__ dlow) {
+  float ca[K], cb[K];  // dL/dp_c = ca[c]*[y==c] + cb[c]   (dice_bwd_kernel)
+  const float up = (upstream ? upstream[0] : 1.f) * grad_scale;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float I = sums[k], card = sums[K + k] + sums[2 * K + k];
+    const bool on = sums[2 * K + k] > 0.f && card > eps;
+    ca[k] = on ? -2.f / (K * card) * up : 0.f;
+    cb[k] = on ? 2.f * I / (K * card * card) * up : 0.f;
+  }
+  const int64_t total = (int64_t)B * Hi * Wi;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ix = (int)(i % Wi);
+    const int64_t t = i / Wi;
+    const int iy = (int)(t % Hi), b = (int)(t / Hi);
+    int ylo, yhi, xlo, xhi;
+    cand_range(iy, ry, Ho, ylo, yhi);
+    cand_range(ix, rx, Wo, xlo, xhi);
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      int y0, y1; float ly;
+      src_index2(ry, oy, Hi, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      const int64_t trow = ((int64_t)b * Ho + oy) * Wo;
+      // (runtime loop, indices recomputed per column: holding the window's columns in registers -- 4 x 16 values -- and unrolling
+      // cost 208 registers = two waves per SIMD for a kernel that lives on L1 / L2 latency)
+#pragma unroll 1
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        int x0, x1; float lx;
+        src_index2(rx, ox, Wi, x0, x1, lx);
+        const float w = wy * ((x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f));
+        if (w == 0.f) continue;
+        float x[K], mx = -INFINITY;
+        bilinear_logits<K>(low, b, Hi, Wi, y0, y1, x0, x1, ly, lx, x);
+#pragma unroll
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, x[k]);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { x[k] = expf(x[k] - mx); s += x[k]; }
+        const float inv = 1.f / s;
+        const int y = (int)target[trow + ox];
+        float g[K], dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          x[k] *= inv;
+          g[k] = cb[k] + (y == k ? ca[k] : 0.f);
+          dot += x[k] * g[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += w * (x[k] * (g[k] - dot));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) dlow[i * K + k] = acc[k];
+  }
+}
+
 // ------------------------------------------------------------------ Dice loss (smp binary)
 // smp DiceLoss(mode="binary") (configs/unetplus_config_RGB.yaml: num_classes 1): p = exp(logsigmoid(x)), one class,
 // sums over dims (batch, pixels); the target is used as a 0/1 weight.  Partials have the multiclass layout with K = 1
@@ -1051,6 +1183,39 @@ extern "C" int gdl_dice_loss_fwd(const float* logits, const int64_t* target, int
   K_SWITCH(K, hipLaunchKernelGGL((dice_partial_kernel<KK>), dim3(nblk), dim3(256), 0, s, logits, target, B, HW, ws);
               hipLaunchKernelGGL((dice_final_kernel<KK>), dim3(1), dim3(256), 0, s, ws, nblk, eps, sums, loss));
   GDL_CHECK_LAUNCH("gdl_dice_loss_fwd");
+  return GDL_OK;
+}
+
+// Dice loss (multiclass) of bilinear(low -> [Ho, Wo]) against target [B, Ho, Wo] WITHOUT the full-resolution logits: low = the
+// [B, Hi, Wi, K] f32 map gdl_head_1x1 writes.  sums / loss / workspace as gdl_dice_loss_fwd (workspace of
+// gdl_dice_loss_workspace(B, K, Ho * Wo) bytes).  Upsampling factors up to 16 per direction.
+extern "C" int gdl_dice_loss_lowres_fwd(const float* low, const int64_t* target, int B, int K, int Hi, int Wi, int Ho, int Wo, float eps,
+                                        float* sums, float* loss, float* ws, int64_t ws_bytes, gdl_stream_t stream) {
+  GDL_CHECK_ARG(low && target && sums && loss && ws, "gdl_dice_loss_lowres_fwd: null pointer");
+  GDL_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho >= Hi && Wo >= Wi, "gdl_dice_loss_lowres_fwd: bad sizes (an upsample is expected)");
+  GDL_CHECK_ARG(2 * ((Ho + Hi - 1) / Hi) + 4 <= DICE_LOWRES_MAXW && 2 * ((Wo + Wi - 1) / Wi) + 4 <= DICE_LOWRES_MAXW,
+                "gdl_dice_loss_lowres_fwd: upsampling factors above 16 are not supported");
+  GDL_CHECK_ARG(ws_bytes >= gdl_dice_loss_workspace(B, K, (int64_t)Ho * Wo), "gdl_dice_loss_lowres_fwd: workspace too small");
+  const int nblk = dice_blocks((int64_t)B * Ho * Wo);
+  hipStream_t s = (hipStream_t)stream;
+  K_SWITCH(K, hipLaunchKernelGGL((dice_lowres_partial_kernel<KK>), dim3(nblk), dim3(256), 0, s, low, target, B, Hi, Wi, Ho, Wo, ws);
+              hipLaunchKernelGGL((dice_final_kernel<KK>), dim3(1), dim3(256), 0, s, ws, nblk, eps, sums, loss));
+  GDL_CHECK_LAUNCH("gdl_dice_loss_lowres_fwd");
+  return GDL_OK;
+}
+
+// d loss / d low [B, Hi, Wi, K] (f32, overwritten) from the sums of the forward; upstream (device scalar, may be null) * grad_scale
+// multiplies the gradient.
+extern "C" int gdl_dice_loss_lowres_bwd(const float* low, const int64_t* target, int B, int K, int Hi, int Wi, int Ho, int Wo, float eps,
+                                        const float* sums, const float* upstream, float grad_scale, float* dlow, gdl_stream_t stream) {
+  GDL_CHECK_ARG(low && target && sums && dlow, "gdl_dice_loss_lowres_bwd: null pointer");
+  GDL_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho >= Hi && Wo >= Wi, "gdl_dice_loss_lowres_bwd: bad sizes");
+  GDL_CHECK_ARG(2 * ((Ho + Hi - 1) / Hi) + 4 <= DICE_LOWRES_MAXW && 2 * ((Wo + Wi - 1) / Wi) + 4 <= DICE_LOWRES_MAXW,
+                "gdl_dice_loss_lowres_bwd: upsampling factors above 16 are not supported");
+  const int64_t total = (int64_t)B * Hi * Wi;
+  K_SWITCH(K, hipLaunchKernelGGL((dice_lowres_bwd_kernel<KK>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, low,
+                                 target, B, Hi, Wi, Ho, Wo, sums, eps, upstream, grad_scale, dlow));
+  GDL_CHECK_LAUNCH("gdl_dice_loss_lowres_bwd");
   return GDL_OK;
 }
 

@@ -12,6 +12,7 @@ import os
 
 import logging
 import weakref
+from typing import NamedTuple
 
 import torch
 import torch.distributed as dist
@@ -983,7 +984,56 @@ class _HeadLogits(Function):
         return dfeat, dw.view(weight.shape), (db if ctx.has_bias else None), None, None
 
 
-def head_logits(feat: Tensor, conv: nn.Conv2d, size, chan_scale: Tensor | None = None) -> Tensor:
+class _Head1x1(Function):
+    """The classifier alone: NHWC features -> [B, h, w, K] f32 logits at the feature resolution (the first half of _HeadLogits)."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, chan_scale):
+        low = ops.head_1x1(feat, weight.detach(), None if bias is None else bias.detach(), chan_scale)
+        ctx.save_for_backward(feat, weight, chan_scale)
+        ctx.has_bias = bias is not None
+        return low
+
+    @staticmethod
+    def backward(ctx, dlow):
+        feat, weight, chan_scale = ctx.saved_tensors
+        dfeat, dw, db = ops.head_1x1_bwd(feat, dlow.contiguous(), weight.detach(), chan_scale, need_dfeat=ctx.needs_input_grad[0])
+        return dfeat, dw.view(weight.shape), (db if ctx.has_bias else None), None
+
+
+class LowresLogits(NamedTuple):
+    """Logits that have NOT been resized to the image yet: ``low`` [B, h, w, K] f32 (NHWC, as the 1x1 head writes them) and the
+    ``size`` the reference's final ``F.interpolate(..., mode="bilinear")`` (dofa.py:89-105) would give them.  What a training
+    step hands to ``gdlhip.nn.DiceLoss`` instead of the [B, K, H, W] tensor (round 5: the loss and its gradient are evaluated
+    from ``low`` directly; the 168 MB of full-resolution logits per head are never written or read)."""
+
+    low: Tensor
+    size: tuple
+
+    def materialise(self) -> Tensor:
+        """The [B, K, H, W] f32 logits the reference's forward returns (differentiable)."""
+        return _UpsampleLogits.apply(self.low, (int(self.size[0]), int(self.size[1])))
+
+
+class _UpsampleLogits(Function):
+    @staticmethod
+    def forward(ctx, low, size):
+        ctx.low_size = (low.shape[1], low.shape[2])
+        return ops.upsample_logits(low, size)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.upsample_logits_bwd(g.contiguous(), ctx.low_size), None
+
+
+FUSE_LOWRES_DICE = os.environ.get("GDL_LOWRES_DICE", "1") != "0"   # A/B switch: 0 = training steps materialise the full-resolution logits
+
+
+def head_logits(feat: Tensor, conv: nn.Conv2d, size, chan_scale: Tensor | None = None, lowres: bool = False):
+    """1x1 classifier + bilinear resize to ``size``: NCHW f32 logits; ``lowres``: the classifier's own map and the target size
+    (LowresLogits) for a loss that does not need the resized tensor."""
+    if lowres:
+        return LowresLogits(_Head1x1.apply(feat, conv.weight, conv.bias, chan_scale), (int(size[0]), int(size[1])))
     return _HeadLogits.apply(feat, conv.weight, conv.bias, chan_scale, (int(size[0]), int(size[1])))
 
 
@@ -1001,6 +1051,22 @@ class _DiceLoss(Function):
     def backward(ctx, g):
         logits, target, sums = ctx.saved_tensors
         return ops.dice_loss_bwd(logits, target, sums, g.contiguous().float(), 1.0, ctx.eps), None, None
+
+
+class _DiceLowres(Function):
+    """smp DiceLoss(mode='multiclass') of bilinear(low -> size), forward and backward from the low-resolution map."""
+
+    @staticmethod
+    def forward(ctx, low, target, size, eps):
+        loss, sums = ops.dice_loss_lowres_fwd(low, target, size, eps)
+        ctx.save_for_backward(low, target, sums)
+        ctx.size, ctx.eps = size, eps
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        low, target, sums = ctx.saved_tensors
+        return ops.dice_loss_lowres_bwd(low, target, ctx.size, sums, g.contiguous().float(), 1.0, ctx.eps), None, None, None
 
 
 class _DiceBinaryLoss(Function):
@@ -1037,7 +1103,15 @@ class DiceLoss(nn.Module):
             raise NotImplementedError(msg)
         self.mode, self.eps = mode, eps
 
-    def forward(self, y_pred: Tensor, y_true: Tensor) -> Tensor:
+    def forward(self, y_pred, y_true: Tensor) -> Tensor:
+        if isinstance(y_pred, LowresLogits):
+            # a training step's not-yet-resized logits: the loss (and its gradient) straight from the low-resolution map
+            size = (int(y_pred.size[0]), int(y_pred.size[1]))
+            yt = y_true[:, 0] if y_true.dim() == 4 and y_true.shape[1] == 1 else y_true
+            if (self.mode == "multiclass" and FUSE_LOWRES_DICE and ops.dice_lowres_ok(y_pred.low, size)
+                    and y_pred.low.dtype == torch.float32 and tuple(yt.shape[1:]) == size):
+                return _DiceLowres.apply(y_pred.low.contiguous(), yt.long().contiguous(), size, self.eps)
+            y_pred = y_pred.materialise()
         if y_pred.dtype != torch.float32 or not y_pred.is_contiguous():
             y_pred = y_pred.float().contiguous()
         if self.mode == "binary":

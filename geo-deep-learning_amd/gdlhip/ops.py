@@ -1558,6 +1558,41 @@ def dice_loss_bwd(logits: Tensor, target: Tensor, sums: Tensor, upstream: Tensor
     return out
 
 
+def dice_lowres_ok(low: Tensor, size: tuple[int, int]) -> bool:
+    """Shapes gdl_dice_loss_lowres_* take: an upsample by at most 16 per direction, at most 16 classes."""
+    if low.dim() != 4 or low.shape[3] > 16:
+        return False
+    hi, wi = low.shape[1], low.shape[2]
+    return size[0] >= hi and size[1] >= wi and -(-size[0] // hi) <= 16 and -(-size[1] // wi) <= 16
+
+
+def dice_loss_lowres_fwd(low: Tensor, target: Tensor, size: tuple[int, int], eps: float = 1e-7):
+    """Dice(multiclass) of bilinear(low -> size) vs target [B, H, W] without the full-resolution logits: (loss, sums)."""
+    _need_cuda(low, target)
+    if low.dtype != torch.float32 or not low.is_contiguous() or low.dim() != 4:
+        raise ValueError("dice_loss_lowres: contiguous f32 NHWC low-resolution logits [B, h, w, K] expected")
+    B, Hi, Wi, K = low.shape
+    if target.dtype != torch.int64 or not target.is_contiguous() or tuple(target.shape) != (B, size[0], size[1]):
+        raise ValueError(f"dice_loss_lowres: contiguous int64 target [B, {size[0]}, {size[1]}] expected, got {tuple(target.shape)}")
+    sums = torch.empty(3 * K, device=low.device, dtype=torch.float32)
+    loss = torch.empty((), device=low.device, dtype=torch.float32)
+    lib = _lib.load()
+    nbytes = lib.gdl_dice_loss_workspace(B, K, size[0] * size[1])
+    ws = torch.empty(nbytes // 4, device=low.device, dtype=torch.float32)
+    check(lib.gdl_dice_loss_lowres_fwd(_p(low), _p(target), B, K, Hi, Wi, size[0], size[1], eps, _p(sums), _p(loss), _p(ws), nbytes,
+                                       _stream()), "gdl_dice_loss_lowres_fwd")
+    return loss, sums
+
+
+def dice_loss_lowres_bwd(low: Tensor, target: Tensor, size: tuple[int, int], sums: Tensor, upstream: Tensor | None,
+                         grad_scale: float = 1.0, eps: float = 1e-7) -> Tensor:
+    B, Hi, Wi, K = low.shape
+    dlow = torch.empty_like(low)
+    check(_lib.load().gdl_dice_loss_lowres_bwd(_p(low), _p(target), B, K, Hi, Wi, size[0], size[1], eps, _p(sums), _p(upstream),
+                                               grad_scale, _p(dlow), _stream()), "gdl_dice_loss_lowres_bwd")
+    return dlow
+
+
 def dice_binary_loss_fwd(logits: Tensor, target: Tensor, eps: float = 1e-7):
     """smp DiceLoss(mode="binary"): logits [B,1,H,W] (or any shape) f32, target of the same numel, int64 0/1."""
     _need_cuda(logits, target)

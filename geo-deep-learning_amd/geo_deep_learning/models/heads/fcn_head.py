@@ -29,7 +29,7 @@ class FCNHead(nn.Module):
         self.dropout = nn.Dropout2d(dropout_ratio) if dropout_ratio > 0 else nn.Identity()
         self.cls_seg = nn.Conv2d(channels, num_classes, kernel_size=1)
 
-    def forward_logits(self, x_nhwc: torch.Tensor, size, drop_mask: torch.Tensor | None = None) -> torch.Tensor:
+    def forward_logits(self, x_nhwc: torch.Tensor, size, drop_mask: torch.Tensor | None = None, lowres: bool = False):
         """convs -> Dropout2d (per (sample, channel) scale folded into the classifier) -> 1x1 ->
         bilinear to ``size``.  ``drop_mask`` [B, channels] of 0/1 pins the draw (tests)."""
         feats = self.convs[0].forward_nhwc(x_nhwc)
@@ -40,7 +40,7 @@ class FCNHead(nn.Module):
                 drop_mask = torch.empty((feats.shape[0], self.channels), device=feats.device,
                                         dtype=torch.float32).bernoulli_(keep)
             chan_scale = (drop_mask.to(device=feats.device, dtype=torch.float32) / keep).contiguous()
-        return gnn.head_logits(feats, self.cls_seg, size, chan_scale)
+        return gnn.head_logits(feats, self.cls_seg, size, chan_scale, lowres=lowres)
 
     def forward(self, inputs: torch.Tensor | list[torch.Tensor]) -> torch.Tensor:
         x = inputs[self.in_index] if isinstance(inputs, (list, tuple)) else inputs

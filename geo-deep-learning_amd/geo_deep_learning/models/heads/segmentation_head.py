@@ -23,9 +23,9 @@ class SegmentationHead(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, num_classes, kernel_size=1)
 
-    def forward_logits(self, x_nhwc: torch.Tensor, size) -> torch.Tensor:
-        """head conv + bilinear resize to ``size`` fused: NCHW f32 logits (dofa.py:89-96)."""
-        return gnn.head_logits(x_nhwc, self.conv, size)
+    def forward_logits(self, x_nhwc: torch.Tensor, size, lowres: bool = False):
+        """head conv + bilinear resize to ``size`` fused: NCHW f32 logits (dofa.py:89-96); ``lowres``: gdlhip.nn.LowresLogits."""
+        return gnn.head_logits(x_nhwc, self.conv, size, lowres=lowres)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         xn = gnn.to_compute(ops.as_nhwc(x), gnn.compute_dtype())

@@ -45,12 +45,15 @@ class DOFASegmentationModel(BaseSegmentationModel):
             self._freeze_layers(layers=freeze_layers)
 
     def forward(self, x: torch.Tensor, wavelengths: torch.Tensor, drop_masks=None,
-                aux_drop_mask: torch.Tensor | None = None) -> SegmentationOutput:
-        """dofa.py:83-107.  ``drop_masks`` / ``aux_drop_mask`` pin the stochastic draws (tests)."""
+                aux_drop_mask: torch.Tensor | None = None, lowres_logits: bool = False) -> SegmentationOutput:
+        """dofa.py:83-107.  ``drop_masks`` / ``aux_drop_mask`` pin the stochastic draws (tests).  ``lowres_logits`` (not in the
+        reference; off by default): ``out`` / ``aux`` come back as ``gdlhip.nn.LowresLogits`` -- the two heads' own maps plus the
+        size the final ``F.interpolate`` would give them -- for a training step whose loss (``gdlhip.nn.DiceLoss``) evaluates the
+        resize on the fly.  It travels through ``DistributedDataParallel.forward`` as a keyword argument."""
         image_size = x.shape[2:]
         with gnn.counter_batch():       # the BatchNorm step counters of the pass advance in one launch
             feats = self.neck.forward_nhwc(self.encoder.forward_features_nhwc(x, wavelengths, drop_masks))
             dec = self.decoder.forward_nhwc(feats)
-            out = self.head.forward_logits(dec, image_size)
-            aux = self.aux_head.forward_logits(feats[-1], image_size, aux_drop_mask)
+            out = self.head.forward_logits(dec, image_size, lowres=lowres_logits)
+            aux = self.aux_head.forward_logits(feats[-1], image_size, aux_drop_mask, lowres=lowres_logits)
         return self.output_struct(out=out, aux=aux)

@@ -82,16 +82,21 @@ class SegmentationDOFA(SegmentationTaskHooks, LightningModule):
     def forward(self, image: Tensor, wavelengths: Tensor) -> Tensor:
         return self.model(image, wavelengths)
 
-    def _loss(self, batch: dict[str, Any]):
+    def _loss(self, batch: dict[str, Any], lowres_logits: bool = False):
         x, y, wv = batch["image"], batch["mask"], batch["wavelengths"]
         y = y.squeeze(1).long()
-        outputs = self(x, wv)
+        # lowres_logits (training only): the loss is all the step needs from the logits, and gdlhip's DiceLoss evaluates it -- and its
+        # gradient -- from the heads' own 144 x 144 maps; the reference's F.interpolate to 512 x 512 (dofa.py:89-105) and the 168 MB
+        # tensor it produces per head exist only where something reads them (validation / test: masks, metrics)
+        outputs = self.model(x, wv, lowres_logits=True) if lowres_logits else self(x, wv)
         loss = self.loss(outputs.out, y) + 0.4 * self.loss(outputs.aux, y)
         return outputs, y, loss, x.shape[0]
 
     def training_step(self, batch: dict[str, Any], batch_idx: int) -> Tensor:  # noqa: ARG002
         """segmentation_dofa.py:213-241."""
-        _, _, loss, bs = self._loss(batch)
+        from gdlhip import nn as gnn
+        fused = gnn.FUSE_LOWRES_DICE and isinstance(self.loss, gnn.DiceLoss) and self.loss.mode == "multiclass"
+        _, _, loss, bs = self._loss(batch, lowres_logits=fused)
         self.train_samples_count += bs
         self._log_loss("train_loss", loss, bs)
         return loss

@@ -470,6 +470,16 @@ int gdl_dice_loss_fwd(const float* logits, const int64_t* target, int B, int K, 
 int gdl_dice_loss_bwd(const float* logits, const int64_t* target, int B, int K, int64_t HW, float eps,
                       const float* sums, const float* upstream, float grad_scale, float* dlogits,
                       int accumulate, gdl_stream_t stream);
+/* The same loss WITHOUT the full-resolution logits (round 5): the reference's training step computes
+ * DiceLoss(F.interpolate(head(x), size=image_size, mode="bilinear")) (dofa.py:89-105, segmentation_dofa.py:226-229) and only needs the
+ * loss and its gradient.  low = the [B, Hi, Wi, K] f32 map of gdl_head_1x1; the bilinear logit of every [Ho, Wo] pixel is
+ * evaluated on the fly (same expression as gdl_upsample_logits).  _fwd: sums / loss / ws as gdl_dice_loss_fwd with
+ * HW = Ho * Wo.  _bwd: dlow [B, Hi, Wi, K] f32 = d loss / d low in one pass (gather form, fixed order), scaled by
+ * upstream[0] (device scalar, may be null) * grad_scale.  Upsampling factors up to 16. */
+int gdl_dice_loss_lowres_fwd(const float* low, const int64_t* target, int B, int K, int Hi, int Wi, int Ho, int Wo, float eps,
+                             float* sums, float* loss, float* ws, int64_t ws_bytes, gdl_stream_t stream);
+int gdl_dice_loss_lowres_bwd(const float* low, const int64_t* target, int B, int K, int Hi, int Wi, int Ho, int Wo, float eps,
+                             const float* sums, const float* upstream, float grad_scale, float* dlow, gdl_stream_t stream);
 
 /* smp DiceLoss(mode="binary", smooth=0, eps=1e-7) on `total` = B*H*W logits of the single class (the reference's
  * UNet++ config: configs/unetplus_config_RGB.yaml:40-47 with num_classes 1; smp 0.5.0 losses/dice.py): p =

@@ -615,6 +615,45 @@ def test_wgrad_row_segment_kernel(B, H, W, C, N):
     assert (acc - 1 - dw).abs().max().item() <= 1e-3 * dw.abs().max().item() + 1e-5
 
 
+@pytest.mark.parametrize("B,K,hi,wi,ho,wo", [(2, 5, 9, 9, 32, 32), (2, 5, 36, 36, 128, 128), (1, 3, 7, 5, 7, 5), (3, 16, 6, 10, 50, 41),
+                                             (2, 2, 4, 4, 64, 64), (1, 5, 144, 144, 512, 512)])
+def test_dice_loss_from_low_resolution_logits(B, K, hi, wi, ho, wo):
+    """Round 5: gdl_dice_loss_lowres_fwd / _bwd -- DiceLoss(F.interpolate(low, size, bilinear)) and its gradient w.r.t. ``low``
+    without the [B, K, H, W] logits (dofa.py:89-105 + segmentation_dofa.py:226-229).  Against (a) the materialised path it replaces
+    (gdl_upsample_logits -> gdl_dice_loss_fwd / _bwd -> gdl_upsample_logits_bwd: same per-pixel expressions) and (b) torch autograd
+    of interpolate -> softmax -> the smp Dice formula in f64; with an upstream scale (the 0.4 of the auxiliary head) and a class
+    that does not occur in the target."""
+    from oracle.model import dice_loss_multiclass
+    low = rnd(B, hi, wi, K, seed=3) * 2.0
+    tgt = torch.randint(0, max(K - 1, 1), (B, ho, wo), generator=torch.Generator().manual_seed(4))     # class K-1 never occurs
+    lowd, tgtd = low.to(DEV), tgt.to(DEV)
+    assert ops.dice_lowres_ok(lowd, (ho, wo))
+    loss, sums = ops.dice_loss_lowres_fwd(lowd, tgtd, (ho, wo))
+    full = ops.upsample_logits(lowd, (ho, wo))
+    loss2, sums2 = ops.dice_loss_fwd(full, tgtd)
+    assert abs(loss.item() - loss2.item()) <= 1e-6 and torch.allclose(sums, sums2, rtol=1e-6, atol=1e-3)
+    up = torch.tensor(0.4, device=DEV)
+    dlow = ops.dice_loss_lowres_bwd(lowd, tgtd, (ho, wo), sums, up)
+    dlow2 = ops.upsample_logits_bwd(ops.dice_loss_bwd(full, tgtd, sums2, up), (hi, wi))
+    close(dlow, dlow2, torch.float32, "d low vs the materialised path", scale=dlow2.abs().max().item() + 1e-12)
+    # the definition
+    lr = low.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ref = dice_loss_multiclass(F.interpolate(lr, size=(ho, wo), mode="bilinear", align_corners=False), tgt)
+    (0.4 * ref).backward()
+    assert abs(loss.item() - ref.item()) <= 2e-6, (loss.item(), ref.item())
+    close(dlow.permute(0, 3, 1, 2), lr.grad.float(), torch.float32, "d low vs torch", scale=lr.grad.abs().max().item() + 1e-12)
+    # through the module: LowresLogits -> DiceLoss == DiceLoss(materialised logits), gradients into the low-resolution map
+    crit = gnn.DiceLoss(mode="multiclass")
+    a = lowd.clone().requires_grad_(True)
+    b_ = lowd.clone().requires_grad_(True)
+    la = crit(gnn.LowresLogits(a, (ho, wo)), tgtd)
+    lb = crit(gnn.LowresLogits(b_, (ho, wo)).materialise(), tgtd)
+    (0.4 * la).backward()
+    (0.4 * lb).backward()
+    assert abs(la.item() - lb.item()) <= 1e-6
+    close(a.grad, b_.grad, torch.float32, "module path", scale=b_.grad.abs().max().item() + 1e-12)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("K", [5, 1, 12, 16])
 def test_head_and_logit_upsample(dtype, K):
