@@ -2,6 +2,8 @@
 // kernel packing, casts, broadcast adds, u8 normalise, classifier tail, Dice loss, Adam.
 #include <type_traits>
 
+#include <atomic>
+
 #include "gdl_common.h"
 
 namespace {
@@ -223,21 +225,21 @@ __global__ __launch_bounds__(256) void iou_counts_kernel(const int64_t* __restri
 }
 
 // ------------------------------------------------------------------ classifier tail
-// 1x1 conv to K<=16 classes: a wave walks a run of pixels, 4 channels per lane per step.  Round 5: with one pixel per wave (one
-// 8-byte load per lane in flight) the kernel ran at 2.5 TB/s on the 340 MB decoder output; a wave now owns HEAD_RUN consecutive
-// pixels, requests four rows before it multiplies, and -- for C <= 256, the shape of both heads -- keeps its weight vectors in
-// registers across the run.  Per-pixel arithmetic and the order of every sum are unchanged (bit-identical outputs).
-constexpr int HEAD_RUN = 16;
+// 1x1 conv to K<=16 classes: one wave per pixel, 4 channels per lane per step.
 template <typename T, int K>
 __global__ __launch_bounds__(256) void head_1x1_kernel(const void* __restrict__ feat, int64_t P, int C, int64_t f_sP,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        const float* __restrict__ chan_scale, int64_t pix_per_img,
                                                        float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int64_t p_begin = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * HEAD_RUN;
-  if (p_begin >= P) return;
-  const int64_t p_end = p_begin + HEAD_RUN < P ? p_begin + HEAD_RUN : P;
-  auto load = [&](int64_t p, int c, float (&v)[4]) {
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  float acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0.f;
+  const float* cs = chan_scale ? chan_scale + (p / pix_per_img) * C : nullptr;
+  for (int c = lane * 4; c < C; c += 256) {
+    float v[4];
     if constexpr (sizeof(T) == 4) {
       const float4 t = *(const float4*)((const float*)feat + p * f_sP + c);
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -246,62 +248,20 @@ __global__ __launch_bounds__(256) void head_1x1_kernel(const void* __restrict__ 
       v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
       v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
     }
-  };
-  auto finish = [&](int64_t p, float (&acc)[K]) {
+    if (cs) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] *= cs[c + j];
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const float s = wave_sum(acc[k]);
-      if (lane == 0) out[p * K + k] = s + (bias ? bias[k] : 0.f);
+      const float4 ww = *(const float4*)(w + (int64_t)k * C + c);
+      acc[k] += (v[0] * ww.x + v[1] * ww.y) + (v[2] * ww.z + v[3] * ww.w);
     }
-  };
-  if (C <= 256) {
-    const int c = lane * 4;
-    const bool on = c < C;
-    float4 ww[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) ww[k] = on ? *(const float4*)(w + (int64_t)k * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t p = p_begin; p < p_end; p += 4) {
-      float v[4][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f;
-        if (on && p + u < p_end) load(p + u, c, v[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (p + u >= p_end) break;
-        if (chan_scale && on) {
-          const float* cs = chan_scale + ((p + u) / pix_per_img) * C + c;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[u][j] *= cs[j];
-        }
-        float acc[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = (v[u][0] * ww[k].x + v[u][1] * ww[k].y) + (v[u][2] * ww[k].z + v[u][3] * ww[k].w);
-        finish(p + u, acc);
-      }
-    }
-    return;
   }
-  for (int64_t p = p_begin; p < p_end; ++p) {
-    float acc[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0.f;
-    const float* cs = chan_scale ? chan_scale + (p / pix_per_img) * C : nullptr;
-    for (int c = lane * 4; c < C; c += 256) {
-      float v[4];
-      load(p, c, v);
-      if (cs) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= cs[c + j];
-      }
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float4 wk = *(const float4*)(w + (int64_t)k * C + c);
-        acc[k] += (v[0] * wk.x + v[1] * wk.y) + (v[2] * wk.z + v[3] * wk.w);
-      }
-    }
-    finish(p, acc);
+  for (int k = 0; k < K; ++k) {
+    const float s = wave_sum(acc[k]);
+    if (lane == 0) out[p * K + k] = s + (bias ? bias[k] : 0.f);
   }
 }
 
@@ -381,14 +341,9 @@ __global__ __launch_bounds__(256) void head_1x1_bwd_w_partial(const void* __rest
     }
   };
   int64_t p = p0 + wv;
-  for (; p + 28 < p1; p += 32) {      // eight pixel rows in flight per wave (round 5; four ran at 2.5 TB/s, one at 2), same summation order
-    float v[8][4];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) load(p + 4 * u, v[u]);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) add(p + 4 * u, v[u]);
-  }
-  for (; p + 12 < p1; p += 16) {
+  for (; p + 12 < p1; p += 16) {      // four pixel rows in flight per wave (one at a time ran at 2 TB/s), same summation order
+    // (round 5: eight rows in flight need 134 registers -- three waves per SIMD -- and run 1.6 x SLOWER; a forward kernel that
+    //  walks 16-pixel runs per wave with four rows in flight loses the same way: 243 us against 133 -- profiles/r05n_*)
     float v[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) load(p + 4 * u, v[u]);
@@ -814,6 +769,182 @@ __global__ __launch_bounds__(256) void dice_lowres_bwd_kernel(const float* __res
   }
 }
 
+// The same gradient with every full-resolution pixel's softmax evaluated ONCE (the gather kernel above evaluates it once per
+// low-resolution logit that interpolates into it: four times, 272 us at batch 32 -- no faster than the three launches it replaced).
+// A workgroup owns a DT_H x DT_W tile of full-resolution pixels:
+//   1. dL/dlogit of its pixels -> LDS (K x 2048 floats);
+//   2. transposed bilinear, rows: tmp[k][iy][c] = sum over the tile's rows of wy(row -> iy) dl[k][row][c] for the low-resolution rows
+//      the tile touches (LDS);
+//   3. columns: part[k][iy][ix] = sum_c wx(c -> ix) tmp[k][iy][c] -> the tile's partial patch in the workspace.
+// dice_lowres_bwd_reduce_kernel then adds, per low-resolution logit, the patches of the (at most four) tiles that touch it, in a
+// fixed order.  No atomics, f32, deterministic.  K <= 8 (LDS); more classes take the gather kernel.
+constexpr int DT_H = 32, DT_W = 64, DT_MAXN = 36;     // tile; bound on the low-resolution rows / columns one tile side can touch
+
+struct DiceTile {
+  const float* low; const int64_t* target; const float* sums; const float* upstream; float* ws; float* dlow;
+  int B, Hi, Wi, Ho, Wo, tiles_y, tiles_x, ny_max, nx_max;
+  float eps, grad_scale;
+};
+
+// low-resolution index range [lo, hi] that the full-resolution positions [p0, p1] interpolate from
+__device__ __forceinline__ void touched_range(float ratio, int p0, int p1, int in_size, int& lo, int& hi) {
+  int a0, a1, b0, b1; float l;
+  src_index2(ratio, p0, in_size, a0, a1, l);
+  src_index2(ratio, p1, in_size, b0, b1, l);
+  lo = a0; hi = b1;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void dice_lowres_bwd_tile_kernel(const DiceTile a) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  float* dl = dsm;                                   // [K][DT_H][DT_W]
+  float* tmp = dsm + K * DT_H * DT_W;                // [K][ny_max][DT_W]
+  float* wyt = tmp + K * a.ny_max * DT_W;            // [ny_max][DT_H]  weight of tile row r for low-resolution row iy_lo + j
+  float* wxt = wyt + a.ny_max * DT_H;                // [nx_max][DT_W]  the same for columns
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x % a.tiles_x, ty = (blockIdx.x / a.tiles_x) % a.tiles_y, b = blockIdx.x / (a.tiles_x * a.tiles_y);
+  const int oy0 = ty * DT_H, ox0 = tx * DT_W;
+  const int rows = a.Ho - oy0 < DT_H ? a.Ho - oy0 : DT_H, cols = a.Wo - ox0 < DT_W ? a.Wo - ox0 : DT_W;
+  const float ry = (float)a.Hi / (float)a.Ho, rx = (float)a.Wi / (float)a.Wo;
+  float ca[K], cb[K];
+  const float up = (a.upstream ? a.upstream[0] : 1.f) * a.grad_scale;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float I = a.sums[k], card = a.sums[K + k] + a.sums[2 * K + k];
+    const bool on = a.sums[2 * K + k] > 0.f && card > a.eps;
+    ca[k] = on ? -2.f / (K * card) * up : 0.f;
+    cb[k] = on ? 2.f * I / (K * card * card) * up : 0.f;
+  }
+  // ---- 1. dL/dlogit of the tile (zeros outside the image)
+  for (int i = tid; i < DT_H * DT_W; i += 256) {
+    const int r = i / DT_W, c = i - r * DT_W;
+    float v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = 0.f;
+    if (r < rows && c < cols) {
+      const int oy = oy0 + r, ox = ox0 + c;
+      int y0, y1, x0, x1; float ly, lx;
+      src_index2(ry, oy, a.Hi, y0, y1, ly);
+      src_index2(rx, ox, a.Wi, x0, x1, lx);
+      float x[K], mx = -INFINITY;
+      bilinear_logits<K>(a.low, b, a.Hi, a.Wi, y0, y1, x0, x1, ly, lx, x);
+#pragma unroll
+      for (int k = 0; k < K; ++k) mx = fmaxf(mx, x[k]);
+      float sden = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) { x[k] = expf(x[k] - mx); sden += x[k]; }
+      const float inv = 1.f / sden;
+      const int y = (int)a.target[((int64_t)b * a.Ho + oy) * a.Wo + ox];
+      float g[K], dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        x[k] *= inv;
+        g[k] = cb[k] + (y == k ? ca[k] : 0.f);
+        dot += x[k] * g[k];
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) v[k] = x[k] * (g[k] - dot);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) dl[(k * DT_H + r) * DT_W + c] = v[k];
+  }
+  // the low-resolution rows iy_lo .. iy_hi / columns ix_lo .. ix_hi this tile touches, and the two 1-D weight tables
+  int iy_lo, iy_hi, ix_lo, ix_hi;
+  touched_range(ry, oy0, oy0 + rows - 1, a.Hi, iy_lo, iy_hi);
+  touched_range(rx, ox0, ox0 + cols - 1, a.Wi, ix_lo, ix_hi);
+  const int ny = iy_hi - iy_lo + 1, nx = ix_hi - ix_lo + 1;
+  for (int i = tid; i < ny * DT_H; i += 256) {
+    const int j = i / DT_H, r = i - j * DT_H;
+    float wv = 0.f;
+    if (r < rows) {
+      int y0, y1; float ly;
+      src_index2(ry, oy0 + r, a.Hi, y0, y1, ly);
+      wv = (y0 == iy_lo + j ? 1.f - ly : 0.f) + (y1 == iy_lo + j ? ly : 0.f);
+    }
+    wyt[i] = wv;
+  }
+  for (int i = tid; i < nx * DT_W; i += 256) {
+    const int q = i / DT_W, c = i - q * DT_W;
+    float wv = 0.f;
+    if (c < cols) {
+      int x0, x1; float lx;
+      src_index2(rx, ox0 + c, a.Wi, x0, x1, lx);
+      wv = (x0 == ix_lo + q ? 1.f - lx : 0.f) + (x1 == ix_lo + q ? lx : 0.f);
+    }
+    wxt[i] = wv;
+  }
+  __syncthreads();
+  // ---- 2. rows
+  for (int i = tid; i < ny * DT_W; i += 256) {
+    const int j = i / DT_W, c = i - j * DT_W;
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    for (int r = 0; r < rows; ++r) {
+      const float wy = wyt[j * DT_H + r];
+      if (wy != 0.f) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += wy * dl[(k * DT_H + r) * DT_W + c];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) tmp[(k * a.ny_max + j) * DT_W + c] = acc[k];
+  }
+  __syncthreads();
+  // ---- 3. columns -> the tile's partial patch [ny_max][nx_max][K] in the workspace (entries beyond ny / nx are never read)
+  float* patch = a.ws + (int64_t)blockIdx.x * a.ny_max * a.nx_max * K;
+  for (int i = tid; i < ny * nx; i += 256) {
+    const int j = i / nx, q = i - j * nx;
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    for (int c = 0; c < cols; ++c) {
+      const float wx = wxt[q * DT_W + c];
+      if (wx != 0.f) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += wx * tmp[(k * a.ny_max + j) * DT_W + c];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) patch[(j * a.nx_max + q) * K + k] = acc[k];
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void dice_lowres_bwd_reduce_kernel(const DiceTile a) {
+  const int64_t total = (int64_t)a.B * a.Hi * a.Wi;
+  const float ry = (float)a.Hi / (float)a.Ho, rx = (float)a.Wi / (float)a.Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ix = (int)(i % a.Wi);
+    const int64_t t = i / a.Wi;
+    const int iy = (int)(t % a.Hi), b = (int)(t / a.Hi);
+    int ylo, yhi, xlo, xhi;
+    cand_range(iy, ry, a.Ho, ylo, yhi);              // full-resolution rows / columns that can interpolate from (iy, ix)
+    cand_range(ix, rx, a.Wo, xlo, xhi);
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    for (int ty = ylo / DT_H; ty <= yhi / DT_H; ++ty) {
+      const int oy0 = ty * DT_H, rows = a.Ho - oy0 < DT_H ? a.Ho - oy0 : DT_H;
+      int iy_lo, iy_hi;
+      touched_range(ry, oy0, oy0 + rows - 1, a.Hi, iy_lo, iy_hi);
+      if (iy < iy_lo || iy > iy_hi) continue;
+      for (int tx = xlo / DT_W; tx <= xhi / DT_W; ++tx) {
+        const int ox0 = tx * DT_W, cols = a.Wo - ox0 < DT_W ? a.Wo - ox0 : DT_W;
+        int ix_lo, ix_hi;
+        touched_range(rx, ox0, ox0 + cols - 1, a.Wi, ix_lo, ix_hi);
+        if (ix < ix_lo || ix > ix_hi) continue;
+        const float* patch = a.ws + ((int64_t)(b * a.tiles_y + ty) * a.tiles_x + tx) * a.ny_max * a.nx_max * K;
+        const float* src = patch + ((iy - iy_lo) * a.nx_max + (ix - ix_lo)) * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += src[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) a.dlow[i * K + k] = acc[k];
+  }
+}
+
 // ------------------------------------------------------------------ Dice loss (smp binary)
 // smp DiceLoss(mode="binary") (configs/unetplus_config_RGB.yaml: num_classes 1): p = exp(logsigmoid(x)), one class,
 // sums over dims (batch, pixels); the target is used as a 0/1 weight.  Partials have the multiclass layout with K = 1
@@ -1138,7 +1269,7 @@ extern "C" int gdl_head_1x1(const void* feat, int dtype, int64_t P, int C, int64
                             gdl_stream_t stream) {
   GDL_CHECK_ARG(feat && w && out && C % 4 == 0 && f_sP % 4 == 0 && pix_per_img > 0, "gdl_head_1x1: bad args");
   hipStream_t s = (hipStream_t)stream;
-  const unsigned grid = (unsigned)((P + 4 * HEAD_RUN - 1) / (4 * HEAD_RUN));
+  const unsigned grid = (unsigned)((P + 3) / 4);
   K_SWITCH(K, if (dtype == GDL_BF16) hipLaunchKernelGGL((head_1x1_kernel<uint16_t, KK>), dim3(grid), dim3(256), 0, s, feat, P, C, f_sP, w, bias, chan_scale, pix_per_img, out);
               else hipLaunchKernelGGL((head_1x1_kernel<float, KK>), dim3(grid), dim3(256), 0, s, feat, P, C, f_sP, w, bias, chan_scale, pix_per_img, out));
   GDL_CHECK_LAUNCH("gdl_head_1x1");
@@ -1253,11 +1384,52 @@ extern "C" int gdl_dice_loss_lowres_fwd(const float* low, const int64_t* target,
   return GDL_OK;
 }
 
+static std::atomic<int> g_dice_tiled{1};
+extern "C" void gdl_debug_set_dice_lowres_tiled(int on) { g_dice_tiled = on; }   // A/B hook: 0 = the gather kernel for every class count
+
+static bool dice_tile_dims(int K, int Hi, int Wi, int Ho, int Wo, int& ny_max, int& nx_max) {
+  // low-resolution rows / columns one tile side can touch: DT * ratio + 2 (an upper bound for ratios <= 1)
+  ny_max = (int)((int64_t)DT_H * Hi / Ho) + 3;
+  nx_max = (int)((int64_t)DT_W * Wi / Wo) + 3;
+  return g_dice_tiled && K <= 8 && ny_max <= DT_MAXN && nx_max <= DT_MAXN + DT_MAXN;
+}
+
+// bytes of scratch gdl_dice_loss_lowres_bwd needs (0: none -- the gather kernel)
+extern "C" int64_t gdl_dice_loss_lowres_bwd_workspace(int B, int K, int Hi, int Wi, int Ho, int Wo) {
+  int ny, nx;
+  if (B <= 0 || Hi <= 0 || Wi <= 0 || Ho < Hi || Wo < Wi || !dice_tile_dims(K, Hi, Wi, Ho, Wo, ny, nx)) return 0;
+  const int64_t tiles = (int64_t)B * ((Ho + DT_H - 1) / DT_H) * ((Wo + DT_W - 1) / DT_W);
+  return tiles * ny * nx * K * (int64_t)sizeof(float);
+}
+
 // d loss / d low [B, Hi, Wi, K] (f32, overwritten) from the sums of the forward; upstream (device scalar, may be null) * grad_scale
-// multiplies the gradient.
+// multiplies the gradient.  ws: gdl_dice_loss_lowres_bwd_workspace() bytes (may be null when that is 0).
 extern "C" int gdl_dice_loss_lowres_bwd(const float* low, const int64_t* target, int B, int K, int Hi, int Wi, int Ho, int Wo, float eps,
-                                        const float* sums, const float* upstream, float grad_scale, float* dlow, gdl_stream_t stream) {
+                                        const float* sums, const float* upstream, float grad_scale, float* dlow, float* ws,
+                                        int64_t ws_bytes, gdl_stream_t stream) {
   GDL_CHECK_ARG(low && target && sums && dlow, "gdl_dice_loss_lowres_bwd: null pointer");
+  {
+    int ny, nx;
+    const int64_t need = gdl_dice_loss_lowres_bwd_workspace(B, K, Hi, Wi, Ho, Wo);
+    if (need > 0 && ws && ws_bytes >= need && dice_tile_dims(K, Hi, Wi, Ho, Wo, ny, nx)) {
+      DiceTile a;
+      a.low = low; a.target = target; a.sums = sums; a.upstream = upstream; a.ws = ws; a.dlow = dlow;
+      a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo;
+      a.tiles_y = (Ho + DT_H - 1) / DT_H; a.tiles_x = (Wo + DT_W - 1) / DT_W; a.ny_max = ny; a.nx_max = nx;
+      a.eps = eps; a.grad_scale = grad_scale;
+      const unsigned tiles = (unsigned)(B * a.tiles_y * a.tiles_x);
+      const int64_t total = (int64_t)B * Hi * Wi;
+      hipStream_t st = (hipStream_t)stream;
+      K_SWITCH(K, if (KK <= 8) {
+                    const size_t lds = ((size_t)KK * (DT_H + ny) * DT_W + (size_t)ny * DT_H + (size_t)nx * DT_W) * sizeof(float);
+                    GDL_SET_MAX_LDS_ONCE((dice_lowres_bwd_tile_kernel<(KK <= 8 ? KK : 8)>), 160 * 1024);
+                    hipLaunchKernelGGL((dice_lowres_bwd_tile_kernel<(KK <= 8 ? KK : 8)>), dim3(tiles), dim3(256), lds, st, a);
+                    hipLaunchKernelGGL((dice_lowres_bwd_reduce_kernel<(KK <= 8 ? KK : 8)>), dim3(grid_for(total)), dim3(256), 0, st, a);
+                  });
+      GDL_CHECK_LAUNCH("gdl_dice_loss_lowres_bwd");
+      return GDL_OK;
+    }
+  }
   GDL_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho >= Hi && Wo >= Wi, "gdl_dice_loss_lowres_bwd: bad sizes");
   GDL_CHECK_ARG(2 * ((Ho + Hi - 1) / Hi) + 4 <= DICE_LOWRES_MAXW && 2 * ((Wo + Wi - 1) / Wi) + 4 <= DICE_LOWRES_MAXW,
                 "gdl_dice_loss_lowres_bwd: upsampling factors above 16 are not supported");

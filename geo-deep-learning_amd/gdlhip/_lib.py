@@ -155,7 +155,8 @@ SIGNATURES = {
     "gdl_dice_loss_fwd": (c_i, [c_p, c_p, c_i, c_i, c_l, c_f, c_p, c_p, c_p, c_l, c_p]),
     "gdl_dice_loss_bwd": (c_i, [c_p, c_p, c_i, c_i, c_l, c_f, c_p, c_p, c_f, c_p, c_i, c_p]),
     "gdl_dice_loss_lowres_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_l, c_p]),
-    "gdl_dice_loss_lowres_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p, c_p]),
+    "gdl_dice_loss_lowres_bwd_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "gdl_dice_loss_lowres_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_p]),
     "gdl_pad_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_i, c_i, c_i, c_p]),
     "gdl_subpix4_weights": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "gdl_dice_binary_loss_fwd": (c_i, [c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_l, c_p]),

@@ -1588,8 +1588,11 @@ def dice_loss_lowres_bwd(low: Tensor, target: Tensor, size: tuple[int, int], sum
                          grad_scale: float = 1.0, eps: float = 1e-7) -> Tensor:
     B, Hi, Wi, K = low.shape
     dlow = torch.empty_like(low)
-    check(_lib.load().gdl_dice_loss_lowres_bwd(_p(low), _p(target), B, K, Hi, Wi, size[0], size[1], eps, _p(sums), _p(upstream),
-                                               grad_scale, _p(dlow), _stream()), "gdl_dice_loss_lowres_bwd")
+    lib = _lib.load()
+    nbytes = lib.gdl_dice_loss_lowres_bwd_workspace(B, K, Hi, Wi, size[0], size[1])
+    ws = torch.empty(nbytes // 4, device=low.device, dtype=torch.float32) if nbytes else None
+    check(lib.gdl_dice_loss_lowres_bwd(_p(low), _p(target), B, K, Hi, Wi, size[0], size[1], eps, _p(sums), _p(upstream),
+                                       grad_scale, _p(dlow), _p(ws), nbytes, _stream()), "gdl_dice_loss_lowres_bwd")
     return dlow
 
 

@@ -475,11 +475,15 @@ int gdl_dice_loss_bwd(const float* logits, const int64_t* target, int B, int K, 
  * loss and its gradient.  low = the [B, Hi, Wi, K] f32 map of gdl_head_1x1; the bilinear logit of every [Ho, Wo] pixel is
  * evaluated on the fly (same expression as gdl_upsample_logits).  _fwd: sums / loss / ws as gdl_dice_loss_fwd with
  * HW = Ho * Wo.  _bwd: dlow [B, Hi, Wi, K] f32 = d loss / d low in one pass (gather form, fixed order), scaled by
- * upstream[0] (device scalar, may be null) * grad_scale.  Upsampling factors up to 16. */
+ * upstream[0] (device scalar, may be null) * grad_scale.  Upsampling factors up to 16.  With K <= 8 and a workspace of
+ * gdl_dice_loss_lowres_bwd_workspace() bytes the gradient is formed tile by tile (every full-resolution softmax evaluated once,
+ * partial patches summed in a fixed order by a second kernel); otherwise by one gather kernel (ws may be null). */
 int gdl_dice_loss_lowres_fwd(const float* low, const int64_t* target, int B, int K, int Hi, int Wi, int Ho, int Wo, float eps,
                              float* sums, float* loss, float* ws, int64_t ws_bytes, gdl_stream_t stream);
+int64_t gdl_dice_loss_lowres_bwd_workspace(int B, int K, int Hi, int Wi, int Ho, int Wo);
 int gdl_dice_loss_lowres_bwd(const float* low, const int64_t* target, int B, int K, int Hi, int Wi, int Ho, int Wo, float eps,
-                             const float* sums, const float* upstream, float grad_scale, float* dlow, gdl_stream_t stream);
+                             const float* sums, const float* upstream, float grad_scale, float* dlow, float* ws, int64_t ws_bytes,
+                             gdl_stream_t stream);
 
 /* smp DiceLoss(mode="binary", smooth=0, eps=1e-7) on `total` = B*H*W logits of the single class (the reference's
  * UNet++ config: configs/unetplus_config_RGB.yaml:40-47 with num_classes 1; smp 0.5.0 losses/dice.py): p =
