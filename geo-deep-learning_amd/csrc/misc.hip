@@ -798,8 +798,8 @@ template <int K>
 __global__ __launch_bounds__(256) void dice_lowres_bwd_tile_kernel(const DiceTile a) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float* dl = dsm;                                   // [K][DT_H][DT_W]
-  float* tmp = dsm + K * DT_H * DT_W;                // [K][ny_max][DT_W]
-  float* wyt = tmp + K * a.ny_max * DT_W;            // [ny_max][DT_H]  weight of tile row r for low-resolution row iy_lo + j
+  float* tmp = dsm + K * DT_H * DT_W;                // [K][ny_max][DT_W + 1]  (+1: phase 3's threads differ in j at equal c)
+  float* wyt = tmp + K * a.ny_max * (DT_W + 1);      // [ny_max][DT_H]  weight of tile row r for low-resolution row iy_lo + j
   float* wxt = wyt + a.ny_max * DT_H;                // [nx_max][DT_W]  the same for columns
   const int tid = threadIdx.x;
   const int tx = blockIdx.x % a.tiles_x, ty = (blockIdx.x / a.tiles_x) % a.tiles_y, b = blockIdx.x / (a.tiles_x * a.tiles_y);
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256) void dice_lowres_bwd_tile_kernel(const DiceTil
       }
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) tmp[(k * a.ny_max + j) * DT_W + c] = acc[k];
+    for (int k = 0; k < K; ++k) tmp[(k * a.ny_max + j) * (DT_W + 1) + c] = acc[k];
   }
   __syncthreads();
   // ---- 3. columns -> the tile's partial patch [ny_max][nx_max][K] in the workspace (entries beyond ny / nx are never read)
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(256) void dice_lowres_bwd_tile_kernel(const DiceTil
       const float wx = wxt[q * DT_W + c];
       if (wx != 0.f) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] += wx * tmp[(k * a.ny_max + j) * DT_W + c];
+        for (int k = 0; k < K; ++k) acc[k] += wx * tmp[(k * a.ny_max + j) * (DT_W + 1) + c];
       }
     }
 #pragma unroll
@@ -1421,7 +1421,7 @@ extern "C" int gdl_dice_loss_lowres_bwd(const float* low, const int64_t* target,
       const int64_t total = (int64_t)B * Hi * Wi;
       hipStream_t st = (hipStream_t)stream;
       K_SWITCH(K, if (KK <= 8) {
-                    const size_t lds = ((size_t)KK * (DT_H + ny) * DT_W + (size_t)ny * DT_H + (size_t)nx * DT_W) * sizeof(float);
+                    const size_t lds = ((size_t)KK * DT_H * DT_W + (size_t)KK * ny * (DT_W + 1) + (size_t)ny * DT_H + (size_t)nx * DT_W) * sizeof(float);
                     GDL_SET_MAX_LDS_ONCE((dice_lowres_bwd_tile_kernel<(KK <= 8 ? KK : 8)>), 160 * 1024);
                     hipLaunchKernelGGL((dice_lowres_bwd_tile_kernel<(KK <= 8 ? KK : 8)>), dim3(tiles), dim3(256), lds, st, a);
                     hipLaunchKernelGGL((dice_lowres_bwd_reduce_kernel<(KK <= 8 ? KK : 8)>), dim3(grid_for(total)), dim3(256), 0, st, a);
