@@ -779,6 +779,8 @@ __global__ __launch_bounds__(256) void dice_lowres_bwd_kernel(const float* __res
 // dice_lowres_bwd_reduce_kernel then adds, per low-resolution logit, the patches of the (at most four) tiles that touch it, in a
 // fixed order.  No atomics, f32, deterministic.  K <= 8 (LDS); more classes take the gather kernel.
 constexpr int DT_H = 32, DT_W = 64, DT_MAXN = 36;     // tile; bound on the low-resolution rows / columns one tile side can touch
+constexpr int DT_T = 1024;    // threads per tile: two pixels each.  With 256 (eight pixels each, LDS allowing two workgroups per CU =
+                              // two waves per SIMD) phase 1 was a chain of eight L2 round trips per thread: 215 us at batch 32
 
 struct DiceTile {
   const float* low; const int64_t* target; const float* sums; const float* upstream; float* ws; float* dlow;
@@ -795,7 +797,7 @@ __device__ __forceinline__ void touched_range(float ratio, int p0, int p1, int i
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void dice_lowres_bwd_tile_kernel(const DiceTile a) {
+__global__ __launch_bounds__(DT_T) void dice_lowres_bwd_tile_kernel(const DiceTile a) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   float* dl = dsm;                                   // [K][DT_H][DT_W]
   float* tmp = dsm + K * DT_H * DT_W;                // [K][ny_max][DT_W + 1]  (+1: phase 3's threads differ in j at equal c)
@@ -816,7 +818,7 @@ __global__ __launch_bounds__(256) void dice_lowres_bwd_tile_kernel(const DiceTil
     cb[k] = on ? 2.f * I / (K * card * card) * up : 0.f;
   }
   // ---- 1. dL/dlogit of the tile (zeros outside the image)
-  for (int i = tid; i < DT_H * DT_W; i += 256) {
+  for (int i = tid; i < DT_H * DT_W; i += DT_T) {
     const int r = i / DT_W, c = i - r * DT_W;
     float v[K];
 #pragma unroll
@@ -853,7 +855,7 @@ __global__ __launch_bounds__(256) void dice_lowres_bwd_tile_kernel(const DiceTil
   touched_range(ry, oy0, oy0 + rows - 1, a.Hi, iy_lo, iy_hi);
   touched_range(rx, ox0, ox0 + cols - 1, a.Wi, ix_lo, ix_hi);
   const int ny = iy_hi - iy_lo + 1, nx = ix_hi - ix_lo + 1;
-  for (int i = tid; i < ny * DT_H; i += 256) {
+  for (int i = tid; i < ny * DT_H; i += DT_T) {
     const int j = i / DT_H, r = i - j * DT_H;
     float wv = 0.f;
     if (r < rows) {
@@ -863,7 +865,7 @@ __global__ __launch_bounds__(256) void dice_lowres_bwd_tile_kernel(const DiceTil
     }
     wyt[i] = wv;
   }
-  for (int i = tid; i < nx * DT_W; i += 256) {
+  for (int i = tid; i < nx * DT_W; i += DT_T) {
     const int q = i / DT_W, c = i - q * DT_W;
     float wv = 0.f;
     if (c < cols) {
@@ -875,7 +877,7 @@ __global__ __launch_bounds__(256) void dice_lowres_bwd_tile_kernel(const DiceTil
   }
   __syncthreads();
   // ---- 2. rows
-  for (int i = tid; i < ny * DT_W; i += 256) {
+  for (int i = tid; i < ny * DT_W; i += DT_T) {
     const int j = i / DT_W, c = i - j * DT_W;
     float acc[K];
 #pragma unroll
@@ -893,7 +895,7 @@ __global__ __launch_bounds__(256) void dice_lowres_bwd_tile_kernel(const DiceTil
   __syncthreads();
   // ---- 3. columns -> the tile's partial patch [ny_max][nx_max][K] in the workspace (entries beyond ny / nx are never read)
   float* patch = a.ws + (int64_t)blockIdx.x * a.ny_max * a.nx_max * K;
-  for (int i = tid; i < ny * nx; i += 256) {
+  for (int i = tid; i < ny * nx; i += DT_T) {
     const int j = i / nx, q = i - j * nx;
     float acc[K];
 #pragma unroll
@@ -1423,7 +1425,7 @@ extern "C" int gdl_dice_loss_lowres_bwd(const float* low, const int64_t* target,
       K_SWITCH(K, if (KK <= 8) {
                     const size_t lds = ((size_t)KK * DT_H * DT_W + (size_t)KK * ny * (DT_W + 1) + (size_t)ny * DT_H + (size_t)nx * DT_W) * sizeof(float);
                     GDL_SET_MAX_LDS_ONCE((dice_lowres_bwd_tile_kernel<(KK <= 8 ? KK : 8)>), 160 * 1024);
-                    hipLaunchKernelGGL((dice_lowres_bwd_tile_kernel<(KK <= 8 ? KK : 8)>), dim3(tiles), dim3(256), lds, st, a);
+                    hipLaunchKernelGGL((dice_lowres_bwd_tile_kernel<(KK <= 8 ? KK : 8)>), dim3(tiles), dim3(DT_T), lds, st, a);
                     hipLaunchKernelGGL((dice_lowres_bwd_reduce_kernel<(KK <= 8 ? KK : 8)>), dim3(grid_for(total)), dim3(256), 0, st, a);
                   });
       GDL_CHECK_LAUNCH("gdl_dice_loss_lowres_bwd");
