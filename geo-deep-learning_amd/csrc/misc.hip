@@ -1368,17 +1368,27 @@ extern "C" int gdl_dice_loss_fwd(const float* logits, const int64_t* target, int
   return GDL_OK;
 }
 
+// (four times the workgroups of dice_partial_kernel: the scattered 4-byte loads of the on-the-fly bilinear logit are a chain of L2
+// round trips per pixel, and 512 workgroups = two waves per SIMD do not cover it)
+static int dice_lowres_blocks(int64_t total) {
+  int64_t g = (total + 1023) / 1024;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+extern "C" int64_t gdl_dice_loss_lowres_workspace(int B, int K, int Ho, int Wo) {
+  return (int64_t)dice_lowres_blocks((int64_t)B * Ho * Wo) * 3 * K * sizeof(float);
+}
+
 // Dice loss (multiclass) of bilinear(low -> [Ho, Wo]) against target [B, Ho, Wo] WITHOUT the full-resolution logits: low = the
-// [B, Hi, Wi, K] f32 map gdl_head_1x1 writes.  sums / loss / workspace as gdl_dice_loss_fwd (workspace of
-// gdl_dice_loss_workspace(B, K, Ho * Wo) bytes).  Upsampling factors up to 16 per direction.
+// [B, Hi, Wi, K] f32 map gdl_head_1x1 writes.  sums / loss as gdl_dice_loss_fwd; workspace of gdl_dice_loss_lowres_workspace(B, K, Ho,
+// Wo) bytes.  Upsampling factors up to 16 per direction.
 extern "C" int gdl_dice_loss_lowres_fwd(const float* low, const int64_t* target, int B, int K, int Hi, int Wi, int Ho, int Wo, float eps,
                                         float* sums, float* loss, float* ws, int64_t ws_bytes, gdl_stream_t stream) {
   GDL_CHECK_ARG(low && target && sums && loss && ws, "gdl_dice_loss_lowres_fwd: null pointer");
   GDL_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho >= Hi && Wo >= Wi, "gdl_dice_loss_lowres_fwd: bad sizes (an upsample is expected)");
   GDL_CHECK_ARG(2 * ((Ho + Hi - 1) / Hi) + 4 <= DICE_LOWRES_MAXW && 2 * ((Wo + Wi - 1) / Wi) + 4 <= DICE_LOWRES_MAXW,
                 "gdl_dice_loss_lowres_fwd: upsampling factors above 16 are not supported");
-  GDL_CHECK_ARG(ws_bytes >= gdl_dice_loss_workspace(B, K, (int64_t)Ho * Wo), "gdl_dice_loss_lowres_fwd: workspace too small");
-  const int nblk = dice_blocks((int64_t)B * Ho * Wo);
+  GDL_CHECK_ARG(ws_bytes >= gdl_dice_loss_lowres_workspace(B, K, Ho, Wo), "gdl_dice_loss_lowres_fwd: workspace too small");
+  const int nblk = dice_lowres_blocks((int64_t)B * Ho * Wo);
   hipStream_t s = (hipStream_t)stream;
   K_SWITCH(K, hipLaunchKernelGGL((dice_lowres_partial_kernel<KK>), dim3(nblk), dim3(256), 0, s, low, target, B, Hi, Wi, Ho, Wo, ws);
               hipLaunchKernelGGL((dice_final_kernel<KK>), dim3(1), dim3(256), 0, s, ws, nblk, eps, sums, loss));

@@ -154,6 +154,7 @@ SIGNATURES = {
     "gdl_dice_loss_workspace": (c_l, [c_i, c_i, c_l]),
     "gdl_dice_loss_fwd": (c_i, [c_p, c_p, c_i, c_i, c_l, c_f, c_p, c_p, c_p, c_l, c_p]),
     "gdl_dice_loss_bwd": (c_i, [c_p, c_p, c_i, c_i, c_l, c_f, c_p, c_p, c_f, c_p, c_i, c_p]),
+    "gdl_dice_loss_lowres_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "gdl_dice_loss_lowres_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_l, c_p]),
     "gdl_dice_loss_lowres_bwd_workspace": (c_l, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "gdl_dice_loss_lowres_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_p]),

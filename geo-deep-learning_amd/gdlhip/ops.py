@@ -1577,7 +1577,7 @@ def dice_loss_lowres_fwd(low: Tensor, target: Tensor, size: tuple[int, int], eps
     sums = torch.empty(3 * K, device=low.device, dtype=torch.float32)
     loss = torch.empty((), device=low.device, dtype=torch.float32)
     lib = _lib.load()
-    nbytes = lib.gdl_dice_loss_workspace(B, K, size[0] * size[1])
+    nbytes = lib.gdl_dice_loss_lowres_workspace(B, K, size[0], size[1])
     ws = torch.empty(nbytes // 4, device=low.device, dtype=torch.float32)
     check(lib.gdl_dice_loss_lowres_fwd(_p(low), _p(target), B, K, Hi, Wi, size[0], size[1], eps, _p(sums), _p(loss), _p(ws), nbytes,
                                        _stream()), "gdl_dice_loss_lowres_fwd")

@@ -473,11 +473,12 @@ int gdl_dice_loss_bwd(const float* logits, const int64_t* target, int B, int K, 
 /* The same loss WITHOUT the full-resolution logits (round 5): the reference's training step computes
  * DiceLoss(F.interpolate(head(x), size=image_size, mode="bilinear")) (dofa.py:89-105, segmentation_dofa.py:226-229) and only needs the
  * loss and its gradient.  low = the [B, Hi, Wi, K] f32 map of gdl_head_1x1; the bilinear logit of every [Ho, Wo] pixel is
- * evaluated on the fly (same expression as gdl_upsample_logits).  _fwd: sums / loss / ws as gdl_dice_loss_fwd with
- * HW = Ho * Wo.  _bwd: dlow [B, Hi, Wi, K] f32 = d loss / d low in one pass (gather form, fixed order), scaled by
+ * evaluated on the fly (same expression as gdl_upsample_logits).  _fwd: sums / loss as gdl_dice_loss_fwd, ws of
+ * gdl_dice_loss_lowres_workspace() bytes.  _bwd: dlow [B, Hi, Wi, K] f32 = d loss / d low in one pass (gather form, fixed order), scaled by
  * upstream[0] (device scalar, may be null) * grad_scale.  Upsampling factors up to 16.  With K <= 8 and a workspace of
  * gdl_dice_loss_lowres_bwd_workspace() bytes the gradient is formed tile by tile (every full-resolution softmax evaluated once,
  * partial patches summed in a fixed order by a second kernel); otherwise by one gather kernel (ws may be null). */
+int64_t gdl_dice_loss_lowres_workspace(int B, int K, int Ho, int Wo);
 int gdl_dice_loss_lowres_fwd(const float* low, const int64_t* target, int B, int K, int Hi, int Wi, int Ho, int Wo, float eps,
                              float* sums, float* loss, float* ws, int64_t ws_bytes, gdl_stream_t stream);
 int64_t gdl_dice_loss_lowres_bwd_workspace(int B, int K, int Hi, int Wi, int Ho, int Wo);

@@ -631,7 +631,7 @@ def test_dice_loss_from_low_resolution_logits(B, K, hi, wi, ho, wo):
     loss, sums = ops.dice_loss_lowres_fwd(lowd, tgtd, (ho, wo))
     full = ops.upsample_logits(lowd, (ho, wo))
     loss2, sums2 = ops.dice_loss_fwd(full, tgtd)
-    assert abs(loss.item() - loss2.item()) <= 1e-6 and torch.allclose(sums, sums2, rtol=1e-6, atol=1e-3)
+    assert abs(loss.item() - loss2.item()) <= 1e-6 and torch.allclose(sums, sums2, rtol=2e-6, atol=1e-3)
     up = torch.tensor(0.4, device=DEV)
     dlow = ops.dice_loss_lowres_bwd(lowd, tgtd, (ho, wo), sums, up)
     dlow2 = ops.upsample_logits_bwd(ops.dice_loss_bwd(full, tgtd, sums2, up), (hi, wi))
