@@ -702,7 +702,8 @@ __global__ __launch_bounds__(256) void dice_lowres_partial_kernel(const float* _
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-constexpr int DICE_LOWRES_MAXW = 36;     // gather window bound (2 * factor + 4 <= 36: upsampling factors up to 16)
+constexpr int DICE_LOWRES_MAX_FACTOR = 64;   // (every loop below is a run-time loop; the bound only keeps the K > 8 gather kernel's
+                                             // window -- (2 * factor + 4)^2 softmax evaluations per low-resolution logit -- finite)
 
 template <int K>
 __global__ __launch_bounds__(256) void dice_lowres_bwd_kernel(const float* __restrict__ low, const int64_t* __restrict__ target, int B,
@@ -1385,8 +1386,8 @@ extern "C" int gdl_dice_loss_lowres_fwd(const float* low, const int64_t* target,
                                         float* sums, float* loss, float* ws, int64_t ws_bytes, gdl_stream_t stream) {
   GDL_CHECK_ARG(low && target && sums && loss && ws, "gdl_dice_loss_lowres_fwd: null pointer");
   GDL_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho >= Hi && Wo >= Wi, "gdl_dice_loss_lowres_fwd: bad sizes (an upsample is expected)");
-  GDL_CHECK_ARG(2 * ((Ho + Hi - 1) / Hi) + 4 <= DICE_LOWRES_MAXW && 2 * ((Wo + Wi - 1) / Wi) + 4 <= DICE_LOWRES_MAXW,
-                "gdl_dice_loss_lowres_fwd: upsampling factors above 16 are not supported");
+  GDL_CHECK_ARG((Ho + Hi - 1) / Hi <= DICE_LOWRES_MAX_FACTOR && (Wo + Wi - 1) / Wi <= DICE_LOWRES_MAX_FACTOR,
+                "gdl_dice_loss_lowres_fwd: upsampling factors above 64 are not supported");
   GDL_CHECK_ARG(ws_bytes >= gdl_dice_loss_lowres_workspace(B, K, Ho, Wo), "gdl_dice_loss_lowres_fwd: workspace too small");
   const int nblk = dice_lowres_blocks((int64_t)B * Ho * Wo);
   hipStream_t s = (hipStream_t)stream;
@@ -1420,6 +1421,9 @@ extern "C" int gdl_dice_loss_lowres_bwd(const float* low, const int64_t* target,
                                         const float* sums, const float* upstream, float grad_scale, float* dlow, float* ws,
                                         int64_t ws_bytes, gdl_stream_t stream) {
   GDL_CHECK_ARG(low && target && sums && dlow, "gdl_dice_loss_lowres_bwd: null pointer");
+  GDL_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho >= Hi && Wo >= Wi, "gdl_dice_loss_lowres_bwd: bad sizes");
+  GDL_CHECK_ARG((Ho + Hi - 1) / Hi <= DICE_LOWRES_MAX_FACTOR && (Wo + Wi - 1) / Wi <= DICE_LOWRES_MAX_FACTOR,
+                "gdl_dice_loss_lowres_bwd: upsampling factors above 64 are not supported");
   {
     int ny, nx;
     const int64_t need = gdl_dice_loss_lowres_bwd_workspace(B, K, Hi, Wi, Ho, Wo);
@@ -1442,9 +1446,6 @@ extern "C" int gdl_dice_loss_lowres_bwd(const float* low, const int64_t* target,
       return GDL_OK;
     }
   }
-  GDL_CHECK_ARG(B > 0 && Hi > 0 && Wi > 0 && Ho >= Hi && Wo >= Wi, "gdl_dice_loss_lowres_bwd: bad sizes");
-  GDL_CHECK_ARG(2 * ((Ho + Hi - 1) / Hi) + 4 <= DICE_LOWRES_MAXW && 2 * ((Wo + Wi - 1) / Wi) + 4 <= DICE_LOWRES_MAXW,
-                "gdl_dice_loss_lowres_bwd: upsampling factors above 16 are not supported");
   const int64_t total = (int64_t)B * Hi * Wi;
   K_SWITCH(K, hipLaunchKernelGGL((dice_lowres_bwd_kernel<KK>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, low,
                                  target, B, Hi, Wi, Ho, Wo, sums, eps, upstream, grad_scale, dlow));

@@ -1559,11 +1559,12 @@ def dice_loss_bwd(logits: Tensor, target: Tensor, sums: Tensor, upstream: Tensor
 
 
 def dice_lowres_ok(low: Tensor, size: tuple[int, int]) -> bool:
-    """Shapes gdl_dice_loss_lowres_* take: an upsample by at most 16 per direction, at most 16 classes."""
+    """Shapes gdl_dice_loss_lowres_* take: an upsample by at most 64 per direction (DOFA's auxiliary head: 16 x 16 -> 512 x 512), at
+    most 16 classes."""
     if low.dim() != 4 or low.shape[3] > 16:
         return False
     hi, wi = low.shape[1], low.shape[2]
-    return size[0] >= hi and size[1] >= wi and -(-size[0] // hi) <= 16 and -(-size[1] // wi) <= 16
+    return size[0] >= hi and size[1] >= wi and -(-size[0] // hi) <= 64 and -(-size[1] // wi) <= 64
 
 
 def dice_loss_lowres_fwd(low: Tensor, target: Tensor, size: tuple[int, int], eps: float = 1e-7):

@@ -86,8 +86,8 @@ class SegmentationDOFA(SegmentationTaskHooks, LightningModule):
         x, y, wv = batch["image"], batch["mask"], batch["wavelengths"]
         y = y.squeeze(1).long()
         # lowres_logits (training only): the loss is all the step needs from the logits, and gdlhip's DiceLoss evaluates it -- and its
-        # gradient -- from the heads' own 144 x 144 maps; the reference's F.interpolate to 512 x 512 (dofa.py:89-105) and the 168 MB
-        # tensor it produces per head exist only where something reads them (validation / test: masks, metrics)
+        # gradient -- from the heads' own maps (128 x 128 main, 16 x 16 auxiliary); the reference's F.interpolate to 512 x 512
+        # (dofa.py:89-105) and the 168 MB tensor it produces per head exist only where something reads them (validation / test)
         outputs = self.model(x, wv, lowres_logits=True) if lowres_logits else self(x, wv)
         loss = self.loss(outputs.out, y) + 0.4 * self.loss(outputs.aux, y)
         return outputs, y, loss, x.shape[0]

@@ -616,7 +616,7 @@ def test_wgrad_row_segment_kernel(B, H, W, C, N):
 
 
 @pytest.mark.parametrize("B,K,hi,wi,ho,wo", [(2, 5, 9, 9, 32, 32), (2, 5, 36, 36, 128, 128), (1, 3, 7, 5, 7, 5), (3, 16, 6, 10, 50, 41),
-                                             (2, 2, 4, 4, 64, 64), (1, 5, 144, 144, 512, 512)])
+                                             (2, 2, 4, 4, 64, 64), (1, 5, 144, 144, 512, 512), (2, 5, 16, 16, 512, 512), (1, 12, 3, 3, 96, 160)])
 def test_dice_loss_from_low_resolution_logits(B, K, hi, wi, ho, wo):
     """Round 5: gdl_dice_loss_lowres_fwd / _bwd -- DiceLoss(F.interpolate(low, size, bilinear)) and its gradient w.r.t. ``low``
     without the [B, K, H, W] logits (dofa.py:89-105 + segmentation_dofa.py:226-229).  Against (a) the materialised path it replaces
