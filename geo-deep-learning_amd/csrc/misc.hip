@@ -265,6 +265,77 @@ __global__ __launch_bounds__(256) void head_1x1_kernel(const void* __restrict__ 
   }
 }
 
+// The same head as a skinny MFMA GEMM (round 5): D[class][pixel] = W[class][c] . feat[pixel][c] with v_mfma_f32_16x16x32_bf16.
+// The wave-per-pixel kernel above runs at 1.3 TB/s on the decoder output (340 MB, 267 us at batch 32): every pixel re-reads the
+// K x C weights through the L1 (10 bytes of L1 traffic per byte of features), spends ~100 VALU instructions on five 64-lane
+// butterflies, and a wave lives for one 8-byte load per lane.  Here a wave owns 16-pixel tiles (16 x C bf16, contiguous in HBM):
+//   * NKS coalesced 16-byte loads per lane fetch the tile (the NEXT tile's are issued before this tile's MFMAs: 8 KB in flight per
+//     wave), a wave-private LDS slot re-shapes it into B fragments (chunk index XOR row: conflict-free both ways);
+//   * the f32 weights live in registers as bf16 hi + lo fragments (w = hi + lo to 2^-17: f32-grade logits), two MFMAs per 32 channels;
+//   * lane (pixel j, group g) ends with classes 4g .. 4g+3 of its pixel: 4-float stores.
+// Dense bf16 features with C = 32 NKS and no Dropout2d scale; everything else takes the kernel above.
+template <int NKS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void head_1x1_mfma_kernel(const uint16_t* __restrict__ feat, int64_t P, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, int K, float* __restrict__ out) {
+  constexpr int C = NKS * 32, ROW = C * 2, TILE = 16 * ROW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned char* st = hsm + wv * TILE;
+  const int j = lane & 15, g = lane >> 4;
+  bf16x8_t wh[NKS], wl[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x0 = j < K ? w[(int64_t)j * C + 32 * ks + 8 * g + 2 * e] : 0.f;
+      const float x1 = j < K ? w[(int64_t)j * C + 32 * ks + 8 * g + 2 * e + 1] : 0.f;
+      hi[e] = pack_bf16x2(x0, x1);
+      lo[e] = pack_bf16x2(x0 - __uint_as_float(hi[e] << 16), x1 - __uint_as_float(hi[e] & 0xffff0000u));
+    }
+    wh[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+    wl[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+  }
+  float bv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bv[r] = (bias && 4 * g + r < K) ? bias[4 * g + r] : 0.f;
+  const int64_t ntiles = (P + 15) / 16, stride = (int64_t)gridDim.x * 4;
+  uint4 rg[NKS];
+  auto gload = [&](int64_t tile) {
+    const unsigned char* base = (const unsigned char*)feat + tile * TILE;
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) {
+      const int off = u * 1024 + lane * 16;
+      rg[u] = tile * 16 + off / ROW < P ? *(const uint4*)(base + off) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  int64_t t = (int64_t)blockIdx.x * 4 + wv;
+  if (t < ntiles) gload(t);
+  for (; t < ntiles; t += stride) {
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) {
+      const int off = u * 1024 + lane * 16, row = off / ROW, c = (off % ROW) >> 4;
+      *(uint4*)(st + row * ROW + ((c ^ (row & 15)) << 4)) = rg[u];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (wave-private slot: the LDS queue is in order, no barrier needed)
+    if (t + stride < ntiles) gload(t + stride);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, *(const uint4*)(st + j * ROW + (((4 * ks + g) ^ j) << 4)));
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], fb, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], fb, acc, 0, 0, 0);
+    }
+    const int64_t p = t * 16 + j;
+    if (p < P) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * g + r < K) out[p * K + 4 * g + r] = acc[r] + bv[r];
+    }
+    asm volatile("" ::: "memory");                          // the next tile's LDS writes stay behind this tile's fragment reads
+  }
+}
+
 // backward of the 1x1 head wrt features and weights
 //  dfeat[p,c] = sum_k dlog[p,k] * w[k,c] (* chan_scale) ; dw[k,c] = sum_p dlog[p,k]*feat[p,c]*cs ; db[k] = sum_p dlog[p,k]
 template <typename T, int K>
@@ -293,6 +364,51 @@ __global__ __launch_bounds__(256) void head_1x1_bwd_feat_kernel(const float* __r
     }
     if constexpr (sizeof(T) == 4) *(float4*)((float*)dfeat + p * d_sP + c) = make_float4(o[0], o[1], o[2], o[3]);
     else *(uint2*)((uint16_t*)dfeat + p * d_sP + c) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+  }
+}
+
+// The same for dense bf16 gradients with the weights in registers (round 5): a lane owns EIGHT fixed channels (one 16-byte store) and
+// walks pixels; the kernel above re-reads its K float4 weight vectors from the L1 for every 8 bytes it stores (164 us for 340 MB).
+// Per-element arithmetic: the same products added in the same order, as explicit fused multiply-adds.  256 % (C / 8) == 0, no
+// Dropout2d scale.
+template <int K>
+__global__ __launch_bounds__(256) void head_1x1_bwd_feat8_kernel(const float* __restrict__ dlog, int64_t P, int C,
+                                                                 const float* __restrict__ w, uint16_t* __restrict__ dfeat) {
+  const int cv = C >> 3, q = threadIdx.x % cv, ro = threadIdx.x / cv, rpb = 256 / cv;
+  float wr[K][8];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float4 a = *(const float4*)(w + (int64_t)k * C + q * 8), b = *(const float4*)(w + (int64_t)k * C + q * 8 + 4);
+    wr[k][0] = a.x; wr[k][1] = a.y; wr[k][2] = a.z; wr[k][3] = a.w; wr[k][4] = b.x; wr[k][5] = b.y; wr[k][6] = b.z; wr[k][7] = b.w;
+  }
+  const int64_t step = (int64_t)gridDim.x * rpb;
+  auto one = [&](int64_t p, const float (&gk)[K]) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = fmaf(gk[k], wr[k][e], o[e]);
+    }
+    *(uint4*)(dfeat + p * C + q * 8) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+  };
+  int64_t p = (int64_t)blockIdx.x * rpb + ro;
+  for (; p + 3 * step < P; p += 4 * step) {       // four pixels' gradients requested before the first is used
+    float gk[4][K];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) gk[u][k] = dlog[(p + u * step) * K + k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(p + u * step, gk[u]);
+  }
+  for (; p < P; p += step) {
+    float gk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) gk[k] = dlog[p * K + k];
+    one(p, gk);
   }
 }
 
@@ -371,25 +487,105 @@ __global__ __launch_bounds__(256) void head_1x1_bwd_w_partial(const void* __rest
   if (blockIdx.x == 0 && t < K) wsb[(int64_t)K * C + t] = (redb[0][t] + redb[1][t]) + (redb[2][t] + redb[3][t]);
 }
 
+// dw partials for dense bf16 features (round 5): the shape of bn_bwd_partial8 -- a workgroup owns whole pixel rows, a lane EIGHT fixed
+// channels (16-byte loads), four rows requested before the first is used (4 KB in flight per wave; the kernel above keeps 2 KB and
+// pays one L2 round trip for the gradients after every batch of feature loads: 1.5-1.9 TB/s).  256 % (C / 8) == 0, K <= 8.
 template <int K>
-__global__ __launch_bounds__(256) void head_1x1_bwd_w_final(const float* __restrict__ ws, int nsplit, int C,
-                                                            float* __restrict__ dw, float* __restrict__ db) {
-  // outputs 0..K*C-1 = dw, K*C..K*C+K-1 = db; block = 8 outputs x 32 split groups
-  __shared__ double part[32][8];
+__global__ __launch_bounds__(256) void head_1x1_bwd_w_partial8(const uint16_t* __restrict__ feat, const float* __restrict__ dlog,
+                                                               int64_t P, int C, float* __restrict__ ws) {
+  __shared__ float red[256][9];             // [thread][channel | bias term] (+1: bank spread)
+  const int G = C >> 3, R = 256 / G;        // lanes per pixel, pixel rows per block step
+  const int t = threadIdx.x, g = t % G, prow = t / G;
+  const int nsplit = gridDim.x;
+  const int64_t per = (P + nsplit - 1) / nsplit;
+  const int64_t p0 = per * blockIdx.x, p1 = p0 + per < P ? p0 + per : P;
+  float acc[K][8], accb[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    accb[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+  }
+  auto add = [&](const uint4& xv, const float (&gk)[K]) {
+    float v[8];
+    v[0] = __uint_as_float(xv.x << 16); v[1] = __uint_as_float(xv.x & 0xffff0000u);
+    v[2] = __uint_as_float(xv.y << 16); v[3] = __uint_as_float(xv.y & 0xffff0000u);
+    v[4] = __uint_as_float(xv.z << 16); v[5] = __uint_as_float(xv.z & 0xffff0000u);
+    v[6] = __uint_as_float(xv.w << 16); v[7] = __uint_as_float(xv.w & 0xffff0000u);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      accb[k] += gk[k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[k][j] = fmaf(gk[k], v[j], acc[k][j]);
+    }
+  };
+  int64_t p = p0 + prow;
+  for (; p + 3 * R < p1; p += 4 * R) {
+    uint4 xv[4];
+    float gk[4][K];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xv[u] = *(const uint4*)(feat + (p + (int64_t)u * R) * C + 8 * g);
+#pragma unroll
+      for (int k = 0; k < K; ++k) gk[u][k] = dlog[(p + (int64_t)u * R) * K + k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) add(xv[u], gk[u]);
+  }
+  for (; p < p1; p += R) {
+    float gk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) gk[k] = dlog[p * K + k];
+    add(*(const uint4*)(feat + p * C + 8 * g), gk);
+  }
+  float* wsb = ws + (int64_t)blockIdx.x * (K + 1) * C;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[t][j] = acc[k][j];
+    red[t][8] = accb[k];
+    __syncthreads();
+    for (int c = t; c < C; c += 256) {
+      float ss = 0.f;
+      for (int r = 0; r < R; ++r) ss += red[r * G + (c >> 3)][c & 7];
+      wsb[(int64_t)k * C + c] = ss;
+    }
+    if (t == 0) {
+      float sb = 0.f;
+      for (int r = 0; r < R; ++r) sb += red[r * G][8];
+      wsb[(int64_t)K * C + k] = sb;
+    }
+    __syncthreads();
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(1024) void head_1x1_bwd_w_final(const float* __restrict__ ws, int nsplit, int C,
+                                                             float* __restrict__ dw, float* __restrict__ db) {
+  // outputs 0..K*C-1 = dw, K*C..K*C+K-1 = db; block = 8 outputs x 128 split groups (round 5: up to 2048 partial rows)
+  __shared__ double part[128][8];
   const int cl = threadIdx.x & 7, grp = threadIdx.x >> 3;
   const int i = blockIdx.x * 8 + cl;
   const int total = K * C + (db ? K : 0);
   double s = 0;
   if (i < total) {
     const int64_t off = i < K * C ? i : (int64_t)K * C + (i - K * C);
-    for (int sp = grp; sp < nsplit; sp += 32) s += ws[(int64_t)sp * (K + 1) * C + off];
+    s = ordered_sum8<double>(grp, nsplit, 128, [&](int sp) { return ws[(int64_t)sp * (K + 1) * C + off]; });
   }
   part[grp][cl] = s;
+  __syncthreads();
+  if (grp < 8) {          // 128 -> 8 -> 1, fixed order
+    s = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += part[grp * 16 + g][cl];
+  }
+  __syncthreads();
+  if (grp < 8) part[grp][cl] = s;
   __syncthreads();
   if (grp != 0 || i >= total) return;
   s = 0;
 #pragma unroll
-  for (int g = 0; g < 32; ++g) s += part[g][cl];
+  for (int g = 0; g < 8; ++g) s += part[g][cl];
   if (i < K * C) dw[i] = (float)s;
   else db[i - K * C] = (float)s;
 }
@@ -1267,11 +1463,35 @@ extern "C" int gdl_scale_outer(void* x, int dtype, const float* s, int64_t outer
     default: gdl_set_error("num classes K=%d unsupported (1..16)", K); return GDL_ERR_UNSUPPORTED; \
   }
 
+static int gdl_num_cus() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    return cus;
+  }();
+  return n;
+}
+
+// A/B hook: 0 = the round-4 head kernels (wave per pixel forward, L1-resident weights in the feature gradient) for every shape
+static std::atomic<int> g_head_mfma{1};
+extern "C" void gdl_debug_set_head_mfma(int on) { g_head_mfma = on; }
+
 extern "C" int gdl_head_1x1(const void* feat, int dtype, int64_t P, int C, int64_t f_sP, const float* w,
                             const float* bias, const float* chan_scale, int64_t pix_per_img, float* out, int K,
                             gdl_stream_t stream) {
   GDL_CHECK_ARG(feat && w && out && C % 4 == 0 && f_sP % 4 == 0 && pix_per_img > 0, "gdl_head_1x1: bad args");
   hipStream_t s = (hipStream_t)stream;
+  if (g_head_mfma.load(std::memory_order_relaxed) && dtype == GDL_BF16 && !chan_scale && f_sP == C && (C == 128 || C == 256) && K >= 1 &&
+      K <= 16 && P >= 1024 && (uintptr_t)feat % 16 == 0) {
+    const int64_t ntiles = (P + 15) / 16;
+    const int cap = 3 * gdl_num_cus();     // all workgroups resident at once (155 registers: three waves per SIMD), each wave walks its share
+    const unsigned blocks = (unsigned)((ntiles + 3) / 4 < cap ? (ntiles + 3) / 4 : cap);
+    if (C == 256) hipLaunchKernelGGL((head_1x1_mfma_kernel<8>), dim3(blocks), dim3(256), 4 * 16 * 512, s, (const uint16_t*)feat, P, w, bias, K, out);
+    else hipLaunchKernelGGL((head_1x1_mfma_kernel<4>), dim3(blocks), dim3(256), 4 * 16 * 256, s, (const uint16_t*)feat, P, w, bias, K, out);
+    GDL_CHECK_LAUNCH("gdl_head_1x1(mfma)");
+    return GDL_OK;
+  }
   const unsigned grid = (unsigned)((P + 3) / 4);
   K_SWITCH(K, if (dtype == GDL_BF16) hipLaunchKernelGGL((head_1x1_kernel<uint16_t, KK>), dim3(grid), dim3(256), 0, s, feat, P, C, f_sP, w, bias, chan_scale, pix_per_img, out);
               else hipLaunchKernelGGL((head_1x1_kernel<float, KK>), dim3(grid), dim3(256), 0, s, feat, P, C, f_sP, w, bias, chan_scale, pix_per_img, out));
@@ -1279,9 +1499,15 @@ extern "C" int gdl_head_1x1(const void* feat, int dtype, int64_t P, int C, int64
   return GDL_OK;
 }
 
+// partial rows of the weight gradient: one workgroup each.  Round 5: up to 2048 (eight workgroups per CU) -- with 512 the main head's
+// 340 MB were read by two workgroups per CU, 16 KB in flight per CU: 1.5 TB/s
+static int head_bwd_nsplit(int64_t P) {
+  int64_t ns = P / 256; if (ns < 1) ns = 1; if (ns > 2048) ns = 2048;
+  return (int)ns;
+}
+
 extern "C" int64_t gdl_head_1x1_bwd_workspace(int64_t P, int C, int K) {
-  int64_t ns = P / 256; if (ns < 1) ns = 1; if (ns > 512) ns = 512;
-  return ns * (K + 1) * (int64_t)C * sizeof(float);
+  return (int64_t)head_bwd_nsplit(P) * (K + 1) * (int64_t)C * sizeof(float);
 }
 
 extern "C" int gdl_head_1x1_bwd(const void* feat, int dtype, const float* dlog, int64_t P, int C, int64_t f_sP,
@@ -1291,19 +1517,29 @@ extern "C" int gdl_head_1x1_bwd(const void* feat, int dtype, const float* dlog, 
   GDL_CHECK_ARG(feat && dlog && w && dw && ws && C % 4 == 0 && f_sP % 4 == 0, "gdl_head_1x1_bwd: bad args");
   GDL_CHECK_ARG(ws_bytes >= gdl_head_1x1_bwd_workspace(P, C, K), "gdl_head_1x1_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  int64_t ns = P / 256; if (ns < 1) ns = 1; if (ns > 512) ns = 512;
-  const int nsplit = (int)ns;
+  const int nsplit = head_bwd_nsplit(P);
   dim3 gridw((C + 255) / 256, nsplit);
   const int64_t total = P * (C / 4);
+  const bool feat8 = g_head_mfma.load(std::memory_order_relaxed) && dtype == GDL_BF16 && dfeat && !chan_scale && d_sP == C && C % 8 == 0 &&
+                     C / 8 <= 256 && 256 % (C / 8) == 0 && K <= 8 && (uintptr_t)dfeat % 16 == 0 && P >= 1024;
   K_SWITCH(K,
     if (dtype == GDL_BF16) {
-      if (dfeat) hipLaunchKernelGGL((head_1x1_bwd_feat_kernel<uint16_t, KK>), dim3(grid_for(total)), dim3(256), 0, s, dlog, P, C, w, chan_scale, pix_per_img, dfeat, d_sP);
-      hipLaunchKernelGGL((head_1x1_bwd_w_partial<uint16_t, KK>), gridw, dim3(256), 0, s, feat, dlog, P, C, f_sP, chan_scale, pix_per_img, ws);
+      if constexpr (KK <= 8) {
+        if (feat8) hipLaunchKernelGGL((head_1x1_bwd_feat8_kernel<KK>), dim3(4 * gdl_num_cus()), dim3(256), 0, s, dlog, P, C, w, (uint16_t*)dfeat);   // (all resident at once: 74 registers allow six waves per SIMD, 8 per CU left a third of the grid for a second round)
+      }
+      if (dfeat && !feat8) hipLaunchKernelGGL((head_1x1_bwd_feat_kernel<uint16_t, KK>), dim3(grid_for(total)), dim3(256), 0, s, dlog, P, C, w, chan_scale, pix_per_img, dfeat, d_sP);
+      bool w8 = false;
+      if constexpr (KK <= 8) {
+        w8 = g_head_mfma.load(std::memory_order_relaxed) && !chan_scale && f_sP == C && C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0 &&
+             (uintptr_t)feat % 16 == 0 && P >= 1024;
+        if (w8) hipLaunchKernelGGL((head_1x1_bwd_w_partial8<KK>), dim3(nsplit), dim3(256), 0, s, (const uint16_t*)feat, dlog, P, C, ws);
+      }
+      if (!w8) hipLaunchKernelGGL((head_1x1_bwd_w_partial<uint16_t, KK>), gridw, dim3(256), 0, s, feat, dlog, P, C, f_sP, chan_scale, pix_per_img, ws);
     } else {
       if (dfeat) hipLaunchKernelGGL((head_1x1_bwd_feat_kernel<float, KK>), dim3(grid_for(total)), dim3(256), 0, s, dlog, P, C, w, chan_scale, pix_per_img, dfeat, d_sP);
       hipLaunchKernelGGL((head_1x1_bwd_w_partial<float, KK>), gridw, dim3(256), 0, s, feat, dlog, P, C, f_sP, chan_scale, pix_per_img, ws);
     }
-    hipLaunchKernelGGL((head_1x1_bwd_w_final<KK>), dim3((KK * C + KK + 7) / 8), dim3(256), 0, s, ws, nsplit, C, dw, db));
+    hipLaunchKernelGGL((head_1x1_bwd_w_final<KK>), dim3((KK * C + KK + 7) / 8), dim3(1024), 0, s, ws, nsplit, C, dw, db));
   GDL_CHECK_LAUNCH("gdl_head_1x1_bwd");
   return GDL_OK;
 }

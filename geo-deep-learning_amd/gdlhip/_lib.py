@@ -226,6 +226,9 @@ def load() -> C.CDLL:
     if os.environ.get("GDL_WGRAD_ROWS_XCD") is not None:   # tuning hook: 1 = all tiles of a pixel range of wgrad_rows_kernel on one XCD
         lib.gdl_debug_set_wgrad_rows_xcd.argtypes = [C.c_int]
         lib.gdl_debug_set_wgrad_rows_xcd(int(os.environ["GDL_WGRAD_ROWS_XCD"]))
+    if os.environ.get("GDL_HEAD_MFMA") is not None:     # tuning hook: 0 = the round-4 classifier-head kernels (wave per pixel)
+        lib.gdl_debug_set_head_mfma.argtypes = [C.c_int]
+        lib.gdl_debug_set_head_mfma(int(os.environ["GDL_HEAD_MFMA"]))
     if os.environ.get("GDL_WGRAD_MODE") is not None:   # tuning hook: kernel-selection bits of gdl_debug_force_wgrad_small
         lib.gdl_debug_force_wgrad_small.argtypes = [C.c_int]
         lib.gdl_debug_force_wgrad_small(int(os.environ["GDL_WGRAD_MODE"]))

@@ -616,7 +616,7 @@ def test_wgrad_row_segment_kernel(B, H, W, C, N):
 
 
 @pytest.mark.parametrize("B,K,hi,wi,ho,wo", [(2, 5, 9, 9, 32, 32), (2, 5, 36, 36, 128, 128), (1, 3, 7, 5, 7, 5), (3, 16, 6, 10, 50, 41),
-                                             (2, 2, 4, 4, 64, 64), (1, 5, 144, 144, 512, 512), (2, 5, 16, 16, 512, 512), (1, 12, 3, 3, 96, 160)])
+                                             (2, 2, 4, 4, 64, 64), (1, 5, 144, 144, 512, 512), (2, 5, 16, 16, 512, 512), (2, 5, 18, 18, 512, 512), (1, 12, 3, 3, 96, 160)])
 def test_dice_loss_from_low_resolution_logits(B, K, hi, wi, ho, wo):
     """Round 5: gdl_dice_loss_lowres_fwd / _bwd -- DiceLoss(F.interpolate(low, size, bilinear)) and its gradient w.r.t. ``low``
     without the [B, K, H, W] logits (dofa.py:89-105 + segmentation_dofa.py:226-229).  Against (a) the materialised path it replaces
@@ -676,6 +676,46 @@ def test_head_and_logit_upsample(dtype, K):
     close(dfeat.permute(0, 3, 1, 2), fr.grad, dtype, "head dfeat")
     close(dw, wr.grad, dtype, "head dw")
     close(db, br.grad, dtype, "head db")
+
+
+@pytest.mark.parametrize("C", [256, 128])
+@pytest.mark.parametrize("K,B,H,W", [(5, 2, 36, 36), (1, 1, 35, 31), (12, 1, 40, 40), (16, 3, 21, 17), (5, 4, 144, 144)])
+def test_head_mfma_and_register_weight_kernels(K, B, H, W, C):
+    """Round 5: the classifier head as a skinny MFMA GEMM (gdl_head_1x1 for dense bf16 features, C = 128 / 256: 16-pixel tiles staged
+    through a wave-private LDS slot, f32 weights as bf16 hi + lo fragments) and its feature gradient with the weights in registers
+    (dofa.py:89-96 / segmentation_head.py).  Against the wave-per-pixel kernels they replace (forward: f32-grade agreement; feature
+    gradient: to a bf16 ulp; weight gradient from up to 2048 partial rows) and against torch in f64; ragged last tile (P % 16 != 0)."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_set_head_mfma.argtypes = [ctypes.c_int]
+    feat = q(rnd(B, H, W, C), torch.bfloat16)
+    w, bias = rnd(K, C, seed=1) * 0.1, rnd(K, seed=2)
+    fd, wd, bd = feat.to(DEV, torch.bfloat16), w.to(DEV), bias.to(DEV)
+    dlow = (rnd(B, H, W, K, seed=5) * 0.01).to(DEV)
+    try:
+        lib.gdl_debug_set_head_mfma(0)
+        low_old = ops.head_1x1(fd, wd, bd)
+        dfeat_old, dw_old, db_old = ops.head_1x1_bwd(fd, dlow, wd, None)
+    finally:
+        lib.gdl_debug_set_head_mfma(1)
+    low = ops.head_1x1(fd, wd, bd)
+    dfeat, dw, db = ops.head_1x1_bwd(fd, dlow, wd, None)
+    ref = torch.einsum("bhwc,kc->bhwk", feat.double(), w.double()) + bias.double()
+    scale = ref.abs().max().item()
+    assert (low.cpu().double() - ref).abs().max().item() <= 2e-5 * scale, "MFMA head vs f64"
+    assert (low - low_old).abs().max().item() <= 2e-5 * scale, "MFMA head vs the wave-per-pixel kernel"
+    dfeat_ref = torch.einsum("bhwk,kc->bhwc", dlow.cpu().double(), w.double())
+    close(dfeat, dfeat_ref.float(), torch.bfloat16, "head dfeat vs f64", scale=dfeat_ref.abs().max().item())
+    # (same products in the same order; the two kernels may differ in which multiply-adds the compiler fused: one bf16 ulp)
+    assert (dfeat.float() - dfeat_old.float()).abs().max().item() <= 2.0 ** -7 * dfeat_ref.abs().max().item()
+    close(dw, dw_old, torch.float32, "head dw", scale=dw_old.abs().max().item())
+    close(db, db_old, torch.float32, "head db", scale=db_old.abs().max().item())
+    dw_ref = torch.einsum("bhwk,bhwc->kc", dlow.cpu().double(), feat.double())
+    close(dw, dw_ref.float(), torch.float32, "head dw vs f64", scale=dw_ref.abs().max().item())
+    # no bias
+    low_nb = ops.head_1x1(fd, wd, None)
+    assert (low_nb.cpu().double() + bias.double() - ref).abs().max().item() <= 2e-5 * scale
 
 
 @pytest.mark.parametrize("K", [2, 9, 16])
