@@ -438,8 +438,9 @@ int gdl_scale_outer(void* x, int dtype, const float* s, int64_t outer, int64_t i
                     gdl_stream_t stream);
 
 /* ---- classifier tail -------------------------------------------------------------------
- * 1x1 conv to K<=8 classes (+bias) on NHWC features -> f32 NHWC logits [P][K]
- * (segmentation_head.py:22-26, fcn_head.py:73): */
+ * 1x1 conv to K<=16 classes (+bias) on NHWC features -> f32 NHWC logits [P][K]
+ * (segmentation_head.py:22-26, fcn_head.py:73).  Dense bf16 features with C = 128 / 256 and no Dropout2d scale run as a skinny
+ * MFMA GEMM (16-pixel tiles, f32 weights as bf16 hi + lo fragments: f32-grade logits); every other shape one wave per pixel: */
 int gdl_head_1x1(const void* feat, int dtype, int64_t P, int C, int64_t f_sP, const float* w,
                  const float* bias, const float* chan_scale, int64_t pix_per_img, float* out, int K,
                  gdl_stream_t stream);
@@ -475,7 +476,7 @@ int gdl_dice_loss_bwd(const float* logits, const int64_t* target, int B, int K, 
  * loss and its gradient.  low = the [B, Hi, Wi, K] f32 map of gdl_head_1x1; the bilinear logit of every [Ho, Wo] pixel is
  * evaluated on the fly (same expression as gdl_upsample_logits).  _fwd: sums / loss as gdl_dice_loss_fwd, ws of
  * gdl_dice_loss_lowres_workspace() bytes.  _bwd: dlow [B, Hi, Wi, K] f32 = d loss / d low in one pass (gather form, fixed order), scaled by
- * upstream[0] (device scalar, may be null) * grad_scale.  Upsampling factors up to 16.  With K <= 8 and a workspace of
+ * upstream[0] (device scalar, may be null) * grad_scale.  Upsampling factors up to 64 (DOFA's auxiliary head: 18 -> 512).  With K <= 8 and a workspace of
  * gdl_dice_loss_lowres_bwd_workspace() bytes the gradient is formed tile by tile (every full-resolution softmax evaluated once,
  * partial patches summed in a fixed order by a second kernel); otherwise by one gather kernel (ws may be null). */
 int64_t gdl_dice_loss_lowres_workspace(int B, int K, int Ho, int Wo);
