@@ -481,12 +481,17 @@ def test_batchnorm_small_map_single_launch(dtype, B, H, W, C, relu):
         close(db, db2, torch.float32, "dbeta vs multi-launch", scale=max(db2.abs().max().item(), 1.0))
         close(dx, dx2, dtype, "dx vs multi-launch", scale=dx2.float().abs().max().item() + 1e-3)
         # vs torch: with the ReLU, an element whose bn(x) is at f32 round-off level may sit on the other side of zero in torch's
-        # evaluation -- one such element moves a per-channel sum by |dy * xhat| (seen: 7e-2 on a sum of 96).  The tight check is
-        # the one against the multi-launch kernels above (same per-element expressions); against torch the sums get 20 x slack
-        loose = 20.0 if relu else 1.0
-        close(dg, gr.grad, dtype, "dgamma", scale=loose * max(gr.grad.abs().max().item(), 1.0))
-        close(db, br.grad, dtype, "dbeta", scale=loose * max(br.grad.abs().max().item(), 1.0))
-        close(dx.permute(0, 3, 1, 2), xr.grad, dtype, "dx vs torch", scale=loose * (xr.grad.abs().max().item() + 1e-3))
+        # evaluation, and one such element moves its channel's sums by |dy| and |dy * xhat| (seen: 0.3 on a sum of 124).  The
+        # check against the multi-launch kernels above covers every channel (same per-element expressions); against torch the
+        # channels that hold a pre-activation within 1e-4 of zero (f64 evaluation) are left out, the rest compare at full tolerance
+        ok = torch.ones(C, dtype=torch.bool)
+        if relu:
+            pre = F.batch_norm(xr.detach().double(), None, None, g.double(), b.double(), True, 0.0, 1e-5)
+            ok = (pre.abs() >= 1e-4).all(dim=3).all(dim=2).all(dim=0)
+            assert int(ok.sum()) >= C // 2, "too few channels left to compare"
+        close(dg.cpu()[ok], gr.grad[ok], dtype, "dgamma", scale=max(gr.grad.abs().max().item(), 1.0))
+        close(db.cpu()[ok], br.grad[ok], dtype, "dbeta", scale=max(br.grad.abs().max().item(), 1.0))
+        close(dx.cpu()[..., ok].permute(0, 3, 1, 2), xr.grad[:, ok], dtype, "dx vs torch", scale=xr.grad.abs().max().item() + 1e-3)
         # in place over x (what the ConvModule node does with its saved convolution output)
         xin = xd.clone()
         dx3, _, _ = ops.bn_small_bwd(xin, dyd, mean2, var2, gd, bd, 1e-5, relu, out=xin)
