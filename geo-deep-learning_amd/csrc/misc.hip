@@ -336,6 +336,102 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
+// The same for C = 256 NW channels and / or a Dropout2d channel scale (SegFormer's 768-wide decoder, segformer_mlp.py:64-65,120-125; the
+// DOFA heads in training when the map's pixel count is a multiple of 16).  The NW waves of a workgroup each take a 256-channel slice
+// of the SAME 16-pixel tile (their 128 weight registers are that slice's hi / lo fragments), the partial 16 x 16 products meet in the
+// LDS and wave 0 adds them in a fixed order.  A workgroup walks a CONTIGUOUS range of tiles, so the image index changes a handful of
+// times: with a channel scale the fragments are those of w * scale[image] (the scale folded into the weights in f32 before the
+// hi / lo split -- the features stay the bf16 values in memory), rebuilt when the image changes.  pix_per_img % 16 == 0 then (no tile
+// straddles two images).
+template <int NW, bool SCALE>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SCALE ? 2 : 3, SCALE ? 2 : 3)))   // (SCALE: rebuilding the fragments
+void head_1x1_mfma_wide_kernel(                                                 //  mid-loop spills 55 registers at three waves per SIMD)
+const uint16_t* __restrict__ feat, int64_t P, const float* __restrict__ w, const float* __restrict__ bias,
+                               const float* __restrict__ chan_scale, int64_t pix_per_img, int K, float* __restrict__ out) {
+  constexpr int NKS = 8, C = 256 * NW, ROW = 512, TILE = 16 * ROW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* st = hsm + wv * TILE;
+  f32x4_t* red = (f32x4_t*)(hsm + NW * TILE);      // [2][NW][64]
+  const int j = lane & 15, g = lane >> 4;
+  bf16x8_t wh[NKS], wl[NKS];
+  auto load_w = [&](const float* cs) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      uint32_t hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = wv * 256 + 32 * ks + 8 * g + 2 * e;
+        float x0 = j < K ? w[(int64_t)j * C + c] : 0.f, x1 = j < K ? w[(int64_t)j * C + c + 1] : 0.f;
+        if (SCALE) { x0 *= cs[c]; x1 *= cs[c + 1]; }
+        hi[e] = pack_bf16x2(x0, x1);
+        lo[e] = pack_bf16x2(x0 - __uint_as_float(hi[e] << 16), x1 - __uint_as_float(hi[e] & 0xffff0000u));
+      }
+      wh[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+      wl[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+    }
+  };
+  float bv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bv[r] = (bias && 4 * g + r < K) ? bias[4 * g + r] : 0.f;
+  const int64_t ntiles = (P + 15) / 16;
+  const int64_t tpb = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * tpb, t1 = t0 + tpb < ntiles ? t0 + tpb : ntiles;
+  uint4 rg[NKS];
+  auto gload = [&](int64_t tile) {
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) {
+      const int64_t row = tile * 16 + 2 * u + (lane >> 5);
+      rg[u] = row < P ? *(const uint4*)(feat + row * C + wv * 256 + (lane & 31) * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  if (!SCALE) load_w(nullptr);
+  int64_t img = -1;
+  int par = 0;
+  if (t0 < t1) gload(t0);
+  for (int64_t t = t0; t < t1; ++t) {
+    if (SCALE) {
+      const int64_t b = (t * 16) / pix_per_img;
+      if (b != img) { img = b; load_w(chan_scale + b * C); }
+    }
+#pragma unroll
+    for (int u = 0; u < NKS; ++u) {
+      const int row = 2 * u + (lane >> 5), c = lane & 31;
+      *(uint4*)(st + row * ROW + ((c ^ (row & 15)) << 4)) = rg[u];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (t + 1 < t1) gload(t + 1);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, *(const uint4*)(st + j * ROW + (((4 * ks + g) ^ j) << 4)));
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], fb, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], fb, acc, 0, 0, 0);
+    }
+    if (NW > 1) {
+      red[(par * NW + wv) * 64 + lane] = acc;
+      __syncthreads();          // one barrier per tile: the two parities of `red` alternate, wave 0 is past its reads of a parity
+                                // before anyone passes the NEXT barrier and writes that parity again
+      if (wv == 0) {
+#pragma unroll
+        for (int q = 1; q < NW; ++q) {
+          const f32x4_t o = red[(par * NW + q) * 64 + lane];
+          acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3];
+        }
+      }
+      par ^= 1;
+    }
+    const int64_t p = t * 16 + j;
+    if (wv == 0 && p < P) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * g + r < K) out[p * K + 4 * g + r] = acc[r] + bv[r];
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
 // backward of the 1x1 head wrt features and weights
 //  dfeat[p,c] = sum_k dlog[p,k] * w[k,c] (* chan_scale) ; dw[k,c] = sum_p dlog[p,k]*feat[p,c]*cs ; db[k] = sum_p dlog[p,k]
 template <typename T, int K>
@@ -546,6 +642,150 @@ __global__ __launch_bounds__(256) void head_1x1_bwd_w_partial8(const uint16_t* _
     red[t][8] = accb[k];
     __syncthreads();
     for (int c = t; c < C; c += 256) {
+      float ss = 0.f;
+      for (int r = 0; r < R; ++r) ss += red[r * G + (c >> 3)][c & 7];
+      wsb[(int64_t)k * C + c] = ss;
+    }
+    if (t == 0) {
+      float sb = 0.f;
+      for (int r = 0; r < R; ++r) sb += red[r * G][8];
+      wsb[(int64_t)K * C + k] = sb;
+    }
+    __syncthreads();
+  }
+}
+
+// General forms of the two kernels above: TPB = 256 or 192 threads (C / 8 lanes per pixel must divide it: 96 lanes for SegFormer's 768
+// channels) and an optional Dropout2d channel scale, held per lane for the image it is working in (a workgroup walks a contiguous
+// pixel range: the eight scale values are re-read a handful of times).  Arithmetic as in the 4-channel kernels: the scale multiplies
+// the finished feature-gradient sum / the feature value before it enters the weight-gradient sum.
+template <int K, int TPB, bool SCALE>
+__global__ __launch_bounds__(TPB) void head_1x1_bwd_feat8g_kernel(const float* __restrict__ dlog, int64_t P, int C, const float* __restrict__ w,
+                                                                  const float* __restrict__ chan_scale, int64_t pix_per_img,
+                                                                  uint16_t* __restrict__ dfeat) {
+  const int G = C >> 3, q = threadIdx.x % G, ro = threadIdx.x / G, R = TPB / G;
+  float wr[K][8];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float4 a = *(const float4*)(w + (int64_t)k * C + q * 8), b = *(const float4*)(w + (int64_t)k * C + q * 8 + 4);
+    wr[k][0] = a.x; wr[k][1] = a.y; wr[k][2] = a.z; wr[k][3] = a.w; wr[k][4] = b.x; wr[k][5] = b.y; wr[k][6] = b.z; wr[k][7] = b.w;
+  }
+  const int64_t per = (P + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = per * blockIdx.x, p1 = p0 + per < P ? p0 + per : P;
+  float csr[8];
+  int64_t bc = -1;
+  auto one = [&](int64_t p, const float (&gk)[K]) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = fmaf(gk[k], wr[k][e], o[e]);
+    }
+    if (SCALE) {
+      const int64_t b = p / pix_per_img;
+      if (b != bc) {
+        bc = b;
+        const float4 a = *(const float4*)(chan_scale + b * C + q * 8), c4 = *(const float4*)(chan_scale + b * C + q * 8 + 4);
+        csr[0] = a.x; csr[1] = a.y; csr[2] = a.z; csr[3] = a.w; csr[4] = c4.x; csr[5] = c4.y; csr[6] = c4.z; csr[7] = c4.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] *= csr[e];
+    }
+    *(uint4*)(dfeat + p * C + q * 8) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+  };
+  if (ro >= R) return;
+  int64_t p = p0 + ro;
+  for (; p + 3 * R < p1; p += 4 * R) {
+    float gk[4][K];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) gk[u][k] = dlog[(p + (int64_t)u * R) * K + k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(p + (int64_t)u * R, gk[u]);
+  }
+  for (; p < p1; p += R) {
+    float gk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) gk[k] = dlog[p * K + k];
+    one(p, gk);
+  }
+}
+
+template <int K, int TPB, bool SCALE>
+__global__ __launch_bounds__(TPB) void head_1x1_bwd_w_partial8g(const uint16_t* __restrict__ feat, const float* __restrict__ dlog, int64_t P,
+                                                                int C, const float* __restrict__ chan_scale, int64_t pix_per_img,
+                                                                float* __restrict__ ws) {
+  __shared__ float red[TPB][9];
+  const int G = C >> 3, R = TPB / G;
+  const int t = threadIdx.x, g = t % G, prow = t / G;
+  const int nsplit = gridDim.x;
+  const int64_t per = (P + nsplit - 1) / nsplit;
+  const int64_t p0 = per * blockIdx.x, p1 = p0 + per < P ? p0 + per : P;
+  float acc[K][8], accb[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    accb[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+  }
+  float csr[8];
+  int64_t bc = -1;
+  auto add = [&](int64_t p, const uint4& xv, const float (&gk)[K]) {
+    float v[8];
+    v[0] = __uint_as_float(xv.x << 16); v[1] = __uint_as_float(xv.x & 0xffff0000u);
+    v[2] = __uint_as_float(xv.y << 16); v[3] = __uint_as_float(xv.y & 0xffff0000u);
+    v[4] = __uint_as_float(xv.z << 16); v[5] = __uint_as_float(xv.z & 0xffff0000u);
+    v[6] = __uint_as_float(xv.w << 16); v[7] = __uint_as_float(xv.w & 0xffff0000u);
+    if (SCALE) {
+      const int64_t b = p / pix_per_img;
+      if (b != bc) {
+        bc = b;
+        const float4 a = *(const float4*)(chan_scale + b * C + g * 8), c4 = *(const float4*)(chan_scale + b * C + g * 8 + 4);
+        csr[0] = a.x; csr[1] = a.y; csr[2] = a.z; csr[3] = a.w; csr[4] = c4.x; csr[5] = c4.y; csr[6] = c4.z; csr[7] = c4.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= csr[j];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      accb[k] += gk[k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[k][j] = fmaf(gk[k], v[j], acc[k][j]);
+    }
+  };
+  if (prow < R) {
+    int64_t p = p0 + prow;
+    for (; p + 3 * R < p1; p += 4 * R) {
+      uint4 xv[4];
+      float gk[4][K];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xv[u] = *(const uint4*)(feat + (p + (int64_t)u * R) * C + 8 * g);
+#pragma unroll
+        for (int k = 0; k < K; ++k) gk[u][k] = dlog[(p + (int64_t)u * R) * K + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) add(p + (int64_t)u * R, xv[u], gk[u]);
+    }
+    for (; p < p1; p += R) {
+      float gk[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) gk[k] = dlog[p * K + k];
+      add(p, *(const uint4*)(feat + p * C + 8 * g), gk);
+    }
+  }
+  float* wsb = ws + (int64_t)blockIdx.x * (K + 1) * C;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[t][j] = acc[k][j];
+    red[t][8] = accb[k];
+    __syncthreads();
+    for (int c = t; c < C; c += TPB) {
       float ss = 0.f;
       for (int r = 0; r < R; ++r) ss += red[r * G + (c >> 3)][c & 7];
       wsb[(int64_t)k * C + c] = ss;
@@ -1492,6 +1732,30 @@ extern "C" int gdl_head_1x1(const void* feat, int dtype, int64_t P, int C, int64
     GDL_CHECK_LAUNCH("gdl_head_1x1(mfma)");
     return GDL_OK;
   }
+  if (g_head_mfma.load(std::memory_order_relaxed) && dtype == GDL_BF16 && f_sP == C && C % 256 == 0 && C <= 1024 && K >= 1 && K <= 16 &&
+      P >= 1024 && (uintptr_t)feat % 16 == 0 && (!chan_scale || pix_per_img % 16 == 0)) {
+    // 256 NW channels and / or a Dropout2d scale: NW waves per tile, contiguous tile ranges
+    const int NW = C / 256;
+    const int64_t ntiles = (P + 15) / 16;
+    const int64_t cap = (int64_t)((chan_scale ? 8 : 12) / NW) * gdl_num_cus();      // every workgroup resident: 2 / 3 waves per SIMD
+    const unsigned blocks = (unsigned)(ntiles < cap ? ntiles : cap);
+    const size_t lds = (size_t)NW * (16 * 512 + 2 * 64 * 16);
+    const uint16_t* f = (const uint16_t*)feat;
+#define GDL_HEAD_WIDE(NWV, SC) hipLaunchKernelGGL((head_1x1_mfma_wide_kernel<NWV, SC>), dim3(blocks), dim3(64 * NWV), lds, s, f, P, w, bias, chan_scale, pix_per_img, K, out)
+    switch (NW * 2 + (chan_scale ? 1 : 0)) {
+      case 2: GDL_HEAD_WIDE(1, false); break;
+      case 3: GDL_HEAD_WIDE(1, true); break;
+      case 4: GDL_HEAD_WIDE(2, false); break;
+      case 5: GDL_HEAD_WIDE(2, true); break;
+      case 6: GDL_HEAD_WIDE(3, false); break;
+      case 7: GDL_HEAD_WIDE(3, true); break;
+      case 8: GDL_HEAD_WIDE(4, false); break;
+      default: GDL_HEAD_WIDE(4, true); break;
+    }
+#undef GDL_HEAD_WIDE
+    GDL_CHECK_LAUNCH("gdl_head_1x1(mfma, wide)");
+    return GDL_OK;
+  }
   const unsigned grid = (unsigned)((P + 3) / 4);
   K_SWITCH(K, if (dtype == GDL_BF16) hipLaunchKernelGGL((head_1x1_kernel<uint16_t, KK>), dim3(grid), dim3(256), 0, s, feat, P, C, f_sP, w, bias, chan_scale, pix_per_img, out);
               else hipLaunchKernelGGL((head_1x1_kernel<float, KK>), dim3(grid), dim3(256), 0, s, feat, P, C, f_sP, w, bias, chan_scale, pix_per_img, out));
@@ -1522,19 +1786,37 @@ extern "C" int gdl_head_1x1_bwd(const void* feat, int dtype, const float* dlog, 
   const int64_t total = P * (C / 4);
   const bool feat8 = g_head_mfma.load(std::memory_order_relaxed) && dtype == GDL_BF16 && dfeat && !chan_scale && d_sP == C && C % 8 == 0 &&
                      C / 8 <= 256 && 256 % (C / 8) == 0 && K <= 8 && (uintptr_t)dfeat % 16 == 0 && P >= 1024;
+  // general wide forms (a Dropout2d scale, or C / 8 lanes per pixel that only divide 192 threads: SegFormer's 768 channels)
+  const int G8 = C % 8 == 0 ? C / 8 : 0;
+  const int tpb = G8 == 0 ? 0 : (G8 <= 256 && 256 % G8 == 0) ? 256 : (G8 <= 192 && 192 % G8 == 0) ? 192 : 0;
+  const bool gen_ok = g_head_mfma.load(std::memory_order_relaxed) && dtype == GDL_BF16 && tpb != 0 && K <= 8 && P >= 1024 &&
+                      (uintptr_t)chan_scale % 16 == 0 && (uintptr_t)w % 16 == 0 && (chan_scale || tpb == 192);
+  const bool feat8g = gen_ok && dfeat && !feat8 && d_sP == C && (uintptr_t)dfeat % 16 == 0;
+  const bool w8g = gen_ok && f_sP == C && (uintptr_t)feat % 16 == 0;
   K_SWITCH(K,
     if (dtype == GDL_BF16) {
       if constexpr (KK <= 8) {
+        if (feat8g) {
+          const dim3 gg(4 * gdl_num_cus());
+          if (tpb == 256) hipLaunchKernelGGL((head_1x1_bwd_feat8g_kernel<KK, 256, true>), gg, dim3(256), 0, s, dlog, P, C, w, chan_scale, pix_per_img, (uint16_t*)dfeat);
+          else if (chan_scale) hipLaunchKernelGGL((head_1x1_bwd_feat8g_kernel<KK, 192, true>), gg, dim3(192), 0, s, dlog, P, C, w, chan_scale, pix_per_img, (uint16_t*)dfeat);
+          else hipLaunchKernelGGL((head_1x1_bwd_feat8g_kernel<KK, 192, false>), gg, dim3(192), 0, s, dlog, P, C, w, chan_scale, pix_per_img, (uint16_t*)dfeat);
+        }
+        if (w8g) {
+          if (tpb == 256) hipLaunchKernelGGL((head_1x1_bwd_w_partial8g<KK, 256, true>), dim3(nsplit), dim3(256), 0, s, (const uint16_t*)feat, dlog, P, C, chan_scale, pix_per_img, ws);
+          else if (chan_scale) hipLaunchKernelGGL((head_1x1_bwd_w_partial8g<KK, 192, true>), dim3(nsplit), dim3(192), 0, s, (const uint16_t*)feat, dlog, P, C, chan_scale, pix_per_img, ws);
+          else hipLaunchKernelGGL((head_1x1_bwd_w_partial8g<KK, 192, false>), dim3(nsplit), dim3(192), 0, s, (const uint16_t*)feat, dlog, P, C, chan_scale, pix_per_img, ws);
+        }
         if (feat8) hipLaunchKernelGGL((head_1x1_bwd_feat8_kernel<KK>), dim3(4 * gdl_num_cus()), dim3(256), 0, s, dlog, P, C, w, (uint16_t*)dfeat);   // (all resident at once: 74 registers allow six waves per SIMD, 8 per CU left a third of the grid for a second round)
       }
-      if (dfeat && !feat8) hipLaunchKernelGGL((head_1x1_bwd_feat_kernel<uint16_t, KK>), dim3(grid_for(total)), dim3(256), 0, s, dlog, P, C, w, chan_scale, pix_per_img, dfeat, d_sP);
+      if (dfeat && !feat8 && !feat8g) hipLaunchKernelGGL((head_1x1_bwd_feat_kernel<uint16_t, KK>), dim3(grid_for(total)), dim3(256), 0, s, dlog, P, C, w, chan_scale, pix_per_img, dfeat, d_sP);
       bool w8 = false;
       if constexpr (KK <= 8) {
         w8 = g_head_mfma.load(std::memory_order_relaxed) && !chan_scale && f_sP == C && C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0 &&
              (uintptr_t)feat % 16 == 0 && P >= 1024;
         if (w8) hipLaunchKernelGGL((head_1x1_bwd_w_partial8<KK>), dim3(nsplit), dim3(256), 0, s, (const uint16_t*)feat, dlog, P, C, ws);
       }
-      if (!w8) hipLaunchKernelGGL((head_1x1_bwd_w_partial<uint16_t, KK>), gridw, dim3(256), 0, s, feat, dlog, P, C, f_sP, chan_scale, pix_per_img, ws);
+      if (!w8 && !w8g) hipLaunchKernelGGL((head_1x1_bwd_w_partial<uint16_t, KK>), gridw, dim3(256), 0, s, feat, dlog, P, C, f_sP, chan_scale, pix_per_img, ws);
     } else {
       if (dfeat) hipLaunchKernelGGL((head_1x1_bwd_feat_kernel<float, KK>), dim3(grid_for(total)), dim3(256), 0, s, dlog, P, C, w, chan_scale, pix_per_img, dfeat, d_sP);
       hipLaunchKernelGGL((head_1x1_bwd_w_partial<float, KK>), gridw, dim3(256), 0, s, feat, dlog, P, C, f_sP, chan_scale, pix_per_img, ws);

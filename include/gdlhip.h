@@ -439,8 +439,9 @@ int gdl_scale_outer(void* x, int dtype, const float* s, int64_t outer, int64_t i
 
 /* ---- classifier tail -------------------------------------------------------------------
  * 1x1 conv to K<=16 classes (+bias) on NHWC features -> f32 NHWC logits [P][K]
- * (segmentation_head.py:22-26, fcn_head.py:73).  Dense bf16 features with C = 128 / 256 and no Dropout2d scale run as a skinny
- * MFMA GEMM (16-pixel tiles, f32 weights as bf16 hi + lo fragments: f32-grade logits); every other shape one wave per pixel: */
+ * (segmentation_head.py:22-26, fcn_head.py:73, segformer_mlp.py:64-65).  Dense bf16 features with C = 128 / 256 / 512 / 768 / 1024 run
+ * as a skinny MFMA GEMM (16-pixel tiles, f32 weights as bf16 hi + lo fragments: f32-grade logits; a Dropout2d chan_scale [B][C] is
+ * folded into the weights per image when pix_per_img % 16 == 0 and C % 256 == 0); every other shape one wave per pixel: */
 int gdl_head_1x1(const void* feat, int dtype, int64_t P, int C, int64_t f_sP, const float* w,
                  const float* bias, const float* chan_scale, int64_t pix_per_img, float* out, int K,
                  gdl_stream_t stream);

@@ -683,44 +683,55 @@ def test_head_and_logit_upsample(dtype, K):
     close(db, br.grad, dtype, "head db")
 
 
-@pytest.mark.parametrize("C", [256, 128])
+@pytest.mark.parametrize("scale", [False, True])
+@pytest.mark.parametrize("C", [256, 128, 768, 512, 1024])
 @pytest.mark.parametrize("K,B,H,W", [(5, 2, 36, 36), (1, 1, 35, 31), (12, 1, 40, 40), (16, 3, 21, 17), (5, 4, 144, 144)])
-def test_head_mfma_and_register_weight_kernels(K, B, H, W, C):
-    """Round 5: the classifier head as a skinny MFMA GEMM (gdl_head_1x1 for dense bf16 features, C = 128 / 256: 16-pixel tiles staged
-    through a wave-private LDS slot, f32 weights as bf16 hi + lo fragments) and its feature gradient with the weights in registers
-    (dofa.py:89-96 / segmentation_head.py).  Against the wave-per-pixel kernels they replace (forward: f32-grade agreement; feature
-    gradient: to a bf16 ulp; weight gradient from up to 2048 partial rows) and against torch in f64; ragged last tile (P % 16 != 0)."""
+def test_head_mfma_and_register_weight_kernels(K, B, H, W, C, scale):
+    """Round 5: the classifier head as a skinny MFMA GEMM (gdl_head_1x1 for dense bf16 features: 16-pixel tiles staged through a
+    wave-private LDS slot, f32 weights as bf16 hi + lo fragments; C = 128 / 256 one wave per tile, C = 512 / 768 / 1024 -- SegFormer's
+    decoder, segformer_mlp.py:64-65 -- 256-channel slices on the waves of a workgroup; a Dropout2d scale folded into the weights per
+    image) and its gradients with register-resident weights (dofa.py:89-96 / segmentation_head.py / fcn_head.py:73).  Against the
+    wave-per-pixel kernels they replace (forward: f32-grade agreement; feature gradient: to a bf16 ulp; weight gradient from up to 2048
+    partial rows) and against torch in f64; ragged last tile (P % 16 != 0), images that are not a multiple of 16 pixels (scale: old path)."""
     import ctypes
     from gdlhip import _lib
     lib = _lib.load()
     lib.gdl_debug_set_head_mfma.argtypes = [ctypes.c_int]
+    if B * H * W * C > 2 ** 26 and C > 768:
+        pytest.skip("largest map only up to 768 channels")
     feat = q(rnd(B, H, W, C), torch.bfloat16)
     w, bias = rnd(K, C, seed=1) * 0.1, rnd(K, seed=2)
+    cs = (torch.rand(B, C, generator=torch.Generator().manual_seed(3)) < 0.9).float() / 0.9 if scale else None
+    csd = None if cs is None else cs.to(DEV)
     fd, wd, bd = feat.to(DEV, torch.bfloat16), w.to(DEV), bias.to(DEV)
     dlow = (rnd(B, H, W, K, seed=5) * 0.01).to(DEV)
     try:
         lib.gdl_debug_set_head_mfma(0)
-        low_old = ops.head_1x1(fd, wd, bd)
-        dfeat_old, dw_old, db_old = ops.head_1x1_bwd(fd, dlow, wd, None)
+        low_old = ops.head_1x1(fd, wd, bd, csd)
+        dfeat_old, dw_old, db_old = ops.head_1x1_bwd(fd, dlow, wd, csd)
     finally:
         lib.gdl_debug_set_head_mfma(1)
-    low = ops.head_1x1(fd, wd, bd)
-    dfeat, dw, db = ops.head_1x1_bwd(fd, dlow, wd, None)
-    ref = torch.einsum("bhwc,kc->bhwk", feat.double(), w.double()) + bias.double()
-    scale = ref.abs().max().item()
-    assert (low.cpu().double() - ref).abs().max().item() <= 2e-5 * scale, "MFMA head vs f64"
-    assert (low - low_old).abs().max().item() <= 2e-5 * scale, "MFMA head vs the wave-per-pixel kernel"
+    low = ops.head_1x1(fd, wd, bd, csd)
+    dfeat, dw, db = ops.head_1x1_bwd(fd, dlow, wd, csd)
+    fs = feat.double() if cs is None else feat.double() * cs.double()[:, None, None, :]
+    ref = torch.einsum("bhwc,kc->bhwk", fs, w.double()) + bias.double()
+    sc = ref.abs().max().item()
+    assert (low.cpu().double() - ref).abs().max().item() <= 2e-5 * sc, "MFMA head vs f64"
+    assert (low - low_old).abs().max().item() <= 2e-5 * sc, "MFMA head vs the wave-per-pixel kernel"
     dfeat_ref = torch.einsum("bhwk,kc->bhwc", dlow.cpu().double(), w.double())
+    if cs is not None:
+        dfeat_ref = dfeat_ref * cs.double()[:, None, None, :]
     close(dfeat, dfeat_ref.float(), torch.bfloat16, "head dfeat vs f64", scale=dfeat_ref.abs().max().item())
     # (same products in the same order; the two kernels may differ in which multiply-adds the compiler fused: one bf16 ulp)
     assert (dfeat.float() - dfeat_old.float()).abs().max().item() <= 2.0 ** -7 * dfeat_ref.abs().max().item()
     close(dw, dw_old, torch.float32, "head dw", scale=dw_old.abs().max().item())
     close(db, db_old, torch.float32, "head db", scale=db_old.abs().max().item())
-    dw_ref = torch.einsum("bhwk,bhwc->kc", dlow.cpu().double(), feat.double())
+    dw_ref = torch.einsum("bhwk,bhwc->kc", dlow.cpu().double(), fs)
     close(dw, dw_ref.float(), torch.float32, "head dw vs f64", scale=dw_ref.abs().max().item())
+    close(db, dlow.cpu().double().sum((0, 1, 2)).float(), torch.float32, "head db vs f64", scale=max(db_old.abs().max().item(), 1e-3))
     # no bias
-    low_nb = ops.head_1x1(fd, wd, None)
-    assert (low_nb.cpu().double() + bias.double() - ref).abs().max().item() <= 2e-5 * scale
+    low_nb = ops.head_1x1(fd, wd, None, csd)
+    assert (low_nb.cpu().double() + bias.double() - ref).abs().max().item() <= 2e-5 * sc
 
 
 @pytest.mark.parametrize("K", [2, 9, 16])
