@@ -381,3 +381,51 @@ def test_bench_stdout_line_is_short_and_ends_with_the_headline_extras():
         assert needle in tail, needle
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
     assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+
+
+def test_dofa_training_step_asks_for_low_resolution_logits_only_where_the_loss_can_use_them(monkeypatch):
+    """Round 5 host logic (tasks_with_models/segmentation_dofa.py): ``training_step`` hands the heads' not-yet-resized maps
+    (``lowres_logits=True``) to gdlhip's multiclass DiceLoss and to nothing else; validation / test, a binary or foreign loss, and
+    GDL_LOWRES_DICE=0 get the reference's full-resolution logits (dofa.py:89-105)."""
+    from types import SimpleNamespace
+    from gdlhip import nn as gnn
+    from tasks_with_models.segmentation_dofa import SegmentationDOFA
+    calls = []
+
+    class Model(torch.nn.Module):
+        def forward(self, x, wv, lowres_logits=False):
+            calls.append(bool(lowres_logits))
+            out = torch.zeros(x.shape[0], 5, 8, 8, requires_grad=True)
+            return SimpleNamespace(out=out, aux=out)
+
+    class FakeDice(gnn.DiceLoss):       # the class the task tests for; no kernel behind it here
+        def forward(self, y_pred, y_true):
+            return y_pred.sum() * 0.0
+
+    class Foreign(torch.nn.Module):
+        def forward(self, y_pred, y_true):
+            return y_pred.sum() * 0.0
+
+    def task_with(loss):
+        t = SegmentationDOFA("dofa_base", pretrained=False, image_size=(8, 8), num_classes=5, max_samples=1, loss=loss)
+        t.model = Model()
+        return t
+
+    batch = {"image": torch.zeros(2, 3, 8, 8), "mask": torch.zeros(2, 1, 8, 8, dtype=torch.int64), "wavelengths": torch.tensor([0.6, 0.5, 0.4])}
+    monkeypatch.setattr(gnn, "FUSE_LOWRES_DICE", True)
+    t = task_with(FakeDice(mode="multiclass"))
+    t.training_step(batch, 0)
+    assert calls == [True]
+    calls.clear()
+    monkeypatch.setattr(gnn, "predict_mask", lambda logits: logits.argmax(1))      # (the mask kernel needs a GPU)
+    with torch.no_grad():
+        t.validation_step(batch, 0)
+    assert calls == [False], "validation needs the full-resolution logits (masks, metrics)"
+    calls.clear()
+    task_with(FakeDice(mode="binary")).training_step(batch, 0)
+    task_with(Foreign()).training_step(batch, 0)
+    assert calls == [False, False]
+    calls.clear()
+    monkeypatch.setattr(gnn, "FUSE_LOWRES_DICE", False)
+    task_with(FakeDice(mode="multiclass")).training_step(batch, 0)
+    assert calls == [False]
