@@ -113,19 +113,20 @@ def synthetic_batch(batch: int, device, seed: int, model: str = "dofa"):
 
 def timed(fn, steps: int, warmup: int, world: int, device) -> float:
     """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks."""
+    sync = torch.cuda.synchronize if torch.device(device).type == "cuda" else (lambda: None)   # (cpu: the launch-path dry run)
     for _ in range(warmup):
         fn()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -506,8 +507,58 @@ def compact_line(out: dict, details: list) -> dict:
     return line
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` started as ONE process (no WORLD_SIZE in the environment): re-execute this file under
+    torch.distributed.run with N ranks on this node, the way the driver launches it, and hand its exit code back.  Rank 0's JSON
+    line passes through to our stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: starting the ranks myself: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes fails without it on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, json_out, world: int, rank: int) -> None:
+    """GDL_BENCH_DRY_RUN=1: the launch path of `--gpus N` without a GPU -- process group (gloo), barrier-bracketed timing with the
+    max over ranks, one JSON line from rank 0 -- around a toy CPU step.  tests/test_distributed_cpu.py drives it; the line says
+    `dry_run` and carries no throughput claim."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    torch.manual_seed(42 + rank)
+    net = torch.nn.Linear(64, 64)
+    model = DDP(net) if world > 1 else net
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    x = torch.randn(args.batch, 64)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        model(x).square().mean().backward()
+        opt.step()
+    dt = timed(step, args.steps, args.warmup, world, "cpu")
+    ranks = dist.get_world_size() if world > 1 else 1
+    if rank == 0:
+        json_out.write(json.dumps({"metric": "dry run of the bench.py launch path (toy CPU step, no throughput claim)", "dry_run": True,
+                                   "value": round(args.batch * world * args.steps / dt, 3), "unit": "toy samples/s", "n_gpus": world,
+                                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+                                   "scaling": "weak", "ddp": {"backend": "gloo", "ranks": ranks}}) + "\n")
+        json_out.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     # RCCL prints a version banner to the C-level stdout of every rank: keep a private handle on the real stdout for
     # the ONE JSON line and send everything else written to fd 1 to stderr
     sys.stdout.flush()
@@ -516,10 +567,16 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0 and world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): measuring {world}", file=sys.stderr)
+    if os.environ.get("GDL_BENCH_DRY_RUN") == "1":
+        dry_run(args, json_out, world, rank)
+        return
+    if torch.cuda.device_count() < max(world, local + 1):
+        if rank == 0:
+            print(f"bench.py: --gpus {world} needs {world} visible devices (one process per GPU), this node shows "
+                  f"{torch.cuda.device_count()}", file=sys.stderr)
+        sys.exit(3)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist_on = world > 1 or args.force_ddp

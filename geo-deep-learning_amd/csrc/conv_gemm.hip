@@ -427,6 +427,7 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   if (variant == 6) return conv_gemm_dual_launch(k, s);
   if (variant == 8) return conv_gemm_w4_launch(k, s);
   if (variant == 9) return conv_gemm_persist_launch(k, s);
+  if (variant == 10) return conv_gemm_w4p_launch(k, s);
   if (a.dtype == GDL_BF16) {
     if (variant == 4) return conv3x3_sf_launch(k, s);
     if (variant == 3 && k.dbg == 7) return launch_x<bf16_tag, 2, 4, 4, 2, false, true, false, false, true>(k, s);
@@ -454,6 +455,9 @@ static std::atomic<int> g_w4_enabled{1};
 extern "C" void gdl_debug_set_conv_w4(int on) { g_w4_enabled = on; }  // A/B hook: 256^2 one-wave-per-SIMD tile
 static std::atomic<int> g_persist_enabled{1};
 extern "C" void gdl_debug_set_conv_persist(int on) { g_persist_enabled = on; }  // A/B hook: persistent 256^2 tile for dense 1x1 layers
+static std::atomic<int> g_w4p_enabled{1};
+static std::atomic<int> g_w4p_min_n{768};
+extern "C" void gdl_debug_set_conv_w4p(int on) { g_w4p_enabled = on != 0; if (on > 1) g_w4p_min_n = on; }  // A/B hook: persistent 256^2 tile with deferred stores (conv_gemm_w4p.hip)
 static std::atomic<int> g_dual_enabled{1};
 extern "C" void gdl_debug_set_conv_dual(int on) { g_dual_enabled = on; }  // A/B hook: dual-resident 256 x 128 tile
 static std::atomic<int> g_ngroup_kb{2560};
@@ -498,6 +502,7 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
       !(g_forced_variant == 6 && !conv_gemm_dual_applicable(a)) &&
       !(g_forced_variant == 8 && !conv_gemm_w4_applicable(a)) &&
       !(g_forced_variant == 9 && !conv_gemm_persist_applicable(a)) &&
+      !(g_forced_variant == 10 && !conv_gemm_w4p_applicable(a)) &&
       !(g_forced_variant == 7 && !conv3x3_narrow_applicable(a)))
     return g_forced_variant;
   // narrow 3x3 layers on large maps: direct kernel, one staged window per 4 x 64 pixels (HBM-bound layers)
@@ -516,6 +521,10 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
     // 256 x 128 workgroups per CU put one's epilogue under the other's K loop (+5..9 %, profiles/r04a_bench_short_k_*); for
     // every other epilogue the 256^2 tile is as fast or faster
     if (g_dual_enabled && a.act == GDL_ACT_GELU && ksteps <= 16 && t256 >= 1024 && conv_gemm_dual_applicable(a)) return 6;
+    // dense 1x1 layers with bf16 outputs, 12 .. 39 K-steps and at least two rounds of tiles: one persistent workgroup per CU, one
+    // wave per SIMD, the finished tile parked in registers and stored from the MFMA shadows of the next tile's K loop
+    // (conv_gemm_w4p.hip; ViT qkv 1022 -> 1092 TF/s, the neck's tap products 1061 -> 1142, tools/bench_w4p.py)
+    if (g_w4p_enabled && t256 >= 512 && a.N >= g_w4p_min_n && ksteps >= 12 && ksteps < 40 && conv_gemm_w4p_applicable(a)) return 10;
     // deep-K layers: one wave per SIMD, every load in an MFMA shadow (conv_gemm_w4.hip): its K-step is ~12 % shorter, its
     // epilogue (four waves instead of eight) ~1.8 x longer -- it wins from about 40 K-steps on (ViT fc2 +8 %, tap data
     // gradients +9 %, the 768-channel 3x3 convolutions +2.5 %; tools/bench_w4.py, profiles/r04d_*)
@@ -545,7 +554,7 @@ extern "C" int64_t gdl_conv_gemm_stats_rows(const gdl_conv_args* ap) {
   const int64_t M = (int64_t)a.B * a.Ho * a.Wo;
   const int v = gdl_conv_gemm_plan(ap, nullptr);
   int bm, bn, tm;
-  if (v == 3 || v == 4 || v == 8 || v == 9) { bm = 256; bn = 256; tm = 4; }
+  if (v == 3 || v == 4 || v == 8 || v == 9 || v == 10) { bm = 256; bn = 256; tm = 4; }
   else if (v == 1) { bm = 128; bn = 128; tm = 2; }
   else return 0;
   if (M % bm != 0 || a.N % bn != 0) return 0;

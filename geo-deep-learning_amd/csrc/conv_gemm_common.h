@@ -17,6 +17,7 @@ struct KArgs {
   int n_group;  // tile order: N tiles are walked in groups of n_group (0 = all): [group][tile_m][tile_n in group], see tile_order()
   int in_dense, out_dense, res_dense;
   unsigned in_span, w_span;   // bytes addressed from the (z-offset) operand base: buffer num_records
+  unsigned out_span;          // conv_gemm_w4p.hip only: the same for the output (stores of rows past M are range-checked away)
   int tap_inner;              // K order: 1 = channel chunk outer / filter tap inner (default), 0 = tap outer
   int dbg;                    // tuning experiments only: 1 = no DMA after the first tile, 2 = no MFMA
   int epi_v2;                 // A/B hook (gdl_debug_set_conv_epilogue): 0 = the round-2 epilogue (conv_epilogue_rows)
@@ -104,6 +105,10 @@ int conv_gemm_w4_launch(const KArgs& k, hipStream_t stream);
 // persistent 256 x 256 ping-pong tile for dense 1x1 bf16 layers: next tile's first stage in flight under the epilogue (conv_gemm_persist.hip)
 bool conv_gemm_persist_applicable(const gdl_conv_args& a);
 int conv_gemm_persist_launch(const KArgs& k, hipStream_t stream);
+// persistent 256 x 256 tile, one wave per SIMD, finished tile parked in registers and stored from the next tile's MFMA shadows
+// (conv_gemm_w4p.hip): dense 1x1 bf16 layers with bf16 outputs and at least 12 K-steps
+bool conv_gemm_w4p_applicable(const gdl_conv_args& a);
+int conv_gemm_w4p_launch(const KArgs& k, hipStream_t stream);
 // direct 3x3 kernel for C in {8,16,32} on large dense maps, outputs in 32-channel slices (conv3x3_narrow.hip)
 bool conv3x3_narrow_applicable(const gdl_conv_args& a);
 int conv3x3_narrow_launch(const KArgs& k, hipStream_t stream);

@@ -211,6 +211,9 @@ def load() -> C.CDLL:
     if os.environ.get("GDL_CONV_PERSIST") is not None:    # tuning hook: 0 = never pick the persistent 256^2 tile (dense 1x1 layers)
         lib.gdl_debug_set_conv_persist.argtypes = [C.c_int]
         lib.gdl_debug_set_conv_persist(int(os.environ["GDL_CONV_PERSIST"]))
+    if os.environ.get("GDL_CONV_W4P") is not None:        # tuning hook: 0 = never pick the persistent deferred-store 256^2 tile
+        lib.gdl_debug_set_conv_w4p.argtypes = [C.c_int]
+        lib.gdl_debug_set_conv_w4p(int(os.environ["GDL_CONV_W4P"]))
     if os.environ.get("GDL_FLASH_FWD") is not None:       # tuning hook: 2 = the round-2 attention forward (64-query waves)
         lib.gdl_debug_set_flash_fwd.argtypes = [C.c_int, C.c_float]
         lib.gdl_debug_set_flash_fwd(int(os.environ["GDL_FLASH_FWD"]), float(os.environ.get("GDL_FLASH_DEFER", "6")))

@@ -169,6 +169,7 @@ class KernelTimer:
                6: "conv_gemm_dual_kernel (256x128 tiles, four waves, two workgroups resident per CU)",
                8: "conv_gemm_w4_kernel (256x256 tiles, one wave per SIMD, every load in an MFMA shadow)",
                9: "conv_gemm_persist_kernel (256x256 ping-pong tiles, one persistent workgroup per CU, next tile's first stage under the epilogue)",
+               10: "conv_gemm_w4p_kernel (256x256 tiles, one persistent workgroup per CU, one wave per SIMD, finished tile parked in registers and stored from the next tile's MFMA shadows)",
                7: "conv3x3_narrow_kernel (direct 3x3, C <= 32, one staged window per 4 x 64 pixels x 32 output channels)"}
 
     def __init__(self) -> None:

@@ -97,8 +97,9 @@ int64_t gdl_conv_gemm_stats_rows(const gdl_conv_args* a);
 /* Which kernel variant the call above will launch (0 = 64x64 tiles, 1 = 128x128, 2 = 256x256 / 8 waves, 3 = 256x256 with
  * alternating loader halves, 4 = 256x256 3x3 with shared activation staging, 5 = 256x64 for narrow outputs, 6 = dual-resident
  * 256x128 tile (GELU layers), 7 = direct 3x3 for 8 / 16 / 32 input channels, 8 = 256x256 with one wave per SIMD (>= 40
- * K-steps), 9 = persistent 256x256 for dense 1x1 layers) and its algorithmic flops 2*M*N*K (for roofline accounting in
- * bench.py). */
+ * K-steps), 9 = persistent 256x256 for dense 1x1 layers, 10 = persistent 256x256 with one wave per SIMD whose finished tile
+ * is parked in registers and stored from the MFMA shadows of the next tile's K loop) and its algorithmic flops 2*M*N*K (for
+ * roofline accounting in bench.py). */
 int gdl_conv_gemm_plan(const gdl_conv_args* a, int64_t* flops);
 
 /* Weight gradient of the same convolution:

@@ -1130,6 +1130,49 @@ def test_conv_persistent_tile(M, N, K):
         assert torch.equal(outs[9, key], outs[1, key]), f"persistent tile vs 128^2 tile differ ({key})"
 
 
+@pytest.mark.parametrize("B,T,N,K", [(26, 1297, 1024, 768), (13, 2600, 512, 1024), (1, 512, 256, 768), (32, 2048, 768, 768)])
+def test_conv_parked_tile(B, T, N, K):
+    """The persistent one-wave-per-SIMD tile whose finished tile is parked in registers and stored from the MFMA shadows of the next
+    tile's K loop (variant 10, conv_gemm_w4p.hip): more tiles than CUs (528 / 266 / 768: workgroups take a second and third tile; and
+    one call of two tiles), 12 / 16 K-steps (the "exactly twelve" and the "more" instantiations), an M tail whose rows must be
+    dropped by the store descriptor's range check, bias-only outputs, folded BatchNorm + ReLU, output into a channel slice of a
+    wider buffer -- all bit-identical to the 128^2 tile -- and BatchNorm partial statistics from phase 1 through the planner."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
+    dtype = torch.bfloat16
+    M = B * T
+    x = q(rnd(M, K), dtype).to(DEV, dtype).view(B, 1, T, K)
+    w = (q(rnd(N, K, seed=1), dtype) * 0.1).to(DEV, dtype)
+    bias, scale, shift = rnd(N, seed=2).to(DEV), rnd(N, seed=3).to(DEV), rnd(N, seed=5).to(DEV)
+    outs = {}
+    try:
+        for v in (10, 1):
+            lib.gdl_debug_force_conv_variant(v)
+            outs[v, "bf16"] = ops.conv_gemm(x, w, bias=bias)
+            outs[v, "nobias"] = ops.conv_gemm(x, w)
+            outs[v, "bnrelu"] = ops.conv_gemm(x, w, bias=bias, scale=scale, shift=shift, act=ops.ACT_RELU)
+            wide = torch.zeros(B, 1, T, N + 64, device=DEV, dtype=dtype)
+            ops.conv_gemm(x, w, bias=bias, out=wide[..., 32:32 + N])
+            outs[v, "slice"] = wide
+    finally:
+        lib.gdl_debug_force_conv_variant(-1)
+    pre = x.view(M, K).float().cpu() @ w.float().cpu().t() + bias.cpu()
+    close(outs[10, "bf16"].view(M, N), pre, dtype, "parked tile")
+    close(outs[10, "bnrelu"].view(M, N), F.relu(pre * scale.cpu() + shift.cpu()), dtype, "parked tile, folded BN + ReLU")
+    for key in [k2 for (v, k2) in outs if v == 10]:
+        assert torch.equal(outs[10, key], outs[1, key]), f"parked tile vs 128^2 tile differ ({key})"
+    if M % 256 == 0 and (M // 256) * (N // 256) >= 512:      # statistics follow the planner's own choice (forced variants emit none)
+        y, part, rows = ops.conv_gemm(x, w, bias=bias, want_stats=True)
+        assert rows == M // 128, "the planner should have picked a 256^2 tile with 128-pixel partial rows"
+        assert torch.equal(y, outs[1, "bf16"])
+        yb = y.view(M, N).double().cpu()
+        ref_s = torch.stack([yb.sum(0), (yb * yb).sum(0)])
+        got = part.double().sum(0).cpu()
+        assert ((got - ref_s).abs() <= 1e-4 * ref_s.abs().max()).all(), "BatchNorm partial statistics from phase 1"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,C,N,R", [(2, 37, 23, 64, 64, 3), (1, 50, 50, 128, 32, 1), (3, 16, 16, 192, 64, 3),
                                          # C divides the K chunk: several filter taps are packed into one chunk

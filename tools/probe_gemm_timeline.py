@@ -64,7 +64,7 @@ def run(name, m, k, n, kind, odt, variant, dbg):
     lib.gdl_debug_set_conv_probe(None)
     lib.gdl_debug_set_conv_dbg(0)
     lib.gdl_debug_force_conv_variant(-1)
-    tm = 256 if variant in (2, 3, 4, 6, 8, 9) else 128
+    tm = 256 if variant in (2, 3, 4, 6, 8, 9, 10) else 128
     tn = 128 if variant == 6 else tm
     nb = min(2048, ((m + tm - 1) // tm) * ((n + tn - 1) // tn))
     kl = buf[:4096].view(2048, 2)[:nb].double().cpu()
@@ -99,6 +99,12 @@ if len(sys.argv) > 2 and sys.argv[2] == "persist":   # one-tile 256^2 ping-pong 
             ("neck taps 768->6912 @36", B * 36 * 36, 768, 6912, None, bf)]
     for shp in SHAPES[:2] + [SHAPES[4]] + K256:
         for variant, dbg in ((3, 0), (9, 0), (9, 11)):
+            run(*shp, variant, dbg)
+    sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "parked":   # parked tile (10: as is / 20: phase-2 stores dropped / 21: no phase 1) vs the persistent 8-wave tile and w4
+    K256 = [("dgrad lateral 256->768 @144", B * 144 * 144, 256, 768, None, bf), ("fuse taps 256->2304 @72", B * 72 * 72, 256, 2304, None, bf)]
+    for shp in [SHAPES[0], SHAPES[4], ("neck taps 768->6912 @36", B * 36 * 36, 768, 6912, None, bf)]:
+        for variant, dbg in ((9, 0), (8, 0), (10, 0), (10, 20), (10, 21)):
             run(*shp, variant, dbg)
     sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "epilogue_parts":   # round-3 epilogue: as is / without its global stores (10) / without residual loads (11)
