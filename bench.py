@@ -172,13 +172,17 @@ def build_task(model: str, device, dist_on: bool, local: int, capturable: bool =
 
 
 def make_steps(task, optimizer, get_batch, use_bf16: bool):
+    from gdlhip.markers import rng      # roctx ranges (GDL_ROCTX=1): forward groups in the model, loss / backward / optimizer here
+
     def train_step():
         task.train()
         optimizer.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16), rng("forward+loss"):
             loss = task.training_step(get_batch(), 0)
-        loss.backward()
-        optimizer.step()
+        with rng("backward"):
+            loss.backward()
+        with rng("optimizer"):
+            optimizer.step()
 
     def infer_step():
         task.eval()
@@ -585,6 +589,7 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")     # (whole-step capture under DDP: gdlhip/graphs.py)
         dist.init_process_group("nccl", device_id=device)
 
     from gdlhip import ops

@@ -1785,7 +1785,8 @@ extern "C" int gdl_head_1x1_bwd(const void* feat, int dtype, const float* dlog, 
   dim3 gridw((C + 255) / 256, nsplit);
   const int64_t total = P * (C / 4);
   const bool feat8 = g_head_mfma.load(std::memory_order_relaxed) && dtype == GDL_BF16 && dfeat && !chan_scale && d_sP == C && C % 8 == 0 &&
-                     C / 8 <= 256 && 256 % (C / 8) == 0 && K <= 8 && (uintptr_t)dfeat % 16 == 0 && P >= 1024;
+                     C / 8 <= 256 && 256 % (C / 8) == 0 && K <= 8 && (uintptr_t)dfeat % 16 == 0 && P >= 1024 &&
+                     (uintptr_t)w % 16 == 0;      // (the kernel reads the weights with float4 loads: a view at an odd offset takes the general path)
   // general wide forms (a Dropout2d scale, or C / 8 lanes per pixel that only divide 192 threads: SegFormer's 768 channels)
   const int G8 = C % 8 == 0 ? C / 8 : 0;
   const int tpb = G8 == 0 ? 0 : (G8 <= 256 && 256 % G8 == 0) ? 256 : (G8 <= 192 && 192 % G8 == 0) ? 192 : 0;
@@ -1899,7 +1900,7 @@ extern "C" int64_t gdl_dice_loss_lowres_workspace(int B, int K, int Ho, int Wo) 
 
 // Dice loss (multiclass) of bilinear(low -> [Ho, Wo]) against target [B, Ho, Wo] WITHOUT the full-resolution logits: low = the
 // [B, Hi, Wi, K] f32 map gdl_head_1x1 writes.  sums / loss as gdl_dice_loss_fwd; workspace of gdl_dice_loss_lowres_workspace(B, K, Ho,
-// Wo) bytes.  Upsampling factors up to 16 per direction.
+// Wo) bytes.  Upsampling factors up to 64 per direction.
 extern "C" int gdl_dice_loss_lowres_fwd(const float* low, const int64_t* target, int B, int K, int Hi, int Wi, int Ho, int Wo, float eps,
                                         float* sums, float* loss, float* ws, int64_t ws_bytes, gdl_stream_t stream) {
   GDL_CHECK_ARG(low && target && sums && loss && ws, "gdl_dice_loss_lowres_fwd: null pointer");

@@ -57,9 +57,20 @@ def capturable_process_group(group=None) -> bool:
     if not (dist.is_available() and dist.is_initialized()):
         return True
     try:
-        return str(dist.get_backend(group)).lower() == "nccl"
+        if str(dist.get_backend(group)).lower() != "nccl":
+            return False
     except (RuntimeError, ValueError):
         return False
+    import os
+    if os.environ.get("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0") not in ("0", ""):
+        # torch's notes on DDP under CUDA graphs: the watchdog's error handling must be off (geo_deep_learning/train.py and
+        # bench.py set it before init_process_group); with it on, say why the step stays eager instead of dying in the capture
+        import logging
+        logging.getLogger(__name__).warning("TORCH_NCCL_ASYNC_ERROR_HANDLING=%s: the DDP training step is not captured into a "
+                                            "hipGraph (set it to 0 before init_process_group)",
+                                            os.environ["TORCH_NCCL_ASYNC_ERROR_HANDLING"])
+        return False
+    return True
 
 
 def ddp_on_side_stream(module: torch.nn.Module, **ddp_kwargs) -> torch.nn.parallel.DistributedDataParallel:

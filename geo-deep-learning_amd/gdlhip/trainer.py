@@ -30,6 +30,8 @@ import torch
 import torch.distributed as dist
 from torch import Tensor, nn
 
+from .markers import rng
+
 logger = logging.getLogger(__name__)
 
 try:  # pragma: no cover - lightning is absent in the build image
@@ -127,7 +129,9 @@ class MiniTrainer:
         # its shapes are static; True = whenever it can be captured; False = never.  Batches of another shape (a ragged last
         # batch) run eagerly through the same optimizer.
         # Under DDP (round 5) the captured step includes the collectives; only the nccl (RCCL) backend can be recorded, the ranks
-        # agree on the capture's outcome, and a failed capture leaves the training state untouched (gdlhip.graphs).
+        # agree on preconditions and outcome through the process group's store (_agree), and a failed capture leaves the training
+        # state untouched (gdlhip.graphs).  With MORE THAN ONE rank "auto" keeps the step eager (round 6): that capture asks
+        # for graph_step=True.
         self.graph_step = graph_step
         self.graph_max_batch = 8
         self.force_ddp = force_ddp           # wrap in DDP even with ONE rank (the single-GPU RCCL tests of the capture path)
@@ -247,6 +251,14 @@ class MiniTrainer:
         want_graph = self.graph_step not in (False, "off", "false", None) and device.type == "cuda" and self.accumulate_grad_batches == 1
         self._stream = None
         self._ddp_active = self.world_size > 1 or (self.force_ddp and dist.is_available() and dist.is_initialized())
+        if want_graph and self._ddp_active and self.world_size > 1 and self.graph_step == "auto":
+            # The whole-step capture with RCCL collectives inside has run on ONE-rank groups and on two ranks sharing a GPU over
+            # gloo only (no box with two devices was available): "auto" does not bet a multi-GPU training run on it.  A failed
+            # capture there is not a fallback but a dead process group.  graph_step=True asks for it explicitly
+            # (tests/test_hip_tasks.py::test_ddp_captured_step_world2_rccl_* run it wherever two devices exist).
+            logger.info("MiniTrainer: graph_step='auto' keeps the DDP step eager at world size %d; pass graph_step=True to capture "
+                        "it (RCCL collectives inside the hipGraph)", self.world_size)
+            want_graph = False
         if self._ddp_active:
             if self.sync_batchnorm:
                 model.model = nn.SyncBatchNorm.convert_sync_batchnorm(model.model)
@@ -398,9 +410,10 @@ class MiniTrainer:
                 # an eager step between replays (ragged batch): `p.grad` still names the graph's static gradient buffers, which
                 # hold the last replay's gradients -- backward would ADD to them
                 step_opt.zero_grad(set_to_none=True)
-            with self._autocast(device):
+            with self._autocast(device), rng("forward+loss"):
                 loss = model.training_step(batch, i)
-            (loss / self.accumulate_grad_batches).backward()
+            with rng("backward"):
+                (loss / self.accumulate_grad_batches).backward()
             pending = True
             if (i + 1) % self.accumulate_grad_batches == 0:
                 optimizer_step()
@@ -409,37 +422,71 @@ class MiniTrainer:
             optimizer_step()
         self.training = False
 
+    def _agree(self, tag: str, verdict: str, timeout_s: float = 120.0) -> str:
+        """All ranks' verdicts on one question, through the process group's key-value store and NOT through a collective: the
+        questions are asked exactly when ranks may be out of step with each other (one failed before the warm-up collectives, one
+        died inside a capture) -- a 1-element all-reduce issued by the failing rank would pair up with a peer's DDP bucket
+        all-reduce.  Returns the worst verdict ("fatal" < "no" < "ok"); a rank that does not answer within the timeout counts as
+        "fatal".  Every call uses a fresh key generation."""
+        if not (getattr(self, "_ddp_active", False) and self.world_size > 1 and dist.is_available() and dist.is_initialized()):
+            return verdict
+        from datetime import timedelta
+        self._agree_gen = getattr(self, "_agree_gen", 0) + 1
+        store = dist.distributed_c10d._get_default_store()
+        base = f"gdl_agree/{tag}/{self._agree_gen}"
+        store.set(f"{base}/{self.global_rank}", verdict)
+        keys = [f"{base}/{r}" for r in range(self.world_size)]
+        try:
+            store.wait(keys, timedelta(seconds=timeout_s))
+            got = [store.get(k).decode() for k in keys]
+        except Exception as exc:  # noqa: BLE001  (timeout: a peer is gone)
+            logger.error("MiniTrainer: no answer from every rank on '%s' within %.0f s (%s)", tag, timeout_s, exc)
+            return "fatal"
+        order = {"fatal": 0, "no": 1, "ok": 2}
+        return min(got, key=lambda g: order.get(g, 0))
+
     def _graph_step(self, model, step_opt, batch, device) -> bool:
         """One training step as a hipGraph replay; False = this batch has to run eagerly (no graph yet and the batch is too
         large for "auto", another shape than the captured one, or the capture failed)."""
         from gdlhip.graphs import GraphCaptureFatal, GraphedTrainStep
         tensors = {k: v for k, v in batch.items() if isinstance(v, Tensor) and v.is_cuda} if isinstance(batch, dict) else {}
-        if not tensors:
+        multi = getattr(self, "_ddp_active", False) and self.world_size > 1
+        if not tensors and not (multi and self._graphed is None):
             return False
         if self._graphed is None:
-            lead = max(v.shape[0] for v in tensors.values() if v.dim() > 0)
-            if self.graph_step == "auto" and lead > self.graph_max_batch:
-                self._graph_ok = False       # GPU-bound step: a graph buys nothing and doubles the activation memory
+            lead = max((v.shape[0] for v in tensors.values() if v.dim() > 0), default=0)
+            # rank-local reasons not to capture (no device tensors in the batch; "auto" and a GPU-bound batch size) are settled
+            # with the peers BEFORE anybody constructs GraphedTrainStep: its eleven warm-up iterations are DDP collectives, and a
+            # rank that skipped them would leave the others waiting in a bucket all-reduce (advisor, round 5)
+            local_ok = bool(tensors) and not (self.graph_step == "auto" and lead > self.graph_max_batch)
+            pre = self._agree("precondition", "ok" if local_ok else "no")
+            if pre != "ok":
+                if pre == "fatal":
+                    raise RuntimeError("MiniTrainer: a rank did not answer before the hipGraph capture of the DDP step")
+                self._graph_ok = False       # GPU-bound step (a graph buys nothing and doubles the activation memory), or a peer's veto
                 return False
             amp = torch.bfloat16 if self.precision in ("bf16-mixed", "bf16", "16-mixed", "16") else None
-            failure = None
+            failure, fatal = None, None
             try:
                 # (under DDP the warm-up is raised to the 11 eager iterations torch asks for; all of them are undone)
                 self._graphed = GraphedTrainStep(model, step_opt, batch, autocast_dtype=amp, warmup=2, restore_state=True)
-            except GraphCaptureFatal:
-                raise                    # the device / RNG state of this process is gone: do not train on as if nothing happened
+            except GraphCaptureFatal as exc:
+                fatal = exc              # the device / RNG state of this process is gone; tell the peers BEFORE raising
             except Exception as exc:  # noqa: BLE001  (anything the capture cannot record: fall back to eager steps for good)
                 failure, self._graphed = f"{type(exc).__name__}: {exc}", None
                 logger.debug("capture traceback", exc_info=True)
                 self.capture_traceback = traceback.format_exc()[-3000:]
-            if getattr(self, "_ddp_active", False) and self.world_size > 1:
-                # every rank ran the same warm-up collectives and then recorded (not ran) the captured ones: the process group is
-                # in step.  One all-reduce decides for everybody -- a rank replaying while another launches eagerly is legal for
-                # RCCL (same kernels in the same order) but a rank that FAILED would otherwise train differently
-                flag = torch.tensor([0.0 if failure else 1.0], device=device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if flag.item() < 1.0 and failure is None:
-                    failure, self._graphed = "the capture failed on another rank", None
+            # every rank ran the same warm-up collectives and then recorded (not ran) the captured ones.  The outcome is agreed
+            # through the store: all replay, or all run eagerly, or -- one rank's capture died with a HIP error -- all stop with
+            # a message instead of waiting for that rank in the next collective until the watchdog fires
+            outcome = self._agree("capture", "fatal" if fatal is not None else "no" if failure else "ok")
+            if fatal is not None:
+                raise fatal
+            if outcome == "fatal":
+                raise GraphCaptureFatal("the hipGraph capture of the DDP training step died on another rank (or that rank did not "
+                                        "answer): stopping this rank too; rerun with graph_step=False")
+            if outcome != "ok" and failure is None:
+                failure, self._graphed = "the capture failed on another rank", None
             if failure is not None:
                 logger.warning("MiniTrainer: hipGraph capture of the training step failed (%s); running eagerly", failure)
                 self._graph_ok = False

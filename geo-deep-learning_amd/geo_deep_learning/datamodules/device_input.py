@@ -54,6 +54,8 @@ class DeviceInputStage:
         self._pinned: dict = {}      # (key, shape, dtype) -> ring of pinned host buffers
         self._slot_events: list = [None] * (self.depth + 1)   # copy-done event of the batch that last used a ring slot
         self._slot = 0
+        import threading
+        self._stage_lock = threading.Lock()                   # serialises _stage between a finishing and a starting worker thread
         self.bytes_h2d = 0
 
     # ------------------------------------------------------------------ staging
@@ -186,15 +188,24 @@ class DeviceInputStage:
             return False
 
         def work() -> None:
+            # torch.set_num_threads stores a PROCESS-wide default that threads created later inherit (the autograd engine's,
+            # later workers'), not just this thread's OpenMP team: put the previous value back on the way out (advisor, round 5)
+            prev_threads = torch.get_num_threads()
             try:
                 torch.cuda.set_device(dev_index)
-                torch.set_num_threads(self.host_threads)      # (OpenMP: this thread's team only)
+                torch.set_num_threads(self.host_threads)
                 for batch in self.batches:
-                    if not put(self._stage(batch)):
+                    if stop.is_set():
+                        return
+                    with self._stage_lock:                    # one stager at a time touches the pinned ring and its slot counter
+                        staged = self._stage(batch)
+                    if not put(staged):
                         return
                 put(done)
             except BaseException as exc:  # noqa: BLE001  (handed to the consumer)
                 put(exc)
+            finally:
+                torch.set_num_threads(prev_threads)
 
         worker = threading.Thread(target=work, name="gdl-input-stage", daemon=True)
         worker.start()
@@ -207,7 +218,17 @@ class DeviceInputStage:
                     raise item
                 yield self._finish(*item)
         finally:
+            # an early exit of the consumer (limit_*_batches, fast_dev_run, an exception in the step): stop the worker, empty
+            # the queue so that a blocked put() returns, and WAIT for it -- a worker still inside `for batch in self.batches` /
+            # _stage when the stage is iterated again would share the loader, the slot counter and the pinned ring with the
+            # next worker and could overwrite a pinned slot whose copy is still in flight (advisor, round 5)
             stop.set()
+            while worker.is_alive():
+                try:
+                    q.get_nowait()
+                except queue_mod.Empty:
+                    pass
+                worker.join(timeout=0.05)
 
     def __len__(self) -> int:
         return len(self.batches)  # type: ignore[arg-type]

@@ -11,6 +11,7 @@ from geo_deep_learning.models.heads.segmentation_head import SegmentationHead, S
 from geo_deep_learning.models.necks.multilevel_neck import MultiLevelNeck
 from gdlhip import nn as gnn
 from gdlhip import ops
+from gdlhip.markers import rng
 
 from .base import BaseSegmentationModel
 
@@ -52,8 +53,13 @@ class DOFASegmentationModel(BaseSegmentationModel):
         resize on the fly.  It travels through ``DistributedDataParallel.forward`` as a keyword argument."""
         image_size = x.shape[2:]
         with gnn.counter_batch():       # the BatchNorm step counters of the pass advance in one launch
-            feats = self.neck.forward_nhwc(self.encoder.forward_features_nhwc(x, wavelengths, drop_masks))
-            dec = self.decoder.forward_nhwc(feats)
-            out = self.head.forward_logits(dec, image_size, lowres=lowres_logits)
-            aux = self.aux_head.forward_logits(feats[-1], image_size, aux_drop_mask, lowres=lowres_logits)
+            with rng("encoder"):        # (roctx ranges for rocprofv3 --marker-trace: GDL_ROCTX=1, gdlhip/markers.py)
+                taps = self.encoder.forward_features_nhwc(x, wavelengths, drop_masks)
+            with rng("neck"):
+                feats = self.neck.forward_nhwc(taps)
+            with rng("decoder"):
+                dec = self.decoder.forward_nhwc(feats)
+            with rng("heads"):
+                out = self.head.forward_logits(dec, image_size, lowres=lowres_logits)
+                aux = self.aux_head.forward_logits(feats[-1], image_size, aux_drop_mask, lowres=lowres_logits)
         return self.output_struct(out=out, aux=aux)

@@ -23,6 +23,7 @@ from torch import Tensor
 from geo_deep_learning.models.segmentation.dofa import DOFASegmentationModel
 from geo_deep_learning.tasks_with_models._common import LightningModule, SegmentationTaskHooks
 from geo_deep_learning.utils.models import load_weights_from_checkpoint
+from gdlhip.markers import rng
 
 logger = logging.getLogger(__name__)
 
@@ -89,7 +90,8 @@ class SegmentationDOFA(SegmentationTaskHooks, LightningModule):
         # gradient -- from the heads' own maps (128 x 128 main, 16 x 16 auxiliary); the reference's F.interpolate to 512 x 512
         # (dofa.py:89-105) and the 168 MB tensor it produces per head exist only where something reads them (validation / test)
         outputs = self.model(x, wv, lowres_logits=True) if lowres_logits else self(x, wv)
-        loss = self.loss(outputs.out, y) + 0.4 * self.loss(outputs.aux, y)
+        with rng("loss"):
+            loss = self.loss(outputs.out, y) + 0.4 * self.loss(outputs.aux, y)
         return outputs, y, loss, x.shape[0]
 
     def training_step(self, batch: dict[str, Any], batch_idx: int) -> Tensor:  # noqa: ARG002

@@ -148,8 +148,14 @@ def init_distributed() -> bool:
     os.environ.setdefault("MASTER_PORT", "29500")
     use_gpu = torch.cuda.is_available()
     if use_gpu:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group("nccl" if use_gpu else "gloo")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        # the whole-step capture under DDP (gdlhip.graphs) needs the process group's asynchronous error handling off -- its
+        # watchdog polls events of earlier collectives while a capture records -- and an eagerly bound device
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo")
     return True
 
 

@@ -178,7 +178,7 @@ def _conv_args(B, H, W, C, N, R, dtype=1, stride=1, aux=False, act=0):
 def test_conv_tile_selection(lib):
     """gdl_conv_gemm_plan: which tile a layer gets (0 = 64^2, 1 = 128^2, 3 = 256^2 ping-pong, 4 = 3x3 shared staging,
     5 = 256x64, 6 = dual-resident 256x128, 7 = direct 3x3 for C <= 32 on large dense maps, 8 = 256^2 with one wave per SIMD,
-    9 = persistent 256^2 ping-pong) and the algorithmic flops it reports."""
+    9 = persistent 256^2 ping-pong, 10 = persistent parked tile) and the algorithmic flops it reports."""
     from gdlhip import ops
     import ctypes as C
 
@@ -191,7 +191,10 @@ def test_conv_tile_selection(lib):
     v, fl = plan(32, 144, 144, 768, 768, 3)                  # DOFA neck conv: 108 K-steps -> one wave per SIMD (round 4)
     assert v == 8 and fl == 2 * 32 * 144 * 144 * 768 * 9 * 768
     assert plan(32, 144, 144, 768, 256, 1)[0] == 9           # lateral 1x1: persistent 256^2 ping-pong (dense 1x1, more tiles than CUs)
-    assert plan(1, 1, 32 * 1297, 768, 2304, 1)[0] == 9       # ViT qkv
+    # ViT qkv (N >= 768, 12 K-steps, 1467 tiles): the parked tile -- one wave per SIMD, outputs stored from the next tile's MFMA shadows (round 6)
+    assert plan(1, 1, 32 * 1297, 768, 2304, 1)[0] == 10
+    assert plan(32, 36, 36, 768, 6912, 1)[0] == 10           # the neck's nine tap products in one GEMM
+    assert plan(32, 72, 72, 256, 2304, 1)[0] == 9            # K = 256 (4 K-steps): HBM-bound, stays on the 8-wave persistent tile
     assert plan(1, 1, 32 * 1297, 768, 3072, 1, act=ops.ACT_GELU)[0] == 6   # ViT fc1: GELU epilogue, 12 K-steps -> two workgroups per CU
     assert plan(32, 1, 1297, 3072, 768, 1)[0] == 8           # ViT fc2: 48 K-steps -> one wave per SIMD
     assert plan(32, 36, 36, 768, 768, 3)[0] == 8             # neck 3x3 at 36^2: 108 K-steps

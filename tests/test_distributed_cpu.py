@@ -61,3 +61,63 @@ def test_syncbn_exchange_world2():
         p.join(180)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _agree_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gdlhip.trainer import MiniTrainer
+        tr = MiniTrainer(max_epochs=1, accelerator="cpu", enable_checkpointing=False, logger=False)
+        tr._ddp_active = True
+        out = [tr._agree("t", "ok"),                                   # unanimous
+               tr._agree("t", "no" if rank == 1 else "ok"),            # one rank's veto reaches everybody
+               tr._agree("t", "fatal" if rank == 0 else "ok")]         # ... and so does a dead capture
+        if rank == 0:                                                   # rank 1 never answers the fourth question: a timeout is "fatal"
+            out.append(tr._agree("alone", "ok", timeout_s=2.0))
+        # the protocol used no collective: the process group is still in step
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        out.append(t.item())
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_capture_verdicts_are_agreed_through_the_store_not_a_collective():
+    """MiniTrainer._agree (advisor, round 5): the ranks settle "do we capture the DDP step" / "did the capture work" through the
+    process group's key-value store, so a rank that failed before the warm-up collectives, or whose capture died, cannot pair a
+    flag all-reduce with a peer's bucket all-reduce; a rank that never answers counts as a dead capture after the timeout."""
+    world, port = 2, 29500 + (os.getpid() + 7) % 2000
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret[0] == ["ok", "no", "fatal", "fatal", 1.0]
+    assert ret[1] == ["ok", "no", "fatal", 1.0]
+
+
+def test_bench_gpus2_starts_its_own_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2` started as ONE process (the way the driver starts --gpus 1) re-executes itself under
+    torch.distributed.run with two ranks, and rank 0 prints exactly one JSON line with ddp.ranks == 2 (the launch path on CPU:
+    GDL_BENCH_DRY_RUN=1 swaps the HIP step for a toy step and RCCL for gloo -- reference: configs/dofa_config_RGB.yaml:3-13)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, GDL_BENCH_DRY_RUN="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                          capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, proc.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ddp"]["ranks"] == 2 and line["steps"] == 3 and line["dry_run"] is True
+    assert "starting the ranks myself" in proc.stderr

@@ -466,14 +466,19 @@ def test_eval_after_train_sees_fresh_running_stats():
 
 
 # ------------------------------------------------------------------------------------------------ N > 1 on one GPU
-def _ddp_gpu_worker(rank, world, port, ret):
-    """One of two processes sharing GPU 0 (gloo backend on device tensors): HIP model under SyncBatchNorm + DDP on its
-    half of the batch."""
+def _ddp_gpu_worker(rank, world, port, ret, backend="gloo"):
+    """One of two processes: HIP model under SyncBatchNorm + DDP on its half of the batch.  backend "gloo": both share GPU 0
+    (gloo on device tensors -- what a one-GPU box can run); "nccl": one GPU per rank over RCCL (needs two devices)."""
     import os
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ref = oracle.DOFASegmentationModel("dofa_tiny_test", (112, 112), num_classes=5, _encoder_kwargs=TINY,
                                            freeze_layers=["encoder"])
@@ -482,7 +487,7 @@ def _ddp_gpu_worker(rank, world, port, ret):
         m = DOFASegmentationModel(enc, (112, 112), num_classes=5, pretrained=False, freeze_layers=["encoder"])
         m.load_state_dict(sd)
         m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m.to(DEV).train())
-        ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], gradient_as_bucket_view=True)
+        ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[dev], gradient_as_bucket_view=True)
         batch, masks, aux = _ddp_case()
         lo, hi = rank * 2, rank * 2 + 2
         mk = [(a[lo:hi], b[lo:hi]) for a, b in masks]
@@ -508,17 +513,32 @@ def _ddp_case():
     return batch, masks, aux
 
 
+NEEDS_TWO_GPUS = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL between devices "
+                                    "(configs/dofa_config_RGB.yaml:3-13: `devices: -1`, DDP, sync_batchnorm)")
+
+
+@NEEDS_TWO_GPUS
+def test_ddp_syncbn_world2_rccl_matches_full_batch_oracle():
+    """The twin of the test below on RCCL: one GPU per rank, backend nccl -- gradient buckets and the 7 + 7 SyncBatchNorm
+    messages cross xGMI instead of the host.  Skipped on one-GPU boxes (collected everywhere)."""
+    _run_ddp_world2("nccl")
+
+
 def test_ddp_syncbn_world2_on_one_gpu_matches_full_batch_oracle():
     """DDP + SyncBatchNorm of the HIP path at world size 2 (configs/dofa_config_RGB.yaml:3-13), both ranks on this one
     GPU over gloo: per-rank loss on half the batch, gradients averaged by DDP, batch statistics exchanged by
     gnn.sync_batch_stats / sync_sum_pair.  Oracle: ONE process on the full batch (its BatchNorm sees all four tiles =
     what SyncBN computes) with loss = mean of the two half-batch Dice losses (= what DDP's gradient averaging optimises)."""
+    _run_ddp_world2("gloo")
+
+
+def _run_ddp_world2(backend):
     import os
     import torch.multiprocessing as mp
     world, port = 2, 29900 + os.getpid() % 2000
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_ddp_gpu_worker, args=(r, world, port, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_ddp_gpu_worker, args=(r, world, port, ret, backend)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -553,6 +573,77 @@ def test_ddp_syncbn_world2_on_one_gpu_matches_full_batch_oracle():
     for name, b0 in r0["bufs"].items():
         assert torch.equal(b0, r1["bufs"][name]), name
         assert torch.allclose(b0, rb[name], atol=2e-5, rtol=1e-4), name
+
+
+def _ddp_capture_worker(rank, world, port, ret, root):
+    """One of two RCCL ranks (one GPU each): the same two-epoch MiniTrainer run three times -- eager DDP, graph_step="auto" (which
+    must stay eager at world size 2) and graph_step=True (whole step captured, RCCL collectives inside the hipGraph)."""
+    import os
+    from functools import partial
+    import torch.distributed as dist
+    from gdlhip.trainer import seed_everything
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", TORCH_NCCL_ASYNC_ERROR_HANDLING="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    out = {}
+    try:
+        batches = [synthetic_batch(4, 3, 112, 5, 10 * rank + s) for s in (1, 2, 3, 4)] + [synthetic_batch(2, 3, 112, 5, 10 * rank + 5)]
+        for bt in batches:
+            bt["mask"] = (bt["image"][:, :1] * 1.2 + 2).clamp(0, 4).long()
+        for mode in (False, "auto", True):
+            seed_everything(42)
+            _, task = _dofa_task(optimizer=partial(torch.optim.Adam, lr=1e-3))
+            for blk in task.model.encoder.blocks:            # deterministic on every side
+                blk.drop_prob = 0.0
+            task.model.aux_head.dropout_ratio = 0.0
+            tr = MiniTrainer(max_epochs=2, precision="32", gradient_clip_val=1.0, default_root_dir=os.path.join(root, f"{rank}_{mode}"),
+                             graph_step=mode, sync_batchnorm=True)
+            tr.fit(task, train_dataloaders=batches, val_dataloaders=[batches[0]])
+            torch.cuda.synchronize()
+            out[str(mode)] = {"graphed": tr.graphed_steps, "steps": tr.global_step,
+                              "train_loss": tr.callback_metrics["train_loss"], "val_loss": tr.callback_metrics["val_loss"],
+                              "params": {n: p.detach().cpu() for n, p in task.named_parameters() if p.requires_grad},
+                              "bufs": {n: b.detach().cpu() for n, b in task.named_buffers() if n.endswith("running_mean")},
+                              "trace": getattr(tr, "capture_traceback", None)}
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@NEEDS_TWO_GPUS
+def test_ddp_captured_step_world2_rccl_matches_eager(tmp_path):
+    """What DESIGN.md section 5 says had never run: the whole DDP training step -- SyncBatchNorm all-reduces, bucket all-reduces
+    overlapping backward, clip, Adam -- captured into one hipGraph PER RANK with TWO RCCL ranks, against the eager DDP trainer
+    on the same data: every full batch a replay (8 of 10 steps; the ragged ones stay eager), equal epoch means, parameters
+    equal to the tolerance of the one-rank capture test, ranks bit-identical to each other, and graph_step="auto" stays eager
+    at world size 2 (round 6).  Skipped on one-GPU boxes (collected everywhere)."""
+    import os
+    import torch.multiprocessing as mp
+    world, port = 2, 29900 + (os.getpid() + 11) % 2000
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_ddp_capture_worker, args=(r, world, port, ret, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        eager, auto, cap = ret[rank]["False"], ret[rank]["auto"], ret[rank]["True"]
+        assert eager["graphed"] == 0 and auto["graphed"] == 0, "graph_step='auto' must keep a multi-rank DDP step eager"
+        assert cap["graphed"] == 8, cap["trace"]
+        assert eager["steps"] == cap["steps"] == 10
+        assert abs(eager["train_loss"] - cap["train_loss"]) < 1e-5 and abs(eager["val_loss"] - cap["val_loss"]) < 1e-5
+        assert abs(eager["train_loss"] - auto["train_loss"]) < 1e-6
+        for n, p in cap["params"].items():
+            d = (p - eager["params"][n]).abs()
+            assert d.max().item() <= 8e-3 and (d > 1e-4).float().mean().item() < 2e-2, (n, d.max().item())
+    for mode in ("False", "True"):                               # DDP: both ranks hold the same model
+        for n, p in ret[0][mode]["params"].items():
+            assert torch.equal(p, ret[1][mode]["params"][n]), (mode, n)
+        for n, b in ret[0][mode]["bufs"].items():
+            assert torch.equal(b, ret[1][mode]["bufs"][n]), (mode, n)
 
 
 def test_graphed_train_step_matches_eager():
