@@ -43,16 +43,66 @@ def mark_flat(weight: Tensor) -> None:
 
 
 def mark_groups(weight: Tensor, groups: int) -> None:
-    """A grouped convolution's parameter ([N, C / groups, R, S], torchvision ResNeXt ``conv2``).  The kernels see it as the
-    block-diagonal DENSE filter [N, R*S, C] (zeros between groups): forward, data gradient and weight gradient are then the
-    ordinary implicit-GEMM calls and the parameter's gradient is the block diagonal of the dense one.  Correct and
-    deterministic, at groups x the multiply-adds of the grouped form on these layers (the encoder the reference's shipped
-    UNet++ config names, resnext101_32x8d, is a boundary requirement, not the benchmarked configuration)."""
+    """A grouped convolution's parameter ([N, C / groups, R, S], torchvision ResNeXt ``conv2``).  Round 6: it runs as ONE batched
+    implicit-GEMM launch over SUPER-GROUPS of at least 32 channels (``supergroups``: resnext101_32x8d's 8-channel groups four at
+    a time as a 32 -> 32 block-diagonal filter, its 16-channel groups two at a time, 32 and 64 channels as they are): forward,
+    stride-1 data gradient and weight gradient are batched calls over channel slices (ops.conv_gemm_grouped), 4 x / 2 x / 1 x
+    the grouped form's multiply-adds instead of the 32 x of the block-diagonal DENSE filter of round 3 -- which stays the path
+    for padded channel counts, the f32 parity runs' narrow cases and the stride-2 data gradient (col2im over a dense GEMM)."""
     weight._gdl_groups = int(groups)
 
 
 def _groups(weight: Tensor) -> int:
     return getattr(weight, "_gdl_groups", 1)
+
+
+GROUPED_BATCHED = __import__("os").environ.get("GDL_GROUPED_DENSE", "0") != "1"     # A/B switch: 1 = the round-3 dense form
+
+
+def supergroups(weight: Tensor, cpad: int, npad: int, cd: torch.dtype) -> tuple[int, int, int, int] | None:
+    """(Z, per, c, n) when the grouped parameter can run as Z batched problems of `per` groups each (c input / n output
+    channels per problem), else None (dense block-diagonal fallback)."""
+    g = _groups(weight)
+    if g == 1 or not GROUPED_BATCHED or weight.dim() != 4:
+        return None
+    nt, cg, _, _ = weight.shape
+    ng = nt // g
+    if cpad != cg * g or npad != nt:              # padded channel counts: the slices would not line up
+        return None
+    per = 1 if min(cg, ng) >= 32 else max(1, 32 // min(cg, ng))
+    if g % per or (per * cg) % grain(cd) or (per * ng) % grain(cd):
+        return None
+    return g // per, per, per * cg, per * ng
+
+
+def grouped_operands(weight: Tensor, cd: torch.dtype, sg: tuple[int, int, int, int]) -> tuple[Tensor, Tensor]:
+    """(forward operand [Z, n, R*S*c], stride-1 data-gradient operand [Z, c, (R*S flipped)*n]) in the compute dtype: per
+    super-group the block-diagonal filter of its `per` groups."""
+    def build():
+        Z, per, c, n = sg
+        nt, cg, r, s = weight.shape
+        ng = nt // (Z * per)
+        m = conv_weight_matrix(weight).view(Z, per, ng, r * s, cg)                  # [z, group in z, out, tap, in]
+        blk = torch.zeros((Z, per, ng, r * s, per, cg), device=weight.device, dtype=torch.float32)
+        idx = torch.arange(per, device=weight.device)
+        blk[:, idx, :, :, idx, :] = m.permute(1, 0, 2, 3, 4)                        # group i: outputs i*ng.., inputs i*cg..
+        blk = blk.view(Z, n, r * s, c)
+        fwd = blk.reshape(Z, n, r * s * c)
+        dgr = blk.flip(2).permute(0, 3, 2, 1).reshape(Z, c, r * s * n)              # out = sum_taps dy[. - tap] * w[n, tap, c]
+        return fwd.to(cd).contiguous(), dgr.to(cd).contiguous()
+    return cached((weight,), f"grpw:{cd}:{sg}", build)
+
+
+def _grouped_param_grad(dw: Tensor, weight: Tensor, sg: tuple[int, int, int, int]) -> Tensor:
+    """[Z, n, R*S*c] f32 -> the parameter's [N, C/groups, R, S]: the block diagonal inside every super-group."""
+    Z, per, c, n = sg
+    nt, cg, r, s = weight.shape
+    ng = nt // (Z * per)
+    d = dw.view(Z, per, ng, r * s, per, cg)
+    idx = torch.arange(per, device=dw.device)
+    d = d[:, idx, :, :, idx, :]                                                     # [per, Z, ng, taps, cg]
+    d = d.permute(1, 0, 2, 3, 4).reshape(nt, r, s, cg)
+    return d.permute(0, 3, 1, 2)
 
 
 STEM_BLOCK = 4     # pixels per side of a space-to-depth block
@@ -272,8 +322,11 @@ class _ConvBNTrain(Function):
         cpad, npad = x.shape[-1], pad_to(n, grain(cd))
         if cpad < c or cpad % grain(cd):
             raise ValueError(f"conv input has {cpad} channels, weight expects {c} (padded to a multiple of {grain(cd)})")
+        sg = supergroups(weight, cpad, npad, cd)
         if hasattr(weight, "_gdl_stem"):
             y = stem_conv(x, weight, npad)
+        elif sg is not None:
+            y = ops.conv_gemm_grouped(x, grouped_operands(weight, cd, sg)[0], R=r, S=s, stride=stride, pad=pad)
         else:
             wq, _ = padded_operands(weight, cd, cpad, npad)
             y = ops.conv_gemm(x, wq, R=r, S=s, stride=stride, pad=pad)
@@ -309,14 +362,21 @@ class _ConvBNTrain(Function):
         dy = ops.bn_bwd_dx(y, gout, mean, var, g, b, eps, relu, sg, sb, p_local, out=y)
         dw = None
         stem = hasattr(weight, "_gdl_stem")
+        sg = supergroups(weight, cpad, npad, x.dtype)
         if ctx.needs_input_grad[1]:
-            dw = (stem_param_grad(x, dy, weight) if stem else
-                  _param_grad(ops.conv_wgrad(x, dy, R=r, S=s, stride=stride, pad=pad), weight, cpad))
+            if sg is not None:
+                dw = _grouped_param_grad(ops.conv_wgrad_grouped(x, dy, Z=sg[0], R=r, S=s, stride=stride, pad=pad), weight, sg)
+            else:
+                dw = (stem_param_grad(x, dy, weight) if stem else
+                      _param_grad(ops.conv_wgrad(x, dy, R=r, S=s, stride=stride, pad=pad), weight, cpad))
         dx = None
         if ctx.needs_input_grad[0]:
             if stem:
                 raise NotImplementedError("gdlhip: no gradient with respect to the raw image of a stem convolution")
-            dx = _conv_dx(dy, weight, x.dtype, cpad, npad, stride, pad, (x.shape[1], x.shape[2]))
+            if sg is not None and stride == 1:
+                dx = ops.conv_gemm_grouped(dy, grouped_operands(weight, x.dtype, sg)[1], R=r, S=s, pad=r - 1 - pad)
+            else:
+                dx = _conv_dx(dy, weight, x.dtype, cpad, npad, stride, pad, (x.shape[1], x.shape[2]))
         return dx, dw, dgamma[:n], dbeta[:n], None, None, None, None, None, None, None, None
 
 
@@ -347,6 +407,11 @@ def conv_bn(x: Tensor, weight: Tensor, norm: nn.Module, *, stride: int = 1, pad:
         return _padvec(scale, npad), _padvec(shift, npad)
     scale, shift = cached((norm.weight, norm.bias, norm.running_mean, norm.running_var), f"bnfold:{npad}", fold)
     act = ACT_NONE if not relu else (ACT_RELU if resid is None else ACT_RESID_RELU)
+    sg = supergroups(weight, cpad, npad, cd)
+    if sg is not None and resid is None:
+        # batched grouped convolution (no epilogue vectors per z), then the folded BatchNorm + ReLU as one pass
+        y = ops.conv_gemm_grouped(x, grouped_operands(weight, cd, sg)[0], R=r, S=s, stride=stride, pad=pad)
+        return ops.bn_apply(y, norm.running_mean, norm.running_var, norm.weight.detach(), norm.bias.detach(), norm.eps, relu)
     if hasattr(weight, "_gdl_stem"):
         if resid is not None:
             raise ValueError("a stem convolution takes no residual operand")

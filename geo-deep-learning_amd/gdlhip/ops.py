@@ -246,6 +246,69 @@ def batched_gemm_raw(a: ConvArgs) -> None:
     _launch_conv_gemm(a, "gdl_conv_gemm(batched)")
 
 
+def conv_gemm_grouped(x: Tensor, w: Tensor, *, R: int, S: int, stride: int = 1, pad: int = 0, out: Tensor | None = None) -> Tensor:
+    """Grouped convolution as ONE batched implicit-GEMM launch: x NHWC [B,H,W,Z*c], w [Z, n, R*S*c] (K order r,s,c) -> out
+    [B,Ho,Wo,Z*n]; problem z reads channels z*c.. of x with filter w[z] and writes channels z*n.. of out (grid.z = z: the
+    operands are channel slices addressed through the batch strides of gdl_conv_args, nothing is copied).  No epilogue terms:
+    per-channel vectors are not offset per z by the kernels."""
+    _need_cuda(x, w)
+    x4 = _nhwc4(x, "conv_gemm_grouped input")
+    B, H, W, Ct = x4.shape
+    Z, n, kk = w.shape
+    c = kk // (R * S)
+    if w.dim() != 3 or c * R * S != kk or Z * c != Ct or not w.is_contiguous() or w.dtype != x.dtype:
+        raise ValueError(f"conv_gemm_grouped: weight must be contiguous [Z, n, {R * S}*c] {x.dtype} with Z*c = {Ct}, got {tuple(w.shape)} {w.dtype}")
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - S) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Z * n), device=x.device, dtype=x.dtype)
+    o4 = _nhwc4(out, "conv_gemm_grouped out")
+    if tuple(o4.shape) != (B, Ho, Wo, Z * n):
+        raise ValueError(f"conv_gemm_grouped: out shape {tuple(o4.shape)} != {(B, Ho, Wo, Z * n)}")
+    a = ConvArgs()
+    a.inp, a.dtype = x4.data_ptr(), dt(x4)
+    a.B, a.H, a.W, a.C = B, H, W, c
+    a.in_sB, a.in_sH, a.in_sW = x4.stride(0), x4.stride(1), x4.stride(2)
+    a.Ho, a.Wo, a.R, a.S, a.stride, a.pad = Ho, Wo, R, S, stride, pad
+    a.w, a.w_sN, a.N = w.data_ptr(), kk, n
+    a.out, a.out_dtype = o4.data_ptr(), dt(o4)
+    a.out_sB, a.out_sH, a.out_sW = o4.stride(0), o4.stride(1), o4.stride(2)
+    a.alpha, a.act = 1.0, ACT_NONE
+    a.nz, a.nz_inner = Z, 1
+    a.in_sZ0, a.w_sZ0, a.out_sZ0 = c, n * kk, n
+    _launch_conv_gemm(a, "gdl_conv_gemm(grouped)")
+    return out
+
+
+def conv_wgrad_grouped(x: Tensor, dy: Tensor, *, Z: int, R: int, S: int, stride: int = 1, pad: int = 0) -> Tensor:
+    """Weight gradient of conv_gemm_grouped: dw [Z, n, R*S*c] f32, problem z = channel slices z*c.. of x and z*n.. of dy."""
+    _need_cuda(x, dy)
+    x4, dy4 = _nhwc4(x, "wgrad x"), _nhwc4(dy, "wgrad dy")
+    if x4.dtype != dy4.dtype:
+        raise ValueError("conv_wgrad_grouped: x and dy dtypes differ")
+    B, H, W, Ct = x4.shape
+    _, Ho, Wo, Nt = dy4.shape
+    if Ct % Z or Nt % Z:
+        raise ValueError("conv_wgrad_grouped: channel counts must be multiples of Z")
+    c, n = Ct // Z, Nt // Z
+    dw = torch.empty((Z, n, R * S * c), device=x.device, dtype=torch.float32)
+    a = WgradArgs()
+    a.inp, a.dy, a.dtype = x4.data_ptr(), dy4.data_ptr(), dt(x4)
+    a.B, a.H, a.W, a.C = B, H, W, c
+    a.in_sB, a.in_sH, a.in_sW = x4.stride(0), x4.stride(1), x4.stride(2)
+    a.Ho, a.Wo, a.R, a.S, a.stride, a.pad, a.N = Ho, Wo, R, S, stride, pad, n
+    a.dy_sB, a.dy_sH, a.dy_sW = dy4.stride(0), dy4.stride(1), dy4.stride(2)
+    a.dw, a.dw_sN, a.accumulate = dw.data_ptr(), R * S * c, 0
+    a.nz, a.nz_inner = Z, 1
+    a.in_sZ0, a.dy_sZ0, a.dw_sZ0 = c, n, n * R * S * c
+    lib = _lib.load()
+    nbytes = lib.gdl_conv_wgrad_workspace(C.byref(a))
+    ws = torch.empty(max(nbytes, 4) // 4, device=x.device, dtype=torch.float32)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    check(lib.gdl_conv_wgrad(C.byref(a), _stream()), "gdl_conv_wgrad(grouped)")
+    return dw
+
+
 def conv_wgrad(x: Tensor, dy: Tensor, *, R: int, S: int, stride: int = 1, pad: int = 0,
                dw: Tensor | None = None, accumulate: bool = False) -> Tensor:
     """dw[N, R*S*C] (f32) = sum_pixels dy[.., n] * x[.. + tap, c]."""

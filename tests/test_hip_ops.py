@@ -1130,6 +1130,67 @@ def test_conv_persistent_tile(M, N, K):
         assert torch.equal(outs[9, key], outs[1, key]), f"persistent tile vs 128^2 tile differ ({key})"
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,groups,stride", [(256, 32, 1), (512, 32, 1), (1024, 32, 1), (2048, 32, 1), (256, 32, 2), (128, 32, 1)])
+def test_grouped_conv_as_batched_supergroups(dtype, C, groups, stride):
+    """ResNeXt's grouped 3x3 (torchvision Bottleneck.conv2; the reference's shipped UNet++ encoder is resnext101_32x8d,
+    configs/unetplus_config_RGB.yaml:37) as one batched implicit-GEMM launch over super-groups of >= 32 channels
+    (gdlhip.cnn.supergroups / ops.conv_gemm_grouped): 8-, 16-, 32- and 64-channel groups, stride 1 and 2 -- forward, data gradient
+    and the parameter's gradient against F.conv2d(groups=...) and its autograd, through the training-mode Conv -> BatchNorm -> ReLU
+    node that the encoders use, and against the block-diagonal DENSE form of round 3 (GDL_GROUPED_DENSE)."""
+    from gdlhip import cnn
+    torch.manual_seed(3)
+    b, h, w_ = 2, 20, 24
+    conv = torch.nn.Conv2d(C, C, 3, padding=1, stride=stride, groups=groups, bias=False)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        conv.weight.copy_(q(conv.weight * 2.0, dtype))
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+    x = q(rnd(b, C, h, w_, seed=5), dtype)
+    xr = x.clone().requires_grad_(True)
+    yr = F.relu(bn(conv(xr)))
+    gy = rnd(*yr.shape, seed=6)
+    yr.backward(gy)
+    conv_g = torch.nn.Conv2d(C, C, 3, padding=1, stride=stride, groups=groups, bias=False).to(DEV)
+    bn_g = torch.nn.BatchNorm2d(C).to(DEV)
+    conv_g.load_state_dict(conv.state_dict()); bn_g.load_state_dict({k: v for k, v in bn.state_dict().items()})
+    bn_g.running_mean.zero_(); bn_g.running_var.fill_(1.0); bn_g.num_batches_tracked.zero_()
+    cnn.mark_groups(conv_g.weight, groups)
+    outs = {}
+    for dense in (False, True):
+        cnn.GROUPED_BATCHED = not dense
+        try:
+            conv_g.weight.grad = None
+            xg = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype).requires_grad_(True)
+            sg = cnn.supergroups(conv_g.weight, C, C, dtype)
+            assert (sg is None) == dense
+            if sg is not None:
+                cg = C // groups
+                assert sg == (C // max(32, cg), max(1, 32 // cg), max(32, cg), max(32, cg))
+            y = cnn.conv_bn(xg, conv_g.weight, bn_g, stride=stride, pad=1, relu=True)
+            y.backward(gy.permute(0, 2, 3, 1).contiguous().to(DEV, dtype))
+            outs[dense] = (y.detach().float().cpu().permute(0, 3, 1, 2), xg.grad.float().cpu().permute(0, 3, 1, 2),
+                           conv_g.weight.grad.float().cpu().clone())
+        finally:
+            cnn.GROUPED_BATCHED = True
+    # f32: both forms against torch autograd.  bf16: the forward against torch; the gradients of a conv -> train-mode BatchNorm ->
+    # ReLU chain on two small images move by several per cent with the bf16 rounding of the conv output alone (ReLU mask flips,
+    # the mean subtraction of BatchNorm's backward), for either form -- there the batched form is held to the dense one
+    rel = lambda a_, r_: ((a_ - r_).norm() / (r_.norm() + 1e-30)).item()      # noqa: E731
+    for dense in (False, True):
+        y, dx, dw = outs[dense]
+        close(y, yr.detach(), dtype, f"grouped conv + BN + ReLU (dense={dense})")
+        assert dw.shape == conv.weight.grad.shape
+        if dtype == torch.float32:
+            close(dx, xr.grad, dtype, f"grouped conv data gradient (dense={dense})", scale=xr.grad.abs().max().item())
+            close(dw, conv.weight.grad, dtype, f"grouped conv parameter gradient (dense={dense})", scale=conv.weight.grad.abs().max().item())
+        else:
+            assert rel(dx, xr.grad.detach()) < 0.1 and rel(dw, conv.weight.grad) < 0.1, (rel(dx, xr.grad.detach()), rel(dw, conv.weight.grad))
+    tight = 1e-5 if dtype == torch.float32 else 3e-2
+    assert rel(outs[False][0], outs[True][0]) < tight and rel(outs[False][1], outs[True][1]) < tight and rel(outs[False][2], outs[True][2]) < tight
+
+
 @pytest.mark.parametrize("B,T,N,K", [(26, 1297, 1024, 768), (13, 2600, 512, 1024), (1, 512, 256, 768), (32, 2048, 768, 768)])
 def test_conv_parked_tile(B, T, N, K):
     """The persistent one-wave-per-SIMD tile whose finished tile is parked in registers and stored from the MFMA shadows of the next
