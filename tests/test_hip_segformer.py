@@ -162,6 +162,53 @@ def test_segformer_b2_512_train_matches_oracle():
     assert not bad, bad[:10]
 
 
+def test_segformer_b2_512_train_bf16_no_worse_than_torch_autocast():
+    """configs[2] at the benchmarked dtype (round-5 review, item 9): one bf16 training step of SegFormer-B2 at 512 x 512 (every
+    parameter trainable, DropPath / Dropout2d draws pinned) through the HIP path under autocast against the oracle run by torch
+    under `autocast("cuda", bfloat16)`; truth = the oracle's f32 step on this GPU.  Loss error and per-parameter gradient errors
+    (relative L2) of the build at most a quarter above torch's own."""
+    import copy
+    seed, nc, b = 11, 5, 2
+    ora, m = _build("mit_b2", seed)
+    m.train()
+    batch = synthetic_batch(b, 3, 512, nc, seed)
+    masks = mit_drop_masks(m.encoder.depths, 0.1, b, seed)
+    dmask = chan_mask(b, m.decoder.linear_pred.in_channels, seed)
+    tref = copy.deepcopy(ora).to(DEV).train()
+    tgt = batch["mask"].squeeze(1).long().to(DEV)
+    runs = {}
+    for name, amp in (("f32", False), ("torch_bf16", True)):
+        tref.zero_grad(set_to_none=True)
+        # (MIOpen's train-mode batch_norm segfaults on the 1 x 1 pyramid-pooling maps in this image: torch's native kernels)
+        with torch.backends.cudnn.flags(enabled=False), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            yo = tref(batch["image"].to(DEV), [(a.to(DEV), c.to(DEV)) for a, c in masks], dmask.to(DEV))
+            lo = dice_loss_multiclass(yo.float(), tgt)
+        with torch.backends.cudnn.flags(enabled=False):
+            lo.backward()
+        runs[name] = (lo.item(), {n: p.grad.detach().float().cpu() for n, p in tref.named_parameters() if p.grad is not None})
+    del tref
+    _, loss = _train_step(m, batch, masks, dmask, autocast=True)
+    ours = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None}
+    l32, g32 = runs["f32"]
+    lt, gt = runs["torch_bf16"]
+
+    def errs(got):
+        out = {}
+        for n, g in got.items():
+            r = g32[n]
+            if r.norm().item() > 1e-8 and r.numel() >= 16:
+                out[n] = ((g.double() - r.double()).norm() / r.double().norm()).item()
+        return out
+    e_ours, e_torch = errs(ours), errs(gt)
+    med = lambda d: float(np.median(list(d.values())))      # noqa: E731
+    print(f"SegFormer-B2 bf16 training step vs the f32 oracle -- loss error: build {abs(loss.item() - l32):.2e}, torch autocast "
+          f"{abs(lt - l32):.2e}; gradient error over {len(e_ours)} tensors: build median {med(e_ours):.4f} max {max(e_ours.values()):.4f}, "
+          f"torch autocast median {med(e_torch):.4f} max {max(e_torch.values()):.4f}")
+    assert abs(loss.item() - l32) <= 1.25 * abs(lt - l32) + 2e-3
+    assert med(e_ours) <= 1.25 * med(e_torch) + 1e-3
+    assert max(e_ours.values()) <= 1.25 * max(e_torch.values()) + 1e-2
+
+
 # ------------------------------------------------------------------ S7: channel-adaptive stem (use_dynamic_encoder=True)
 def _build_dynamic(enc, seed, nc=5):
     ora = OracleSegFormer(enc, 3, nc, use_dynamic_encoder=True).eval()
