@@ -455,7 +455,7 @@ static std::atomic<int> g_w4_enabled{1};
 extern "C" void gdl_debug_set_conv_w4(int on) { g_w4_enabled = on; }  // A/B hook: 256^2 one-wave-per-SIMD tile
 static std::atomic<int> g_persist_enabled{1};
 extern "C" void gdl_debug_set_conv_persist(int on) { g_persist_enabled = on; }  // A/B hook: persistent 256^2 tile for dense 1x1 layers
-static std::atomic<int> g_w4p_enabled{1};
+static std::atomic<int> g_w4p_enabled{0};   // see the planner: measured faster per layer, not end to end -- opt-in (GDL_CONV_W4P=1)
 static std::atomic<int> g_w4p_min_n{768};
 extern "C" void gdl_debug_set_conv_w4p(int on) { g_w4p_enabled = on != 0; if (on > 1) g_w4p_min_n = on; }  // A/B hook: persistent 256^2 tile with deferred stores (conv_gemm_w4p.hip)
 static std::atomic<int> g_dual_enabled{1};
@@ -521,9 +521,12 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
     // 256 x 128 workgroups per CU put one's epilogue under the other's K loop (+5..9 %, profiles/r04a_bench_short_k_*); for
     // every other epilogue the 256^2 tile is as fast or faster
     if (g_dual_enabled && a.act == GDL_ACT_GELU && ksteps <= 16 && t256 >= 1024 && conv_gemm_dual_applicable(a)) return 6;
-    // dense 1x1 layers with bf16 outputs, 12 .. 39 K-steps and at least two rounds of tiles: one persistent workgroup per CU, one
-    // wave per SIMD, the finished tile parked in registers and stored from the MFMA shadows of the next tile's K loop
-    // (conv_gemm_w4p.hip; ViT qkv 1022 -> 1092 TF/s, the neck's tap products 1061 -> 1142, tools/bench_w4p.py)
+    // dense 1x1 layers with bf16 outputs, N >= 768, 12 .. 39 K-steps and at least two rounds of tiles: one persistent workgroup per
+    // CU, one wave per SIMD, the finished tile parked in registers and stored from the MFMA shadows of the next tile's K loop
+    // (conv_gemm_w4p.hip).  OPT-IN (gdl_debug_set_conv_w4p / GDL_CONV_W4P=1): per layer it is faster -- ViT qkv 1022 -> 1092 TF/s, the
+    // neck's tap products 1061 -> 1142 (tools/bench_w4p.py) -- but three same-box A/B runs of the whole step say +-0: 879.3-880.0 vs
+    // 879.5-880.3 train tiles/s at batch 32 (+0.3 % inference), 951.6 vs 949.6 at batch 64 (profiles/r06g_*, r06n_*).  The GEMM
+    // phases run at the 1400 W power cap (tools/probe_power_clock.sh): cycles saved there come back as clock, not as time.
     if (g_w4p_enabled && t256 >= 512 && a.N >= g_w4p_min_n && ksteps >= 12 && ksteps < 40 && conv_gemm_w4p_applicable(a)) return 10;
     // deep-K layers: one wave per SIMD, every load in an MFMA shadow (conv_gemm_w4.hip): its K-step is ~12 % shorter, its
     // epilogue (four waves instead of eight) ~1.8 x longer -- it wins from about 40 K-steps on (ViT fc2 +8 %, tap data

@@ -19,6 +19,13 @@
 // neck's tap products 414.9 -> 385.6 us, its 1x1 convolutions 51.9 -> 50.0 us, the K-loop is not slowed by the stores (2292 vs
 // 2276 cycles per K-step with the stores dropped).
 //
+// STATUS: opt-in (GDL_CONV_W4P=1 / gdl_debug_set_conv_w4p).  Faster per layer, but the whole training / inference step does not
+// move: three same-box A/B repetitions each at per-GPU batch 32 (879.3-880.0 vs 879.5-880.3 train tiles/s, +0.3 % inference) and 64
+// (951.6 vs 949.6).  These GEMMs run at the chip's 1400 W power cap at ~1.83 GHz (tools/probe_power_clock.sh: the same
+// instruction stream on zero operands draws 1080 W at 2.39 GHz and runs 26 % faster): an instruction stream with fewer stall cycles
+// does the same bit flips per tile, and the cycles it saves come back as a lower clock.  The kernel stays as a tested variant and
+// as the record of what "take the epilogue off the critical path" buys on this chip.
+//
 // What was built beside it, measured and REMOVED (profiles/r06*):
 //   * the same for 4 / 8 K-steps (K = 256 decoder layers: eight stores per K-step): those layers are HBM-bound at the 3-3.4 TB/s this
 //     read/write mix reaches, the 8-wave kernel's store burst serves them better (dgrad lateral 144: 383 vs 406 us);

@@ -191,10 +191,17 @@ def test_conv_tile_selection(lib):
     v, fl = plan(32, 144, 144, 768, 768, 3)                  # DOFA neck conv: 108 K-steps -> one wave per SIMD (round 4)
     assert v == 8 and fl == 2 * 32 * 144 * 144 * 768 * 9 * 768
     assert plan(32, 144, 144, 768, 256, 1)[0] == 9           # lateral 1x1: persistent 256^2 ping-pong (dense 1x1, more tiles than CUs)
-    # ViT qkv (N >= 768, 12 K-steps, 1467 tiles): the parked tile -- one wave per SIMD, outputs stored from the next tile's MFMA shadows (round 6)
-    assert plan(1, 1, 32 * 1297, 768, 2304, 1)[0] == 10
-    assert plan(32, 36, 36, 768, 6912, 1)[0] == 10           # the neck's nine tap products in one GEMM
-    assert plan(32, 72, 72, 256, 2304, 1)[0] == 9            # K = 256 (4 K-steps): HBM-bound, stays on the 8-wave persistent tile
+    assert plan(1, 1, 32 * 1297, 768, 2304, 1)[0] == 9       # ViT qkv
+    # the parked tile (variant 10, round 6) is opt-in: faster per layer, +-0 end to end (see gdl_conv_gemm_plan)
+    lib.gdl_debug_set_conv_w4p.argtypes = [C.c_int]
+    lib.gdl_debug_set_conv_w4p(1)
+    try:
+        assert plan(1, 1, 32 * 1297, 768, 2304, 1)[0] == 10     # N >= 768, 12 K-steps, 1467 tiles
+        assert plan(32, 36, 36, 768, 6912, 1)[0] == 10          # the neck's nine tap products in one GEMM
+        assert plan(32, 72, 72, 256, 2304, 1)[0] == 9           # K = 256 (4 K-steps): HBM-bound, stays on the 8-wave persistent tile
+        assert plan(32, 144, 144, 768, 256, 1)[0] == 9          # N = 256: one tile per row block, memory-bound
+    finally:
+        lib.gdl_debug_set_conv_w4p(0)
     assert plan(1, 1, 32 * 1297, 768, 3072, 1, act=ops.ACT_GELU)[0] == 6   # ViT fc1: GELU epilogue, 12 K-steps -> two workgroups per CU
     assert plan(32, 1, 1297, 3072, 768, 1)[0] == 8           # ViT fc2: 48 K-steps -> one wave per SIMD
     assert plan(32, 36, 36, 768, 768, 3)[0] == 8             # neck 3x3 at 36^2: 108 K-steps

@@ -1225,7 +1225,12 @@ def test_conv_parked_tile(B, T, N, K):
     for key in [k2 for (v, k2) in outs if v == 10]:
         assert torch.equal(outs[10, key], outs[1, key]), f"parked tile vs 128^2 tile differ ({key})"
     if M % 256 == 0 and (M // 256) * (N // 256) >= 512:      # statistics follow the planner's own choice (forced variants emit none)
-        y, part, rows = ops.conv_gemm(x, w, bias=bias, want_stats=True)
+        lib.gdl_debug_set_conv_w4p.argtypes = [ctypes.c_int]
+        lib.gdl_debug_set_conv_w4p(1)                        # (the parked tile is opt-in)
+        try:
+            y, part, rows = ops.conv_gemm(x, w, bias=bias, want_stats=True)
+        finally:
+            lib.gdl_debug_set_conv_w4p(0)
         assert rows == M // 128, "the planner should have picked a 256^2 tile with 128-pixel partial rows"
         assert torch.equal(y, outs[1, "bf16"])
         yb = y.view(M, N).double().cpu()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Aggregate the rocprofv3 --pmc passes of tools/pmc_bench_traffic.sh (one bench.py training step at batch 32):
+"""Aggregate the rocprofv3 --pmc passes of tools/pmc_bench_traffic.sh (one bench.py training step at the bench default per-GPU batch, 64 since round 6):
 per kernel, launches and mean per-launch FETCH_SIZE / WRITE_SIZE / L2 hit rate / MFMA-busy share, and the JSON that
 bench.py reads for `roofline.traffic` (profiles/pmc_dominant_kernel_traffic.json).
 
@@ -46,13 +46,14 @@ NAMES = (("conv3x3_sf_kernel<bf16_tag>", "conv3x3_sf_kernel<bf16>"),
          ("conv_gemm_dual_kernel", "conv_gemm_dual_kernel"),
          ("conv_gemm_w4_kernel", "conv_gemm_w4_kernel"),
          ("conv_gemm_persist_kernel", "conv_gemm_persist_kernel"),
+         ("conv_gemm_w4p_kernel", "conv_gemm_w4p_kernel"),
          ("conv_gemm_kernel<bf16_tag, 2, 4, 4, 2, false, true", "conv_gemm_kernel<bf16,2,4,4,2,pingpong>"),
          ("conv_gemm_kernel<bf16_tag, 2, 2, 2, 2", "conv_gemm_kernel<bf16,2,2,2,2>"),
          ("conv_gemm_kernel<bf16_tag, 2, 2, 1, 1", "conv_gemm_kernel<bf16,2,2,1,1>"),
          ("conv_gemm_kernel<bf16_tag, 4, 1, 2, 2", "conv_gemm_kernel<bf16,4,1,2,2>"),
          ("conv3x3_narrow_kernel", "conv3x3_narrow_kernel"))
 NOTE = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over one bench.py training step at "
-        "batch 32, mean over the step's launches of this kernel class; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B "
+        "per-GPU batch of tools/pmc_bench_traffic.sh (64 since round 6; 32 before), mean over the step's launches of this kernel class; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B "
         "request), KiB -> bytes; tools/pmc_bench_traffic.sh")
 entries = []
 for prof_name, bench_name in NAMES:

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_traffic
 mkdir -p $O
-CMD="python $R/bench.py --batch 32 --steps 1 --warmup 1 --mode train --no-cpu-baseline --no-kernel-timer --no-extras --no-input-stage --min-seconds 0"
+CMD="python $R/bench.py --batch ${GDL_PMC_BATCH:-64} --steps 1 --warmup 1 --mode train --no-cpu-baseline --no-kernel-timer --no-extras --no-input-stage --min-seconds 0"
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
