@@ -309,6 +309,11 @@ def conv_wgrad_grouped(x: Tensor, dy: Tensor, *, Z: int, R: int, S: int, stride:
     return dw
 
 
+# (Round 6, measured and removed: weight gradients launched on a SIDE stream -- leaves of the backward pass, MFMA-bound, meant to
+# share the chip with the HBM-bound BatchNorm-backward / gather kernels that follow on the main stream; joined by an autograd engine
+# callback at the end of backward.  Three same-box A/B repetitions at batch 64: 936.5-944.1 without, 934.7-937.7 with
+# (profiles/r06o_*): a GEMM-class workgroup takes a CU's whole register file and LDS, so nothing co-resides with it, and the GEMM
+# phases already sit at the power cap.)
 def conv_wgrad(x: Tensor, dy: Tensor, *, R: int, S: int, stride: int = 1, pad: int = 0,
                dw: Tensor | None = None, accumulate: bool = False) -> Tensor:
     """dw[N, R*S*C] (f32) = sum_pixels dy[.., n] * x[.. + tap, c]."""
