@@ -2,6 +2,7 @@
 // HBM-bound: one thread per (pixel, 4-channel vector); f32 arithmetic; gather formulation in
 // both directions (no atomics -> deterministic backward).
 #include "gdl_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -1313,6 +1314,294 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
   }
 }
 
+// ---- version 3 (round 6): ONE source of factor 2 or 4, Ho % 4 == 0 -- a ROLLING window of low-resolution rows.
+// Versions 1 and 2 stage the whole 3 (4) x WC pixel window of every 4 x 16 patch: each tap-product pixel travels L2 -> LDS 4.5 times
+// (factor 4) and, because the patches that share it run at different times, 2.4 times from memory (PMC: 1383 MB fetched per
+// launch for 574 MB of tap products at batch 32) -- the kernel moved its over-fetched bytes at 4.5 TB/s and was memory-bound on them.
+// Here a workgroup owns a COLUMN = (image, 64-channel chunk, strip of 16 output columns) and walks it top to bottom, four
+// output rows per step: the window rows live in a ring of LDS row slots and only the CPS = 4 / factor new low-resolution rows of
+// the next step are fetched (one step ahead, by LDS-DMA).  The strips of one (image, chunk) are walked by neighbouring
+// workgroups of ONE XCD at the same pace, so the one or two window columns two strips share come out of that L2.
+// What makes one set-up per workgroup enough (a strip's columns all look alike):
+//   * rows outside the image are CLAMPED in the DMA address instead of re-weighted: torch's clamp of the source index is the
+//     same as bilinear weights on an edge-replicated map ((1 - l) z[0] + l z[0] = z[0], exact in f32), so the row weights
+//     of every step are the interior ones;
+//   * the convolution's zero padding touches the first and the last step only (tap row -1 of output row 0, tap row Ho of
+//     output row Ho - 1): there the weight fragments of those (lane, K-step) pairs are replaced by zeros.
+// A step's output leaves through the LDS tile at the TOP of the next step -- after that step's wait for its window rows, so no
+// wait ever counts on the order in which loads and stores retire -- and has the whole step to be acknowledged.
+// STATS: per-channel sum and sum of squares of the bf16-rounded outputs on the matrix cores, straight from the tile: with the
+// tile fragment F (K = 32 pixels x 16 channels) as BOTH operands the diagonal of F^T F is the sum of squares, ones^T F the sum;
+// the accumulators run over the whole column, so a launch writes B * strips partial rows (version 2: one per patch = 36 x as
+// many, reduced by shuffles and two extra barriers per step: 1510 us with statistics against 1082 us without at batch 64).
+struct TapRArgs {
+  const uint16_t* z;
+  uint16_t* out;
+  const float* addvec;
+  float* stats;
+  int Hi, Wi, N, Ho, Wo, B, relu;
+  int nstrips, G, ncols, nchunks;   // strips per image row, column groups per XCD, columns = B * chunks, chunks = N / 64
+};
+
+// D = steps the row fetches run ahead.  One step ahead leaves a workgroup one memory latency per step (factor 4, four workgroups per
+// CU: 4.1 us per step and workgroup, 3.1 TB/s); D > 1: the wait at the top of a step leaves the later fetches -- and the stores
+// between them, every wave issues the same number in a strip that lies inside the image -- in flight (vmcnt retires in order).
+template <int LF, bool STATS, int D>
+__global__ __launch_bounds__(256, LF == 2 ? 3 : 2) void resize_conv3x3_fwd_sum_roll_kernel(const TapRArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WIN = LF == 1 ? 4 : 3, CPS = 4 >> LF, NA = 3 * WIN, NKS = (NA + 1) / 2;
+  constexpr int WC = (12 >> LF) + WIN, ROWS = WC * 9, PIECES = (ROWS + 7) / 8, SLOT = PIECES * 1024;
+  constexpr int NSLOT = WIN + D * CPS, MAXP = (PIECES + 3) / 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int grp = idx / a.nstrips, strip = idx - grp * a.nstrips;
+  const int oxb0 = strip * 16, wcb0 = (oxb0 >> LF) - 1;
+  unsigned char* tile = smem;                              // [4 rows][16 pixels] x 128 B; the two weight tables during the set-up
+  unsigned char* ring = smem + 4 * 16 * 128;
+  const unsigned lds_ring = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ring);
+  // ---- set-up: once per workgroup
+  bf16x8_t wf[NKS];
+  int raddr[NKS][2];
+  unsigned doff[MAXP];
+  unsigned wyq = 0, ptop = 0, pbot = 0;                     // per K-step: window row (2 bits each), zero-padding masks (1 bit each)
+  {
+    float* TY = (float*)tile;                              // [4][12]: output row of the patch x (tap row, window row)
+    float* TX = TY + 64;                                   // [16][16]: output column of the strip x (tap column, window column)
+    if (tid < 48) {
+      const int py = tid / 12, ai = tid - py * 12;
+      float w = 0.f;
+      if (ai < NA) {
+        const int r = ai / WIN, wy = ai - r * WIN;
+        const float s = ((float)(py + r - 1) + 0.5f) * (1.f / (float)(1 << LF)) - 0.5f;   // relative to the step's first cell, NOT clamped
+        const float fl = floorf(s);
+        const int y0 = (int)fl, rr = wy - 1;
+        const float ly = s - fl;
+        w = (y0 == rr ? 1.f - ly : 0.f) + (y0 + 1 == rr ? ly : 0.f);
+      }
+      TY[tid] = w;
+    }
+    {
+      const int pc = tid >> 4, bi = tid & 15;
+      float w = 0.f;
+      if (bi < NA) {
+        const int s3 = bi / WIN, dx = bi - s3 * WIN, pos = oxb0 + pc + s3 - 1;
+        if (pos >= 0 && pos < a.Wo) {
+          int x0, x1; float lx;
+          src_index((float)a.Wi / (float)a.Wo, pos, a.Wi, x0, x1, lx);
+          const int col = ((oxb0 + (pc & ~3)) >> LF) - 1 + dx;
+          w = (x0 == col ? 1.f - lx : 0.f) + (x1 == col ? lx : 0.f);
+        }
+      }
+      TX[tid] = w;
+    }
+    __syncthreads();
+    const int wcj = (4 * wave) >> LF;
+    float txv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) txv[e] = TX[(4 * wave + (L & 3)) * 16 + 8 * (g & 1) + e];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int ai = 2 * ks + (g >> 1);
+      const float ty = TY[(L >> 2) * 12 + ai];             // zero for ai >= NA
+      uint32_t pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(ty * txv[2 * e], ty * txv[2 * e + 1]);
+      wf[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+      const int r = ai / WIN, wy = ai - r * WIN;
+      if (ai < NA) wyq |= (unsigned)wy << (2 * ks);
+      if (ai < NA && (L >> 2) == 0 && r == 0) ptop |= 1u << ks;
+      if (ai < NA && (L >> 2) == 3 && r == 2) pbot |= 1u << ks;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int bq = 8 * (g & 1) + 4 * h + (L >> 2);
+        const bool ok = ai < NA && bq < NA;
+        const int s3 = bq / WIN, dx = bq - s3 * WIN;
+        const int R = ok ? ((wcj + dx) * 9 + 3 * r + s3) : 0;          // row inside the slot of window row wy
+        raddr[ks][h] = R * 128 + (((((L & 3) >> 1) ^ tm_swz(R))) << 4) + (L & 1) * 8;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int piece = wave + 4 * i;
+      const int R = piece * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ tm_swz(R);
+      const int pc = R / 9, t = R - pc * 9;
+      const int col = wcb0 + pc;
+      const bool ok = R < ROWS && col >= 0 && col < a.Wi;
+      doff[i] = ok ? (unsigned)((((col * 9 + t) * a.N) * 2) + chunk * 16) : kTmOob;
+    }
+    __syncthreads();                                       // the tables are dead: the tile may be written
+  }
+  const int nsteps = a.Ho >> 2;
+  const bool fullstrip = oxb0 + 16 <= a.Wo;                // every thread stores its two pieces of every tile
+  const int npw = (PIECES - wave + 3) / 4;                 // DMA instructions of this wave per window row
+  const int64_t row_bytes = (int64_t)a.Wi * 9 * a.N * 2;   // one low-resolution row of the source
+  const int gg = xcd * a.G + grp, gstride = 8 * a.G;
+  bool primed = false;
+  for (int col = gg; col < a.ncols; col += gstride) {
+    const int b = col / a.nchunks, c = col - b * a.nchunks;
+    const srd_t srd = make_srd(a.z + (int64_t)b * a.Hi * a.Wi * 9 * a.N, (unsigned)((int64_t)a.Hi * row_bytes));
+    auto issue_row = [&](const srd_t& sd, int cc, int y, int slot) {      // logical row y (-1 .. Hi) of chunk cc -> ring slot
+      const int yc = y < 0 ? 0 : (y > a.Hi - 1 ? a.Hi - 1 : y);
+      const unsigned soff = (unsigned)((int64_t)yc * row_bytes) + (unsigned)(cc * 128);
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i)
+        if (wave + 4 * i < PIECES) dma16_buf(doff[i], sd, soff, lds_ring + slot * SLOT + (wave + 4 * i) * 1024);
+    };
+    // the rows step s adds to the window (step 0: all of it), s0s = the ring slot of that step's first window row
+    auto issue_step = [&](const srd_t& sd, int cc, int s, int s0s) {
+      if (s == 0) {
+#pragma unroll
+        for (int y = 0; y < WIN; ++y) issue_row(sd, cc, y - 1, y);
+      } else {
+#pragma unroll
+        for (int j = 0; j < CPS; ++j) {
+          int slot = s0s + WIN - CPS + j;
+          slot -= slot >= NSLOT ? NSLOT : 0;
+          issue_row(sd, cc, s * CPS + WIN - CPS - 1 + j, slot);
+        }
+      }
+    };
+    if (!primed) {
+#pragma unroll
+      for (int s = 0; s < D; ++s)
+        if (s < nsteps) issue_step(srd, c, s, (s * CPS) % NSLOT);
+    }
+    // the accumulators start from the per-channel addend (kept in registers for the column: no ordinary load -- whose wait the
+    // compiler would place without knowing of the fetches in flight -- inside the step loop)
+    f32x4_t addv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const float4 v = a.addvec ? *(const float4*)(a.addvec + c * 64 + 16 * nt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      addv[nt] = f32x4_t{v.x, v.y, v.z, v.w};
+    }
+    f32x4_t sd1 = {0.f, 0.f, 0.f, 0.f}, sd2 = {0.f, 0.f, 0.f, 0.f};
+    uint16_t* obase = a.out + (int64_t)b * a.Ho * a.Wo * a.N + c * 64;
+    auto flush = [&](int step) {                           // the tile of `step` -> global memory (+ statistics)
+      int t = tid;
+      asm volatile("" : "+v"(t));                          // (addresses from an opaque thread id: not kept in registers across the steps)
+      uint16_t* orow = obase + (int64_t)step * 4 * a.Wo * a.N;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = t + 256 * u, pp = i >> 3, chunk = i & 7;
+        const uint4 v = *(const uint4*)(tile + pp * 128 + ((chunk ^ (pp & 7)) << 4));
+        if (oxb0 + (pp & 15) < a.Wo) *(uint4*)(orow + ((int64_t)(pp >> 4) * a.Wo + oxb0 + (pp & 15)) * a.N + chunk * 8) = v;
+      }
+      if constexpr (STATS) {                               // wave w: channels 16 w .. 16 w + 15 of the chunk, all 64 pixels
+        const int l = t & 15, gq = (t >> 4) & 3;
+        const tm_s16x8_t one8 = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int p0 = 32 * k2 + 8 * gq + (l >> 2), p1 = p0 + 4;
+          const int base = (l & 1) * 8, s16 = 2 * wave + ((l & 3) >> 1);
+          const tm_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(tile + p0 * 128 + ((s16 ^ (p0 & 7)) << 4) + base));
+          const tm_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(tile + p1 * 128 + ((s16 ^ (p1 & 7)) << 4) + base));
+          const tm_s16x8_t zv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const bf16x8_t f = __builtin_bit_cast(bf16x8_t, zv);
+          sd1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, one8), f, sd1, 0, 0, 0);
+          sd2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, f, sd2, 0, 0, 0);
+        }
+      }
+    };
+    int s0 = 0;                                            // ring slot of the step's first window row
+#pragma unroll 1
+    for (int i = 0; i < nsteps; ++i) {
+      asm volatile("" : "+s"(s0));                         // (opaque: the step loop is not unrolled over the ring's period with every fragment address kept)
+      // (lgkmcnt(0) in every wait: hipcc drops its own LDS wait in front of the barrier below -- behind these asm statements the
+      // last ds_write of the previous step's tile was still in flight when other waves read the tile: one patch row of the last
+      // channel tile wrong in 1 of 4 launches)
+      // this wave's pieces of step i's rows have landed.  Steady state (the fetch of step i was followed by two stores, then
+      // D - 1 times by a fetch and two stores): those may stay in flight
+      if (D > 1 && fullstrip && i > D && i + D <= nsteps) {
+        if (npw == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + (D - 1) * (2 * CPS + 2)) : "memory");
+        else if (npw == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + (D - 1) * (1 * CPS + 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __syncthreads();                                    // ... everyone's; step i - 1 is computed and its tile written
+      if (i + D < nsteps) {
+        int sn = s0 + D * CPS;
+        sn -= sn >= NSLOT ? NSLOT : 0;
+        issue_step(srd, c, i + D, sn);
+      }
+      if (i > 0) flush(i - 1);
+      f32x4_t acc[4];
+      // ---- the step's four patches (one per wave) on the matrix cores: K-steps outside, the four channel tiles inside
+      const bool top = i == 0, bot = i == nsteps - 1;
+      auto run = [&](auto border) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          int slot = s0 + (int)((wyq >> (2 * ks)) & 3u);
+          slot -= slot >= NSLOT ? NSLOT : 0;
+          const int ad0 = raddr[ks][0] + slot * SLOT, ad1 = raddr[ks][1] + slot * SLOT;
+          bf16x8_t w = wf[ks];
+          if constexpr (decltype(border)::value) {
+            const bool kill = (top && ((ptop >> ks) & 1u)) || (bot && ((pbot >> ks) & 1u));
+            const uint4 wz = __builtin_bit_cast(uint4, w);
+            w = __builtin_bit_cast(bf16x8_t, make_uint4(kill ? 0u : wz.x, kill ? 0u : wz.y, kill ? 0u : wz.z, kill ? 0u : wz.w));
+          }
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const tm_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(ring + (ad0 ^ (nt << 5))));
+            const tm_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(ring + (ad1 ^ (nt << 5))));
+            const tm_s16x8_t zv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zv), w, ks == 0 ? addv[nt] : acc[nt], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (top || bot) run(std::true_type{}); else run(std::false_type{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();                                    // everyone has flushed the previous tile
+      {
+        int t = lane;
+        asm volatile("" : "+v"(t));
+        const int l = t & 15, gq = t >> 4;
+        const int pp = (l >> 2) * 16 + 4 * wave + (l & 3);
+        const bool pxvalid = oxb0 + 4 * wave + (l & 3) < a.Wo;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int ch = 16 * nt + 4 * gq;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[nt][e];
+            if (a.relu) v[e] = fmaxf(v[e], 0.f);
+            v[e] = pxvalid ? v[e] : 0.f;                   // columns beyond the image: zeros (not stored; the statistics count them as nothing)
+          }
+          *(uint2*)(tile + pp * 128 + ((((ch >> 3) ^ (pp & 7))) << 4) + (ch & 7) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
+      }
+      s0 += CPS;
+      s0 -= s0 >= NSLOT ? NSLOT : 0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                      // the last tile is written; nobody reads the ring any more
+    const int ncol = col + gstride;
+    primed = ncol < a.ncols;
+    if (primed) {                                          // the next column's first rows travel under this column's tail
+      const int nb = ncol / a.nchunks, nc = ncol - nb * a.nchunks;
+      const srd_t nsrd = make_srd(a.z + (int64_t)nb * a.Hi * a.Wi * 9 * a.N, (unsigned)((int64_t)a.Hi * row_bytes));
+#pragma unroll
+      for (int s = 0; s < D; ++s)
+        if (s < nsteps) issue_step(nsrd, nc, s, (s * CPS) % NSLOT);
+    }
+    flush(nsteps - 1);
+    if constexpr (STATS) {
+      const int64_t prow = (int64_t)b * a.nstrips + strip;
+      float* srow = a.stats + prow * 2 * a.N + c * 64 + 16 * wave + L;
+      if (g == 0) srow[0] = sd1[0];
+      if (g == (L >> 2)) {
+        const int e = L & 3;
+        srow[a.N] = e == 0 ? sd2[0] : (e == 1 ? sd2[1] : (e == 2 ? sd2[2] : sd2[3]));
+      }
+    }
+  }
+}
+
 // ---- the BACKWARD gather on the matrix cores (bf16, N % 64 == 0, factors 2 and 4): G_t = U^T S_t^T dy as ONE pass.
 // For a low-resolution pixel q the nine maps are a small dense product that is the same for every channel:
 //   G[q, t, n] = sum_p W[p, t] dy[p, n],   p = the (2F + 2)^2 output pixels whose tap positions interpolate from q,
@@ -1774,8 +2063,12 @@ static int tapsum_num_cus() {
   }();
   return n;
 }
+static int g_tapsum_roll = 1;
+constexpr int kRollDepth4 = 3;    // factor 4: steps the row fetches of version 3 run ahead (ring of 3 + depth slots of 7 KiB, three workgroups per CU)
+extern "C" void gdl_debug_set_tapsum_roll(int on) { g_tapsum_roll = on; }  // A/B hook: 0 = versions 1 / 2 where version 3 (rolling row window) applies
+// stat_rows (with stats): the number of partial rows the launch wrote (<= gdl_resize_conv3x3_fwd_sum_bn_rows)
 static int tapsum_launch(const void* const* zs, const int* hs, const int* ws, int nsrc, int dtype, int B, int N, void* out, int Ho, int Wo,
-                         const float* addvec, int relu, float* stats, hipStream_t st) {
+                         const float* addvec, int relu, float* stats, hipStream_t st, int64_t* stat_rows = nullptr) {
   GDL_CHECK_ARG(zs && hs && ws && out && nsrc >= 1 && nsrc <= 3, "gdl_resize_conv3x3_fwd_sum: 1..3 sources");
   GDL_CHECK_ARG(dtype == GDL_F32 || dtype == GDL_BF16, "gdl_resize_conv3x3_fwd_sum: bad dtype");
   GDL_CHECK_ARG(B > 0 && Ho > 0 && Wo > 0 && N > 0, "gdl_resize_conv3x3_fwd_sum: bad sizes");
@@ -1807,6 +2100,30 @@ static int tapsum_launch(const void* const* zs, const int* hs, const int* ws, in
     }
     m.nsrc = nsrc; m.N = N; m.Ho = Ho; m.Wo = Wo; m.B = B; m.out = (uint16_t*)out; m.addvec = addvec; m.relu = relu;
     m.nslots = 0; m.slot_off[0] = m.slot_off[1] = m.slot_off[2] = 0;
+    if (stat_rows) *stat_rows = (int64_t)B * ((Ho + 3) / 4) * ((Wo + 15) / 16);
+    // version 3 (rolling row window): one source of factor 2 or 4 whose output rows come in whole patches
+    if (g_tapsum_roll && nsrc == 1 && (m.LF[0] == 1 || m.LF[0] == 2) && Ho % 4 == 0 && (g_tapsum_mfma == 1 || stats)) {
+      TapRArgs r;
+      r.z = m.z[0]; r.out = m.out; r.addvec = addvec; r.stats = stats;
+      r.Hi = m.H[0]; r.Wi = m.W[0]; r.N = N; r.Ho = Ho; r.Wo = Wo; r.B = B; r.relu = relu;
+      r.nstrips = (Wo + 15) / 16; r.nchunks = N / 64; r.ncols = B * r.nchunks;
+      const int occ = m.LF[0] == 2 ? 3 : 2, slots = tapsum_num_cus() / 8 * occ;         // resident workgroups per XCD (launch bounds)
+      int G = slots / r.nstrips;
+      if (G > (r.ncols + 7) / 8) G = (r.ncols + 7) / 8;
+      if (G < 1) G = 1;
+      r.G = G;
+      const dim3 grid((unsigned)(8 * G * r.nstrips));
+      const size_t lds = 4 * 16 * 128 + (size_t)(m.LF[0] == 2 ? (3 + (g_tapsum_roll == 2 ? 1 : kRollDepth4)) * 7 : 6 * 12) * 1024;
+#define TAPR(LF_, ST_, D_) do { GDL_SET_MAX_LDS_ONCE((resize_conv3x3_fwd_sum_roll_kernel<LF_, ST_, D_>), 160 * 1024);                    \
+    hipLaunchKernelGGL((resize_conv3x3_fwd_sum_roll_kernel<LF_, ST_, D_>), grid, dim3(256), lds, st, r); } while (0)
+      if (m.LF[0] == 2 && g_tapsum_roll == 2) { if (stats) TAPR(2, true, 1); else TAPR(2, false, 1); }      // (A/B: one step ahead)
+      else if (m.LF[0] == 2) { if (stats) TAPR(2, true, kRollDepth4); else TAPR(2, false, kRollDepth4); }
+      else { if (stats) TAPR(1, true, 1); else TAPR(1, false, 1); }
+#undef TAPR
+      if (stat_rows) *stat_rows = (int64_t)B * r.nstrips;
+      GDL_CHECK_LAUNCH("gdl_resize_conv3x3_fwd_sum");
+      return GDL_OK;
+    }
     // the staging loop writes whole 1 KiB pieces (8 rows): round a window up to that
     auto window_bytes_lf = [&](int cols, int lf) { const int win = lf == 1 ? 4 : 3; return (win * (((cols - 4) >> lf) + win) * 9 * 128 + 1023) / 1024 * 1024; };
     // version 2 (all channels of a 4 x 16 pixel block per workgroup, windows double-buffered) where three blocks fit a CU: ONE
@@ -1976,9 +2293,10 @@ extern "C" int gdl_resize_conv3x3_fwd_sum_bn(const void* const* zs, const int* h
   GDL_CHECK_ARG(workspace && mean && var, "gdl_resize_conv3x3_fwd_sum_bn: null pointer");
   const int64_t rows = gdl_resize_conv3x3_fwd_sum_bn_rows(B, Ho, Wo);
   GDL_CHECK_ARG(ws_bytes >= rows * 2 * N * (int64_t)sizeof(float), "gdl_resize_conv3x3_fwd_sum_bn: workspace too small");
-  const int st = tapsum_launch(zs, hs, ws, nsrc, dtype, B, N, out, Ho, Wo, addvec, 0, workspace, (hipStream_t)stream);
+  int64_t written = rows;
+  const int st = tapsum_launch(zs, hs, ws, nsrc, dtype, B, N, out, Ho, Wo, addvec, 0, workspace, (hipStream_t)stream, &written);
   if (st != GDL_OK) return st;
-  return gdl_bn_stats_finalize(workspace, (int)rows, N, (int64_t)B * Ho * Wo, mean, var, running_mean, running_var, momentum, stream);
+  return gdl_bn_stats_finalize(workspace, (int)written, N, (int64_t)B * Ho * Wo, mean, var, running_mean, running_var, momentum, stream);
 }
 
 extern "C" void gdl_debug_set_flat_resample(int on) { g_flat_resample = on; }

@@ -220,6 +220,9 @@ def load() -> C.CDLL:
     if os.environ.get("GDL_TAPSUM_PERSIST") is not None:  # tuning hook: 0 = one workgroup per patch in the forward gather-sum (round 3)
         lib.gdl_debug_set_tapsum_persist.argtypes = [C.c_int]
         lib.gdl_debug_set_tapsum_persist(int(os.environ["GDL_TAPSUM_PERSIST"]))
+    if os.environ.get("GDL_TAPSUM_ROLL") is not None:     # tuning hook: 0 = versions 1 / 2 of the forward gather-sum where the rolling-window one applies
+        lib.gdl_debug_set_tapsum_roll.argtypes = [C.c_int]
+        lib.gdl_debug_set_tapsum_roll(int(os.environ["GDL_TAPSUM_ROLL"]))
     if os.environ.get("GDL_GATHER_MFMA") is not None:     # tuning hook: 0 = the VALU gathers of the low-resolution backward
         lib.gdl_debug_set_gather_mfma.argtypes = [C.c_int]
         lib.gdl_debug_set_gather_mfma(int(os.environ["GDL_GATHER_MFMA"]))

@@ -1831,6 +1831,61 @@ def test_resize_conv3x3_fwd_sum_with_batchnorm_statistics(B, H, W, N, factors):
     close(rv, bn.running_var, torch.float32, "running_var")
 
 
+@pytest.mark.parametrize("B,H,W,N,f", [(1, 4, 16, 64, 4), (1, 4, 8, 64, 2), (2, 8, 24, 128, 2), (2, 72, 72, 192, 2), (1, 144, 144, 128, 4),
+                                       (5, 16, 512, 512, 4), (3, 8, 488, 1024, 2), (2, 36, 40, 64, 4)])
+def test_resize_conv3x3_fwd_sum_rolling_window(B, H, W, N, f):
+    """Round 6, version 3 of the forward gather-sum (one source of factor 2 / 4, H % 4 == 0): a workgroup walks a column
+    (image, 64 channels, 16 output columns) top to bottom over a ring of low-resolution rows, rows outside the image clamped in
+    the DMA address, the zero padding as masked weight fragments in the first and last step, BatchNorm statistics on the matrix
+    cores.  Against torch on the CPU (every pixel, border lines separately), against version 2 (same formula, another summation
+    order), and the statistics against the output they describe.  Shapes: one step (top and bottom at once), strips that end
+    outside the image (W % 16 != 0), more columns than resident workgroup groups (a workgroup walks several)."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_set_tapsum_roll.argtypes = [ctypes.c_int]
+    dtype = torch.bfloat16
+    z = q(rnd(B, H // f, W // f, 9 * N, seed=31 + f), dtype)
+    zt = z.view(B, H // f, W // f, 9, N).permute(0, 3, 4, 1, 2)
+    ref = torch.zeros(B, N, H, W)
+    for t in range(9):
+        up = F.pad(F.interpolate(zt[:, t].float(), size=(H, W), mode="bilinear", align_corners=False), (1, 1, 1, 1))
+        ref += up[:, :, t // 3:t // 3 + H, t % 3:t % 3 + W]
+    ref = ref.permute(0, 2, 3, 1)
+    add = rnd(N, seed=5)
+    zd = z.to(DEV, dtype)
+    y = ops.resize_conv3x3_fwd_sum([zd], (H, W))
+    y2 = ops.resize_conv3x3_fwd_sum([zd], (H, W), addvec=add.to(DEV), relu=True)
+    rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    y3, mean, var = ops.resize_conv3x3_fwd_sum_bn([zd], (H, W), addvec=add.to(DEV), running_mean=rm, running_var=rv, momentum=0.1)
+    lib.gdl_debug_set_tapsum_roll(0)
+    try:
+        v = ops.resize_conv3x3_fwd_sum([zd], (H, W))
+        v3, vmean, vvar = ops.resize_conv3x3_fwd_sum_bn([zd], (H, W), addvec=add.to(DEV))
+    finally:
+        lib.gdl_debug_set_tapsum_roll(1)
+    close(y, ref, dtype, "tap sum")
+    for name, sl in (("top", (slice(None), 0)), ("bottom", (slice(None), -1)), ("left", (slice(None), slice(None), 0)),
+                     ("right", (slice(None), slice(None), -1))):
+        close(y[sl], ref[sl], dtype, f"tap sum {name} line", scale=ref.abs().max().item())
+    close(y2, F.relu(ref + add), dtype, "tap sum + shift + ReLU")
+    # version 2 sums the same products in another order: one bf16 step apart at most, and only rarely
+    dv = (y.float() - v.float()).abs()
+    assert dv.max().item() <= 2.0 ** -7 * ref.abs().max().item(), dv.max().item()
+    assert (dv > 0).float().mean().item() < 0.02, (dv > 0).float().mean().item()
+    d3 = (y3.float() - v3.float()).abs()
+    assert (d3 > 0).float().mean().item() < 0.02
+    yf = y3.float().cpu().reshape(-1, N)
+    close(mean, yf.mean(0), torch.float32, "mean", scale=yf.abs().max().item())
+    close(var, yf.var(0, unbiased=False), torch.float32, "var")
+    close(mean, vmean, torch.float32, "mean vs version 2", scale=yf.abs().max().item())
+    close(var, vvar, torch.float32, "var vs version 2")
+    bn = torch.nn.BatchNorm2d(N).train()
+    bn(y3.float().cpu().permute(0, 3, 1, 2))
+    close(rm, bn.running_mean, torch.float32, "running_mean", scale=yf.abs().max().item())
+    close(rv, bn.running_var, torch.float32, "running_var")
+
+
 def _rel_l2(got, ref):
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     return float((got - ref).norm() / ref.norm().clamp_min(1e-12))
