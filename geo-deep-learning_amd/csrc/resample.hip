@@ -1314,82 +1314,84 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
   }
 }
 
-// ---- version 3 (round 6): ONE source of factor 2 or 4, Ho % 4 == 0 -- a ROLLING window of low-resolution rows.
+// ---- version 3 (round 6): sources of factor 2 / 4 (one source, Ho % 4 == 0) or 2 + 4 + 8 (UperNet's fpn_bottleneck, Ho % 8 == 0)
+// -- a ROLLING window of low-resolution rows.
 // Versions 1 and 2 stage the whole 3 (4) x WC pixel window of every 4 x 16 patch: each tap-product pixel travels L2 -> LDS 4.5 times
 // (factor 4) and, because the patches that share it run at different times, 2.4 times from memory (PMC: 1383 MB fetched per
 // launch for 574 MB of tap products at batch 32) -- the kernel moved its over-fetched bytes at 4.5 TB/s and was memory-bound on them.
 // Here a workgroup owns a COLUMN = (image, 64-channel chunk, strip of 16 output columns) and walks it top to bottom, four
-// output rows per step: the window rows live in a ring of LDS row slots and only the CPS = 4 / factor new low-resolution rows of
-// the next step are fetched (one step ahead, by LDS-DMA).  The strips of one (image, chunk) are walked by neighbouring
-// workgroups of ONE XCD at the same pace, so the one or two window columns two strips share come out of that L2.
+// output rows per step: the window rows live in a ring of LDS row slots and only the new low-resolution rows of a later step
+// are fetched (D steps ahead, by LDS-DMA).  The strips of one (image, chunk) are walked by neighbouring workgroups of ONE XCD
+// at the same pace, so the one or two window columns two strips share come out of that L2.
 // What makes one set-up per workgroup enough (a strip's columns all look alike):
 //   * rows outside the image are CLAMPED in the DMA address instead of re-weighted: torch's clamp of the source index is the
 //     same as bilinear weights on an edge-replicated map ((1 - l) z[0] + l z[0] = z[0], exact in f32), so the row weights
 //     of every step are the interior ones;
 //   * the convolution's zero padding touches the first and the last step only (tap row -1 of output row 0, tap row Ho of
-//     output row Ho - 1): there the weight fragments of those (lane, K-step) pairs are replaced by zeros.
-// A step's output leaves through the LDS tile at the TOP of the next step -- after that step's wait for its window rows, so no
-// wait ever counts on the order in which loads and stores retire -- and has the whole step to be acknowledged.
-// STATS: per-channel sum and sum of squares of the bf16-rounded outputs on the matrix cores, straight from the tile: with the
-// tile fragment F (K = 32 pixels x 16 channels) as BOTH operands the diagonal of F^T F is the sum of squares, ones^T F the sum;
-// the accumulators run over the whole column, so a launch writes B * strips partial rows (version 2: one per patch = 36 x as
-// many, reduced by shuffles and two extra barriers per step: 1510 us with statistics against 1082 us without at batch 64).
-struct TapRArgs {
-  const uint16_t* z;
-  uint16_t* out;
-  const float* addvec;
-  float* stats;
-  int Hi, Wi, N, Ho, Wo, B, relu;
-  int nstrips, G, ncols, nchunks;   // strips per image row, column groups per XCD, columns = B * chunks, chunks = N / 64
-};
-
-// D = steps the row fetches run ahead.  One step ahead leaves a workgroup one memory latency per step (factor 4, four workgroups per
-// CU: 4.1 us per step and workgroup, 3.1 TB/s); D > 1: the wait at the top of a step leaves the later fetches -- and the stores
-// between them, every wave issues the same number in a strip that lies inside the image -- in flight (vmcnt retires in order).
-template <int LF, bool STATS, int D>
-__global__ __launch_bounds__(256, LF == 2 ? 3 : 2) void resize_conv3x3_fwd_sum_roll_kernel(const TapRArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int WIN = LF == 1 ? 4 : 3, CPS = 4 >> LF, NA = 3 * WIN, NKS = (NA + 1) / 2;
-  constexpr int WC = (12 >> LF) + WIN, ROWS = WC * 9, PIECES = (ROWS + 7) / 8, SLOT = PIECES * 1024;
-  constexpr int NSLOT = WIN + D * CPS, MAXP = (PIECES + 3) / 4;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = lane & 15, g = lane >> 4;
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int grp = idx / a.nstrips, strip = idx - grp * a.nstrips;
-  const int oxb0 = strip * 16, wcb0 = (oxb0 >> LF) - 1;
-  unsigned char* tile = smem;                              // [4 rows][16 pixels] x 128 B; the two weight tables during the set-up
-  unsigned char* ring = smem + 4 * 16 * 128;
-  const unsigned lds_ring = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ring);
-  // ---- set-up: once per workgroup
-  bf16x8_t wf[NKS];
-  int raddr[NKS][2];
+//     output row Ho - 1): those two steps use weight fragments with these products zeroed (kept beside the interior ones).
+// The K dimension is PACKED: k = (tap row, window row) * NA + (tap column, window column), NA = 3 WIN, K = NA^2 = 81 (144 for
+// factor 2) in 3 (5) steps of 32 -- versions 1 / 2 pad the inner index to 16 (5 and 6 steps).  Compute was the bound of the
+// first form of this kernel (fpn_bottleneck: 809 us of matrix-core + LDS work against 608 us for all its memory traffic).
+// A step's output leaves through the LDS tile at the TOP of the next step and has the whole step to be acknowledged.
+// D = steps the row fetches run ahead.  One step ahead leaves a workgroup one memory latency per step (factor 4, four workgroups
+// per CU: 4.1 us per step and workgroup, 3.1 TB/s); D > 1: the wait at the top of a step leaves the later fetches -- and the
+// stores between them; every wave issues the same number in a strip that lies inside the image -- in flight (vmcnt retires in
+// order).
+// STATS (one source): per-channel sum and sum of squares of the bf16-rounded outputs on the matrix cores, straight from the
+// tile: with the tile fragment F (K = 32 pixels x 16 channels) as BOTH operands the diagonal of F^T F is the sum of squares,
+// ones^T F the sum; the accumulators run over the whole column, so a launch writes B * strips partial rows (version 2: one per
+// patch = 36 x as many, reduced by shuffles and two extra barriers per step: 1510 us with statistics against 1082 us without
+// at batch 64).
+// Three sources: one ring per source and one set of accumulators.  Factor 8: a step of four output rows is half a cell -- two
+// row phases with their own weight fragments, a new window row every other step.  One workgroup per CU (the three rings are
+// 96 + 35 + 20 KiB at D = 2); pieces a wave does not have, and the factor-8 source's idle steps, are fetches whose lanes are all
+// out of range (zeros into a spare KiB, no memory traffic), so one vmcnt immediate serves every wave and step.
+template <int LF, int D>
+struct RollSrc {
+  static constexpr int WIN = LF == 1 ? 4 : 3, NPH = LF == 3 ? 2 : 1;
+  static constexpr int NA = 3 * WIN, KR = NA * NA, NKS = (KR + 31) / 32;
+  static constexpr int WC = (12 >> LF) + WIN, ROWS = WC * 9, PIECES = (ROWS + 7) / 8, SLOT = PIECES * 1024;
+  static constexpr int RPS = LF == 1 ? 2 : 1;              // new window rows of a step that fetches
+  static constexpr int NSLOT = WIN + (LF == 3 ? (D + 1) / 2 : D * RPS);
+  static constexpr int MAXP = (PIECES + 3) / 4, NDMA = RPS * MAXP, BYTES = NSLOT * SLOT;
+  bf16x8_t wf[NPH][NKS];                                   // weight fragments (B operand: column = pixel of the patch)
+  bf16x8_t wft[NKS], wfb[NKS];                             // ... of the first step (first phase) / the last step (last phase)
+  unsigned araddr[NKS][2];                                 // ring-relative byte offset of the lane's two fragment pieces, window row 0 of the step in slot 0
   unsigned doff[MAXP];
-  unsigned wyq = 0, ptop = 0, pbot = 0;                     // per K-step: window row (2 bits each), zero-padding masks (1 bit each)
-  {
-    float* TY = (float*)tile;                              // [4][12]: output row of the patch x (tap row, window row)
-    float* TX = TY + 64;                                   // [16][16]: output column of the strip x (tap column, window column)
-    if (tid < 48) {
-      const int py = tid / 12, ai = tid - py * 12;
+  srd_t srd;
+  unsigned lds;                                            // LDS address of the ring
+  int Hi;
+  int64_t row_bytes;
+
+  // the weight tables live in `tab` (>= 128 + 256 floats) during the call; two barriers inside
+  __device__ __forceinline__ void setup(float* tab, unsigned lds_ring, int Hi_, int Wi, int Wo, int N, int oxb0, int tid, int wave) {
+    const int lane = tid & 63, L = lane & 15, g = lane >> 4;
+    Hi = Hi_;
+    lds = lds_ring;
+    row_bytes = (int64_t)Wi * 9 * N * 2;
+    float* TY = tab;                                       // [NPH][4][12] (64 floats per phase)
+    float* TX = tab + 128;                                 // [16][16]
+    if (tid < 48 * NPH) {
+      const int ph = tid / 48, q = tid - ph * 48, py = q / 12, ai = q - py * 12;
       float w = 0.f;
       if (ai < NA) {
         const int r = ai / WIN, wy = ai - r * WIN;
-        const float s = ((float)(py + r - 1) + 0.5f) * (1.f / (float)(1 << LF)) - 0.5f;   // relative to the step's first cell, NOT clamped
+        const float s = ((float)(4 * ph + py + r - 1) + 0.5f) * (1.f / (float)(1 << LF)) - 0.5f;   // relative to the cell, not clamped
         const float fl = floorf(s);
         const int y0 = (int)fl, rr = wy - 1;
         const float ly = s - fl;
         w = (y0 == rr ? 1.f - ly : 0.f) + (y0 + 1 == rr ? ly : 0.f);
       }
-      TY[tid] = w;
+      TY[ph * 64 + q] = w;
     }
     {
       const int pc = tid >> 4, bi = tid & 15;
       float w = 0.f;
       if (bi < NA) {
         const int s3 = bi / WIN, dx = bi - s3 * WIN, pos = oxb0 + pc + s3 - 1;
-        if (pos >= 0 && pos < a.Wo) {
+        if (pos >= 0 && pos < Wo) {
           int x0, x1; float lx;
-          src_index((float)a.Wi / (float)a.Wo, pos, a.Wi, x0, x1, lx);
+          src_index((float)Wi / (float)Wo, pos, Wi, x0, x1, lx);
           const int col = ((oxb0 + (pc & ~3)) >> LF) - 1 + dx;
           w = (x0 == col ? 1.f - lx : 0.f) + (x1 == col ? lx : 0.f);
         }
@@ -1397,29 +1399,37 @@ __global__ __launch_bounds__(256, LF == 2 ? 3 : 2) void resize_conv3x3_fwd_sum_r
       TX[tid] = w;
     }
     __syncthreads();
-    const int wcj = (4 * wave) >> LF;
-    float txv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) txv[e] = TX[(4 * wave + (L & 3)) * 16 + 8 * (g & 1) + e];
+    const int wcj = (4 * wave) >> LF, wcb0 = (oxb0 >> LF) - 1;
+    const int py = L >> 2, px = 4 * wave + (L & 3);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      const int ai = 2 * ks + (g >> 1);
-      const float ty = TY[(L >> 2) * 12 + ai];             // zero for ai >= NA
-      uint32_t pk[4];
+      float wv[NPH][8], wt[8], wb[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(ty * txv[2 * e], ty * txv[2 * e + 1]);
-      wf[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
-      const int r = ai / WIN, wy = ai - r * WIN;
-      if (ai < NA) wyq |= (unsigned)wy << (2 * ks);
-      if (ai < NA && (L >> 2) == 0 && r == 0) ptop |= 1u << ks;
-      if (ai < NA && (L >> 2) == 3 && r == 2) pbot |= 1u << ks;
+      for (int e = 0; e < 8; ++e) {
+        const int k = 32 * ks + 8 * g + e;
+        const bool ok = k < KR;
+        const int ai = ok ? k / NA : 0, bi = ok ? k - ai * NA : 0;
+        const float tx = TX[px * 16 + bi];
+        const int r = ai / WIN;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) wv[ph][e] = ok ? TY[ph * 64 + py * 12 + ai] * tx : 0.f;
+        wt[e] = (py == 0 && r == 0) ? 0.f : wv[0][e];                 // tap row -1 of output row 0
+        wb[e] = (py == 3 && r == 2) ? 0.f : wv[NPH - 1][e];           // tap row Ho of output row Ho - 1
+      }
+#pragma unroll
+      for (int ph = 0; ph < NPH; ++ph)
+        wf[ph][ks] = __builtin_bit_cast(bf16x8_t, make_uint4(pack_bf16x2(wv[ph][0], wv[ph][1]), pack_bf16x2(wv[ph][2], wv[ph][3]),
+                                                             pack_bf16x2(wv[ph][4], wv[ph][5]), pack_bf16x2(wv[ph][6], wv[ph][7])));
+      wft[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(pack_bf16x2(wt[0], wt[1]), pack_bf16x2(wt[2], wt[3]), pack_bf16x2(wt[4], wt[5]), pack_bf16x2(wt[6], wt[7])));
+      wfb[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(pack_bf16x2(wb[0], wb[1]), pack_bf16x2(wb[2], wb[3]), pack_bf16x2(wb[4], wb[5]), pack_bf16x2(wb[6], wb[7])));
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int bq = 8 * (g & 1) + 4 * h + (L >> 2);
-        const bool ok = ai < NA && bq < NA;
-        const int s3 = bq / WIN, dx = bq - s3 * WIN;
-        const int R = ok ? ((wcj + dx) * 9 + 3 * r + s3) : 0;          // row inside the slot of window row wy
-        raddr[ks][h] = R * 128 + (((((L & 3) >> 1) ^ tm_swz(R))) << 4) + (L & 1) * 8;
+        const int k = 32 * ks + 8 * g + 4 * h + (L >> 2);  // the fragment row this lane supplies (ds_read_b64_tr_b16: four rows x four channel quads per 16 lanes)
+        const bool ok = k < KR;
+        const int ai = ok ? k / NA : 0, bi = ok ? k - ai * NA : 0;
+        const int r = ai / WIN, wy = ai - r * WIN, s3 = bi / WIN, dx = bi - s3 * WIN;
+        const int R = ok ? ((wcj + dx) * 9 + 3 * r + s3) : 0;          // padding: any staged row, its weight is zero
+        araddr[ks][h] = (unsigned)(wy * SLOT + R * 128 + (((((L & 3) >> 1) ^ tm_swz(R))) << 4) + (L & 1) * 8);
       }
     }
 #pragma unroll
@@ -1429,45 +1439,148 @@ __global__ __launch_bounds__(256, LF == 2 ? 3 : 2) void resize_conv3x3_fwd_sum_r
       const int chunk = (lane & 7) ^ tm_swz(R);
       const int pc = R / 9, t = R - pc * 9;
       const int col = wcb0 + pc;
-      const bool ok = R < ROWS && col >= 0 && col < a.Wi;
-      doff[i] = ok ? (unsigned)((((col * 9 + t) * a.N) * 2) + chunk * 16) : kTmOob;
+      const bool ok = piece < PIECES && R < ROWS && col >= 0 && col < Wi;
+      doff[i] = ok ? (unsigned)((((col * 9 + t) * N) * 2) + chunk * 16) : kTmOob;
     }
-    __syncthreads();                                       // the tables are dead: the tile may be written
+    __syncthreads();
   }
+
+  __device__ __forceinline__ void set_image(const uint16_t* z, int b) {
+    srd = make_srd(z + (int64_t)b * Hi * (row_bytes / 2), (unsigned)((int64_t)Hi * row_bytes));
+  }
+  __device__ __forceinline__ void issue_row(int cc, int y, int wave, unsigned lds_dummy, bool pad) const {
+    const int yc = y < 0 ? 0 : (y > Hi - 1 ? Hi - 1 : y);
+    const int slot = (y + 1) % NSLOT;
+    const unsigned soff = (unsigned)((int64_t)yc * row_bytes) + (unsigned)(cc * 128);
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      if (wave + 4 * i < PIECES) dma16_buf(doff[i], srd, soff, lds + slot * SLOT + (wave + 4 * i) * 1024);
+      else if (pad) dma16_buf(kTmOob, srd, 0u, lds_dummy);
+    }
+  }
+  // the window rows step s adds (step 0: the whole window); pad: always NDMA instructions per wave
+  __device__ __forceinline__ void issue_step(int cc, int s, int wave, unsigned lds_dummy, bool pad) const {
+    if (s == 0) {
+#pragma unroll
+      for (int y = 0; y < WIN; ++y) issue_row(cc, y - 1, wave, lds_dummy, false);
+    } else if (LF == 1) {
+      issue_row(cc, 2 * s + 1, wave, lds_dummy, pad);
+      issue_row(cc, 2 * s + 2, wave, lds_dummy, pad);
+    } else if (LF == 2) {
+      issue_row(cc, s + 1, wave, lds_dummy, pad);
+    } else {
+      if ((s & 1) == 0) issue_row(cc, (s >> 1) + 1, wave, lds_dummy, pad);
+      else if (pad) {
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) dma16_buf(kTmOob, srd, 0u, lds_dummy);
+      }
+    }
+  }
+  // step i of the walk: acc += this source's share.  FIRST: the accumulators are not initialised yet and start from addv.
+  // ring = generic pointer to the ring.  PD = K-steps the fragment reads run ahead of the matrix cores (one wave per SIMD: nobody
+  // else covers the LDS round trip of the transposing reads, ~300 cycles with four waves queueing)
+  template <bool FIRST, int PD = 1>
+  __device__ __forceinline__ void compute(const unsigned char* ring, int i, bool top, bool bot, f32x4_t (&acc)[4], const f32x4_t (&addv)[4]) const {
+    const int cell0 = LF == 1 ? 2 * i : (LF == 2 ? i : (i >> 1));
+    unsigned s0b = (unsigned)((cell0 % NSLOT) * SLOT);     // byte offset of the slot of the step's first window row
+    asm volatile("" : "+s"(s0b));                          // (opaque: no unrolling over the ring's period with every address kept)
+    auto run = [&](auto which, auto phase) {
+      constexpr int PH = decltype(phase)::value, WH = decltype(which)::value;   // WH: 0 interior, 1 first step, 2 last step
+      // the fragments of K-step ks + 1 are read while the matrix cores work on K-step ks
+      tm_s16x8_t zb[PD + 1][4];
+      auto load = [&](int ks, tm_s16x8_t (&zf)[4]) {
+        unsigned ad[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned v = araddr[ks][h] + s0b;          // (window row + first slot) mod NSLOT: the offset stays below 2 BYTES
+          const unsigned t = v - (unsigned)BYTES;
+          ad[h] = v < t ? v : t;                           // unsigned min: t wrapped around when v < BYTES
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const tm_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(ring + (ad[0] ^ (unsigned)(nt << 5))));
+          const tm_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(ring + (ad[1] ^ (unsigned)(nt << 5))));
+          zf[nt] = tm_s16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      };
+#pragma unroll
+      for (int ks = 0; ks < PD; ++ks)
+        if (ks < NKS) load(ks, zb[ks % (PD + 1)]);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + PD < NKS) load(ks + PD, zb[(ks + PD) % (PD + 1)]);
+        const bf16x8_t w = WH == 1 ? wft[ks] : (WH == 2 ? wfb[ks] : wf[PH][ks]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zb[ks % (PD + 1)][nt]), w, (FIRST && ks == 0) ? addv[nt] : acc[nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // (the walk has at least two steps: the first one is never the last)
+    if (top) run(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    else if (bot) run(std::integral_constant<int, 2>{}, std::integral_constant<int, NPH - 1>{});
+    else if (NPH == 2 && (i & 1)) run(std::integral_constant<int, 0>{}, std::integral_constant<int, NPH - 1>{});
+    else run(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  }
+};
+
+struct TapRArgs {
+  const uint16_t* z;
+  uint16_t* out;
+  const float* addvec;
+  float* stats;
+  int Hi, Wi, N, Ho, Wo, B, relu;
+  int nstrips, G, ncols, nchunks;   // strips per image row, column groups per XCD, columns = B * chunks, chunks = N / 64
+};
+
+// accumulators of a step -> (ReLU) -> bf16 -> the LDS tile [4 rows][16 pixels] x 128 B, 16-byte slots swizzled by pixel
+__device__ __forceinline__ void roll_to_tile(unsigned char* tile, const f32x4_t (&acc)[4], int relu, int oxb0, int Wo, int lane, int wave) {
+  int t = lane;
+  asm volatile("" : "+v"(t));
+  const int l = t & 15, gq = t >> 4;
+  const int pp = (l >> 2) * 16 + 4 * wave + (l & 3);
+  const bool pxvalid = oxb0 + 4 * wave + (l & 3) < Wo;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int ch = 16 * nt + 4 * gq;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = acc[nt][e];
+      if (relu) v[e] = fmaxf(v[e], 0.f);
+      v[e] = pxvalid ? v[e] : 0.f;                         // columns beyond the image: zeros (not stored; the statistics count them as nothing)
+    }
+    *(uint2*)(tile + pp * 128 + ((((ch >> 3) ^ (pp & 7))) << 4) + (ch & 7) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+  }
+}
+
+template <int LF, bool STATS, int D>
+__global__ __launch_bounds__(256, LF == 2 ? 3 : 2) void resize_conv3x3_fwd_sum_roll_kernel(const TapRArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using S = RollSrc<LF, D>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = lane & 15, g = lane >> 4;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int grp = idx / a.nstrips, strip = idx - grp * a.nstrips;
+  const int oxb0 = strip * 16;
+  unsigned char* tile = smem;                              // [4 rows][16 pixels] x 128 B; the two weight tables during the set-up
+  const unsigned char* ring = smem + 4 * 16 * 128;
+  S s;
+  s.setup((float*)tile, (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)(smem + 4 * 16 * 128)),
+          a.Hi, a.Wi, a.Wo, a.N, oxb0, tid, wave);
   const int nsteps = a.Ho >> 2;
   const bool fullstrip = oxb0 + 16 <= a.Wo;                // every thread stores its two pieces of every tile
-  const int npw = (PIECES - wave + 3) / 4;                 // DMA instructions of this wave per window row
-  const int64_t row_bytes = (int64_t)a.Wi * 9 * a.N * 2;   // one low-resolution row of the source
+  const int npw = (S::PIECES - wave + 3) / 4;              // DMA instructions of this wave per window row
   const int gg = xcd * a.G + grp, gstride = 8 * a.G;
   bool primed = false;
   for (int col = gg; col < a.ncols; col += gstride) {
     const int b = col / a.nchunks, c = col - b * a.nchunks;
-    const srd_t srd = make_srd(a.z + (int64_t)b * a.Hi * a.Wi * 9 * a.N, (unsigned)((int64_t)a.Hi * row_bytes));
-    auto issue_row = [&](const srd_t& sd, int cc, int y, int slot) {      // logical row y (-1 .. Hi) of chunk cc -> ring slot
-      const int yc = y < 0 ? 0 : (y > a.Hi - 1 ? a.Hi - 1 : y);
-      const unsigned soff = (unsigned)((int64_t)yc * row_bytes) + (unsigned)(cc * 128);
-#pragma unroll
-      for (int i = 0; i < MAXP; ++i)
-        if (wave + 4 * i < PIECES) dma16_buf(doff[i], sd, soff, lds_ring + slot * SLOT + (wave + 4 * i) * 1024);
-    };
-    // the rows step s adds to the window (step 0: all of it), s0s = the ring slot of that step's first window row
-    auto issue_step = [&](const srd_t& sd, int cc, int s, int s0s) {
-      if (s == 0) {
-#pragma unroll
-        for (int y = 0; y < WIN; ++y) issue_row(sd, cc, y - 1, y);
-      } else {
-#pragma unroll
-        for (int j = 0; j < CPS; ++j) {
-          int slot = s0s + WIN - CPS + j;
-          slot -= slot >= NSLOT ? NSLOT : 0;
-          issue_row(sd, cc, s * CPS + WIN - CPS - 1 + j, slot);
-        }
-      }
-    };
     if (!primed) {
+      s.set_image(a.z, b);
 #pragma unroll
-      for (int s = 0; s < D; ++s)
-        if (s < nsteps) issue_step(srd, c, s, (s * CPS) % NSLOT);
+      for (int q = 0; q < D; ++q)
+        if (q < nsteps) s.issue_step(c, q, wave, 0u, false);
     }
     // the accumulators start from the per-channel addend (kept in registers for the column: no ordinary load -- whose wait the
     // compiler would place without knowing of the fetches in flight -- inside the step loop)
@@ -1505,78 +1618,28 @@ __global__ __launch_bounds__(256, LF == 2 ? 3 : 2) void resize_conv3x3_fwd_sum_r
         }
       }
     };
-    int s0 = 0;                                            // ring slot of the step's first window row
 #pragma unroll 1
     for (int i = 0; i < nsteps; ++i) {
-      asm volatile("" : "+s"(s0));                         // (opaque: the step loop is not unrolled over the ring's period with every fragment address kept)
       // (lgkmcnt(0) in every wait: hipcc drops its own LDS wait in front of the barrier below -- behind these asm statements the
       // last ds_write of the previous step's tile was still in flight when other waves read the tile: one patch row of the last
       // channel tile wrong in 1 of 4 launches)
       // this wave's pieces of step i's rows have landed.  Steady state (the fetch of step i was followed by two stores, then
       // D - 1 times by a fetch and two stores): those may stay in flight
       if (D > 1 && fullstrip && i > D && i + D <= nsteps) {
-        if (npw == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + (D - 1) * (2 * CPS + 2)) : "memory");
-        else if (npw == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + (D - 1) * (1 * CPS + 2)) : "memory");
+        if (npw == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + (D - 1) * (2 * S::RPS + 2)) : "memory");
+        else if (npw == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + (D - 1) * (1 * S::RPS + 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
       __syncthreads();                                    // ... everyone's; step i - 1 is computed and its tile written
-      if (i + D < nsteps) {
-        int sn = s0 + D * CPS;
-        sn -= sn >= NSLOT ? NSLOT : 0;
-        issue_step(srd, c, i + D, sn);
-      }
+      if (i + D < nsteps) s.issue_step(c, i + D, wave, 0u, false);
       if (i > 0) flush(i - 1);
       f32x4_t acc[4];
-      // ---- the step's four patches (one per wave) on the matrix cores: K-steps outside, the four channel tiles inside
-      const bool top = i == 0, bot = i == nsteps - 1;
-      auto run = [&](auto border) {
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          int slot = s0 + (int)((wyq >> (2 * ks)) & 3u);
-          slot -= slot >= NSLOT ? NSLOT : 0;
-          const int ad0 = raddr[ks][0] + slot * SLOT, ad1 = raddr[ks][1] + slot * SLOT;
-          bf16x8_t w = wf[ks];
-          if constexpr (decltype(border)::value) {
-            const bool kill = (top && ((ptop >> ks) & 1u)) || (bot && ((pbot >> ks) & 1u));
-            const uint4 wz = __builtin_bit_cast(uint4, w);
-            w = __builtin_bit_cast(bf16x8_t, make_uint4(kill ? 0u : wz.x, kill ? 0u : wz.y, kill ? 0u : wz.z, kill ? 0u : wz.w));
-          }
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const tm_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(ring + (ad0 ^ (nt << 5))));
-            const tm_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(ring + (ad1 ^ (nt << 5))));
-            const tm_s16x8_t zv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zv), w, ks == 0 ? addv[nt] : acc[nt], 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      if (top || bot) run(std::true_type{}); else run(std::false_type{});
+      s.template compute<true>(ring, i, i == 0, i == nsteps - 1, acc, addv);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __syncthreads();                                    // everyone has flushed the previous tile
-      {
-        int t = lane;
-        asm volatile("" : "+v"(t));
-        const int l = t & 15, gq = t >> 4;
-        const int pp = (l >> 2) * 16 + 4 * wave + (l & 3);
-        const bool pxvalid = oxb0 + 4 * wave + (l & 3) < a.Wo;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int ch = 16 * nt + 4 * gq;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = acc[nt][e];
-            if (a.relu) v[e] = fmaxf(v[e], 0.f);
-            v[e] = pxvalid ? v[e] : 0.f;                   // columns beyond the image: zeros (not stored; the statistics count them as nothing)
-          }
-          *(uint2*)(tile + pp * 128 + ((((ch >> 3) ^ (pp & 7))) << 4) + (ch & 7) * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        }
-      }
-      s0 += CPS;
-      s0 -= s0 >= NSLOT ? NSLOT : 0;
+      roll_to_tile(tile, acc, a.relu, oxb0, a.Wo, lane, wave);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                      // the last tile is written; nobody reads the ring any more
@@ -1584,10 +1647,10 @@ __global__ __launch_bounds__(256, LF == 2 ? 3 : 2) void resize_conv3x3_fwd_sum_r
     primed = ncol < a.ncols;
     if (primed) {                                          // the next column's first rows travel under this column's tail
       const int nb = ncol / a.nchunks, nc = ncol - nb * a.nchunks;
-      const srd_t nsrd = make_srd(a.z + (int64_t)nb * a.Hi * a.Wi * 9 * a.N, (unsigned)((int64_t)a.Hi * row_bytes));
+      s.set_image(a.z, nb);
 #pragma unroll
-      for (int s = 0; s < D; ++s)
-        if (s < nsteps) issue_step(nsrd, nc, s, (s * CPS) % NSLOT);
+      for (int q = 0; q < D; ++q)
+        if (q < nsteps) s.issue_step(nc, q, wave, 0u, false);
     }
     flush(nsteps - 1);
     if constexpr (STATS) {
@@ -1599,6 +1662,109 @@ __global__ __launch_bounds__(256, LF == 2 ? 3 : 2) void resize_conv3x3_fwd_sum_r
         srow[a.N] = e == 0 ? sd2[0] : (e == 1 ? sd2[1] : (e == 2 ? sd2[2] : sd2[3]));
       }
     }
+  }
+}
+
+struct TapR3Args {
+  const uint16_t* z[3];
+  int H[3], W[3];
+  uint16_t* out;
+  const float* addvec;
+  int N, Ho, Wo, B, relu;
+  int nstrips, nstreams, ncols, nchunks, nblocks;
+  int dbg;                          // tuning probes (gdl_debug_set_tapsum_roll >= 16): 16 = no matrix-core work, 32 = no row fetches after the first window, 64 = no stores
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void resize_conv3x3_fwd_sum_roll3_kernel(const TapR3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using SA = RollSrc<1, D>;
+  using SB = RollSrc<2, D>;
+  using SC = RollSrc<3, D>;
+  constexpr int NDMA = SA::NDMA + SB::NDMA + SC::NDMA;     // per wave and steady-state step
+  constexpr int OA = 4 * 16 * 128, OB = OA + SA::BYTES, OC = OB + SB::BYTES, OD = OC + SC::BYTES;   // rings and the spare KiB behind the tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroup -> (stream of columns, strip): the workgroups of one XCD take consecutive pairs, so the strips of a stream sit on one XCD
+  // (a stream that straddles two XCDs fetches the two window columns at that seam twice)
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  int pair = idx;
+  for (int x = 0; x < xcd; ++x) pair += (a.nblocks - x + 7) >> 3;
+  const int stream = pair / a.nstrips, strip = pair - stream * a.nstrips;
+  const int oxb0 = strip * 16;
+  unsigned char* tile = smem;
+  auto lds_of = [](unsigned char* p) { return (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)p); };
+  const unsigned lds_dummy = lds_of(smem + OD);
+  SA sa; SB sb; SC sc;
+  sa.setup((float*)tile, lds_of(smem + OA), a.H[0], a.W[0], a.Wo, a.N, oxb0, tid, wave);
+  sb.setup((float*)tile, lds_of(smem + OB), a.H[1], a.W[1], a.Wo, a.N, oxb0, tid, wave);
+  sc.setup((float*)tile, lds_of(smem + OC), a.H[2], a.W[2], a.Wo, a.N, oxb0, tid, wave);
+  const int nsteps = a.Ho >> 2;
+  const bool fullstrip = oxb0 + 16 <= a.Wo;
+  const int g = lane >> 4;
+  bool primed = false;
+  for (int col = stream; col < a.ncols; col += a.nstreams) {
+    const int b = col / a.nchunks, c = col - b * a.nchunks;
+    if (!primed) {
+      sa.set_image(a.z[0], b); sb.set_image(a.z[1], b); sc.set_image(a.z[2], b);
+#pragma unroll
+      for (int s = 0; s < D; ++s)
+        if (s < nsteps) { sa.issue_step(c, s, wave, lds_dummy, false); sb.issue_step(c, s, wave, lds_dummy, false); sc.issue_step(c, s, wave, lds_dummy, false); }
+    }
+    f32x4_t addv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const float4 v = a.addvec ? *(const float4*)(a.addvec + c * 64 + 16 * nt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      addv[nt] = f32x4_t{v.x, v.y, v.z, v.w};
+    }
+    uint16_t* obase = a.out + (int64_t)b * a.Ho * a.Wo * a.N + c * 64;
+    auto flush = [&](int step) {
+      int t = tid;
+      asm volatile("" : "+v"(t));
+      uint16_t* orow = obase + (int64_t)step * 4 * a.Wo * a.N;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = t + 256 * u, pp = i >> 3, chunk = i & 7;
+        const uint4 v = *(const uint4*)(tile + pp * 128 + ((chunk ^ (pp & 7)) << 4));
+        if (oxb0 + (pp & 15) < a.Wo) *(uint4*)(orow + ((int64_t)(pp >> 4) * a.Wo + oxb0 + (pp & 15)) * a.N + chunk * 8) = v;
+      }
+    };
+#pragma unroll 1
+    for (int i = 0; i < nsteps; ++i) {
+      // (lgkmcnt(0) with every wait: see the one-source kernel)
+      if (D > 1 && fullstrip && i > D && i + D <= nsteps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + (D - 1) * (NDMA + 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (i + D < nsteps && !(a.dbg & 32)) {
+        sa.issue_step(c, i + D, wave, lds_dummy, true); sb.issue_step(c, i + D, wave, lds_dummy, true); sc.issue_step(c, i + D, wave, lds_dummy, true);
+      }
+      if (i > 0 && !(a.dbg & 64)) flush(i - 1);
+      f32x4_t acc[4];
+      const bool top = i == 0, bot = i == nsteps - 1;
+      if (a.dbg & 16) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = addv[nt];
+      } else {
+        sa.template compute<true, 2>(smem + OA, i, top, bot, acc, addv);
+        sb.template compute<false, 2>(smem + OB, i, top, bot, acc, addv);
+        sc.template compute<false, 2>(smem + OC, i, top, bot, acc, addv);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      roll_to_tile(tile, acc, a.relu, oxb0, a.Wo, lane, wave);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int ncol = col + a.nstreams;
+    primed = ncol < a.ncols;
+    if (primed) {
+      const int nb = ncol / a.nchunks, nc = ncol - nb * a.nchunks;
+      sa.set_image(a.z[0], nb); sb.set_image(a.z[1], nb); sc.set_image(a.z[2], nb);
+#pragma unroll
+      for (int s = 0; s < D; ++s)
+        if (s < nsteps) { sa.issue_step(nc, s, wave, lds_dummy, false); sb.issue_step(nc, s, wave, lds_dummy, false); sc.issue_step(nc, s, wave, lds_dummy, false); }
+    }
+    flush(nsteps - 1);
   }
 }
 
@@ -2101,8 +2267,27 @@ static int tapsum_launch(const void* const* zs, const int* hs, const int* ws, in
     m.nsrc = nsrc; m.N = N; m.Ho = Ho; m.Wo = Wo; m.B = B; m.out = (uint16_t*)out; m.addvec = addvec; m.relu = relu;
     m.nslots = 0; m.slot_off[0] = m.slot_off[1] = m.slot_off[2] = 0;
     if (stat_rows) *stat_rows = (int64_t)B * ((Ho + 3) / 4) * ((Wo + 15) / 16);
+    // version 3 for the three upsampled levels of fpn_bottleneck: factors 2, 4, 8 in that order, whole cells of the coarsest one
+    if (g_tapsum_roll && !stats && nsrc == 3 && m.LF[0] == 1 && m.LF[1] == 2 && m.LF[2] == 3 && Ho % 8 == 0 && g_tapsum_mfma == 1) {
+      constexpr int D3 = 2;
+      TapR3Args r;
+      for (int k = 0; k < 3; ++k) { r.z[k] = m.z[k]; r.H[k] = m.H[k]; r.W[k] = m.W[k]; }
+      r.out = m.out; r.addvec = addvec; r.N = N; r.Ho = Ho; r.Wo = Wo; r.B = B; r.relu = relu;
+      r.nstrips = (Wo + 15) / 16; r.nchunks = N / 64; r.ncols = B * r.nchunks;
+      int streams = tapsum_num_cus() / r.nstrips;            // one workgroup per CU
+      if (streams > r.ncols) streams = r.ncols;
+      if (streams < 1) streams = 1;
+      r.nstreams = streams; r.nblocks = streams * r.nstrips;
+      r.dbg = g_tapsum_roll >= 16 ? g_tapsum_roll : 0;
+      const size_t lds = 4 * 16 * 128 + RollSrc<1, D3>::BYTES + RollSrc<2, D3>::BYTES + RollSrc<3, D3>::BYTES + 1024;
+      static_assert(4 * 16 * 128 + RollSrc<1, D3>::BYTES + RollSrc<2, D3>::BYTES + RollSrc<3, D3>::BYTES + 1024 <= 160 * 1024, "LDS budget");
+      GDL_SET_MAX_LDS_ONCE((resize_conv3x3_fwd_sum_roll3_kernel<D3>), 160 * 1024);
+      hipLaunchKernelGGL((resize_conv3x3_fwd_sum_roll3_kernel<D3>), dim3((unsigned)r.nblocks), dim3(256), lds, st, r);
+      GDL_CHECK_LAUNCH("gdl_resize_conv3x3_fwd_sum");
+      return GDL_OK;
+    }
     // version 3 (rolling row window): one source of factor 2 or 4 whose output rows come in whole patches
-    if (g_tapsum_roll && nsrc == 1 && (m.LF[0] == 1 || m.LF[0] == 2) && Ho % 4 == 0 && (g_tapsum_mfma == 1 || stats)) {
+    if (g_tapsum_roll && nsrc == 1 && (m.LF[0] == 1 || m.LF[0] == 2) && Ho % 4 == 0 && Ho >= 8 && (g_tapsum_mfma == 1 || stats)) {
       TapRArgs r;
       r.z = m.z[0]; r.out = m.out; r.addvec = addvec; r.stats = stats;
       r.Hi = m.H[0]; r.Wi = m.W[0]; r.N = N; r.Ho = Ho; r.Wo = Wo; r.B = B; r.relu = relu;

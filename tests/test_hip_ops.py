@@ -1542,7 +1542,8 @@ def test_resize_conv3x3_bwd_gather_with_batchnorm_backward_fused(B, Hi, Wi, N, f
                                                  (2, 16, 24, 64, (2, 4, 8), 0), (1, 8, 8, 72, (4, 2), 0), (2, 12, 20, 64, (4,), 4),
                                                  (1, 2, 2, 64, (2,), 0), (1, 18, 14, 64, (2,), 0), (1, 8, 72, 128, (4,), 0),
                                                  (2, 32, 48, 192, (8, 4), 0), (1, 144, 144, 64, (2, 4, 8), 0),
-                                                 (4, 240, 256, 64, (4,), 0), (3, 160, 192, 128, (8,), 0)])   # 3840 / 1440 patches: persistent workgroups take several
+                                                 (4, 240, 256, 64, (4,), 0), (3, 160, 192, 128, (8,), 0),    # 3840 / 1440 patches: persistent workgroups take several
+                                                 (4, 32, 272, 384, (2, 4, 8), 0), (1, 8, 16, 64, (2, 4, 8), 0)])   # three rolling rings: several columns per workgroup; one cell of the coarsest level
 def test_resize_conv3x3_fwd_sum(dtype, B, H, W, N, factors, vec, mfma):
     """sum_k sum_t shift_t(bilinear(z_k,t)) (gdl_resize_conv3x3_fwd_sum), the pixel side of the low-resolution forward of
     conv3x3(pad 1)(bilinear resize(x)) (multilevel_neck.py:157-158, upernet.py:144-152): vs torch's interpolate / pad / slice
@@ -1821,7 +1822,13 @@ def test_resize_conv3x3_fwd_sum_with_batchnorm_statistics(B, H, W, N, factors):
     y0 = ops.resize_conv3x3_fwd_sum(zs, (H, W), addvec=add)
     rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
     y, mean, var = ops.resize_conv3x3_fwd_sum_bn(zs, (H, W), addvec=add, running_mean=rm, running_var=rv, momentum=0.1)
-    assert torch.equal(y, y0)
+    if factors == (2, 4, 8):
+        # round 6: the plain call walks three rolling rings (version 3), the statistics variant of three sources is version 2:
+        # the same products in another summation order -- one bf16 step apart at most, and rarely
+        d = (y.float() - y0.float()).abs()
+        assert d.max().item() <= 2.0 ** -7 * y0.float().abs().max().item() and (d > 0).float().mean().item() < 0.02
+    else:
+        assert torch.equal(y, y0)
     bn = torch.nn.BatchNorm2d(N).train()
     bn(y.float().cpu().permute(0, 3, 1, 2))
     yf = y.float().cpu().reshape(-1, N)
