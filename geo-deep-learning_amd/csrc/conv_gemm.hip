@@ -537,7 +537,9 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
     if (g_persist_enabled && t256 > 256 && conv_gemm_persist_applicable(a)) return 9;
     return (g_sf_enabled && conv3x3_sf_applicable(a)) ? 4 : 3;   // ping-pong 256^2 (4: 3x3 with shared staging)
   }
-  if (t128 >= 256 && a.N >= 128) return 1;
+  // (224: the reference's own per-GPU batch 4 gives M = 5188 / 5184 -> 246 tiles for the N = 768 layers; one round of 128^2 tiles on 246 of
+  // 256 CUs beats four rounds of 64^2 tiles: ViT proj 20.0 -> 16.3 us, fc2 48.0 -> 43.0, the neck's 3x3 at 36^2 86.1 -> 80.0; tools/bench_small_m.py)
+  if (t128 >= 224 && a.N >= 128) return 1;
   // narrow outputs (N <= 64: UNet++ decoder, ResNet layer1, MiT stage 1): a 256 (m) x 64 (n) tile, four waves of
   // 64 x 64 -- one LDS fragment read per MFMA instead of the two of the 64^2 tile's 32 x 32 waves
   if (!extra && a.N <= 64 && ((M + 255) / 256) * a.nz >= 256) return 5;

@@ -410,6 +410,7 @@ struct W256 {
   WArgs w;
   unsigned in_span, dy_span;   // bytes, < 2 GiB
   int tiles_n, tiles_y;        // n tiles, taps * c tiles
+  int xcd_group;               // 8 = workgroup ids as dealt by the hardware
 };
 
 
@@ -427,7 +428,15 @@ __global__ __launch_bounds__(512) void wgrad_tr256_kernel(const W256 kk) {
 
   // 1-D grid in (n-tile, tap * c-tile, split) order.  An XCD-major remap (all tiles of one pixel range on one XCD)
   // was measured 5 % SLOWER here: the blocks of a split then pull the same lines from one L2 at the same time.
-  const int lid = blockIdx.x;
+  int lid = blockIdx.x;
+  if (kk.xcd_group < 8) {
+    // experiment (GDL_WGRAD_XCD_GROUP): the workgroups of neighbouring logical ids on xcd_group XCDs instead of all eight
+    const int G = kk.xcd_group, nb = (int)gridDim.x, q8 = nb >> 3, r8 = nb & 7;
+    const int x = lid & 7, i = lid >> 3, s = x / G, m = x - s * G;
+    int base = 0;
+    for (int xx = 0; xx < s * G; ++xx) base += q8 + (xx < r8 ? 1 : 0);
+    lid = base + i * G + m;
+  }
   const int per_split = kk.tiles_n * kk.tiles_y;
   const int bz = lid / per_split, bt = lid - bz * per_split;
   const int by = bt / kk.tiles_n, bx = bt - by * kk.tiles_n;
@@ -954,6 +963,8 @@ int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
 
 static std::atomic<int> g_wgrad_force_v1{0};
 extern "C" void gdl_debug_set_wgrad_old_splits(int on) { g_wgrad_old_splits = on; }  // A/B hook: round-3 split-K rule
+static int g_wgrad_xcd_group = 8;
+extern "C" void gdl_debug_set_wgrad_xcd_group(int g) { g_wgrad_xcd_group = (g == 1 || g == 2 || g == 4) ? g : 8; }   // A/B hook: XCDs a pixel range's tiles are dealt to
 extern "C" void gdl_debug_set_wgrad_rows_xcd(int on) { g_wgrad_rows_xcd = on; }      // A/B hook: XCD grouping of the row-segment kernel
 extern "C" void gdl_debug_force_wgrad_small(int on) { g_wgrad_force_small = on; }  // A/B hook: 128^2 tiles only
 extern "C" void gdl_debug_force_wgrad_v1(int on) { g_wgrad_force_v1 = on; }  // A/B hook: register-transpose kernel
@@ -1025,6 +1036,7 @@ extern "C" int gdl_conv_wgrad(const gdl_wgrad_args* ap, gdl_stream_t stream) {
     GDL_SET_MAX_LDS_ONCE(wgrad_tr256_kernel, 128 * 1024);
     kb.tiles_n = (a.N + 255) / 256;
     kb.tiles_y = a.R * a.S * kb.w.ctiles;
+    kb.xcd_group = g_wgrad_xcd_group;
     dim3 gridb((unsigned)((int64_t)kb.tiles_n * kb.tiles_y * a.nz * k.splits));
     hipLaunchKernelGGL(wgrad_tr256_kernel, gridb, dim3(512), 128 * 1024, s, kb);
   } else if (a.dtype == GDL_BF16 && !g_wgrad_force_v1) hipLaunchKernelGGL(wgrad_tr_kernel, grid, dim3(256), lds, s, k);

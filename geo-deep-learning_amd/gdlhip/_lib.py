@@ -226,6 +226,9 @@ def load() -> C.CDLL:
     if os.environ.get("GDL_GATHER_MFMA") is not None:     # tuning hook: 0 = the VALU gathers of the low-resolution backward
         lib.gdl_debug_set_gather_mfma.argtypes = [C.c_int]
         lib.gdl_debug_set_gather_mfma(int(os.environ["GDL_GATHER_MFMA"]))
+    if os.environ.get("GDL_WGRAD_XCD_GROUP") is not None:   # tuning hook: XCDs (1, 2, 4; 8 = all) the tiles of a pixel range of the 256^2 weight-gradient kernel are dealt to
+        lib.gdl_debug_set_wgrad_xcd_group.argtypes = [C.c_int]
+        lib.gdl_debug_set_wgrad_xcd_group(int(os.environ["GDL_WGRAD_XCD_GROUP"]))
     if os.environ.get("GDL_WGRAD_OLD_SPLITS") is not None:   # tuning hook: 1 = the round-3 split-K rule of the 256^2 weight-gradient kernel
         lib.gdl_debug_set_wgrad_old_splits.argtypes = [C.c_int]
         lib.gdl_debug_set_wgrad_old_splits(int(os.environ["GDL_WGRAD_OLD_SPLITS"]))
