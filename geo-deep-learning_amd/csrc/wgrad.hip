@@ -426,11 +426,13 @@ __global__ __launch_bounds__(512) void wgrad_tr256_kernel(const W256 kk) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  // 1-D grid in (n-tile, tap * c-tile, split) order.  An XCD-major remap (all tiles of one pixel range on one XCD)
-  // was measured 5 % SLOWER here: the blocks of a split then pull the same lines from one L2 at the same time.
+  // 1-D grid in (n-tile, tap * c-tile, split) order, XCD-major since round 6: the tiles of one pixel range sit on ONE XCD and
+  // share its L2 (the hardware deals consecutive workgroup ids to the eight XCDs in turn, so every L2 used to fetch every panel:
+  // PMC 1.28 GB fetched per launch at batch 64, L2 hit 0.32).  The same remap was 5 % slower under the round-3 split rule;
+  // with round 4's fewer, longer splits three same-box A/B runs of the whole step give +0.45 % (991.2 -> 995.7 train tiles/s;
+  // 2 / 4 XCDs per range: +0.2 / +0.3 %).  xcd_group = 8 (gdl_debug_set_wgrad_xcd_group) restores the hardware order.
   int lid = blockIdx.x;
   if (kk.xcd_group < 8) {
-    // experiment (GDL_WGRAD_XCD_GROUP): the workgroups of neighbouring logical ids on xcd_group XCDs instead of all eight
     const int G = kk.xcd_group, nb = (int)gridDim.x, q8 = nb >> 3, r8 = nb & 7;
     const int x = lid & 7, i = lid >> 3, s = x / G, m = x - s * G;
     int base = 0;
@@ -963,7 +965,7 @@ int choose_splits(const gdl_wgrad_args& a, int64_t P, int bkp) {
 
 static std::atomic<int> g_wgrad_force_v1{0};
 extern "C" void gdl_debug_set_wgrad_old_splits(int on) { g_wgrad_old_splits = on; }  // A/B hook: round-3 split-K rule
-static int g_wgrad_xcd_group = 8;
+static int g_wgrad_xcd_group = 1;
 extern "C" void gdl_debug_set_wgrad_xcd_group(int g) { g_wgrad_xcd_group = (g == 1 || g == 2 || g == 4) ? g : 8; }   // A/B hook: XCDs a pixel range's tiles are dealt to
 extern "C" void gdl_debug_set_wgrad_rows_xcd(int on) { g_wgrad_rows_xcd = on; }      // A/B hook: XCD grouping of the row-segment kernel
 extern "C" void gdl_debug_force_wgrad_small(int on) { g_wgrad_force_small = on; }  // A/B hook: 128^2 tiles only
