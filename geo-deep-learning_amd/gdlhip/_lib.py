@@ -11,7 +11,8 @@ import ctypes as C
 import os
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libgdlhip.so"
+# GDL_LIB_PATH: an A/B build of the same sources (csrc/Makefile: BUILD= OUT= EXTRA=), for same-box comparisons only
+LIB_PATH = Path(os.environ.get("GDL_LIB_PATH") or Path(__file__).resolve().parent / "libgdlhip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_MUL_GELU_GRAD, ACT_RESID_RELU = 0, 1, 2, 3, 4
