@@ -1346,16 +1346,17 @@ __global__ __launch_bounds__(256, NSRC == 1 ? 3 : 1) void resize_conv3x3_fwd_sum
 // row phases with their own weight fragments, a new window row every other step.  One workgroup per CU (the three rings are
 // 96 + 35 + 20 KiB at D = 2); pieces a wave does not have, and the factor-8 source's idle steps, are fetches whose lanes are all
 // out of range (zeros into a spare KiB, no memory traffic), so one vmcnt immediate serves every wave and step.
-template <int LF, int D>
+template <int LF, int D, int NW = 4>                       // NW: waves of the workgroup (4: a wave owns a patch; 8: a patch and half of its channel tiles)
 struct RollSrc {
   static constexpr int WIN = LF == 1 ? 4 : 3, NPH = LF == 3 ? 2 : 1;
   static constexpr int NA = 3 * WIN, KR = NA * NA, NKS = (KR + 31) / 32;
   static constexpr int WC = (12 >> LF) + WIN, ROWS = WC * 9, PIECES = (ROWS + 7) / 8, SLOT = PIECES * 1024;
   static constexpr int RPS = LF == 1 ? 2 : 1;              // new window rows of a step that fetches
   static constexpr int NSLOT = WIN + (LF == 3 ? (D + 1) / 2 : D * RPS);
-  static constexpr int MAXP = (PIECES + 3) / 4, NDMA = RPS * MAXP, BYTES = NSLOT * SLOT;
+  static constexpr int MAXP = (PIECES + NW - 1) / NW, NDMA = RPS * MAXP, BYTES = NSLOT * SLOT;
+  static constexpr int NMW = (NKS + 3) / 4;
   bf16x8_t wf[NPH][NKS];                                   // weight fragments (B operand: column = pixel of the patch)
-  bf16x8_t wft[NKS], wfb[NKS];                             // ... of the first step (first phase) / the last step (last phase)
+  unsigned mtop[NMW], mbot[NMW];                           // bit 8 (ks % 4) + e of word ks / 4: element e of K-step ks is zero in the first / last step
   unsigned araddr[NKS][2];                                 // ring-relative byte offset of the lane's two fragment pieces, window row 0 of the step in slot 0
   unsigned doff[MAXP];
   srd_t srd;
@@ -1384,7 +1385,7 @@ struct RollSrc {
       }
       TY[ph * 64 + q] = w;
     }
-    {
+    if (tid < 256) {
       const int pc = tid >> 4, bi = tid & 15;
       float w = 0.f;
       if (bi < NA) {
@@ -1399,11 +1400,14 @@ struct RollSrc {
       TX[tid] = w;
     }
     __syncthreads();
-    const int wcj = (4 * wave) >> LF, wcb0 = (oxb0 >> LF) - 1;
-    const int py = L >> 2, px = 4 * wave + (L & 3);
+    const int pw = wave & 3;                               // the wave's patch
+    const int wcj = (4 * pw) >> LF, wcb0 = (oxb0 >> LF) - 1;
+    const int py = L >> 2, px = 4 * pw + (L & 3);
+#pragma unroll
+    for (int q = 0; q < NMW; ++q) { mtop[q] = 0u; mbot[q] = 0u; }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      float wv[NPH][8], wt[8], wb[8];
+      float wv[NPH][8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = 32 * ks + 8 * g + e;
@@ -1413,15 +1417,13 @@ struct RollSrc {
         const int r = ai / WIN;
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) wv[ph][e] = ok ? TY[ph * 64 + py * 12 + ai] * tx : 0.f;
-        wt[e] = (py == 0 && r == 0) ? 0.f : wv[0][e];                 // tap row -1 of output row 0
-        wb[e] = (py == 3 && r == 2) ? 0.f : wv[NPH - 1][e];           // tap row Ho of output row Ho - 1
+        if (ok && py == 0 && r == 0) mtop[ks >> 2] |= 1u << (8 * (ks & 3) + e);      // tap row -1 of output row 0
+        if (ok && py == 3 && r == 2) mbot[ks >> 2] |= 1u << (8 * (ks & 3) + e);      // tap row Ho of output row Ho - 1
       }
 #pragma unroll
       for (int ph = 0; ph < NPH; ++ph)
         wf[ph][ks] = __builtin_bit_cast(bf16x8_t, make_uint4(pack_bf16x2(wv[ph][0], wv[ph][1]), pack_bf16x2(wv[ph][2], wv[ph][3]),
                                                              pack_bf16x2(wv[ph][4], wv[ph][5]), pack_bf16x2(wv[ph][6], wv[ph][7])));
-      wft[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(pack_bf16x2(wt[0], wt[1]), pack_bf16x2(wt[2], wt[3]), pack_bf16x2(wt[4], wt[5]), pack_bf16x2(wt[6], wt[7])));
-      wfb[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(pack_bf16x2(wb[0], wb[1]), pack_bf16x2(wb[2], wb[3]), pack_bf16x2(wb[4], wb[5]), pack_bf16x2(wb[6], wb[7])));
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int k = 32 * ks + 8 * g + 4 * h + (L >> 2);  // the fragment row this lane supplies (ds_read_b64_tr_b16: four rows x four channel quads per 16 lanes)
@@ -1434,7 +1436,7 @@ struct RollSrc {
     }
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-      const int piece = wave + 4 * i;
+      const int piece = wave + NW * i;
       const int R = piece * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ tm_swz(R);
       const int pc = R / 9, t = R - pc * 9;
@@ -1454,7 +1456,7 @@ struct RollSrc {
     const unsigned soff = (unsigned)((int64_t)yc * row_bytes) + (unsigned)(cc * 128);
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
-      if (wave + 4 * i < PIECES) dma16_buf(doff[i], srd, soff, lds + slot * SLOT + (wave + 4 * i) * 1024);
+      if (wave + NW * i < PIECES) dma16_buf(doff[i], srd, soff, lds + slot * SLOT + (wave + NW * i) * 1024);
       else if (pad) dma16_buf(kTmOob, srd, 0u, lds_dummy);
     }
   }
@@ -1476,19 +1478,19 @@ struct RollSrc {
       }
     }
   }
-  // step i of the walk: acc += this source's share.  FIRST: the accumulators are not initialised yet and start from addv.
-  // ring = generic pointer to the ring.  PD = K-steps the fragment reads run ahead of the matrix cores (one wave per SIMD: nobody
-  // else covers the LDS round trip of the transposing reads, ~300 cycles with four waves queueing)
-  template <bool FIRST, int PD = 1>
-  __device__ __forceinline__ void compute(const unsigned char* ring, int i, bool top, bool bot, f32x4_t (&acc)[4], const f32x4_t (&addv)[4]) const {
+  // step i of the walk: acc += this source's share, for the NTN channel tiles nt0 .. of the wave's patch.  FIRST: the accumulators
+  // are not initialised yet and start from addv.  ring = generic pointer to the ring.  PD = K-steps the fragment reads run ahead
+  // of the matrix cores.
+  template <bool FIRST, int PD, int NTN>
+  __device__ __forceinline__ void compute(const unsigned char* ring, int i, bool top, bool bot, int nt0, f32x4_t (&acc)[NTN],
+                                          const f32x4_t (&addv)[NTN]) const {
     const int cell0 = LF == 1 ? 2 * i : (LF == 2 ? i : (i >> 1));
     unsigned s0b = (unsigned)((cell0 % NSLOT) * SLOT);     // byte offset of the slot of the step's first window row
     asm volatile("" : "+s"(s0b));                          // (opaque: no unrolling over the ring's period with every address kept)
     auto run = [&](auto which, auto phase) {
       constexpr int PH = decltype(phase)::value, WH = decltype(which)::value;   // WH: 0 interior, 1 first step, 2 last step
-      // the fragments of K-step ks + 1 are read while the matrix cores work on K-step ks
-      tm_s16x8_t zb[PD + 1][4];
-      auto load = [&](int ks, tm_s16x8_t (&zf)[4]) {
+      tm_s16x8_t zb[PD + 1][NTN];
+      auto load = [&](int ks, tm_s16x8_t (&zf)[NTN]) {
         unsigned ad[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1497,10 +1499,11 @@ struct RollSrc {
           ad[h] = v < t ? v : t;                           // unsigned min: t wrapped around when v < BYTES
         }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const tm_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(ring + (ad[0] ^ (unsigned)(nt << 5))));
-          const tm_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(ring + (ad[1] ^ (unsigned)(nt << 5))));
-          zf[nt] = tm_s16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        for (int j = 0; j < NTN; ++j) {
+          const unsigned xm = (unsigned)((nt0 + j) << 5);
+          const tm_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(ring + (ad[0] ^ xm)));
+          const tm_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tm_lds_s16x4_ptr)(ring + (ad[1] ^ xm)));
+          zf[j] = tm_s16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
       };
 #pragma unroll
@@ -1509,10 +1512,21 @@ struct RollSrc {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         if (ks + PD < NKS) load(ks + PD, zb[(ks + PD) % (PD + 1)]);
-        const bf16x8_t w = WH == 1 ? wft[ks] : (WH == 2 ? wfb[ks] : wf[PH][ks]);
+        bf16x8_t w = wf[PH][ks];
+        if constexpr (WH != 0) {                           // the zero padding: two steps of a column pay ~25 instructions per K-step here
+          const unsigned bits = ((WH == 1 ? mtop[ks >> 2] : mbot[ks >> 2]) >> (8 * (ks & 3))) & 0xffu;
+          const uint4 wz = __builtin_bit_cast(uint4, w);
+          unsigned wr[4] = {wz.x, wz.y, wz.z, wz.w};
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zb[ks % (PD + 1)][nt]), w, (FIRST && ks == 0) ? addv[nt] : acc[nt], 0, 0, 0);
+          for (int q = 0; q < 4; ++q) {
+            const unsigned m2 = (bits >> (2 * q)) & 3u;
+            wr[q] &= ~(((m2 & 1u) * 0xffffu) | ((m2 >> 1) * 0xffff0000u));
+          }
+          w = __builtin_bit_cast(bf16x8_t, make_uint4(wr[0], wr[1], wr[2], wr[3]));
+        }
+#pragma unroll
+        for (int j = 0; j < NTN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zb[ks % (PD + 1)][j]), w, (FIRST && ks == 0) ? addv[j] : acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -1534,19 +1548,20 @@ struct TapRArgs {
 };
 
 // accumulators of a step -> (ReLU) -> bf16 -> the LDS tile [4 rows][16 pixels] x 128 B, 16-byte slots swizzled by pixel
-__device__ __forceinline__ void roll_to_tile(unsigned char* tile, const f32x4_t (&acc)[4], int relu, int oxb0, int Wo, int lane, int wave) {
+template <int NTN>
+__device__ __forceinline__ void roll_to_tile(unsigned char* tile, const f32x4_t (&acc)[NTN], int relu, int oxb0, int Wo, int lane, int pw, int nt0) {
   int t = lane;
   asm volatile("" : "+v"(t));
   const int l = t & 15, gq = t >> 4;
-  const int pp = (l >> 2) * 16 + 4 * wave + (l & 3);
-  const bool pxvalid = oxb0 + 4 * wave + (l & 3) < Wo;
+  const int pp = (l >> 2) * 16 + 4 * pw + (l & 3);
+  const bool pxvalid = oxb0 + 4 * pw + (l & 3) < Wo;
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int ch = 16 * nt + 4 * gq;
+  for (int j = 0; j < NTN; ++j) {
+    const int ch = 16 * (nt0 + j) + 4 * gq;
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      v[e] = acc[nt][e];
+      v[e] = acc[j][e];
       if (relu) v[e] = fmaxf(v[e], 0.f);
       v[e] = pxvalid ? v[e] : 0.f;                         // columns beyond the image: zeros (not stored; the statistics count them as nothing)
     }
@@ -1636,10 +1651,10 @@ __global__ __launch_bounds__(256, LF == 2 ? 3 : 2) void resize_conv3x3_fwd_sum_r
       if (i + D < nsteps) s.issue_step(c, i + D, wave, 0u, false);
       if (i > 0) flush(i - 1);
       f32x4_t acc[4];
-      s.template compute<true>(ring, i, i == 0, i == nsteps - 1, acc, addv);
+      s.template compute<true, 1, 4>(ring, i, i == 0, i == nsteps - 1, 0, acc, addv);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __syncthreads();                                    // everyone has flushed the previous tile
-      roll_to_tile(tile, acc, a.relu, oxb0, a.Wo, lane, wave);
+      roll_to_tile<4>(tile, acc, a.relu, oxb0, a.Wo, lane, wave, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                      // the last tile is written; nobody reads the ring any more
@@ -1675,16 +1690,21 @@ struct TapR3Args {
   int dbg;                          // tuning probes (gdl_debug_set_tapsum_roll >= 16): 16 = no matrix-core work, 32 = no row fetches after the first window, 64 = no stores
 };
 
+// 512 threads: wave w works on patch w & 3 and the channel tiles 2 (w >> 2), 2 (w >> 2) + 1 -- two waves per SIMD, so that one's LDS
+// round trips and address arithmetic run under the other's matrix-core work (with 256 threads the waves were issuing 60 % of
+// their cycles and parked the rest: 720 us of compute against 608 us for all memory traffic)
 template <int D>
-__global__ __launch_bounds__(256, 1) void resize_conv3x3_fwd_sum_roll3_kernel(const TapR3Args a) {
+__global__ __launch_bounds__(512, 1) void resize_conv3x3_fwd_sum_roll3_kernel(const TapR3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using SA = RollSrc<1, D>;
-  using SB = RollSrc<2, D>;
-  using SC = RollSrc<3, D>;
+  constexpr int NW = 8, NTN = 2;
+  using SA = RollSrc<1, D, NW>;
+  using SB = RollSrc<2, D, NW>;
+  using SC = RollSrc<3, D, NW>;
   constexpr int NDMA = SA::NDMA + SB::NDMA + SC::NDMA;     // per wave and steady-state step
   constexpr int OA = 4 * 16 * 128, OB = OA + SA::BYTES, OC = OB + SB::BYTES, OD = OC + SC::BYTES;   // rings and the spare KiB behind the tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pw = wave & 3, nt0 = 2 * (wave >> 2);
   // workgroup -> (stream of columns, strip): the workgroups of one XCD take consecutive pairs, so the strips of a stream sit on one XCD
   // (a stream that straddles two XCDs fetches the two window columns at that seam twice)
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -1711,47 +1731,45 @@ __global__ __launch_bounds__(256, 1) void resize_conv3x3_fwd_sum_roll3_kernel(co
       for (int s = 0; s < D; ++s)
         if (s < nsteps) { sa.issue_step(c, s, wave, lds_dummy, false); sb.issue_step(c, s, wave, lds_dummy, false); sc.issue_step(c, s, wave, lds_dummy, false); }
     }
-    f32x4_t addv[4];
+    f32x4_t addv[NTN];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const float4 v = a.addvec ? *(const float4*)(a.addvec + c * 64 + 16 * nt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-      addv[nt] = f32x4_t{v.x, v.y, v.z, v.w};
+    for (int j = 0; j < NTN; ++j) {
+      const float4 v = a.addvec ? *(const float4*)(a.addvec + c * 64 + 16 * (nt0 + j) + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      addv[j] = f32x4_t{v.x, v.y, v.z, v.w};
     }
     uint16_t* obase = a.out + (int64_t)b * a.Ho * a.Wo * a.N + c * 64;
-    auto flush = [&](int step) {
+    auto flush = [&](int step) {                           // 512 threads x 16 bytes = the tile
       int t = tid;
       asm volatile("" : "+v"(t));
       uint16_t* orow = obase + (int64_t)step * 4 * a.Wo * a.N;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int i = t + 256 * u, pp = i >> 3, chunk = i & 7;
-        const uint4 v = *(const uint4*)(tile + pp * 128 + ((chunk ^ (pp & 7)) << 4));
-        if (oxb0 + (pp & 15) < a.Wo) *(uint4*)(orow + ((int64_t)(pp >> 4) * a.Wo + oxb0 + (pp & 15)) * a.N + chunk * 8) = v;
-      }
+      const int pp = t >> 3, chunk = t & 7;
+      const uint4 v = *(const uint4*)(tile + pp * 128 + ((chunk ^ (pp & 7)) << 4));
+      if (oxb0 + (pp & 15) < a.Wo) *(uint4*)(orow + ((int64_t)(pp >> 4) * a.Wo + oxb0 + (pp & 15)) * a.N + chunk * 8) = v;
     };
 #pragma unroll 1
     for (int i = 0; i < nsteps; ++i) {
-      // (lgkmcnt(0) with every wait: see the one-source kernel)
-      if (D > 1 && fullstrip && i > D && i + D <= nsteps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + (D - 1) * (NDMA + 2)) : "memory");
+      // (lgkmcnt(0) with every wait: see the one-source kernel.)  Steady state: the fetch of step i was followed by one store, then
+      // D - 1 times by a fetch (NDMA instructions in every wave) and a store
+      if (D > 1 && fullstrip && i > D && i + D <= nsteps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 + (D - 1) * (NDMA + 1)) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __syncthreads();
       if (i + D < nsteps && !(a.dbg & 32)) {
         sa.issue_step(c, i + D, wave, lds_dummy, true); sb.issue_step(c, i + D, wave, lds_dummy, true); sc.issue_step(c, i + D, wave, lds_dummy, true);
       }
       if (i > 0 && !(a.dbg & 64)) flush(i - 1);
-      f32x4_t acc[4];
+      f32x4_t acc[NTN];
       const bool top = i == 0, bot = i == nsteps - 1;
       if (a.dbg & 16) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[nt] = addv[nt];
+        for (int j = 0; j < NTN; ++j) acc[j] = addv[j];
       } else {
-        sa.template compute<true, 2>(smem + OA, i, top, bot, acc, addv);
-        sb.template compute<false, 2>(smem + OB, i, top, bot, acc, addv);
-        sc.template compute<false, 2>(smem + OC, i, top, bot, acc, addv);
+        sa.template compute<true, 1, NTN>(smem + OA, i, top, bot, nt0, acc, addv);
+        sb.template compute<false, 1, NTN>(smem + OB, i, top, bot, nt0, acc, addv);
+        sc.template compute<false, 1, NTN>(smem + OC, i, top, bot, nt0, acc, addv);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __syncthreads();
-      roll_to_tile(tile, acc, a.relu, oxb0, a.Wo, lane, wave);
+      roll_to_tile<NTN>(tile, acc, a.relu, oxb0, a.Wo, lane, pw, nt0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -2279,10 +2297,10 @@ static int tapsum_launch(const void* const* zs, const int* hs, const int* ws, in
       if (streams < 1) streams = 1;
       r.nstreams = streams; r.nblocks = streams * r.nstrips;
       r.dbg = g_tapsum_roll >= 16 ? g_tapsum_roll : 0;
-      const size_t lds = 4 * 16 * 128 + RollSrc<1, D3>::BYTES + RollSrc<2, D3>::BYTES + RollSrc<3, D3>::BYTES + 1024;
-      static_assert(4 * 16 * 128 + RollSrc<1, D3>::BYTES + RollSrc<2, D3>::BYTES + RollSrc<3, D3>::BYTES + 1024 <= 160 * 1024, "LDS budget");
+      const size_t lds = 4 * 16 * 128 + RollSrc<1, D3, 8>::BYTES + RollSrc<2, D3, 8>::BYTES + RollSrc<3, D3, 8>::BYTES + 1024;
+      static_assert(4 * 16 * 128 + RollSrc<1, D3, 8>::BYTES + RollSrc<2, D3, 8>::BYTES + RollSrc<3, D3, 8>::BYTES + 1024 <= 160 * 1024, "LDS budget");
       GDL_SET_MAX_LDS_ONCE((resize_conv3x3_fwd_sum_roll3_kernel<D3>), 160 * 1024);
-      hipLaunchKernelGGL((resize_conv3x3_fwd_sum_roll3_kernel<D3>), dim3((unsigned)r.nblocks), dim3(256), lds, st, r);
+      hipLaunchKernelGGL((resize_conv3x3_fwd_sum_roll3_kernel<D3>), dim3((unsigned)r.nblocks), dim3(512), lds, st, r);
       GDL_CHECK_LAUNCH("gdl_resize_conv3x3_fwd_sum");
       return GDL_OK;
     }
