@@ -42,8 +42,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // (chunk's first tap + piece / pieces-per-tap), which only shifts its pixel offset and its halo bit.
 // TL ("timeline", tuning only, dbg mode 7): per-wave shader-cycle totals of the K loop's phases -> k.probe[10240 + wave*8 + i]
 // of block 0: i = 0 MFMA groups 0-2 (with their fragment reads), 1 wait for own DMA, 2 barrier, 3 DMA issue, 4 last group.
+// S (LDS stages, 2 or 4): with four stages the DMA of tile t+4 is issued at the end of K-step t, so a tile has three K-steps to land
+// instead of one.  For layers whose tiles do not fill the chip twice (the reference's per-GPU batch 4: M = 5188 gives 246 tiles of
+// 128^2 for the N = 768 layers, one workgroup per CU) the K loop is a chain of DMA latencies -- a K-step's 16 MFMAs per wave take
+// 0.25 us, the fetch behind them 0.8-1 us -- and nothing else on the CU hides it.
 template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false, bool CT = false,
-          bool TP = false, bool TL = false>
+          bool TP = false, bool TL = false, int S = 2>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const KArgs k) {
   constexpr int ES = TileTraits<T>::ES;
   constexpr int BKE = TileTraits<T>::BKE;
@@ -54,6 +58,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/waves mismatch");
   static_assert(!PP || NWALL == 8, "ping-pong needs two waves per SIMD");
   static_assert(!TP || (NW == 4 && !PP && !CT), "tap packing relies on the 4-wave DMA geometry");
+  static_assert(S == 2 || (S == 4 && !PP && !TL), "two or four LDS stages; ping-pong loaders and the timeline probe use two");
+  static_assert(S == 2 || 3 * (CA + CB) < 64, "vmcnt is a 6-bit counter");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int STAGE_BYTES = (BM + BN) * 128;  // [A: BM rows | B: BN rows] x 128 B
@@ -240,10 +246,27 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   const unsigned long long t0c = k.probe ? __builtin_readcyclecounter() : 0;
   const unsigned long long t0r = k.probe ? __builtin_amdgcn_s_memrealtime() : 0;
   // tile t is loaded by half (t & 1) in the ping-pong variant, by everyone otherwise
-  issue(0, !PP || half == 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (k.KT > 1) issue(1, !PP || half == 1);
+  // wait_tile(ahead): this wave's share of the oldest outstanding tile has landed when at most `ahead` younger tiles (CA + CB DMA
+  // instructions each; loads return in order) are still in flight
+  auto wait_tile = [&](int ahead) {
+    if (S == 4 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (CA + CB)) : "memory");
+    else if (S == 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (CA + CB)) : "memory");
+    else if (S == 4 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CA + CB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if constexpr (S == 2) {
+    issue(0, !PP || half == 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k.KT > 1) issue(1, !PP || half == 1);
+  } else {
+    // tiles 0 .. S-1 before the loop; K-step kt then issues tile kt + S into the stage tile kt just vacated
+#pragma unroll
+    for (int t = 0; t < S; ++t)
+      if (t < k.KT) issue(t, true);
+    wait_tile(k.KT - 1 < S - 1 ? k.KT - 1 : S - 1);
+    __syncthreads();
+  }
   // all scalar (kernel-argument) loads are complete here: tell the waitcnt inserter, so that inside the loop it can
   // wait for the OLDER fragment reads only (lgkmcnt(6)) instead of draining every LDS read before the first MFMAs
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
@@ -260,7 +283,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
   };
   if constexpr (TL) { __builtin_amdgcn_sched_barrier(0); tl_t = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
   for (int kt = 0; kt < k.KT; ++kt) {
-    const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
+    const unsigned char* st = smem + (kt & (S - 1)) * STAGE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk) {
       fetch(st, kk + 1, (kk + 1) & 1);
@@ -270,13 +293,21 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
     }
     stamp(0);
     if (kt + 1 < k.KT) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt+1 has landed
-      stamp(1);
-      __syncthreads();                                   // ... and everyone's; nobody reads tile kt's stage any more
-      stamp(2);
-      if (kt + 2 < k.KT) issue(kt & 1, (!PP || half == (kt & 1)) && k.dbg != 1);
-      stamp(3);
-      fetch(smem + ((kt + 1) & 1) * STAGE_BYTES, 0, 0);
+      if constexpr (S == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt+1 has landed
+        stamp(1);
+        __syncthreads();                                   // ... and everyone's; nobody reads tile kt's stage any more
+        stamp(2);
+        if (kt + 2 < k.KT) issue(kt & 1, (!PP || half == (kt & 1)) && k.dbg != 1);
+        stamp(3);
+      } else {
+        // issued so far: tiles <= kt + S - 1; tile kt + 1 is needed next
+        const int last = kt + S - 1 < k.KT - 1 ? kt + S - 1 : k.KT - 1;
+        wait_tile(last - (kt + 1));
+        __syncthreads();   // everyone's share of tile kt+1 is there; every wave holds its last fragments of tile kt in registers
+        if (kt + S < k.KT) issue(kt & (S - 1), k.dbg != 1);
+      }
+      fetch(smem + ((kt + 1) & (S - 1)) * STAGE_BYTES, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     mfmas(1);
@@ -304,15 +335,19 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void conv_gemm_kernel(const
 }
 
 template <typename T, int WARPS_M, int WARPS_N, int TM, int TN, bool EXTRA, bool PP = false, bool CT = false,
-          bool TP = false, bool TL = false>
+          bool TP = false, bool TL = false, int S = 2>
 int launch_x(const KArgs& k, hipStream_t stream) {
   constexpr int BM = WARPS_M * TM * 32, BN = WARPS_N * TN * 32;
   KArgs kk = k;
   kk.tiles_m = (k.M + BM - 1) / BM;
   kk.tiles_n = (k.a.N + BN - 1) / BN;
   kk.n_group = conv_n_group(k.a, BM, BN, 32 * (BM * BN >= 65536 ? 1 : BM * BN >= 16384 ? 2 : 4));
-  const size_t lds = 2 * (BM + BN) * 128;
-  auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA, PP, CT, TP, TL>;
+  // (the coalesced epilogue of 64-channel wave tiles needs 8 KiB + 1 KiB of LDS per wave: more than the two stages of a 128^2 tile
+  // shared by eight waves)
+  const size_t lds_k = (size_t)S * (BM + BN) * 128, lds_e = TN == 2 ? (size_t)WARPS_M * WARPS_N * 9216 : 0;
+  static_assert(TN != 2 || S * (BM + BN) * 128 >= WARPS_M * WARPS_N * 9216, "the stages must cover the epilogue's transpose buffers");
+  const size_t lds = lds_k > lds_e ? lds_k : lds_e;
+  auto kern = conv_gemm_kernel<T, WARPS_M, WARPS_N, TM, TN, EXTRA, PP, CT, TP, TL, S>;
   GDL_SET_MAX_LDS_ONCE(kern, lds);   // one flag per template instantiation of launch_x
   dim3 grid(kk.tiles_m * kk.tiles_n, k.a.nz), block(64 * WARPS_M * WARPS_N);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, kk);
@@ -428,6 +463,11 @@ extern "C" int gdl_conv_gemm(const gdl_conv_args* ap, gdl_stream_t stream) {
   if (variant == 8) return conv_gemm_w4_launch(k, s);
   if (variant == 9) return conv_gemm_persist_launch(k, s);
   if (variant == 10) return conv_gemm_w4p_launch(k, s);
+  if (variant == 12) {   // 64^2 tile with four LDS stages (bf16, whole K chunks): few tiles, long K
+    const bool extra = a.aux_out || a.act == GDL_ACT_MUL_GELU_GRAD;
+    return extra ? launch_x<bf16_tag, 2, 2, 1, 1, true, false, false, false, false, 4>(k, s)
+                 : launch_x<bf16_tag, 2, 2, 1, 1, false, false, false, false, false, 4>(k, s);
+  }
   if (a.dtype == GDL_BF16) {
     if (variant == 4) return conv3x3_sf_launch(k, s);
     if (variant == 3 && k.dbg == 7) return launch_x<bf16_tag, 2, 4, 4, 2, false, true, false, false, true>(k, s);
@@ -458,6 +498,8 @@ extern "C" void gdl_debug_set_conv_persist(int on) { g_persist_enabled = on; }  
 static std::atomic<int> g_w4p_enabled{0};   // see the planner: measured faster per layer, not end to end -- opt-in (GDL_CONV_W4P=1)
 static std::atomic<int> g_w4p_min_n{768};
 extern "C" void gdl_debug_set_conv_w4p(int on) { g_w4p_enabled = on != 0; if (on > 1) g_w4p_min_n = on; }  // A/B hook: persistent 256^2 tile with deferred stores (conv_gemm_w4p.hip)
+static std::atomic<int> g_stage4_enabled{1};
+extern "C" void gdl_debug_set_conv_stage4(int on) { g_stage4_enabled = on; }  // A/B hook: four-stage 64^2 tile for few-tile, long-K layers
 static std::atomic<int> g_dual_enabled{1};
 extern "C" void gdl_debug_set_conv_dual(int on) { g_dual_enabled = on; }  // A/B hook: dual-resident 256 x 128 tile
 static std::atomic<int> g_ngroup_kb{2560};
@@ -503,6 +545,7 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
       !(g_forced_variant == 8 && !conv_gemm_w4_applicable(a)) &&
       !(g_forced_variant == 9 && !conv_gemm_persist_applicable(a)) &&
       !(g_forced_variant == 10 && !conv_gemm_w4p_applicable(a)) &&
+      !(g_forced_variant >= 11 && (g_forced_variant != 12 || a.dtype != GDL_BF16 || a.C % 64 != 0)) &&
       !(g_forced_variant == 7 && !conv3x3_narrow_applicable(a)))
     return g_forced_variant;
   // narrow 3x3 layers on large maps: direct kernel, one staged window per 4 x 64 pixels (HBM-bound layers)
@@ -543,6 +586,12 @@ extern "C" int gdl_conv_gemm_plan(const gdl_conv_args* ap, int64_t* flops) {
   // narrow outputs (N <= 64: UNet++ decoder, ResNet layer1, MiT stage 1): a 256 (m) x 64 (n) tile, four waves of
   // 64 x 64 -- one LDS fragment read per MFMA instead of the two of the 64^2 tile's 32 x 32 waves
   if (!extra && a.N <= 64 && ((M + 255) / 256) * a.nz >= 256) return 5;
+  // at most one round of 64^2 tiles and a long K (batch 4: UperNet's pyramid-pooling bottleneck, 3x3 on 1792 channels at 18^2: 84
+  // tiles, 252 K-steps; the neck's 3x3 at 18^2: 252 tiles, 108 K-steps): the K loop of the few resident workgroups is a chain of
+  // DMA latencies -- four LDS stages (tile t+4 requested at K-step t): 125 -> 103 us and 57 -> 48 us; bit-identical results
+  // (tools/bench_small_m.py, profiles/r06q_*).  With more tiles or a shorter K the two-stage tile is faster (more workgroups per CU).
+  const int64_t t64 = ((M + 63) / 64) * ((a.N + 63) / 64) * a.nz;
+  if (g_stage4_enabled && a.dtype == GDL_BF16 && !ctail && t64 <= 256 && ksteps >= 96) return 12;
   return 0;
 }
 

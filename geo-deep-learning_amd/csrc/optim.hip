@@ -92,7 +92,62 @@ __global__ __launch_bounds__(256) void multi_adam_dev_kernel(const int64_t* __re
   }
 }
 
+// Derived GEMM operands of the conv parameters, rebuilt from the freshly updated f32 parameters in ONE launch (the fused optimizer
+// calls it right behind gdl_multi_adam): before, every trainable 3x3 layer cost 2-3 launches per step between the update and its
+// next use -- a strided copy + a cast for the tap-major / channel-slice operands, a transpose for the data-gradient operand: 39
+// launches of 5-12 us per DOFA training step, 3 % of the step at the reference's per-GPU batch 4.
+// table rows (int64 x 10): {src f32 [N][T][C], dst bf16, N, T, C, c0, Cs, mode, first tile, tiles along c}; a tile is 32 output
+// channels x 32 input channels of one tap.  mode 0: dst[n][t][c - c0]   (channel slice c0 .. c0 + Cs of a 3x3 parameter)
+//                                        mode 1: dst[t][n][c - c0]   (tap-major: the nine tap products as one 1x1 convolution)
+//                                        mode 2: dst[c][T-1-t][n]    (data gradient: transposed, taps flipped = gdl_pack_dgrad)
+// Values are rounded exactly like gdl_cast / gdl_pack_dgrad round them: results are bit-identical to the separate launches.
+__global__ __launch_bounds__(256) void multi_repack_kernel(const int64_t* __restrict__ table, int rows) {
+  __shared__ float tile[32][33];
+  const int64_t b = blockIdx.x;
+  int r = 0;
+  while (r + 1 < rows && table[(r + 1) * 10 + 8] <= b) ++r;     // (uniform: scalar loads; rows <= a few dozen)
+  const int64_t* row = table + r * 10;
+  const float* src = (const float*)row[0];
+  uint16_t* dst = (uint16_t*)row[1];
+  const int N = (int)row[2], T = (int)row[3], C = (int)row[4], c0 = (int)row[5], Cs = (int)row[6], mode = (int)row[7];
+  const int tiles_c = (int)row[9], tiles_n = (N + 31) / 32;
+  int local = (int)(b - row[8]);
+  const int t = local / (tiles_n * tiles_c);
+  local -= t * tiles_n * tiles_c;
+  const int n0 = (local / tiles_c) * 32, cs0 = (local % tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (mode != 2) {
+    const int cs = cs0 + tx;
+    for (int j = ty; j < 32; j += 8) {
+      const int n = n0 + j;
+      if (n < N && cs < Cs) {
+        const float v = src[((int64_t)n * T + t) * C + c0 + cs];
+        const int64_t o = mode == 0 ? ((int64_t)n * T + t) * Cs + cs : ((int64_t)t * N + n) * Cs + cs;
+        dst[o] = f32_to_bf16(v);
+      }
+    }
+    return;
+  }
+  for (int j = ty; j < 32; j += 8) {
+    const int n = n0 + j, cs = cs0 + tx;
+    tile[j][tx] = (n < N && cs < Cs) ? src[((int64_t)n * T + t) * C + c0 + cs] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int cs = cs0 + j, n = n0 + tx;
+    if (cs < Cs && n < N) dst[((int64_t)cs * T + (T - 1 - t)) * N + n] = f32_to_bf16(tile[tx][j]);
+  }
+}
+
 }  // namespace
+
+extern "C" int gdl_multi_repack(const int64_t* table, int rows, int64_t total_tiles, gdl_stream_t stream) {
+  GDL_CHECK_ARG(table && rows >= 0 && total_tiles >= 0 && total_tiles < (1ll << 31), "gdl_multi_repack: bad args");
+  if (rows == 0 || total_tiles == 0) return GDL_OK;
+  hipLaunchKernelGGL(multi_repack_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, table, rows);
+  GDL_CHECK_LAUNCH("gdl_multi_repack");
+  return GDL_OK;
+}
 
 extern "C" int gdl_adam_tick(float* state, double beta1, double beta2, gdl_stream_t stream) {
   GDL_CHECK_ARG(state, "gdl_adam_tick: null state");

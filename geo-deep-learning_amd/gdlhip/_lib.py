@@ -169,6 +169,7 @@ SIGNATURES = {
     "gdl_multi_adam": (c_i, [c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
     "gdl_adam_tick": (c_i, [c_p, C.c_double, C.c_double, c_p]),
     "gdl_multi_adam_dev": (c_i, [c_p, c_i, c_p, c_p, c_p]),
+    "gdl_multi_repack": (c_i, [c_p, c_i, c_l, c_p]),
     "gdl_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
 }
 
@@ -206,6 +207,9 @@ def load() -> C.CDLL:
     if os.environ.get("GDL_CONV_DUAL") is not None:       # tuning hook: 0 = never pick the dual-resident 256 x 128 tile
         lib.gdl_debug_set_conv_dual.argtypes = [C.c_int]
         lib.gdl_debug_set_conv_dual(int(os.environ["GDL_CONV_DUAL"]))
+    if os.environ.get("GDL_CONV_STAGE4") is not None:     # tuning hook: 0 = never pick the four-stage 64^2 tile (few tiles, long K)
+        lib.gdl_debug_set_conv_stage4.argtypes = [C.c_int]
+        lib.gdl_debug_set_conv_stage4(int(os.environ["GDL_CONV_STAGE4"]))
     if os.environ.get("GDL_CONV_W4") is not None:         # tuning hook: 0 = never pick the one-wave-per-SIMD 256^2 tile
         lib.gdl_debug_set_conv_w4.argtypes = [C.c_int]
         lib.gdl_debug_set_conv_w4(int(os.environ["GDL_CONV_W4"]))

@@ -268,6 +268,10 @@ class GraphedTrainStep:
             w = p.detach() if p.dim() == 2 else gnn.conv_weight_matrix(p)
             val.copy_(w.reshape(val.shape))
             gnn.refresh_shadow(key, val, p)
+        # ... and so do the operands derived from them in another element order (channel slices, tap-major forms, data-gradient
+        # operands): the capture must find them valid, or it would record their rebuild in front of every use
+        if hasattr(optimizer, "refresh_derived"):
+            optimizer.refresh_derived()
         torch.cuda.set_rng_state(snap["rng"])
         torch.set_rng_state(snap["cpu_rng"])
 

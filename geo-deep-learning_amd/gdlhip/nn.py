@@ -116,6 +116,7 @@ def compute_dtype() -> torch.dtype:
 # ------------------------------------------------------------------ packed-weight cache
 _RAW_WRITES: dict = {}   # id(param) -> number of raw-pointer updates (tensor._version does not see them)
 _CACHE: dict = {}
+_CACHE_BUILDS = [0]      # how often an operand was (re)built: whoever keeps lists of cache entries (FusedAdam.refresh_derived) rescans on a change
 
 
 def mark_updated(p: Tensor) -> None:
@@ -139,6 +140,7 @@ def cached(params: tuple, kind: str, builder):
     if hit is not None and hit[0] == ver and all(r() is p for r, p in zip(hit[2], params)):
         return hit[1]
     val = builder()
+    _CACHE_BUILDS[0] += 1
     if hit is None:
         for p in params:
             weakref.finalize(p, _CACHE.pop, key, None)
@@ -189,11 +191,45 @@ def refresh_shadow(key, val: Tensor, weight: Tensor) -> None:
         _CACHE[key] = ((((weight._version, _RAW_WRITES.get(id(weight), 0), weight.data_ptr())),), val, hit[2])
 
 
+# bf16 operands DERIVED from a conv parameter in another element order (channel slice, tap-major, data gradient): the fused
+# optimizer rebuilds all of them in ONE launch behind its update (gdl_multi_repack) and revalidates their cache entries, like the
+# plain bf16 copies above -- id(weight) -> {cache key: (mode, c0, c1)}
+_DERIVED: dict = {}
+REPACK_SLICE, REPACK_TAPS, REPACK_DGRAD = 0, 1, 2
+REPACK_FUSION = os.environ.get("GDL_REPACK_FUSION", "1") != "0"   # A/B switch: 0 = derived operands are rebuilt on their next use
+
+
+def _register_derived(weight: Tensor, kind: str, cd: torch.dtype, mode: int, c0: int, c1: int) -> None:
+    if cd != torch.bfloat16 or not LAUNCH_FUSION or not REPACK_FUSION or weight.dtype != torch.float32 or not weight.requires_grad:
+        return
+    if not (weight.dim() == 4 and weight.permute(0, 2, 3, 1).is_contiguous()):
+        return                                            # (the kernel reads the parameter's dense [N][T][C] storage)
+    ent = _DERIVED.get(id(weight))
+    if ent is None:
+        ent = _DERIVED[id(weight)] = {}
+        weakref.finalize(weight, _DERIVED.pop, id(weight), None)
+    ent[(kind, id(weight))] = (mode, c0, c1)
+
+
+def derived_operands(weight: Tensor) -> list:
+    """[(cache key, bf16 tensor, mode, c0, c1)] of the derived operands of ``weight`` that exist in the cache right now."""
+    out = []
+    for key, (mode, c0, c1) in _DERIVED.get(id(weight), {}).items():
+        hit = _CACHE.get(key)
+        if hit is None or hit[2][0]() is not weight:
+            continue
+        val = hit[1]
+        if isinstance(val, Tensor) and val.dtype == torch.bfloat16 and val.is_contiguous():
+            out.append((key, val, mode, c0, c1))
+    return out
+
+
 def dgrad_weight(weight: Tensor, cd: torch.dtype) -> Tensor:
     """Flipped / transposed operand for the data gradient of a conv parameter."""
     def build():
         n, c, r, s = weight.shape
         return ops.pack_dgrad(conv_weight_matrix(weight), n, r * s, c, cd)
+    _register_derived(weight, f"dgrad:{cd}", cd, REPACK_DGRAD, 0, weight.shape[1])
     return cached((weight,), f"dgrad:{cd}", build)
 
 
@@ -280,6 +316,8 @@ def tap_weight(weight: Tensor, cd: torch.dtype, c0: int = 0, c1: int | None = No
         n, c = weight.shape[0], weight.shape[1]
         w = conv_weight_matrix(weight).view(n, 9, c)[:, :, c0:c1].permute(1, 0, 2).reshape(9 * n, -1).contiguous()
         return w if cd == torch.float32 else ops.cast(w, cd)
+    if tuple(weight.shape[2:]) == (3, 3):
+        _register_derived(weight, f"tap:{cd}:{c0}:{c1}", cd, REPACK_TAPS, c0, weight.shape[1] if c1 is None else c1)
     return cached((weight,), f"tap:{cd}:{c0}:{c1}", build)
 
 
@@ -289,6 +327,8 @@ def slice_weight(weight: Tensor, cd: torch.dtype, c0: int, c1: int) -> Tensor:
         n, c = weight.shape[0], weight.shape[1]
         w = conv_weight_matrix(weight).view(n, 9, c)[:, :, c0:c1].reshape(n, -1).contiguous()
         return w if cd == torch.float32 else ops.cast(w, cd)
+    if tuple(weight.shape[2:]) == (3, 3):
+        _register_derived(weight, f"slice:{cd}:{c0}:{c1}", cd, REPACK_SLICE, c0, c1)
     return cached((weight,), f"slice:{cd}:{c0}:{c1}", build)
 
 
@@ -1150,6 +1190,8 @@ class FusedAdam(torch.optim.Optimizer):
         # bf16 GEMM operands of the parameters (gemm_weight cache) are rewritten by the update kernel itself
         self.shadows = LAUNCH_FUSION
         self._shadowed: list = []
+        self._repack = None          # (signature, device table, tiles) of the derived-operand rebuild (refresh_derived)
+        self._repack_scan = None     # ((operand builds so far, registered parameters, updated parameters), entries) of the last scan
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -1188,36 +1230,7 @@ class FusedAdam(torch.optim.Optimizer):
                 rows = [(pp + 4 * off, gp + 4 * off, mp + 4 * off, vp + 4 * off, min(self.CHUNK, n - off), sp + 2 * off if sp else 0)
                         for pp, gp, mp, vp, n, sp in sig for off in range(0, n, self.CHUNK)]
                 host = torch.tensor(rows, dtype=torch.int64)
-                if self.capturable:
-                    # under stream capture nothing may be allocated (pinned or device): both buffers exist since the first
-                    # table of this group; the captured H2D copy re-reads the pinned one at every replay
-                    bufs = self._table_bufs.get(key[0])
-                    if bufs is None or bufs["dev"].shape != host.shape:
-                        pin = lambda: torch.empty(host.shape, dtype=torch.int64).pin_memory()      # noqa: E731
-                        bufs = {"eager": [pin(), pin()], "events": [None, None], "capture": pin(), "i": 0,
-                                "dev": torch.empty(host.shape, dtype=torch.int64, device=dev)}
-                        self._table_bufs[key[0]] = bufs
-                    if torch.cuda.is_current_stream_capturing():
-                        # the captured H2D copy re-reads this pinned buffer at every replay: eager rebuilds never touch it
-                        src = bufs["capture"]
-                        src.copy_(host)
-                        bufs["dev"].copy_(src, non_blocking=True)
-                    else:
-                        # eager steps with set_to_none gradients rebuild the table every step; its asynchronous H2D copy reads
-                        # the pinned buffer later, so the host alternates between two and only waits for the copy issued two
-                        # rebuilds ago (long done) instead of overwriting a buffer whose copy has not run yet
-                        i = bufs["i"] = bufs["i"] ^ 1
-                        if bufs["events"][i] is not None:
-                            bufs["events"][i].synchronize()
-                        src = bufs["eager"][i]
-                        src.copy_(host)
-                        bufs["dev"].copy_(src, non_blocking=True)
-                        ev = bufs["events"][i] or torch.cuda.Event()
-                        ev.record()
-                        bufs["events"][i] = ev
-                    hit = (sig, bufs["dev"])
-                else:
-                    hit = (sig, host.to(dev, non_blocking=True))
+                hit = (sig, self._upload(key[0], host, dev))
                 if len(buckets) == len({k[0] for k in buckets}):      # (one step count per group: the usual case -> cacheable)
                     self._tables[key[0]] = hit
                 self.table_builds += 1
@@ -1243,7 +1256,83 @@ class FusedAdam(torch.optim.Optimizer):
         self._shadowed = shadowed
         for key, val, p in shadowed:      # the kernels above rewrote the bf16 GEMM operands too
             refresh_shadow(key, val, p)
+        if self.shadows:
+            self.refresh_derived([p for _, _, p in todo], dev)
         return loss
+
+    def _upload(self, name, host: Tensor, dev) -> Tensor:
+        """A host int64 table on the device.  capturable: under stream capture nothing may be allocated (pinned or device), so
+        both buffers exist since the first table of this name and shape; the captured H2D copy re-reads the pinned one at
+        every replay."""
+        if not self.capturable:
+            return host.to(dev, non_blocking=True)
+        bufs = self._table_bufs.get(name)
+        if bufs is None or bufs["dev"].shape != host.shape:
+            pin = lambda: torch.empty(host.shape, dtype=torch.int64).pin_memory()      # noqa: E731
+            bufs = {"eager": [pin(), pin()], "events": [None, None], "capture": pin(), "i": 0,
+                    "dev": torch.empty(host.shape, dtype=torch.int64, device=dev)}
+            self._table_bufs[name] = bufs
+        if torch.cuda.is_current_stream_capturing():
+            # the captured H2D copy re-reads this pinned buffer at every replay: eager rebuilds never touch it
+            src = bufs["capture"]
+            src.copy_(host)
+            bufs["dev"].copy_(src, non_blocking=True)
+        else:
+            # eager steps with set_to_none gradients rebuild the table every step; its asynchronous H2D copy reads
+            # the pinned buffer later, so the host alternates between two and only waits for the copy issued two
+            # rebuilds ago (long done) instead of overwriting a buffer whose copy has not run yet
+            i = bufs["i"] = bufs["i"] ^ 1
+            if bufs["events"][i] is not None:
+                bufs["events"][i].synchronize()
+            src = bufs["eager"][i]
+            src.copy_(host)
+            bufs["dev"].copy_(src, non_blocking=True)
+            ev = bufs["events"][i] or torch.cuda.Event()
+            ev.record()
+            bufs["events"][i] = ev
+        return bufs["dev"]
+
+    @torch.no_grad()
+    def refresh_derived(self, params=None, dev=None) -> int:
+        """Rebuild, in ONE launch (gdl_multi_repack), every bf16 operand that was derived from the given (default: all) conv
+        parameters in another element order and sits in the operand cache -- channel slices and tap-major forms of the 3x3
+        parameters, data-gradient operands -- and mark the entries current.  Called behind every update; GraphedTrainStep calls
+        it after restoring the parameters.  Returns the number of operands rewritten."""
+        everything = params is None
+        if everything:
+            params = [p for g in self.param_groups for p in g["params"]]
+        # steady state: nothing was built since the last scan (the entries were rewritten in place and revalidated), the same
+        # parameters were updated -> the same entries, no scan
+        scan_key = (_CACHE_BUILDS[0], len(_DERIVED), len(params))
+        if not everything and self._repack_scan is not None and self._repack_scan[0] == scan_key:
+            ents = self._repack_scan[1]
+        else:
+            ents = [(p, *e) for p in params for e in derived_operands(p)]
+            self._repack_scan = None if everything else (scan_key, ents)
+        if not ents:
+            return 0
+        dev = dev or ents[0][0].device
+        sig = tuple((p.data_ptr(), val.data_ptr(), mode, c0, c1) for p, _, val, mode, c0, c1 in ents)
+        hit = self._repack
+        # (inside a stream capture the table is ALWAYS uploaded: the captured copy then restores it from its own pinned buffer
+        # at every replay, whatever eager steps in between wrote into the device buffer -- like the update's chunk tables, whose
+        # gradient addresses change with every capture)
+        if hit is None or hit[0] != sig or (self.capturable and torch.cuda.is_current_stream_capturing()):
+            rows, tile0 = [], 0
+            for p, _, val, mode, c0, c1 in ents:
+                n, c, t = p.shape[0], p.shape[1], p.shape[2] * p.shape[3]
+                cs = c1 - c0
+                if val.numel() != n * t * cs:
+                    msg = f"gdlhip FusedAdam: derived operand {tuple(val.shape)} does not match parameter {tuple(p.shape)}[{c0}:{c1}]"
+                    raise ValueError(msg)
+                tiles_c = (cs + 31) // 32
+                rows.append((p.data_ptr(), val.data_ptr(), n, t, c, c0, cs, mode, tile0, tiles_c))
+                tile0 += t * ((n + 31) // 32) * tiles_c
+            hit = self._repack = (sig, self._upload("repack", torch.tensor(rows, dtype=torch.int64), dev), tile0)
+        ops.multi_repack(hit[1], hit[2])
+        for p, key, val, _, _, _ in ents:
+            refresh_shadow(key, val, p)
+        return len(ents)
 
     def device_state(self, gi: int, dev=None) -> Tensor:
         """The device-side {step, lr, b1, b2, eps, wd, bc1, bc2} of param group gi (capturable mode), created from the group's

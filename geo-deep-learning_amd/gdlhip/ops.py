@@ -1722,6 +1722,12 @@ def multi_adam_dev(table: Tensor, state: Tensor, clip: Tensor | None) -> None:
     check(_lib.load().gdl_multi_adam_dev(_p(table), table.shape[0], _p(state), _p(clip), _stream()), "gdl_multi_adam_dev")
 
 
+def multi_repack(table: Tensor, total_tiles: int) -> None:
+    """Rebuild the bf16 operands derived from 3x3 conv parameters (channel-slice, tap-major, data-gradient layouts) listed in
+    ``table`` (device int64 [rows, 10], see gdl_multi_repack) in one launch."""
+    check(_lib.load().gdl_multi_repack(_p(table), table.shape[0], int(total_tiles), _stream()), "gdl_multi_repack")
+
+
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, b1: float, b2: float,
               eps: float, wd: float, step: int, clip: Tensor | None) -> None:
     bc1, bc2 = 1.0 - b1**step, 1.0 - b2**step

@@ -529,6 +529,13 @@ int gdl_multi_adam(const int64_t* table, int nchunks, float lr, float beta1, flo
  * advances the step and refreshes the two bias corrections, gdl_multi_adam_dev reads everything from `state` */
 int gdl_adam_tick(float* state, double beta1, double beta2, gdl_stream_t stream);   /* betas in double: bc = 1 - beta^step as the host computes it */
 int gdl_multi_adam_dev(const int64_t* table, int nchunks, const float* state, const float* clip_coef, gdl_stream_t stream);
+/* The bf16 GEMM operands DERIVED from 3x3 conv parameters, rebuilt in one launch behind the update (the reference has no
+ * counterpart: cuDNN re-reads the f32 parameter; here they are the operands of models/decoders/upernet.py:144-152 and
+ * models/necks/multilevel_neck.py:157-158 in their low-resolution forms and of every data gradient).  `table`: DEVICE array of
+ * `rows` rows {src f32 [N][T][C], dst bf16, N, T, C, c0, Cs, mode, first_tile, tiles_c} (int64 each; a tile = 32 n x 32 c of
+ * one tap, rows ordered by first_tile, total_tiles = their sum).  mode 0: dst[n][t][c-c0] (channel slice); 1: dst[t][n][c-c0]
+ * (tap-major); 2: dst[c][T-1-t][n] (= gdl_pack_dgrad).  Rounding as gdl_cast: bit-identical to the separate launches. */
+int gdl_multi_repack(const int64_t* table, int rows, int64_t total_tiles, gdl_stream_t stream);
 int gdl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, float bc1, float bc2,
                   const float* clip_coef, gdl_stream_t stream);

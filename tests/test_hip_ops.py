@@ -868,6 +868,66 @@ def test_adam_rewrites_the_bf16_gemm_operands(monkeypatch):
     assert torch.equal(gnn.gemm_weight(lin, torch.bfloat16), lin.detach().to(torch.bfloat16))
 
 
+def test_adam_rebuilds_the_derived_conv_operands_in_one_launch(monkeypatch):
+    """Behind its update the optimizer rebuilds every bf16 operand DERIVED from a conv parameter in another element order --
+    channel slices and tap-major forms of the 3x3 parameters (UperNet's fpn_bottleneck over the concat, the neck's resized
+    convolutions), data-gradient operands -- in ONE launch (gdl_multi_repack), in place, and marks the cache entries current:
+    the next forward launches no repack / cast, and the operands are bit-identical to a rebuild by the separate launches."""
+    torch.manual_seed(2)
+    bf = torch.bfloat16
+    w3 = torch.randn(72, 160, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)   # ragged tiles
+    w1 = torch.randn(96, 40, 1, 1, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    nchw = torch.randn(64, 32, 3, 3, device=DEV).requires_grad_(True)            # not dense [N][T][C]: keeps the rebuild-on-use path
+    frozen = torch.randn(64, 32, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+    params = [w3, w1, nchw]
+
+    def forward_operands():
+        return [gnn.tap_weight(w3, bf), gnn.tap_weight(w3, bf, 32, 96), gnn.slice_weight(w3, bf, 0, 32), gnn.slice_weight(w3, bf, 96, 160),
+                gnn.dgrad_weight(w3, bf), gnn.dgrad_weight(w1, bf), gnn.dgrad_weight(nchw, bf), gnn.tap_weight(frozen, bf)]
+
+    def reference():
+        m3 = w3.detach().permute(0, 2, 3, 1).reshape(72, 9, 160)
+        tap = lambda m, a, b: m[:, :, a:b].permute(1, 0, 2).reshape(9 * m.shape[0], b - a).to(bf)                     # noqa: E731
+        sl = lambda m, a, b: m[:, :, a:b].reshape(m.shape[0], -1).to(bf)                                              # noqa: E731
+        dg = lambda w: w.detach().permute(1, 2, 3, 0).flip(1, 2).reshape(w.shape[1], -1).to(bf)                       # noqa: E731
+        return [tap(m3, 0, 160), tap(m3, 32, 96), sl(m3, 0, 32), sl(m3, 96, 160), dg(w3), dg(w1), dg(nchw),
+                tap(frozen.permute(0, 2, 3, 1).reshape(64, 9, 32), 0, 32)]
+
+    first = forward_operands()
+    for got, want in zip(first, reference()):
+        assert torch.equal(got, want)
+    opt = gnn.FusedAdam(params, lr=1e-2)
+    launches = []
+    for name in ("cast", "pack_dgrad"):
+        real = getattr(ops, name)
+        monkeypatch.setattr(ops, name, lambda *a, _real=real, _n=name, **k: (launches.append(_n), _real(*a, **k))[1])
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    for step in range(3):
+        for p in params:
+            p.grad.copy_(torch.randn_like(p))
+        opt.step()
+        launches.clear()
+        now = forward_operands()
+        assert launches == ["pack_dgrad"], launches                    # only the NCHW-stored parameter is repacked on use
+        assert all(a is b for a, b in zip(now[:6], first[:6])) and now[6] is not first[6] and now[7] is first[7]
+        for i, (got, want) in enumerate(zip(now, reference())):
+            assert torch.equal(got, want), (step, i)
+    assert opt._repack is not None and opt._repack[1].shape[0] == 6
+    # a parameter rewritten by someone else invalidates its operands as before; the optimizer then adopts the rebuilt tensors
+    with torch.no_grad():
+        w3.mul_(0.5)
+    again = forward_operands()
+    assert again[0] is not first[0]
+    for got, want in zip(again, reference()):
+        assert torch.equal(got, want)
+    for p in params:
+        p.grad.copy_(torch.randn_like(p))
+    opt.step()
+    for got, want in zip(forward_operands(), reference()):
+        assert torch.equal(got, want)
+
+
 def test_drop_path_scales_one_launch_per_pass():
     """gnn.drop_path_scales: all DropPath draws of an encoder pass at once -- rows are mask / keep with the block's own keep
     probability (timm drop_path, scale_by_keep), None for blocks that never drop."""
