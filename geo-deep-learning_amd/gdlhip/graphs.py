@@ -299,6 +299,11 @@ class GraphedTrainStep:
         # every operand cache entry that exists now may have been read by the captured kernels through its address (entries that
         # were valid during the capture were not rebuilt inside it): keep them alive as long as the graph
         self._cache_refs = [entry[1] for entry in list(gnn._CACHE.values())]
+        # the bf16 operands the CAPTURED update rewrites in place (plain copies of the parameters and the operands derived from
+        # them in another element order): current after every replay -- __call__ re-adopts them as the cache entries, so that an
+        # eager step between two replays (a ragged last batch) reads and rewrites the SAME tensors instead of building its own
+        # (found in round 6: the first replay after an eager bf16 step ran its forward on operands that missed that step's update)
+        self._graph_operands = list(getattr(optimizer, "_shadowed", [])) + list(getattr(optimizer, "_derived_last", []))
         self._rewritten = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
         self._rewritten += [b for m in task.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training
                             for b in (m.running_mean, m.running_var) if b is not None]
@@ -325,6 +330,8 @@ class GraphedTrainStep:
                 sink(name, value, batch_size)
         for t in self._rewritten:       # the replay rewrote these through raw pointers: eager code must not trust operands
             gnn.mark_updated(t)         # cached from their earlier values (eval-time BatchNorm folds, packed weights)
+        for key, val, p in self._graph_operands:     # ... except the ones the replay itself rewrote from the new parameters
+            gnn.adopt_operand(key, val, p)
         hook = getattr(self.task, "on_graph_replay", None)
         if hook is not None:            # host bookkeeping the captured training_step can no longer do (sample counters)
             hook(self.static)
@@ -333,7 +340,9 @@ class GraphedTrainStep:
 
 class GraphedEvalStep:
     """``out = step(batch)`` == no_grad + autocast(fn(batch)) replayed from a hipGraph; ``fn`` e.g. ``lambda b: task(b["image"],
-    b["wavelengths"])`` or a validation step that returns tensors (their storage is static: copy what must outlive a replay)."""
+    b["wavelengths"])`` or a validation step that returns tensors (their storage is static: copy what must outlive a replay).
+    The graph holds the ADDRESSES of the operands that were current at capture time (bf16 weight copies, BatchNorm-folded
+    weights): it is for serving a model whose parameters no longer change -- capture again after training on."""
 
     def __init__(self, fn, example_batch: dict[str, Any], *, autocast_dtype: torch.dtype | None = torch.bfloat16, warmup: int = 2) -> None:
         self.fn, self.autocast_dtype = fn, autocast_dtype

@@ -224,6 +224,23 @@ def derived_operands(weight: Tensor) -> list:
     return out
 
 
+def adopt_operand(key, val: Tensor, weight: Tensor) -> None:
+    """``val`` was just rewritten from the CURRENT ``weight`` by a kernel that holds its address (a hipGraph replay of the
+    optimizer's update): make it THE cache entry of ``key`` again, whatever an eager step put there in between.  Without this
+    an eager step between two replays builds new operand tensors, the eager update rewrites those, and the next replay's forward
+    reads operands that miss one update."""
+    hit = _CACHE.get(key)
+    if hit is None or hit[1] is not val:
+        _CACHE_BUILDS[0] += 1
+    if hit is not None and hit[2][0]() is weight:
+        refs = hit[2]
+    else:
+        refs = (weakref.ref(weight),)
+        if hit is None:
+            weakref.finalize(weight, _CACHE.pop, key, None)
+    _CACHE[key] = (((weight._version, _RAW_WRITES.get(id(weight), 0), weight.data_ptr()),), val, refs)
+
+
 def dgrad_weight(weight: Tensor, cd: torch.dtype) -> Tensor:
     """Flipped / transposed operand for the data gradient of a conv parameter."""
     def build():
@@ -1191,6 +1208,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.shadows = LAUNCH_FUSION
         self._shadowed: list = []
         self._repack = None          # (signature, device table, tiles) of the derived-operand rebuild (refresh_derived)
+        self._derived_last: list = []   # (cache key, operand, parameter) of the last refresh_derived
         self._repack_scan = None     # ((operand builds so far, registered parameters, updated parameters), entries) of the last scan
 
     @torch.no_grad()
@@ -1332,6 +1350,7 @@ class FusedAdam(torch.optim.Optimizer):
         ops.multi_repack(hit[1], hit[2])
         for p, key, val, _, _, _ in ents:
             refresh_shadow(key, val, p)
+        self._derived_last = [(key, val, p) for p, key, val, _, _, _ in ents]
         return len(ents)
 
     def device_state(self, gi: int, dev=None) -> Tensor:

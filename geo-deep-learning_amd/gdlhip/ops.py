@@ -170,10 +170,12 @@ class KernelTimer:
                8: "conv_gemm_w4_kernel (256x256 tiles, one wave per SIMD, every load in an MFMA shadow)",
                9: "conv_gemm_persist_kernel (256x256 ping-pong tiles, one persistent workgroup per CU, next tile's first stage under the epilogue)",
                10: "conv_gemm_w4p_kernel (256x256 tiles, one persistent workgroup per CU, one wave per SIMD, finished tile parked in registers and stored from the next tile's MFMA shadows)",
-               7: "conv3x3_narrow_kernel (direct 3x3, C <= 32, one staged window per 4 x 64 pixels x 32 output channels)"}
+               7: "conv3x3_narrow_kernel (direct 3x3, C <= 32, one staged window per 4 x 64 pixels x 32 output channels)",
+               12: "conv_gemm_kernel<{dt},2,2,1,1,stages=4> (64x64 tiles, four LDS stages: few tiles, long K)"}
 
     def __init__(self) -> None:
         self.records: list = []
+        self.variants: list = []      # the planner's tile variant of every launch, in launch order
 
     def launch(self, a: ConvArgs, what: str) -> None:
         lib = _lib.load()
@@ -194,6 +196,7 @@ class KernelTimer:
             nbytes += nz * int(a.B) * int(a.Ho) * int(a.Wo) * int(a.N) * (2 if a.resid_dtype == BF16 else 4)
         shape = (nz * int(a.B) * int(a.Ho) * int(a.Wo), int(a.N), int(a.R) * int(a.S) * int(a.C), int(a.R), int(a.S), oes, bool(a.resid))
         self.records.append((key, fl.value, e0, e1, int(a.R) * int(a.S) * int(a.C), nbytes, shape))
+        self.variants.append(variant)
 
     @staticmethod
     def _k_bucket(k: int) -> str:

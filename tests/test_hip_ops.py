@@ -1124,6 +1124,44 @@ def test_conv_dual_resident_tile(B, H, W, C, N, R, stride, variant):
         assert torch.equal(outs[variant, odt], outs[1, odt]), f"variant {variant} vs 128^2 tile differ ({odt})"
 
 
+@pytest.mark.parametrize("B,H,W,C,N,R,K_steps", [(4, 18, 18, 1792, 256, 3, 252),    # UperNet's pyramid-pooling bottleneck at batch 4: 84 tiles
+                                                (4, 18, 18, 768, 768, 3, 108),     # the neck's 3x3 at 18^2: 252 tiles
+                                                (1, 13, 9, 704, 72, 3, 99),        # M and N tails, 11 chunks per tap
+                                                (2, 1, 70, 6144, 200, 1, 96)])     # dense 1x1 rows
+def test_conv_four_stage_tile(B, H, W, C, N, R, K_steps):
+    """The 64^2 tile with FOUR LDS stages (variant 12: the DMA of tile t+4 is issued at K-step t): what the planner picks for
+    bf16 layers with at most one round of tiles and >= 96 K-steps -- vs F.conv2d, and bit-identical to the two-stage 64^2 tile
+    (same tiles, same K order), with bf16 and f32 outputs, bias + ReLU + residual."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_force_conv_variant.argtypes = [ctypes.c_int]
+    dtype = torch.bfloat16
+    x, w = q(rnd(B, C, H, W), dtype), q(rnd(N, C, R, R, seed=1) * 0.05, dtype)
+    bias, resid = rnd(N, seed=2), q(rnd(B, N, H, W, seed=3), dtype)
+    ref = F.relu(F.conv2d(x, w, bias, padding=R // 2)) + resid
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    wq = w.permute(0, 2, 3, 1).reshape(N, -1).contiguous().to(DEV, dtype)
+    rn = resid.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    assert R * R * C // 64 == K_steps
+    outs = {}
+    ops.TIMER = timer = ops.KernelTimer()
+    try:
+        for v in (-1, 12, 0):
+            lib.gdl_debug_force_conv_variant(v)
+            for odt in (torch.float32, torch.bfloat16):
+                outs[v, odt] = ops.conv_gemm(xn, wq, R=R, S=R, pad=R // 2, bias=bias.to(DEV), act=ops.ACT_RELU,
+                                             resid=rn if odt == torch.bfloat16 else rn.float(), out_dtype=odt)
+    finally:
+        lib.gdl_debug_force_conv_variant(-1)
+        ops.TIMER = None
+    assert timer.variants == [12, 12, 12, 12, 0, 0], timer.variants        # the planner's own choice for these shapes is the four-stage tile
+    close(outs[12, torch.float32].permute(0, 3, 1, 2), ref, dtype, "four-stage tile")
+    for odt in (torch.float32, torch.bfloat16):
+        assert torch.equal(outs[12, odt], outs[0, odt]), f"four-stage vs two-stage 64^2 tile differ ({odt})"
+        assert torch.equal(outs[-1, odt], outs[0, odt])
+
+
 @pytest.mark.parametrize("B,H,W,C,N,R,expect", [(8, 72, 72, 768, 256, 1, True),     # 1x1, 162 x 1 tiles of 256^2 -> 128^2 tile
                                               (32, 72, 72, 256, 256, 1, True),    # 648 tiles: persistent 256^2 tile
                                               (8, 72, 72, 256, 256, 3, True),     # 3x3
