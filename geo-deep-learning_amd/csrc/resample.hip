@@ -419,6 +419,62 @@ __global__ __launch_bounds__(256) void bilinear_fwd8_rows_kernel(const void* __r
   V8::st(out, ooff, o);
 }
 
+// Exact integer upsampling factors (F = 2, 4: the FPN top-down path, the pyramid levels of fpn_bottleneck's concat): a thread owns
+// the GAP between four neighbouring input pixels -- the F x F output pixels whose two source rows and two source columns are
+// those four -- loads them once and writes F x F outputs (the row kernel above loads four 16-byte pieces per 16 bytes stored:
+// 2.65 TB/s on a write-bound op).  Gaps -1 and Hi - 1 (Wi - 1) are the clamped borders with F / 2 rows (columns).  Same
+// source indices, weights and expression per output as bilinear_fwd8_rows_kernel: bit-identical results.
+template <int F>
+__global__ __launch_bounds__(256) void bilinear_fwd8_gap_kernel(const void* __restrict__ in, int Hi, int Wi, int C,
+                                                                int64_t isB, int64_t isH, int64_t isW, void* out,
+                                                                int64_t osB, int64_t osH, int64_t osW, const void* acc_src) {
+  // acc_src: nullptr, `out` itself (out += result) or another map with out's strides (out = that + result: the FPN top-down add
+  // without first copying the lateral into the output)
+  const int cv = C / 8;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= (Wi + 1) * cv) return;
+  const int Ho = F * Hi, Wo = F * Wi;
+  const int b = blockIdx.y / (Hi + 1), gy = blockIdx.y - b * (Hi + 1);     // gap gy: output rows F gy - F/2 .. F gy + F/2 - 1
+  const int gx = j / cv, c = (j - gx * cv) * 8;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  const int oy0 = F * gy - F / 2 < 0 ? 0 : F * gy - F / 2, ox0 = F * gx - F / 2 < 0 ? 0 : F * gx - F / 2;
+  int y0, y1, x0, x1; float l;
+  src_index(ry, oy0, Hi, y0, y1, l);
+  src_index(rx, ox0, Wi, x0, x1, l);
+  const int64_t base = (int64_t)b * isB + c;
+  float a[8], bb[8], cc[8], d[8];
+  V8::ld(in, base + y0 * isH + x0 * isW, a);
+  V8::ld(in, base + y0 * isH + x1 * isW, bb);
+  V8::ld(in, base + y1 * isH + x0 * isW, cc);
+  V8::ld(in, base + y1 * isH + x1 * isW, d);
+#pragma unroll
+  for (int jy = 0; jy < F; ++jy) {
+    const int oy = F * gy - F / 2 + jy;
+    if (oy < 0 || oy >= Ho) continue;
+    int t0, t1; float ly;
+    src_index(ry, oy, Hi, t0, t1, ly);
+    const float hy = 1.f - ly;
+#pragma unroll
+    for (int jx = 0; jx < F; ++jx) {
+      const int ox = F * gx - F / 2 + jx;
+      if (ox < 0 || ox >= Wo) continue;
+      float lx;
+      src_index(rx, ox, Wi, t0, t1, lx);
+      const float hx = 1.f - lx;
+      const int64_t ooff = (int64_t)b * osB + (int64_t)oy * osH + (int64_t)ox * osW + c;
+      float o[8];
+      if (acc_src) V8::ld(acc_src, ooff, o);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += hy * (hx * a[e] + lx * bb[e]) + ly * (hx * cc[e] + lx * d[e]);
+      V8::st(out, ooff, o);
+    }
+  }
+}
+
 // NX = upper bound of the horizontal output window of one input pixel (2 * ceil(Wo / Wi) + 4); the window's weights are
 // computed once per thread instead of once per (output row, output column)
 template <int NX>
@@ -483,6 +539,98 @@ __global__ __launch_bounds__(256) void bilinear_bwd8_rows_kernel(const void* __r
     for (int e = 0; e < 8; ++e) acc[e] += o[e];
   }
   V8::st(din, ioff, acc);
+}
+
+// Exact integer factors (F = 2, 4): a thread WALKS DOWN a column of input pixels.  The F gradient rows between input rows g - 1
+// and g feed both of them (weights 1 - ly and ly): they are loaded once and added to two running accumulators, instead of once
+// per input row (the row kernel above fetches 4 F^2 pieces per input pixel, this one 2 F^2 (1 + 1 / RSEG)).  A block column is cut
+// into segments of RSEG input rows for parallelism; the gap rows on a segment border are read by both neighbours.  Every input
+// pixel receives its terms in the row kernel's order (gradient rows ascending, window columns ascending, zero weights skipped)
+// with the same products: bit-identical results.
+template <int F, int RSEG>
+__global__ __launch_bounds__(256) void bilinear_bwd8_walk_kernel(const void* __restrict__ dout, int C, int64_t osB, int64_t osH,
+                                                                 int64_t osW, void* din, int Hi, int Wi, int64_t isB, int64_t isH,
+                                                                 int64_t isW, int accumulate) {
+  const int cv = C / 8, Ho = F * Hi, Wo = F * Wi;
+  // XCD-major block order (as in the row kernel): horizontally neighbouring blocks read overlapping gradient columns (a window
+  // of 2 F columns every F) and vertically neighbouring segments share their border rows -- one XCD walks a contiguous range
+  const int nblk = gridDim.x * gridDim.y;
+  const int id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = id & 7, idx = id >> 3;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int brow = lid / gridDim.x, bx = lid - brow * gridDim.x;
+  const int j = bx * 256 + threadIdx.x;
+  if (j >= Wi * cv) return;
+  const int nseg = (Hi + RSEG - 1) / RSEG;
+  const int b = brow / nseg, seg = brow - b * nseg;
+  const int iy0 = seg * RSEG, iy1 = iy0 + RSEG < Hi ? iy0 + RSEG : Hi;
+  const int ix = j / cv, c = (j - ix * cv) * 8;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  // the window columns with a non-zero weight are exactly F ix - F/2 .. F ix + 3F/2 - 1 (inside the image); a column outside is
+  // fetched from the clamped address -- UNCONDITIONAL loads, so that the 2 F pieces of a gradient row are in flight together
+  // (inside `if (wx[k] == 0.f) continue` every load waited for its predecessor's multiply-adds) -- and its term is not added
+  constexpr int NW = 2 * F;
+  float wx[NW];
+  int64_t coff[NW];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    const int ox = F * ix - F / 2 + k;
+    const bool ok = ox >= 0 && ox < Wo;
+    const int oxc = ox < 0 ? 0 : (ox > Wo - 1 ? Wo - 1 : ox);
+    int x0, x1; float lx;
+    src_index(rx, oxc, Wi, x0, x1, lx);
+    wx[k] = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+    coff[k] = (int64_t)oxc * osW;
+    okmask |= (ok ? 1u : 0u) << k;
+  }
+  const int64_t col = (int64_t)b * osB + c;
+  float up[8], dn[8];        // accumulators of input rows g - 1 and g while gap g is walked
+#pragma unroll
+  for (int e = 0; e < 8; ++e) up[e] = dn[e] = 0.f;
+  for (int g = iy0; g <= iy1; ++g) {                       // gap g: gradient rows F g - F/2 .. F g + F/2 - 1 (source rows g - 1, g)
+#pragma unroll
+    for (int jy = 0; jy < F; ++jy) {
+      const int oy = F * g - F / 2 + jy;
+      if (oy < 0 || oy >= Ho) continue;                    // (uniform)
+      int y0, y1; float ly;
+      src_index(ry, oy, Hi, y0, y1, ly);
+      // weights of this gradient row for input rows g - 1 and g, as the row kernel forms them for each of the two
+      const float w_up = g - 1 >= iy0 ? (y0 == g - 1 ? 1.f - ly : 0.f) + (y1 == g - 1 ? ly : 0.f) : 0.f;
+      const float w_dn = g < iy1 ? (y0 == g ? 1.f - ly : 0.f) + (y1 == g ? ly : 0.f) : 0.f;
+      if (w_up == 0.f && w_dn == 0.f) continue;            // (uniform)
+      const int64_t rowoff = col + (int64_t)oy * osH;
+      float v[NW][8];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) V8::ld(dout, rowoff + coff[k], v[k]);
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        const bool ok = (okmask >> k) & 1u;
+        if (w_up != 0.f) {                                 // (uniform)
+          const float w = w_up * wx[k];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) up[e] = ok ? up[e] + w * v[k][e] : up[e];
+        }
+        if (w_dn != 0.f) {
+          const float w = w_dn * wx[k];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dn[e] = ok ? dn[e] + w * v[k][e] : dn[e];
+        }
+      }
+    }
+    if (g - 1 >= iy0) {                                    // input row g - 1 is complete
+      const int64_t ioff = (int64_t)b * isB + (int64_t)(g - 1) * isH + (int64_t)ix * isW + c;
+      if (accumulate) {
+        float o[8];
+        V8::ld(din, ioff, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) up[e] += o[e];
+      }
+      V8::st(din, ioff, up);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { up[e] = dn[e]; dn[e] = 0.f; }
+  }
 }
 
 // Backward of  y = conv3x3(pad 1)(bilinear_resize(x))  WITHOUT the high-resolution data gradient.
@@ -2504,16 +2652,24 @@ extern "C" int gdl_resize_conv3x3_fwd_sum_bn(const void* const* zs, const int* h
 
 extern "C" void gdl_debug_set_flat_resample(int on) { g_flat_resample = on; }
 
-extern "C" int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int Wi, int C, int64_t isB,
-                                int64_t isH, int64_t isW, void* out, int out_dtype, int Ho, int Wo,
-                                int64_t osB, int64_t osH, int64_t osW, int accumulate,
-                                gdl_stream_t stream) {
+static int bilinear_fwd_impl(const void* in, int in_dtype, int B, int Hi, int Wi, int C, int64_t isB,
+                             int64_t isH, int64_t isW, void* out, int out_dtype, int Ho, int Wo,
+                             int64_t osB, int64_t osH, int64_t osW, int accumulate, const void* base,
+                             gdl_stream_t stream) {
   GDL_CHECK_ARG(in && out, "gdl_bilinear_fwd: null pointer");
   GDL_CHECK_ARG(C % 4 == 0 && isB % 4 == 0 && isH % 4 == 0 && isW % 4 == 0 && osB % 4 == 0 && osH % 4 == 0 &&
                     osW % 4 == 0, "gdl_bilinear_fwd: C and strides must be multiples of 4");
   if (in_dtype == GDL_BF16 && out_dtype == GDL_BF16 && vec8_ok(in, out, C, isB, isH, isW, osB, osH, osW)) {
     const int64_t total8 = (int64_t)B * Ho * Wo * (C / 8);
-    if ((int64_t)B * Ho <= 65535 && !g_flat_resample)
+    const int fac = (Hi > 1 && Wi > 1 && Ho % Hi == 0 && Wo % Wi == 0 && Ho / Hi == Wo / Wi) ? Ho / Hi : 0;
+    const bool gap = (fac == 2 || fac == 4) && (int64_t)B * (Hi + 1) <= 65535 && !g_flat_resample;
+    if (base && !(gap && (uintptr_t)base % 16 == 0)) return GDL_ERR_UNSUPPORTED;      // (the caller copies + accumulates)
+    if (gap) {
+      const dim3 grid((unsigned)(((Wi + 1) * (C / 8) + 255) / 256), (unsigned)(B * (Hi + 1)));
+      const void* acc_src = base ? base : (accumulate ? out : nullptr);
+      if (fac == 2) hipLaunchKernelGGL(bilinear_fwd8_gap_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, isB, isH, isW, out, osB, osH, osW, acc_src);
+      else hipLaunchKernelGGL(bilinear_fwd8_gap_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, isB, isH, isW, out, osB, osH, osW, acc_src);
+    } else if ((int64_t)B * Ho <= 65535 && g_flat_resample != 1)
       hipLaunchKernelGGL(bilinear_fwd8_rows_kernel, dim3((unsigned)((Wo * (C / 8) + 255) / 256), (unsigned)(B * Ho)), dim3(256), 0,
                          (hipStream_t)stream, in, Hi, Wi, C, isB, isH, isW, out, Ho, Wo, osB, osH, osW, accumulate);
     else
@@ -2522,11 +2678,32 @@ extern "C" int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int
     GDL_CHECK_LAUNCH("gdl_bilinear_fwd");
     return GDL_OK;
   }
+  if (base) return GDL_ERR_UNSUPPORTED;
   const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
   DISPATCH2(bilinear_fwd_kernel, in_dtype, out_dtype, dim3(grid_for(total)), dim3(256), 0,
             (hipStream_t)stream, in, B, Hi, Wi, C, isB, isH, isW, out, Ho, Wo, osB, osH, osW, accumulate);
   GDL_CHECK_LAUNCH("gdl_bilinear_fwd");
   return GDL_OK;
+}
+
+extern "C" int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int Wi, int C, int64_t isB,
+                                int64_t isH, int64_t isW, void* out, int out_dtype, int Ho, int Wo,
+                                int64_t osB, int64_t osH, int64_t osW, int accumulate,
+                                gdl_stream_t stream) {
+  return bilinear_fwd_impl(in, in_dtype, B, Hi, Wi, C, isB, isH, isW, out, out_dtype, Ho, Wo, osB, osH, osW, accumulate, nullptr, stream);
+}
+
+extern "C" int gdl_bilinear_fwd_add(const void* in, int in_dtype, int B, int Hi, int Wi, int C, int64_t isB,
+                                    int64_t isH, int64_t isW, const void* base, void* out, int out_dtype, int Ho, int Wo,
+                                    int64_t osB, int64_t osH, int64_t osW, gdl_stream_t stream) {
+  GDL_CHECK_ARG(in && base && out, "gdl_bilinear_fwd_add: null pointer");
+  // one pass where the gap kernel applies (bf16, 16-byte vectors, factor 2 / 4); otherwise the lateral is copied and the resized
+  // map accumulated into it -- same values either way (out = base, then += the interpolation in f32, rounded once)
+  const int st = bilinear_fwd_impl(in, in_dtype, B, Hi, Wi, C, isB, isH, isW, out, out_dtype, Ho, Wo, osB, osH, osW, 0, base, stream);
+  if (st != GDL_ERR_UNSUPPORTED) return st;
+  const int st2 = gdl_copy_cast(base, out_dtype, B, Ho, Wo, C, osB, osH, osW, out, out_dtype, osB, osH, osW, stream);
+  if (st2 != GDL_OK) return st2;
+  return bilinear_fwd_impl(in, in_dtype, B, Hi, Wi, C, isB, isH, isW, out, out_dtype, Ho, Wo, osB, osH, osW, 1, nullptr, stream);
 }
 
 extern "C" int gdl_copy_cast(const void* in, int in_dtype, int B, int H, int W, int C, int64_t isB, int64_t isH, int64_t isW,
@@ -2586,7 +2763,12 @@ extern "C" int gdl_bilinear_bwd(const void* dout, int dout_dtype, int B, int Ho,
     const dim3 grid_rows((unsigned)((Wi * (C / 8) + 255) / 256), (unsigned)(B * Hi));
 #define BWD_ROWS(NX) hipLaunchKernelGGL(bilinear_bwd8_rows_kernel<NX>, grid_rows, dim3(256), 0, (hipStream_t)stream, dout, Ho, \
                                         Wo, C, osB, osH, osW, din, Hi, Wi, isB, isH, isW, accumulate)
-    if ((int64_t)B * Hi <= 65535 && nx <= 20 && !g_flat_resample) {
+    const int fac = (Hi > 1 && Wi > 1 && Ho % Hi == 0 && Wo % Wi == 0 && Ho / Hi == Wo / Wi) ? Ho / Hi : 0;
+    if ((fac == 2 || fac == 4) && (int64_t)B * ((Hi + 7) / 8) <= 65535 && !g_flat_resample) {
+      const dim3 grid((unsigned)((Wi * (C / 8) + 255) / 256), (unsigned)(B * ((Hi + 7) / 8)));
+      if (fac == 2) hipLaunchKernelGGL((bilinear_bwd8_walk_kernel<2, 8>), grid, dim3(256), 0, (hipStream_t)stream, dout, C, osB, osH, osW, din, Hi, Wi, isB, isH, isW, accumulate);
+      else hipLaunchKernelGGL((bilinear_bwd8_walk_kernel<4, 8>), grid, dim3(256), 0, (hipStream_t)stream, dout, C, osB, osH, osW, din, Hi, Wi, isB, isH, isW, accumulate);
+    } else if ((int64_t)B * Hi <= 65535 && nx <= 20 && g_flat_resample != 1) {
       if (nx <= 8) BWD_ROWS(8); else if (nx <= 12) BWD_ROWS(12); else BWD_ROWS(20);
     } else if (nx > 20 && (int64_t)B * Hi * Wi <= 65535 && !g_flat_resample) {
       hipLaunchKernelGGL(bilinear_bwd8_window_kernel, dim3((unsigned)((C / 8 + 31) / 32), (unsigned)(B * Hi * Wi)), dim3(256), 0,

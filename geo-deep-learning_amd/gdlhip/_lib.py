@@ -102,6 +102,8 @@ SIGNATURES = {
     "gdl_bn_small_bwd": (c_i, [c_p, c_p, c_p, c_i, c_l, c_i, c_l, c_l, c_l, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p]),
     "gdl_bilinear_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_i, c_i, c_i,
                                c_l, c_l, c_l, c_i, c_p]),
+    "gdl_bilinear_fwd_add": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_p, c_i, c_i, c_i,
+                                   c_l, c_l, c_l, c_p]),
     "gdl_resize_conv3x3_bwd_gather": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "gdl_resize_conv3x3_bwd_gather_one_pass": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "gdl_resize_conv3x3_bwd_gather_bn": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p,

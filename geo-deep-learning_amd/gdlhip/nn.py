@@ -960,6 +960,8 @@ class _UpsampleAdd(Function):
     @staticmethod
     def forward(ctx, a, b):
         ctx.b_size = (b.shape[1], b.shape[2])
+        if a.dim() == 4 and b.dim() == 4 and a.dtype == b.dtype:
+            return ops.bilinear_add(a, b)          # one pass (bf16, factor 2 / 4), else copy + accumulate inside the library
         out = ops.copy_cast(a, out=torch.empty(a.shape, device=a.device, dtype=a.dtype))
         return ops.bilinear(b, (a.shape[1], a.shape[2]), out=out, accumulate=True)
 

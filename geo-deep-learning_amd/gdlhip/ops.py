@@ -547,6 +547,22 @@ def bilinear(x: Tensor, size: tuple[int, int], out: Tensor | None = None,
     return out
 
 
+def bilinear_add(base: Tensor, x: Tensor) -> Tensor:
+    """base + bilinear(x -> base's size) as a new tensor, in one pass where the fused kernel applies (gdl_bilinear_fwd_add;
+    otherwise copy + accumulate inside the library): UperNet's top-down add (upernet.py:127-135)."""
+    _need_cuda(base, x)
+    b4, x4 = _nhwc4(base, "bilinear_add base"), _nhwc4(x, "bilinear_add x")
+    B, Ho, Wo, Cc = b4.shape
+    if x4.shape[0] != B or x4.shape[3] != Cc or x4.dtype != b4.dtype:
+        raise ValueError(f"bilinear_add: {tuple(x4.shape)} {x4.dtype} does not resize onto {tuple(b4.shape)} {b4.dtype}")
+    b4 = b4 if b4.is_contiguous() else b4.contiguous()
+    out = torch.empty((B, Ho, Wo, Cc), device=base.device, dtype=base.dtype)
+    check(_lib.load().gdl_bilinear_fwd_add(_p(x4), dt(x4), B, x4.shape[1], x4.shape[2], Cc, x4.stride(0), x4.stride(1), x4.stride(2),
+                                           _p(b4), _p(out), dt(out), Ho, Wo, out.stride(0), out.stride(1), out.stride(2), _stream()),
+          "gdl_bilinear_fwd_add")
+    return out
+
+
 GATHER_TWO_PASS = True    # A/B switch (tools / tests): separable two-pass gather for large resize factors
 
 

@@ -282,6 +282,13 @@ int gdl_bilinear_fwd(const void* in, int in_dtype, int B, int Hi, int Wi, int C,
                      int64_t in_sH, int64_t in_sW, void* out, int out_dtype, int Ho, int Wo,
                      int64_t out_sB, int64_t out_sH, int64_t out_sW, int accumulate,
                      gdl_stream_t stream);
+/* out = base + F.interpolate(in -> Ho x Wo): UperNet's top-down path `laterals[i - 1] = laterals[i - 1] + resize(laterals[i])`
+ * (models/decoders/upernet.py:127-135) in ONE pass -- `base` has out's dtype and strides and is not modified.  bf16 maps with
+ * 16-byte aligned rows and a resize factor of exactly 2 or 4 take the fused kernel; any other call copies base and accumulates
+ * (gdl_copy_cast + gdl_bilinear_fwd(accumulate = 1)): same values. */
+int gdl_bilinear_fwd_add(const void* in, int in_dtype, int B, int Hi, int Wi, int C, int64_t in_sB,
+                         int64_t in_sH, int64_t in_sW, const void* base, void* out, int out_dtype, int Ho, int Wo,
+                         int64_t out_sB, int64_t out_sH, int64_t out_sW, gdl_stream_t stream);
 /* Backward of conv3x3(pad 1)(F.interpolate(x, bilinear)) (multilevel_neck.py:56-67,157-158) at LOW resolution: with
  * U = the resize and S_t = the shift of filter tap t (both act on pixels only), dx = sum_t W_t^T G_t and
  * dW_t = sum_q G_t[q] (x) x[q] where G_t = U^T S_t^T dy.  This is the gather that builds the nine maps: dy dense

@@ -529,6 +529,50 @@ def test_bilinear(dtype, hi, ho):
     assert (buf[..., :C] == 1).all()
 
 
+@pytest.mark.parametrize("hi,wi,f,C", [(9, 13, 2, 64), (7, 5, 4, 72), (2, 2, 4, 8), (36, 36, 2, 256), (17, 3, 4, 16)])
+def test_bilinear_integer_factor_gap_kernel(hi, wi, f, C):
+    """bf16 upsampling by exactly 2 or 4 (FPN top-down path, the concat levels): a thread owns the F x F outputs between four
+    input pixels (bilinear_fwd8_gap_kernel) -- bit-identical to the row kernel it replaces (same indices, weights, expression),
+    plain and accumulating into a channel slice, and close to F.interpolate."""
+    import ctypes
+    from gdlhip import _lib
+    lib = _lib.load()
+    lib.gdl_debug_set_flat_resample.argtypes = [ctypes.c_int]
+    B, dtype = 3, torch.bfloat16
+    x = q(rnd(B, hi, wi, C), dtype)
+    size = (f * hi, f * wi)
+    xd = x.to(DEV, dtype)
+    base = q(rnd(B, size[0], size[1], 2 * C, seed=5), dtype).to(DEV, dtype)
+    dy = q(rnd(B, size[0], size[1], C, seed=6), dtype)
+    dyd = dy.to(DEV, dtype)
+    outs = {}
+    try:
+        for mode in (0, 2):                                   # 0 = default (gap kernel), 2 = the row kernel
+            lib.gdl_debug_set_flat_resample(mode)
+            buf = base.clone()
+            ops.bilinear(xd, size, out=buf[..., C:], accumulate=True)
+            dx = ops.bilinear_bwd(dyd, (hi, wi))
+            outs[mode] = (ops.bilinear(xd, size), buf, dx)
+    finally:
+        lib.gdl_debug_set_flat_resample(0)
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    # base + resize(x) in one pass (gdl_bilinear_fwd_add, the FPN top-down add) == copy, then accumulate; base untouched
+    half = base[..., :C].contiguous()
+    keep = half.clone()
+    want = half.clone()
+    ops.bilinear(xd, size, out=want, accumulate=True)
+    assert torch.equal(ops.bilinear_add(half, xd), want) and torch.equal(half, keep)
+    # backward: a thread walks down a column of input pixels, every gradient row loaded once for the two input rows it feeds
+    # (bilinear_bwd8_walk_kernel) -- bit-identical to the row kernel
+    assert torch.equal(outs[0][2], outs[2][2])
+    xr = x.permute(0, 3, 1, 2).float().clone().requires_grad_(True)
+    F.interpolate(xr, size=size, mode="bilinear", align_corners=False).backward(dy.permute(0, 3, 1, 2).float())
+    close(outs[0][2].permute(0, 3, 1, 2), xr.grad, dtype, "bilinear walk kernel (backward)")
+    ref = F.interpolate(x.permute(0, 3, 1, 2).float(), size=size, mode="bilinear", align_corners=False)
+    close(outs[0][0].permute(0, 3, 1, 2), ref, dtype, "bilinear gap kernel")
+    assert torch.equal(outs[0][1][..., :C], base[..., :C])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("hi,s", [(18, 1), (18, 2), (18, 3), (18, 6), (4, 6), (4, 3), (36, 6)])
 def test_adaptive_avgpool(dtype, hi, s):
