@@ -267,6 +267,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // Tried and measured, not kept: staggering the two query tiles of a 64-query wave (S0 S1 | softmax0 | PV0 | softmax1 |
 // PV1, fragments held in registers: 278 -> 268 us); v_pk_fma_f32 / v_pk_add_f32 for the exponent arguments and row sums
 // (20 % fewer VALU instructions, no time: packed f32 issues at half rate); eight-wave blocks of 256 queries (244 us).
+// Round 6, measured and not kept (N = 1297, batch 64, 445-468 us): blocks of three waves (96 queries: 47 padded query rows per head
+// instead of 111) 489-508 us -- five blocks per CU stage K / V 27 % more often; the all-padding second half of the last key tile
+// (17 of 64 keys) skipped behind a uniform branch: 480-490 us -- the second copy of the tile body costs 64 bytes of scratch at the
+// 128-register budget of four waves per SIMD.
 // `defer` > 0: the running maximum is only raised (and O rescaled) when some row's tile maximum exceeds it by more than
 // `defer` in the exp2 domain -- P stays below 2^defer; with the usual slowly growing maxima most tiles skip the rescale.
 template <int NW>
