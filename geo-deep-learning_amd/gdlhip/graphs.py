@@ -26,12 +26,32 @@ eagerly (see ``ddp_warmup`` / ``capturable_process_group`` below and MiniTrainer
 
 from __future__ import annotations
 
+import contextlib
+import gc
+
 from typing import Any
 
 import torch
 from torch import Tensor
 
 from . import nn as gnn
+
+
+@contextlib.contextmanager
+def _no_gc_during_capture():
+    """Collect garbage BEFORE a stream capture and keep the cyclic collector off during it.  torch.cuda.graph no longer collects
+    on entry (torch >= 2.6: only with torch.compiler.config.force_cudagraph_gc), so a collection triggered by the capture's own
+    allocations could finalise earlier graphs, events or pinned buffers in the middle of it -- hipGraphExecDestroy / hipEventDestroy
+    / hipHostFree inside a capture abort the process (seen in round 6: the DDP capture test died with `Aborted` in whole-suite
+    order, depending on how much garbage the tests before it had left)."""
+    gc.collect()
+    was_on = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_on:
+            gc.enable()
 
 
 class GraphCaptureFatal(RuntimeError):
@@ -293,7 +313,7 @@ class GraphedTrainStep:
         mode = "thread_local" if self.ddp is not None else "global"
         ctx = torch.cuda.graph(self.graph, capture_error_mode=mode, **({"stream": self.capture_stream} if self.capture_stream else {}))
         self._capture_ctx = ctx
-        with ctx:
+        with _no_gc_during_capture(), ctx:
             self.loss = self._eager(zero=False)
         self._capture_ctx = None
         # every operand cache entry that exists now may have been read by the captured kernels through its address (entries that
@@ -355,7 +375,7 @@ class GraphedEvalStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with _no_gc_during_capture(), torch.cuda.graph(self.graph):
             self.out = self._eager()
 
     def _eager(self):
