@@ -1319,7 +1319,12 @@ __global__ __launch_bounds__(DT_T) void dice_lowres_bwd_tile_kernel(const DiceTi
     float acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.f;
-    for (int r = 0; r < rows; ++r) {
+    // (only the tile rows that can interpolate from low-resolution row iy_lo + j: 2 / ratio + 3 of the 32 -- same terms, same order)
+    int r_lo, r_hi;
+    cand_range(iy_lo + j, ry, a.Ho, r_lo, r_hi);
+    r_lo = r_lo - oy0 < 0 ? 0 : r_lo - oy0;
+    r_hi = r_hi - oy0 > rows - 1 ? rows - 1 : r_hi - oy0;
+    for (int r = r_lo; r <= r_hi; ++r) {
       const float wy = wyt[j * DT_H + r];
       if (wy != 0.f) {
 #pragma unroll
@@ -1337,7 +1342,11 @@ __global__ __launch_bounds__(DT_T) void dice_lowres_bwd_tile_kernel(const DiceTi
     float acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.f;
-    for (int c = 0; c < cols; ++c) {
+    int c_lo, c_hi;
+    cand_range(ix_lo + q, rx, a.Wo, c_lo, c_hi);
+    c_lo = c_lo - ox0 < 0 ? 0 : c_lo - ox0;
+    c_hi = c_hi - ox0 > cols - 1 ? cols - 1 : c_hi - ox0;
+    for (int c = c_lo; c <= c_hi; ++c) {
       const float wx = wxt[q * DT_W + c];
       if (wx != 0.f) {
 #pragma unroll
