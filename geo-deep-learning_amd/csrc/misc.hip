@@ -1094,6 +1094,36 @@ __device__ __forceinline__ void bilinear_logits(const float* __restrict__ in, in
   for (int k = 0; k < K; ++k) x[k] = hy * (hx * p00[k] + lx * p01[k]) + ly * (hx * p10[k] + lx * p11[k]);
 }
 
+// softmax(dim=1).argmax(dim=1) of the resized logits straight from the head's low-resolution map (validation / test / inference:
+// `outputs.out.softmax(dim=1).argmax(dim=1)`, segmentation_dofa.py:278-281): the bilinear logits of a pixel with the expression of
+// upsample_logits_kernel, then softmax_argmax_kernel's decision -- the same mask, bit for bit, without the [B, K, H, W] f32 tensor
+// (335 MB written and read again at batch 64).
+template <int K>
+__global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __restrict__ low, int B, int Hi, int Wi, int Ho, int Wo,
+                                                              int64_t* __restrict__ mask) {
+  const int64_t total = (int64_t)B * Ho * Wo;
+  const float ry = (float)Hi / (float)Ho, rx = (float)Wi / (float)Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    const int64_t t = i / Wo;
+    const int oy = (int)(t % Ho), b = (int)(t / Ho);
+    int y0, y1, x0, x1; float ly, lx;
+    src_index2(ry, oy, Hi, y0, y1, ly);
+    src_index2(rx, ox, Wi, x0, x1, lx);
+    float x[K], mx = -INFINITY;
+    bilinear_logits<K>(low, b, Hi, Wi, y0, y1, x0, x1, ly, lx, x);
+#pragma unroll
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, x[k]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { x[k] = expf(x[k] - mx); s += x[k]; }
+    int best = 0; float bv = x[0] / s;
+#pragma unroll
+    for (int k = 1; k < K; ++k) { const float v = x[k] / s; if (v > bv) { bv = v; best = k; } }
+    mask[i] = best;
+  }
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void dice_lowres_partial_kernel(const float* __restrict__ low, const int64_t* __restrict__ target,
                                                                   int B, int Hi, int Wi, int Ho, int Wo, float* __restrict__ ws) {
@@ -1865,6 +1895,14 @@ extern "C" int gdl_softmax_argmax(const float* logits, int B, int K, int64_t HW,
   const int64_t total = (int64_t)B * HW;
   K_SWITCH(K, hipLaunchKernelGGL((softmax_argmax_kernel<KK>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, logits, B, HW, mask));
   GDL_CHECK_LAUNCH("gdl_softmax_argmax");
+  return GDL_OK;
+}
+
+extern "C" int gdl_upsample_argmax(const float* low, int B, int Hi, int Wi, int K, int64_t* mask, int Ho, int Wo, gdl_stream_t stream) {
+  GDL_CHECK_ARG(low && mask && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && K >= 2, "gdl_upsample_argmax: bad args");
+  const int64_t total = (int64_t)B * Ho * Wo;
+  K_SWITCH(K, hipLaunchKernelGGL((upsample_argmax_kernel<KK>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, low, B, Hi, Wi, Ho, Wo, mask));
+  GDL_CHECK_LAUNCH("gdl_upsample_argmax");
   return GDL_OK;
 }
 

@@ -152,6 +152,7 @@ SIGNATURES = {
     "gdl_upsample_logits_bwd_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "gdl_upsample_logits_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_l, c_p]),
     "gdl_softmax_argmax": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p]),
+    "gdl_upsample_argmax": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "gdl_class_probs": (c_i, [c_p, c_i, c_i, c_l, c_p, c_p]),
     "gdl_iou_counts": (c_i, [c_p, c_p, c_i, c_l, c_i, c_p, c_p]),
     "gdl_dice_loss_workspace": (c_l, [c_i, c_i, c_l]),

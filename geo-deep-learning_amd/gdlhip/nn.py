@@ -1183,8 +1183,14 @@ class DiceLoss(nn.Module):
         return _DiceLoss.apply(y_pred, y_true.long().contiguous(), self.eps)
 
 
-def predict_mask(logits: Tensor) -> Tensor:
-    """``softmax(dim=1).argmax(dim=1)`` (segmentation_dofa.py:281)."""
+def predict_mask(logits) -> Tensor:
+    """``softmax(dim=1).argmax(dim=1)`` (segmentation_dofa.py:281).  For not-yet-resized logits (LowresLogits) the resize is
+    evaluated per pixel inside the kernel: the same mask without the [B, K, H, W] tensor."""
+    if isinstance(logits, LowresLogits):
+        low = logits.low
+        if low.dtype == torch.float32 and low.dim() == 4 and 2 <= low.shape[3] <= 16:
+            return ops.upsample_argmax(low.contiguous(), logits.size)
+        logits = logits.materialise()
     return ops.softmax_argmax(logits.float().contiguous())
 
 

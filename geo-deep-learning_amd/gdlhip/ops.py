@@ -1593,6 +1593,18 @@ def softmax_argmax(logits: Tensor) -> Tensor:
     return mask
 
 
+def upsample_argmax(low: Tensor, size: tuple[int, int]) -> Tensor:
+    """softmax(dim=1).argmax(dim=1) of bilinear(low -> size) for the head's NHWC f32 map [B, h, w, K] -> int64 [B, H, W], without the
+    resized logits (gdl_upsample_argmax; the same mask as upsample_logits + softmax_argmax)."""
+    _need_cuda(low)
+    if low.dtype != torch.float32 or not low.is_contiguous() or low.dim() != 4 or not 2 <= low.shape[3] <= 16:
+        raise ValueError("upsample_argmax: contiguous f32 NHWC logits [B, h, w, K] with 2..16 classes expected")
+    B, Hi, Wi, K = low.shape
+    mask = torch.empty((B, int(size[0]), int(size[1])), device=low.device, dtype=torch.int64)
+    check(_lib.load().gdl_upsample_argmax(_p(low), B, Hi, Wi, K, _p(mask), int(size[0]), int(size[1]), _stream()), "gdl_upsample_argmax")
+    return mask
+
+
 def class_probs(logits: Tensor) -> Tensor:
     """NCHW f32 logits -> softmax(dim=1) (or sigmoid for one class) probabilities."""
     _need_cuda(logits)

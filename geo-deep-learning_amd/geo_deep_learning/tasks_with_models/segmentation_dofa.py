@@ -86,7 +86,7 @@ class SegmentationDOFA(SegmentationTaskHooks, LightningModule):
     def _loss(self, batch: dict[str, Any], lowres_logits: bool = False):
         x, y, wv = batch["image"], batch["mask"], batch["wavelengths"]
         y = y.squeeze(1).long()
-        # lowres_logits (training only): the loss is all the step needs from the logits, and gdlhip's DiceLoss evaluates it -- and its
+        # lowres_logits: the loss (and, in validation / test, the arg-max mask) is all the step needs from the logits, and gdlhip's DiceLoss evaluates it -- and its
         # gradient -- from the heads' own maps (128 x 128 main, 16 x 16 auxiliary); the reference's F.interpolate to 512 x 512
         # (dofa.py:89-105) and the 168 MB tensor it produces per head exist only where something reads them (validation / test)
         outputs = self.model(x, wv, lowres_logits=True) if lowres_logits else self(x, wv)
@@ -103,15 +103,23 @@ class SegmentationDOFA(SegmentationTaskHooks, LightningModule):
         self._log_loss("train_loss", loss, bs)
         return loss
 
+    def _lowres_eval(self) -> bool:
+        """Validation / test need the two Dice terms and the arg-max mask of ``outputs.out``, nothing else of the logits: with gdlhip's
+        multiclass DiceLoss both come straight from the heads' own maps (``gnn.DiceLoss`` / ``gnn.predict_mask`` on LowresLogits: the
+        same values, bit for bit, as from the resized [B, K, H, W] tensors, which are then never written)."""
+        from gdlhip import nn as gnn
+        return (gnn.FUSE_LOWRES_DICE and isinstance(self.loss, gnn.DiceLoss) and self.loss.mode == "multiclass"
+                and self.num_classes > 1)
+
     def validation_step(self, batch: dict[str, Any], batch_idx: int) -> Tensor:  # noqa: ARG002
         """segmentation_dofa.py:251-283."""
-        outputs, _, loss, bs = self._loss(batch)
+        outputs, _, loss, bs = self._loss(batch, lowres_logits=self._lowres_eval())
         self.val_samples_count += bs
         self._log_loss("val_loss", loss, bs)
         return self._predict(outputs.out)
 
     def test_step(self, batch: dict[str, Any], batch_idx: int) -> None:  # noqa: ARG002
         """segmentation_dofa.py:293-338 (per-class IoU; figure logging not rebuilt)."""
-        outputs, y, loss, bs = self._loss(batch)
+        outputs, y, loss, bs = self._loss(batch, lowres_logits=self._lowres_eval())
         self.test_samples_count += bs
         self._log_test_metrics(self._predict(outputs.out), y, loss, bs)

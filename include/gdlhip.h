@@ -468,6 +468,11 @@ int gdl_upsample_logits_bwd(const float* dout, int B, int Ho, int Wo, int K, flo
 /* softmax(dim=1).argmax(dim=1) on NCHW f32 logits -> int64 mask (segmentation_dofa.py:281) */
 int gdl_softmax_argmax(const float* logits, int B, int K, int64_t HW, int64_t* mask,
                        gdl_stream_t stream);
+/* the same mask from the head's own NHWC f32 map [B,Hi,Wi,K]: softmax(dim=1).argmax(dim=1) of F.interpolate(logits, (Ho, Wo))
+ * (dofa.py:89-95 + segmentation_dofa.py:278-281) without the resized tensor; bit-identical to gdl_upsample_logits +
+ * gdl_softmax_argmax.  K >= 2 classes. */
+int gdl_upsample_argmax(const float* low, int B, int Hi, int Wi, int K, int64_t* mask, int Ho, int Wo,
+                        gdl_stream_t stream);
 /* f.softmax(output, dim=1) (K > 1) / f.sigmoid (K == 1) of the exported inference model (tools/script_model.py:55-59) */
 int gdl_class_probs(const float* logits, int B, int K, int64_t HW, float* probs, gdl_stream_t stream);
 /* smp DiceLoss(mode="multiclass", smooth=0, eps=1e-7) forward+backward on NCHW f32 logits

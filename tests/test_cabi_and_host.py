@@ -394,8 +394,9 @@ def test_bench_stdout_line_is_short_and_ends_with_the_headline_extras():
 
 
 def test_dofa_training_step_asks_for_low_resolution_logits_only_where_the_loss_can_use_them(monkeypatch):
-    """Round 5 host logic (tasks_with_models/segmentation_dofa.py): ``training_step`` hands the heads' not-yet-resized maps
-    (``lowres_logits=True``) to gdlhip's multiclass DiceLoss and to nothing else; validation / test, a binary or foreign loss, and
+    """Host logic of tasks_with_models/segmentation_dofa.py: ``training_step`` (round 5) and ``validation_step`` / ``test_step``
+    (round 6: the mask comes from ``gnn.predict_mask`` on the same low-resolution map) hand the heads' not-yet-resized maps
+    (``lowres_logits=True``) to gdlhip's multiclass DiceLoss and to nothing else; a binary or foreign loss, one class, and
     GDL_LOWRES_DICE=0 get the reference's full-resolution logits (dofa.py:89-105)."""
     from types import SimpleNamespace
     from gdlhip import nn as gnn
@@ -427,15 +428,24 @@ def test_dofa_training_step_asks_for_low_resolution_logits_only_where_the_loss_c
     t.training_step(batch, 0)
     assert calls == [True]
     calls.clear()
-    monkeypatch.setattr(gnn, "predict_mask", lambda logits: logits.argmax(1))      # (the mask kernel needs a GPU)
+    seen = []
+    monkeypatch.setattr(gnn, "predict_mask", lambda logits: (seen.append(logits), logits.argmax(1))[1])      # (the mask kernel needs a GPU)
     with torch.no_grad():
         t.validation_step(batch, 0)
-    assert calls == [False], "validation needs the full-resolution logits (masks, metrics)"
+    assert calls == [True] and len(seen) == 1, "validation: loss and mask both come from the low-resolution maps"
+    calls.clear()
+    for other in (task_with(FakeDice(mode="binary")), task_with(Foreign())):
+        with torch.no_grad():
+            other.validation_step(batch, 0)
+    assert calls == [False, False], "a loss that cannot read low-resolution maps gets the resized logits in validation too"
     calls.clear()
     task_with(FakeDice(mode="binary")).training_step(batch, 0)
     task_with(Foreign()).training_step(batch, 0)
     assert calls == [False, False]
     calls.clear()
     monkeypatch.setattr(gnn, "FUSE_LOWRES_DICE", False)
-    task_with(FakeDice(mode="multiclass")).training_step(batch, 0)
-    assert calls == [False]
+    t = task_with(FakeDice(mode="multiclass"))
+    t.training_step(batch, 0)
+    with torch.no_grad():
+        t.validation_step(batch, 0)
+    assert calls == [False, False]

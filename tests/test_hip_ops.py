@@ -844,6 +844,24 @@ def test_dice_loss_multiclass_accepts_unsqueezed_mask():
     assert gnn.DiceLoss()(logits, y).item() == gnn.DiceLoss()(logits, y[:, 0]).item()
 
 
+@pytest.mark.parametrize("B,h,w,H,W,K", [(2, 36, 36, 128, 128, 5), (3, 16, 16, 512, 512, 5), (2, 9, 13, 33, 40, 2), (1, 18, 18, 64, 64, 16),
+                                        (2, 7, 7, 7, 7, 3)])
+def test_upsample_argmax_bit_exact(B, h, w, H, W, K):
+    """The validation / inference mask straight from the head's low-resolution map (gdl_upsample_argmax) == upsample_logits followed by
+    softmax_argmax, in every pixel -- including maps with many near-ties (logits quantised to a coarse grid) -- and gnn.predict_mask
+    takes that path for LowresLogits."""
+    g = torch.Generator().manual_seed(B * 1000 + h * 10 + K)
+    for scale, grid in ((2.0, None), (1.0, 0.25)):
+        low = torch.randn(B, h, w, K, generator=g) * scale
+        if grid:
+            low = (low / grid).round() * grid
+        low = low.to(DEV)
+        want = ops.softmax_argmax(ops.upsample_logits(low, (H, W)))
+        got = ops.upsample_argmax(low, (H, W))
+        assert got.dtype == torch.int64 and torch.equal(got, want)
+        assert torch.equal(gnn.predict_mask(gnn.LowresLogits(low, (H, W))), want)
+
+
 def test_adam_and_clip():
     torch.manual_seed(0)
     ps = [torch.randn(1000, 3), torch.randn(64, 32, 3, 3).contiguous(memory_format=torch.channels_last)]
